@@ -1,0 +1,190 @@
+/*
+ * pasture_amd — C ABI of the MI355X-native implementation of pasture's per-point attribute-transform hot path.
+ *
+ * The reference (igd-geo/pasture, Rust) has no FFI on this path; its seam is the Rust trait surface
+ * (BorrowedBuffer / InterleavedBuffer / ColumnarBuffer / PointLayout) plus the entry points listed below.  Every
+ * function here names the reference interface it replaces (paths relative to the reference checkout).  A Rust
+ * shim that re-implements those traits on top of this ABI is sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns a pst_status; 0 = ok.  The reference signals precondition violations with
+ *    panic!/assert!/expect; nothing unwinds across this ABI — the shim re-raises codes 2..13 as panic!.
+ *    pst_last_error() returns the panic message of the last failing call on the calling thread.
+ *  - plain pointers and sizes only; no torch / C++ types.  Device pointers are HIP device addresses.
+ *  - all device work is enqueued on the calling thread's current stream (pst_set_stream; default = the null
+ *    stream).  Functions that return results to host memory synchronise that stream before returning; the
+ *    *_async variants do not.
+ *  - there is NO CPU fallback: compute entry points fail with PST_ERR_NO_DEVICE / PST_ERR_HIP when no gfx950
+ *    device is usable.  Host-only logic (layouts, converter mapping construction, argument checks) works
+ *    without a device.
+ */
+#ifndef PASTURE_AMD_H
+#define PASTURE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pst_status {
+  PST_OK = 0,
+  PST_ERR_INVALID_ARGUMENT = 1,
+  PST_ERR_LAYOUT_MISMATCH = 2,         /* buffer_conversion.rs:302-303 assert_eq! on layouts */
+  PST_ERR_RANGE = 3,                   /* buffer_conversion.rs:304-306 range asserts, slice bounds */
+  PST_ERR_MISSING_ATTRIBUTE = 4,       /* .expect("... not found in ... PointLayout") */
+  PST_ERR_INVALID_CONVERSION = 5,      /* attribute_conversion.rs:267-269 "Invalid conversion X -> Y" */
+  PST_ERR_TRANSFORM_TYPE_MISMATCH = 6, /* buffer_conversion.rs:209-213 */
+  PST_ERR_UNSUPPORTED_TRANSFORM = 7,   /* closure outside the closed descriptor set: use the CPU path */
+  PST_ERR_DUPLICATE_ATTRIBUTE = 8,     /* point_layout.rs:783-788 */
+  PST_ERR_INVALID_LAYOUT = 9,          /* point_layout.rs:725-745, Layout::from_size_align failures */
+  PST_ERR_BOUNDS_INVALID = 10,         /* math/bounds.rs:21-26 AABB::from_min_max panic (e.g. all-NaN input) */
+  PST_ERR_TOO_FEW_POINTS = 11,         /* normal_estimation.rs:86-88 */
+  PST_ERR_K_TOO_SMALL = 12,            /* normal_estimation.rs:89-91 */
+  PST_ERR_NOT_ENOUGH_NEIGHBOURS = 13,  /* normal_estimation.rs:471 unwrap on Err */
+  PST_ERR_HIP = 20,
+  PST_ERR_NO_DEVICE = 21,
+  PST_ERR_OUT_OF_MEMORY = 22,
+  PST_ERR_UNSUPPORTED = 23
+} pst_status;
+
+/* PointAttributeDataType, point_layout.rs:23-68; kind = declaration order :25-50 */
+enum {
+  PST_U8 = 0, PST_I8, PST_U16, PST_I16, PST_U32, PST_I32, PST_U64, PST_I64, PST_F32, PST_F64,
+  PST_VEC3U8, PST_VEC3U16, PST_VEC3F32, PST_VEC3I32, PST_VEC3F64, PST_VEC4U8, PST_BYTEARRAY, PST_CUSTOM
+};
+typedef struct pst_datatype {
+  uint32_t kind;
+  uint32_t reserved;
+  uint64_t size_param;  /* ByteArray(length) / Custom.size */
+  uint64_t align_param; /* Custom.min_alignment */
+  uint8_t uuid[16];     /* Custom.name */
+} pst_datatype;
+
+/* PointAttributeMember, point_layout.rs:353-431 */
+typedef struct pst_member {
+  const char* name; /* borrowed from the layout; valid until the layout is destroyed or mutated */
+  pst_datatype datatype;
+  uint64_t offset;
+  uint64_t size;
+} pst_member;
+
+/* Closed set of attribute transformations standing in for the reference's `Fn(T) -> T` closures
+ * (buffer_conversion.rs:14-31, :194-234).  Anything else must stay on the CPU path. */
+enum { PST_XF_NONE = 0, PST_XF_AFFINE = 1, PST_XF_BITFIELD = 2 };
+typedef struct pst_transform {
+  uint32_t kind;
+  uint32_t shift;        /* BITFIELD: (v >> shift) & mask on U8/U16/U32/U64 — raw_readers.rs:61-164 */
+  pst_datatype datatype; /* the closure's T; checked like buffer_conversion.rs:209-213 */
+  double scale[3];       /* AFFINE on F64/Vec3f64: (p*scale)+offset, two roundings, never fused — raw_readers.rs:42-48; */
+  double offset[3];      /*        on F32/Vec3f32: ((p as f64*scale)+offset) as f32 — raw_readers.rs:49-55            */
+  uint64_t mask;
+} pst_transform;
+
+typedef struct pst_mapping_info { /* AttributeMapping, buffer_conversion.rs:41-55 (introspection) */
+  const char* source_name;
+  const char* target_name;
+  pst_datatype source_datatype;
+  pst_datatype target_datatype;
+  uint64_t source_offset;
+  uint64_t target_offset;
+  int32_t has_converter;
+  uint32_t transform_kind;
+  int32_t apply_to_source;
+  int32_t reserved;
+} pst_mapping_info;
+
+typedef struct pst_layout pst_layout;       /* PointLayout,           point_layout.rs:648-997 */
+typedef struct pst_buffer pst_buffer;       /* VectorBuffer :659 / HashMapBuffer :1031 / ExternalMemoryBuffer :1479 (point_buffer.rs) */
+typedef struct pst_converter pst_converter; /* BufferLayoutConverter, buffer_conversion.rs:98-663 */
+
+const char* pst_last_error(void);
+
+/* ---- device / stream ------------------------------------------------------------------------------- */
+int pst_device_count(int* out);
+int pst_set_device(int device);
+int pst_set_stream(void* hip_stream); /* hipStream_t; thread-local; NULL = null stream */
+int pst_stream_synchronize(void);
+
+/* ---- PointLayout ------------------------------------------------------------------------------------ */
+int pst_layout_create(pst_layout** out);                           /* PointLayout::default()            :1011-1023 */
+int pst_layout_destroy(pst_layout* l);
+int pst_layout_clone(const pst_layout* l, pst_layout** out);
+/* add_attribute(attr, FieldAlignment::{Default | Packed(max_alignment)})                               :778-822  */
+int pst_layout_add_attribute(pst_layout* l, const char* name, const pst_datatype* dt, uint32_t packed, uint64_t max_alignment);
+int pst_layout_from_members(const pst_member* members, size_t n, uint64_t type_alignment, pst_layout** out); /* :719-759 */
+int pst_layout_num_attributes(const pst_layout* l, size_t* out);
+int pst_layout_get_member(const pst_layout* l, size_t index, pst_member* out);                           /* at() :898-900 */
+int pst_layout_size_of_point_entry(const pst_layout* l, uint64_t* out);                                  /* :928-931 */
+int pst_layout_alignment(const pst_layout* l, uint64_t* out);
+int pst_layout_equals(const pst_layout* a, const pst_layout* b, int* out);                                /* derive(PartialEq) :646 */
+
+/* ---- buffers ------------------------------------------------------------------------------------------ */
+enum { PST_STORAGE_INTERLEAVED = 0, PST_STORAGE_COLUMNAR = 1 };
+enum { PST_MEM_DEVICE = 0, PST_MEM_PINNED_HOST = 1 };
+/* MakeBufferFromLayout::new_from_layout (:497-500): empty buffer, library-owned memory of `memkind`.
+ * Interleaved: one allocation, stride = size_of_point_entry.  Columnar: one 256-B aligned column per attribute. */
+int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, pst_buffer** out);
+/* ExternalMemoryBuffer<T: AsRef<[u8]>> (:1479-1708): interleaved view over caller-owned device-accessible memory;
+ * len = nbytes / size_of_point_entry; nbytes must be a multiple of the point size (:1488-1497). */
+int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbytes, pst_buffer** out);
+/* Columnar view over caller-owned columns (one device pointer per layout attribute, layout order), `len` points. */
+int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_ptrs, size_t len, pst_buffer** out);
+int pst_buffer_destroy(pst_buffer* b);
+int pst_buffer_len(const pst_buffer* b, size_t* out);                 /* BorrowedBuffer::len :29 */
+int pst_buffer_resize(pst_buffer* b, size_t count);                   /* OwningBuffer::resize :263 — new points zero-filled */
+int pst_buffer_is_columnar(const pst_buffer* b, int* out);            /* as_columnar / as_interleaved probes :143-151 */
+int pst_buffer_layout(const pst_buffer* b, pst_layout** out_clone);   /* point_layout() :33 (returns a clone) */
+int pst_buffer_points_ptr(const pst_buffer* b, void** out);           /* get_point_range_ref(0..len).as_ptr() :524-526 */
+int pst_buffer_column_ptr(const pst_buffer* b, const char* name, const pst_datatype* dt, void** out); /* get_attribute_range_ref :593-599 */
+/* host <-> buffer transfers (synchronous) */
+int pst_buffer_write_points(pst_buffer* b, size_t first, size_t count, const void* host_src);  /* set_point_range :90 */
+int pst_buffer_read_points(const pst_buffer* b, size_t first, size_t count, void* host_dst);   /* get_point_range :45 */
+int pst_buffer_write_attribute(pst_buffer* b, const char* name, const pst_datatype* dt, size_t first, size_t count, const void* host_src); /* set_attribute_range :110 */
+int pst_buffer_read_attribute(const pst_buffer* b, const char* name, const pst_datatype* dt, size_t first, size_t count, void* host_dst);  /* get_attribute_range :71 */
+/* deterministic synthetic points generated on the device (DESIGN.md "Synthetic inputs") */
+int pst_buffer_synth_fill(pst_buffer* b, uint64_t seed, uint64_t first_index);
+
+/* ---- BufferLayoutConverter ------------------------------------------------------------------------- */
+int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_default, pst_converter** out); /* for_layouts :112 / for_layouts_with_default :126 */
+int pst_converter_destroy(pst_converter* c);
+int pst_converter_set_custom_mapping(pst_converter* c, const char* from_name, const pst_datatype* from_dt, const char* to_name,
+                                     const pst_datatype* to_dt);                                       /* :156-183 */
+int pst_converter_set_custom_mapping_with_transformation(pst_converter* c, const char* from_name, const pst_datatype* from_dt,
+                                                         const char* to_name, const pst_datatype* to_dt, const pst_transform* xf,
+                                                         int apply_to_source);                         /* :194-234 */
+int pst_converter_num_mappings(const pst_converter* c, size_t* out);
+int pst_converter_get_mapping(const pst_converter* c, size_t index, pst_mapping_info* out);
+/* convert_into_range :292-359 (convert_into :268 = full ranges). Enqueues on the current stream, then synchronises. */
+int pst_converter_convert_into_range(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1);
+int pst_converter_convert_into_range_async(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1);
+/* convert :242-259 — allocates the target (new_from_layout + resize) and converts into it */
+int pst_converter_convert(const pst_converter* c, pst_buffer* src, uint32_t out_storage, pst_buffer** out);
+/* convert_into_range followed by calculate_bounds(target range) in ONE pass over HBM when the mapping set allows
+ * (columnar Vec3f64 POSITION_3D target); identical results to the two separate calls. */
+int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst,
+                                                 size_t t0, size_t t1, double out_min[3], double out_max[3], int* has_value);
+/* stream-ordered variant: the result record {min[3], max[3]} (6 doubles; seeds +/-f64::MAX if the range is empty)
+ * is written to `device_out6` (device-accessible memory); no host synchronisation, no panic mapping. */
+int pst_converter_convert_into_range_with_bounds_async(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst,
+                                                       size_t t0, size_t t1, double* device_out6);
+
+/* ---- pasture-algorithms loops --------------------------------------------------------------------- */
+/* calculate_bounds, pasture-algorithms/src/bounds.rs:11-85.  has_value = 0 <=> None. */
+int pst_calculate_bounds(const pst_buffer* b, double out_min[3], double out_max[3], int* has_value);
+int pst_calculate_bounds_async(const pst_buffer* b, double* device_out6);
+/* minmax_attribute::<T>, pasture-algorithms/src/minmax.rs:13-51 with T = `dt` (must be the stored datatype) */
+int pst_minmax_attribute(const pst_buffer* b, const char* name, const pst_datatype* dt, void* out_min, void* out_max, int* has_value);
+/* BorrowedMutBufferExt::transform_attribute, point_buffer.rs:391-404, with a closed-set transformation */
+int pst_transform_attribute(pst_buffer* b, const char* name, const pst_datatype* dt, const pst_transform* xf);
+/* compute_normals, pasture-algorithms/src/normal_estimation.rs:79-130: per point (normal[3] f64, curvature f64) to
+ * host arrays; out_knn (nullable, n*k int64, -1 padded) receives the neighbour indices in ascending distance. */
+int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);
+/* device-resident variant: writes the NORMAL attribute (Vec3f32, point_layout.rs:594-597; f64 -> f32 `as` narrowing)
+ * and an F64 "Curvature" attribute of `dst` (columnar or interleaved, same length) without leaving HBM. */
+int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASTURE_AMD_H */

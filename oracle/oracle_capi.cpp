@@ -1,0 +1,373 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see pasture_oracle.hpp header).  C API over the CPU restatement.
+#include "oracle_capi.h"
+
+#include <chrono>
+#include <string>
+
+#include "pasture_oracle.hpp"
+
+using namespace orc;
+
+struct orc_layout { PointLayout l; };
+struct orc_buffer { std::unique_ptr<Buffer> b; };
+struct orc_converter { BufferLayoutConverter c; std::vector<TransformDesc> xf; /* parallel to c.mappings */ };
+
+static thread_local std::string g_last_error;
+
+#define ORC_TRY try {
+#define ORC_CATCH                                                              \
+  }                                                                            \
+  catch (const Panic& p) { g_last_error = p.what(); return p.code; }           \
+  catch (const std::exception& e) { g_last_error = e.what(); return ERR_INVALID_ARGUMENT; } \
+  return OK;
+
+static DataType to_dt(const orc_datatype* d) {
+  if (!d) throw Panic(ERR_INVALID_ARGUMENT, "null datatype");
+  if (d->kind > Custom) throw Panic(ERR_INVALID_ARGUMENT, "invalid datatype kind");
+  DataType t;
+  t.kind = (Kind)d->kind;
+  t.size_param = d->size_param;
+  t.align_param = d->align_param;
+  std::memcpy(t.uuid.data(), d->uuid, 16);
+  return t;
+}
+static orc_datatype from_dt(const DataType& t) {
+  orc_datatype d{};
+  d.kind = t.kind;
+  d.size_param = t.size_param;
+  d.align_param = t.align_param;
+  std::memcpy(d.uuid, t.uuid.data(), 16);
+  return d;
+}
+static TransformDesc to_xf(const orc_transform* x) {
+  if (!x) throw Panic(ERR_INVALID_ARGUMENT, "null transform");
+  TransformDesc t;
+  t.kind = x->kind;
+  t.datatype = to_dt(&x->datatype);
+  for (int c = 0; c < 3; ++c) { t.scale[c] = x->scale[c]; t.offset[c] = x->offset[c]; }
+  t.shift = x->shift;
+  t.mask = x->mask;
+  return t;
+}
+template <typename T> static T* need(T* p, const char* what) {
+  if (!p) throw Panic(ERR_INVALID_ARGUMENT, std::string("null ") + what);
+  return p;
+}
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_last_error.c_str(); }
+
+int orc_layout_create(orc_layout** out) { ORC_TRY *need(out, "out") = new orc_layout(); ORC_CATCH }
+int orc_layout_destroy(orc_layout* l) { delete l; return OK; }
+int orc_layout_clone(const orc_layout* l, orc_layout** out) { ORC_TRY *need(out, "out") = new orc_layout{need(l, "layout")->l}; ORC_CATCH }
+int orc_layout_add_attribute(orc_layout* l, const char* name, const orc_datatype* dt, uint32_t packed, uint64_t max_alignment) {
+  ORC_TRY
+  need(l, "layout")->l.add_attribute(AttributeDef{need(name, "name"), to_dt(dt)},
+                                     packed ? FieldAlignment::Packed(max_alignment) : FieldAlignment::Default());
+  ORC_CATCH
+}
+int orc_layout_from_members(const orc_member* members, size_t n, uint64_t type_alignment, orc_layout** out) {
+  ORC_TRY
+  std::vector<AttributeMember> ms;
+  for (size_t i = 0; i < n; ++i) {
+    DataType t = to_dt(&members[i].datatype);
+    ms.push_back(AttributeMember{AttributeDef{need(members[i].name, "name"), t}, members[i].offset, t.size()});
+  }
+  *need(out, "out") = new orc_layout{PointLayout::from_members_and_alignment(ms, type_alignment)};
+  ORC_CATCH
+}
+int orc_layout_num_attributes(const orc_layout* l, size_t* out) { ORC_TRY *need(out, "out") = need(l, "layout")->l.attributes.size(); ORC_CATCH }
+int orc_layout_get_member(const orc_layout* l, size_t index, orc_member* out) {
+  ORC_TRY
+  const auto& a = need(l, "layout")->l.attributes;
+  if (index >= a.size()) throw Panic(ERR_RANGE, "index out of bounds");
+  need(out, "out")->name = a[index].def.name.c_str();
+  out->datatype = from_dt(a[index].def.datatype);
+  out->offset = a[index].offset;
+  out->size = a[index].size;
+  ORC_CATCH
+}
+int orc_layout_size_of_point_entry(const orc_layout* l, uint64_t* out) { ORC_TRY *need(out, "out") = need(l, "layout")->l.size_of_point_entry(); ORC_CATCH }
+int orc_layout_alignment(const orc_layout* l, uint64_t* out) { ORC_TRY *need(out, "out") = need(l, "layout")->l.mem_align; ORC_CATCH }
+int orc_layout_equals(const orc_layout* a, const orc_layout* b, int* out) { ORC_TRY *need(out, "out") = need(a, "a")->l == need(b, "b")->l; ORC_CATCH }
+
+int orc_buffer_create(const orc_layout* l, uint32_t storage, uint32_t, orc_buffer** out) {
+  ORC_TRY
+  auto* b = new orc_buffer();
+  if (storage == 0) b->b = std::make_unique<VectorBuffer>(need(l, "layout")->l);
+  else if (storage == 1) b->b = std::make_unique<HashMapBuffer>(need(l, "layout")->l);
+  else { delete b; throw Panic(ERR_INVALID_ARGUMENT, "invalid storage kind"); }
+  *need(out, "out") = b;
+  ORC_CATCH
+}
+int orc_buffer_destroy(orc_buffer* b) { delete b; return OK; }
+int orc_buffer_len(const orc_buffer* b, size_t* out) { ORC_TRY *need(out, "out") = need(b, "buffer")->b->len(); ORC_CATCH }
+int orc_buffer_resize(orc_buffer* b, size_t count) { ORC_TRY need(b, "buffer")->b->resize(count); ORC_CATCH }
+int orc_buffer_is_columnar(const orc_buffer* b, int* out) { ORC_TRY *need(out, "out") = need(b, "buffer")->b->as_columnar() != nullptr; ORC_CATCH }
+int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone) { ORC_TRY *need(out_clone, "out") = new orc_layout{need(b, "buffer")->b->point_layout()}; ORC_CATCH }
+
+// set_point_range / get_point_range — point_buffer.rs:792-795 (AoS memcpy), :1294-1315 / :1194-1211 (SoA per attribute x per point)
+int orc_buffer_write_points(orc_buffer* b, size_t first, size_t count, const void* src) {
+  ORC_TRY
+  Buffer& buf = *need(b, "buffer")->b;
+  if (first + count > buf.len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  const size_t stride = buf.point_layout().size_of_point_entry();
+  if (auto* ib = buf.as_interleaved()) {
+    std::memcpy(ib->get_point_range_mut({first, first + count}), src, count * stride);
+  } else {
+    for (auto& a : buf.point_layout().attributes)
+      for (size_t i = 0; i < count; ++i) buf.set_attribute(a.def, first + i, (const uint8_t*)src + i * stride + a.offset);
+  }
+  ORC_CATCH
+}
+int orc_buffer_read_points(const orc_buffer* b, size_t first, size_t count, void* dst) {
+  ORC_TRY
+  const Buffer& buf = *need(b, "buffer")->b;
+  if (first + count > buf.len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  const size_t stride = buf.point_layout().size_of_point_entry();
+  if (auto* ib = buf.as_interleaved()) {  // VectorBuffer::get_point_range: one memcpy of the raw records (:722-729)
+    std::memcpy(dst, ib->get_point_range_ref({first, first + count}), count * stride);
+    return OK;
+  }
+  for (auto& a : buf.point_layout().attributes)  // HashMapBuffer::get_point_range :1194-1211
+    for (size_t i = 0; i < count; ++i) buf.get_attribute_unchecked(a, first + i, (uint8_t*)dst + i * stride + a.offset);
+  ORC_CATCH
+}
+// set_attribute_range / get_attribute_range — point_buffer.rs:797-820, :1340-1347, :71-93
+int orc_buffer_write_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, const void* src) {
+  ORC_TRY
+  Buffer& buf = *need(b, "buffer")->b;
+  AttributeDef def{need(name, "name"), to_dt(dt)};
+  if (!buf.point_layout().get_attribute(def)) throw Panic(ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of this buffer");
+  if (first + count > buf.len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  const size_t s = def.size();
+  for (size_t i = 0; i < count; ++i) buf.set_attribute(def, first + i, (const uint8_t*)src + i * s);
+  ORC_CATCH
+}
+int orc_buffer_read_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, void* dst) {
+  ORC_TRY
+  const Buffer& buf = *need(b, "buffer")->b;
+  AttributeDef def{need(name, "name"), to_dt(dt)};
+  const AttributeMember* m = buf.point_layout().get_attribute(def);
+  if (!m) throw Panic(ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of this buffer");
+  if (first + count > buf.len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  const size_t s = def.size();
+  for (size_t i = 0; i < count; ++i) buf.get_attribute_unchecked(*m, first + i, (uint8_t*)dst + i * s);
+  ORC_CATCH
+}
+
+// Deterministic synthetic fill (DESIGN.md "Synthetic inputs").  Must match
+// pasture_amd/csrc/synth.hip bit for bit.
+static inline uint64_t synth_extra(uint64_t seed, uint64_t g, uint64_t slot, uint64_t c) {
+  return splitmix64((seed ^ 0xD1B54A32D192ED03ull) ^ (g * 1024 + (slot % 32) * 32 + (c % 32)));
+}
+static void synth_value(const AttributeMember& a, size_t slot, uint64_t seed, uint64_t g, uint8_t* out) {
+  const Kind k = a.def.datatype.kind;
+  const std::string& nm = a.def.name;
+  auto unit = [](uint64_t u) { return (double)(u >> 11) * (1.0 / 9007199254740992.0); };
+  if (nm == "Position3D" && (k == Vec3f64 || k == Vec3f32)) {
+    double p[3];
+    synth_position(seed, g, p);
+    if (k == Vec3f64) std::memcpy(out, p, 24);
+    else { float f[3] = {(float)p[0], (float)p[1], (float)p[2]}; std::memcpy(out, f, 12); }
+    return;
+  }
+  if (nm == "LASLocalPosition" && k == Vec3i32) {
+    int32_t v[3];
+    for (int c = 0; c < 3; ++c) v[c] = (int32_t)(splitmix64(seed ^ (3 * g + c)) % 2000000ull);
+    std::memcpy(out, v, 12);
+    return;
+  }
+  uint64_t mask = ~0ull;
+  if (k == U8 && (nm == "ReturnNumber" || nm == "NumberOfReturns")) mask = 7;
+  if (k == U8 && (nm == "ScanDirectionFlag" || nm == "EdgeOfFlightLine")) mask = 1;
+  auto put_int = [&](uint8_t* dst, int c, size_t bytes) {
+    uint64_t e = synth_extra(seed, g, slot, c) & mask;
+    std::memcpy(dst, &e, bytes);  // little endian truncation
+  };
+  switch (k) {
+    case U8: case I8: put_int(out, 0, 1); break;
+    case U16: case I16: put_int(out, 0, 2); break;
+    case U32: case I32: put_int(out, 0, 4); break;
+    case U64: case I64: put_int(out, 0, 8); break;
+    case F32: { float f = (float)(unit(synth_extra(seed, g, slot, 0)) * 1000.0); std::memcpy(out, &f, 4); break; }
+    case F64: { double d = unit(synth_extra(seed, g, slot, 0)) * 1000.0; std::memcpy(out, &d, 8); break; }
+    case Vec3u8: for (int c = 0; c < 3; ++c) put_int(out + c, c, 1); break;
+    case Vec3u16: for (int c = 0; c < 3; ++c) put_int(out + 2 * c, c, 2); break;
+    case Vec3i32: for (int c = 0; c < 3; ++c) put_int(out + 4 * c, c, 4); break;
+    case Vec3f32: for (int c = 0; c < 3; ++c) { float f = (float)(unit(synth_extra(seed, g, slot, c)) * 1000.0); std::memcpy(out + 4 * c, &f, 4); } break;
+    case Vec3f64: for (int c = 0; c < 3; ++c) { double d = unit(synth_extra(seed, g, slot, c)) * 1000.0; std::memcpy(out + 8 * c, &d, 8); } break;
+    default:  // Vec4u8, ByteArray, Custom: raw bytes
+      for (uint64_t j = 0; j < a.size; ++j) out[j] = (uint8_t)(synth_extra(seed, g, slot, j / 8) >> (8 * (j % 8)));
+  }
+}
+int orc_buffer_synth_fill(orc_buffer* b, uint64_t seed, uint64_t first_index) {
+  ORC_TRY
+  Buffer& buf = *need(b, "buffer")->b;
+  const auto& attrs = buf.point_layout().attributes;
+  std::vector<uint8_t> tmp;
+  for (size_t slot = 0; slot < attrs.size(); ++slot) {
+    tmp.resize(attrs[slot].size);
+    for (size_t i = 0; i < buf.len(); ++i) {
+      synth_value(attrs[slot], slot, seed, first_index + i, tmp.data());
+      buf.set_attribute(attrs[slot].def, i, tmp.data());
+    }
+  }
+  ORC_CATCH
+}
+
+int orc_converter_create(const orc_layout* from, const orc_layout* to, int with_default, orc_converter** out) {
+  ORC_TRY
+  auto c = with_default ? BufferLayoutConverter::for_layouts_with_default(need(from, "from")->l, need(to, "to")->l)
+                        : BufferLayoutConverter::for_layouts(need(from, "from")->l, need(to, "to")->l);
+  *need(out, "out") = new orc_converter{std::move(c), {}};
+  ORC_CATCH
+}
+int orc_converter_destroy(orc_converter* c) { delete c; return OK; }
+int orc_converter_set_custom_mapping(orc_converter* c, const char* from_name, const orc_datatype* from_dt, const char* to_name,
+                                     const orc_datatype* to_dt_) {
+  ORC_TRY
+  need(c, "converter")->c.set_custom_mapping(AttributeDef{need(from_name, "name"), to_dt(from_dt)}, AttributeDef{need(to_name, "name"), to_dt(to_dt_)});
+  ORC_CATCH
+}
+int orc_converter_set_custom_mapping_with_transformation(orc_converter* c, const char* from_name, const orc_datatype* from_dt,
+                                                         const char* to_name, const orc_datatype* to_dt_, const orc_transform* xf,
+                                                         int apply_to_source) {
+  ORC_TRY
+  need(c, "converter")->c.set_custom_mapping_with_transformation(AttributeDef{need(from_name, "name"), to_dt(from_dt)},
+                                                                 AttributeDef{need(to_name, "name"), to_dt(to_dt_)}, to_xf(xf),
+                                                                 apply_to_source != 0);
+  ORC_CATCH
+}
+int orc_converter_num_mappings(const orc_converter* c, size_t* out) { ORC_TRY *need(out, "out") = need(c, "converter")->c.mappings.size(); ORC_CATCH }
+int orc_converter_get_mapping(const orc_converter* c, size_t index, orc_mapping_info* out) {
+  ORC_TRY
+  const auto& ms = need(c, "converter")->c.mappings;
+  if (index >= ms.size()) throw Panic(ERR_RANGE, "index out of bounds");
+  const auto& m = ms[index];
+  need(out, "out")->source_name = m.source_attribute.def.name.c_str();
+  out->target_name = m.target_attribute.def.name.c_str();
+  out->source_datatype = from_dt(m.source_attribute.def.datatype);
+  out->target_datatype = from_dt(m.target_attribute.def.datatype);
+  out->source_offset = m.source_attribute.offset;
+  out->target_offset = m.target_attribute.offset;
+  out->has_converter = m.converter != nullptr;
+  out->transform_kind = m.transformation ? 1u : 0u;  // the oracle only knows "has a closure"
+  out->apply_to_source = m.transformation ? (int)m.transformation->apply_to_source_attribute : 0;
+  out->reserved = 0;
+  ORC_CATCH
+}
+int orc_converter_convert_into_range(const orc_converter* c, orc_buffer* src, size_t s0, size_t s1, orc_buffer* dst, size_t t0, size_t t1) {
+  ORC_TRY
+  need(c, "converter")->c.convert_into_range(*need(src, "src")->b, Range{s0, s1}, *need(dst, "dst")->b, Range{t0, t1});
+  ORC_CATCH
+}
+int orc_converter_convert(const orc_converter* c, orc_buffer* src, uint32_t out_storage, orc_buffer** out) {
+  ORC_TRY
+  auto* r = new orc_buffer();
+  try {
+    if (out_storage == 0) r->b = need(c, "converter")->c.convert<VectorBuffer>(*need(src, "src")->b);
+    else r->b = need(c, "converter")->c.convert<HashMapBuffer>(*need(src, "src")->b);
+  } catch (...) { delete r; throw; }
+  *need(out, "out") = r;
+  ORC_CATCH
+}
+
+int orc_calculate_bounds(const orc_buffer* b, double out_min[3], double out_max[3], int* has_value) {
+  ORC_TRY
+  auto r = calculate_bounds(*need(b, "buffer")->b);
+  *need(has_value, "has_value") = r.has_value();
+  if (r) for (int c = 0; c < 3; ++c) { out_min[c] = r->min[c]; out_max[c] = r->max[c]; }
+  ORC_CATCH
+}
+int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, void* out_min, void* out_max, int* has_value) {
+  ORC_TRY
+  *need(has_value, "has_value") = minmax_attribute(*need(b, "buffer")->b, AttributeDef{need(name, "name"), to_dt(dt)}, (uint8_t*)out_min, (uint8_t*)out_max);
+  ORC_CATCH
+}
+int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf) {
+  ORC_TRY
+  transform_attribute(*need(b, "buffer")->b, AttributeDef{need(name, "name"), to_dt(dt)}, to_xf(xf));
+  ORC_CATCH
+}
+int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn) {
+  ORC_TRY
+  compute_normals(*need(b, "buffer")->b, k, out_normals, out_curvature, out_knn);
+  ORC_CATCH
+}
+
+int orc_as_convert(uint32_t from_kind, uint32_t to_kind, const void* in, void* out) {
+  ORC_TRY
+  if (from_kind > Custom || to_kind > Custom) throw Panic(ERR_INVALID_ARGUMENT, "invalid kind");
+  get_generic_converter(DataType::of((Kind)from_kind), DataType::of((Kind)to_kind))((const uint8_t*)in, (uint8_t*)out);
+  ORC_CATCH
+}
+int orc_covariance(const double* points_xyz, size_t n, double out_centroid[3], double out_cov_rowmajor[9], int* ok) {
+  ORC_TRY
+  auto pts = reinterpret_cast<const double (*)[3]>(points_xyz);
+  compute_centroid(pts, n, out_centroid);
+  Mat3 c;
+  *need(ok, "ok") = compute_covariance_matrix(pts, n, c);
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) out_cov_rowmajor[3 * r + k] = c.m[r][k];
+  ORC_CATCH
+}
+int orc_plane_parameter(const double cov_rowmajor[9], double out_normal[3], double* out_curvature) {
+  ORC_TRY
+  Mat3 c;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) c.m[r][k] = cov_rowmajor[3 * r + k];
+  solve_plane_parameter(c, out_normal, *out_curvature);
+  ORC_CATCH
+}
+uint64_t orc_align_to(uint64_t v, uint64_t alignment) { return align_to(v, alignment); }
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int orc_bench_config1(size_t n, int reps, uint64_t seed, double* out_seconds, double out_bounds[6]) {
+  ORC_TRY
+  PointLayout layout = PointLayout::from_attributes({POSITION_3D});
+  VectorBuffer src(layout);
+  src.resize(n);
+  for (size_t i = 0; i < n; ++i) synth_position(seed, i, reinterpret_cast<double*>(src.storage.data() + i * 24));
+  BufferLayoutConverter conv = BufferLayoutConverter::for_layouts(layout, layout);
+  for (int r = 0; r < reps; ++r) {
+    double t0 = now_s();
+    std::unique_ptr<HashMapBuffer> dst = conv.convert<HashMapBuffer>(src);
+    auto bounds = calculate_bounds(*dst);
+    double t1 = now_s();
+    out_seconds[r] = t1 - t0;
+    if (bounds) for (int c = 0; c < 3; ++c) { out_bounds[c] = bounds->min[c]; out_bounds[3 + c] = bounds->max[c]; }
+  }
+  ORC_CATCH
+}
+
+int orc_bench_config2(size_t n, int reps, uint64_t seed, const double scale[3], const double offset[3], double* out_seconds,
+                      double out_bounds[6]) {
+  ORC_TRY
+  PointLayout layout = PointLayout::from_attributes({POSITION_3D});
+  HashMapBuffer src(layout);
+  src.resize(n);
+  {
+    uint8_t* col = src.get_attribute_range_mut(POSITION_3D, {0, n});
+    for (size_t i = 0; i < n; ++i) synth_position(seed, i, reinterpret_cast<double*>(col + i * 24));
+  }
+  BufferLayoutConverter conv = BufferLayoutConverter::for_layouts(layout, layout);
+  TransformDesc xf;
+  xf.kind = XF_AFFINE;
+  xf.datatype = DataType::of(Vec3f64);
+  for (int c = 0; c < 3; ++c) { xf.scale[c] = scale[c]; xf.offset[c] = offset[c]; }
+  conv.set_custom_mapping_with_transformation(POSITION_3D, POSITION_3D, xf, false);
+  for (int r = 0; r < reps; ++r) {
+    double t0 = now_s();
+    std::unique_ptr<HashMapBuffer> dst = conv.convert<HashMapBuffer>(src);
+    auto bounds = calculate_bounds(*dst);
+    double t1 = now_s();
+    out_seconds[r] = t1 - t0;
+    if (bounds) for (int c = 0; c < 3; ++c) { out_bounds[c] = bounds->min[c]; out_bounds[3 + c] = bounds->max[c]; }
+  }
+  ORC_CATCH
+}
+
+}  // extern "C"

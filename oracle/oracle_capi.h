@@ -1,0 +1,118 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see pasture_oracle.hpp header).
+ *
+ * C API over the CPU restatement.  It deliberately has the SAME shape as the product's C ABI
+ * (include/pasture_amd.h) with the prefix `orc_` instead of `pst_`, so that the parity tests can drive the
+ * oracle and the HIP path through one harness.  All memory is host memory.
+ */
+#ifndef PASTURE_ORACLE_CAPI_H
+#define PASTURE_ORACLE_CAPI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_layout orc_layout;
+typedef struct orc_buffer orc_buffer;
+typedef struct orc_converter orc_converter;
+
+typedef struct orc_datatype {
+  uint32_t kind; /* 0..17, declaration order of PointAttributeDataType (point_layout.rs:25-50) */
+  uint32_t reserved;
+  uint64_t size_param;  /* ByteArray length / Custom size */
+  uint64_t align_param; /* Custom min_alignment */
+  uint8_t uuid[16];     /* Custom name */
+} orc_datatype;
+
+typedef struct orc_member {
+  const char* name;
+  orc_datatype datatype;
+  uint64_t offset;
+  uint64_t size;
+} orc_member;
+
+typedef struct orc_transform {
+  uint32_t kind; /* 0 none, 1 affine, 2 bitfield */
+  uint32_t shift;
+  orc_datatype datatype; /* the closure's T */
+  double scale[3];
+  double offset[3];
+  uint64_t mask;
+} orc_transform;
+
+typedef struct orc_mapping_info {
+  const char* source_name;
+  const char* target_name;
+  orc_datatype source_datatype;
+  orc_datatype target_datatype;
+  uint64_t source_offset;
+  uint64_t target_offset;
+  int32_t has_converter;
+  uint32_t transform_kind;
+  int32_t apply_to_source;
+  int32_t reserved;
+} orc_mapping_info;
+
+const char* orc_last_error(void);
+
+int orc_layout_create(orc_layout** out);
+int orc_layout_destroy(orc_layout* l);
+int orc_layout_clone(const orc_layout* l, orc_layout** out);
+int orc_layout_add_attribute(orc_layout* l, const char* name, const orc_datatype* dt, uint32_t packed, uint64_t max_alignment);
+int orc_layout_from_members(const orc_member* members, size_t n, uint64_t type_alignment, orc_layout** out);
+int orc_layout_num_attributes(const orc_layout* l, size_t* out);
+int orc_layout_get_member(const orc_layout* l, size_t index, orc_member* out);
+int orc_layout_size_of_point_entry(const orc_layout* l, uint64_t* out);
+int orc_layout_alignment(const orc_layout* l, uint64_t* out);
+int orc_layout_equals(const orc_layout* a, const orc_layout* b, int* out);
+
+/* storage: 0 = interleaved (VectorBuffer), 1 = columnar (HashMapBuffer). memkind ignored (host). */
+int orc_buffer_create(const orc_layout* l, uint32_t storage, uint32_t memkind, orc_buffer** out);
+int orc_buffer_destroy(orc_buffer* b);
+int orc_buffer_len(const orc_buffer* b, size_t* out);
+int orc_buffer_resize(orc_buffer* b, size_t count);
+int orc_buffer_is_columnar(const orc_buffer* b, int* out);
+int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone);
+int orc_buffer_write_points(orc_buffer* b, size_t first, size_t count, const void* src);
+int orc_buffer_read_points(const orc_buffer* b, size_t first, size_t count, void* dst);
+int orc_buffer_write_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, const void* src);
+int orc_buffer_read_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, void* dst);
+int orc_buffer_synth_fill(orc_buffer* b, uint64_t seed, uint64_t first_index);
+
+int orc_converter_create(const orc_layout* from, const orc_layout* to, int with_default, orc_converter** out);
+int orc_converter_destroy(orc_converter* c);
+int orc_converter_set_custom_mapping(orc_converter* c, const char* from_name, const orc_datatype* from_dt, const char* to_name,
+                                     const orc_datatype* to_dt);
+int orc_converter_set_custom_mapping_with_transformation(orc_converter* c, const char* from_name, const orc_datatype* from_dt,
+                                                         const char* to_name, const orc_datatype* to_dt, const orc_transform* xf,
+                                                         int apply_to_source);
+int orc_converter_num_mappings(const orc_converter* c, size_t* out);
+int orc_converter_get_mapping(const orc_converter* c, size_t index, orc_mapping_info* out);
+int orc_converter_convert_into_range(const orc_converter* c, orc_buffer* src, size_t s0, size_t s1, orc_buffer* dst, size_t t0, size_t t1);
+int orc_converter_convert(const orc_converter* c, orc_buffer* src, uint32_t out_storage, orc_buffer** out);
+
+int orc_calculate_bounds(const orc_buffer* b, double out_min[3], double out_max[3], int* has_value);
+int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, void* out_min, void* out_max, int* has_value);
+int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf);
+int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);
+
+/* single value through the `as` table (attribute_conversion.rs:184-271); ERR_INVALID_CONVERSION if unlisted */
+int orc_as_convert(uint32_t from_kind, uint32_t to_kind, const void* in, void* out);
+/* helpers of normal_estimation.rs exposed for the known-answer tests (:503-550) */
+int orc_covariance(const double* points_xyz, size_t n, double out_centroid[3], double out_cov_rowmajor[9], int* ok);
+int orc_plane_parameter(const double cov_rowmajor[9], double out_normal[3], double* out_curvature);
+uint64_t orc_align_to(uint64_t v, uint64_t alignment);
+
+/* Timed CPU baseline, BASELINE.json configs[0]: n synthetic XYZ f64 points in a VectorBuffer [POSITION_3D] ->
+ * HashMapBuffer via BufferLayoutConverter::for_layouts + calculate_bounds, `reps` runs; writes per-run seconds. */
+int orc_bench_config1(size_t n, int reps, uint64_t seed, double* out_seconds, double out_bounds[6]);
+/* Timed CPU baseline for the bench.py N=1 workload: columnar POSITION_3D -> columnar POSITION_3D with an affine
+ * transformation + calculate_bounds on the result (configs[1] on the CPU path). */
+int orc_bench_config2(size_t n, int reps, uint64_t seed, const double scale[3], const double offset[3], double* out_seconds,
+                      double out_bounds[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

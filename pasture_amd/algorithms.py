@@ -1,0 +1,87 @@
+"""pasture-algorithms loops — Python mirror over the C ABI.
+
+  calculate_bounds   pasture-algorithms/src/bounds.rs:11-85
+  minmax_attribute   pasture-algorithms/src/minmax.rs:13-51
+  transform_attribute  pasture-core/src/containers/point_buffer.rs:391-404 (closed-set transformations)
+  compute_normals    pasture-algorithms/src/normal_estimation.rs:79-130
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .buffers import _Buffer
+from .conversion import Transform
+from .layout import PointAttributeDefinition
+
+
+@dataclass(frozen=True)
+class AABB:
+    """math::AABB<f64>, pasture-core/src/math/bounds.rs:9-26."""
+    _min: Tuple[float, float, float]
+    _max: Tuple[float, float, float]
+
+    def min(self):
+        return self._min
+
+    def max(self):
+        return self._max
+
+    def extent(self):
+        return tuple(b - a for a, b in zip(self._min, self._max))
+
+    @staticmethod
+    def union(a: "AABB", b: "AABB") -> "AABB":  # bounds.rs:109-122
+        return AABB(tuple(x if x < y else y for x, y in zip(a._min, b._min)), tuple(x if x > y else y for x, y in zip(a._max, b._max)))
+
+
+def calculate_bounds(buffer: _Buffer) -> Optional[AABB]:
+    mn, mx, has = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int()
+    buffer.api.calculate_bounds(buffer._h, mn, mx, C.byref(has))
+    return AABB(tuple(mn), tuple(mx)) if has.value else None
+
+
+def calculate_bounds_async(buffer: _Buffer, device_out6_ptr: int) -> None:
+    """Stream-ordered: writes {min xyz, max xyz} (seeds +/-f64::MAX) to device memory, no host synchronisation."""
+    buffer.api.calculate_bounds_async(buffer._h, C.c_void_p(device_out6_ptr))
+
+
+def minmax_attribute(buffer: _Buffer, attribute: PointAttributeDefinition):
+    """Returns (min, max) as numpy scalars / length-3 arrays of the attribute's datatype, or None for an empty buffer."""
+    dt = attribute.datatype()
+    nc = dt.num_components()
+    mn = np.zeros(nc, dtype=dt.numpy_dtype())
+    mx = np.zeros(nc, dtype=dt.numpy_dtype())
+    has = C.c_int()
+    cdt = dt.to_c()
+    buffer.api.minmax_attribute(buffer._h, attribute.name().encode(), C.byref(cdt), mn.ctypes.data_as(C.c_void_p),
+                                mx.ctypes.data_as(C.c_void_p), C.byref(has))
+    if not has.value:
+        return None
+    return (mn[0], mx[0]) if nc == 1 else (mn, mx)
+
+
+def transform_attribute(buffer: _Buffer, attribute: PointAttributeDefinition, transform: Transform) -> None:
+    cdt = attribute.datatype().to_c()
+    x = transform.to_c()
+    buffer.api.transform_attribute(buffer._h, attribute.name().encode(), C.byref(cdt), C.byref(x))
+
+
+def compute_normals(point_cloud: _Buffer, k_nn: int, return_knn: bool = False):
+    """Vec<(Vector3<f64>, f64)> as (normals (n,3) f64, curvature (n,) f64[, knn indices (n,k) int64])."""
+    n = point_cloud.len()
+    normals = np.zeros((n, 3), dtype=np.float64)
+    curv = np.zeros(n, dtype=np.float64)
+    knn = np.full((n, max(k_nn, 1)), -1, dtype=np.int64) if return_knn else None
+    point_cloud.api.compute_normals(point_cloud._h, k_nn, normals.ctypes.data_as(C.POINTER(C.c_double)),
+                                    curv.ctypes.data_as(C.POINTER(C.c_double)),
+                                    knn.ctypes.data_as(C.POINTER(C.c_int64)) if knn is not None else None)
+    return (normals, curv, knn) if return_knn else (normals, curv)
+
+
+def compute_normals_into(point_cloud: _Buffer, k_nn: int, target: _Buffer) -> None:
+    """Device-resident: writes NORMAL (Vec3f32) and "Curvature" (F64) attributes of `target`."""
+    point_cloud.api.compute_normals_into(point_cloud._h, k_nn, target._h)

@@ -1,0 +1,160 @@
+"""BufferLayoutConverter — Python mirror of pasture-core/src/layout/conversion/buffer_conversion.rs:98-663.
+
+The reference accepts arbitrary `Fn(T) -> T` closures for `set_custom_mapping_with_transformation`; a device path
+can only evaluate a CLOSED set, described by `Transform` objects (AFFINE, BITFIELD — every closure the reference's
+own callers use: pasture-io/src/las/raw_readers.rs:42-164, buffer_conversion.rs:780-782).  Anything else must stay
+on the CPU path of the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Type
+
+from . import _capi
+from ._capi import MappingInfoStruct, TransformStruct
+from .buffers import _Buffer, HashMapBuffer, VectorBuffer
+from .layout import PointAttributeDataType, PointAttributeDefinition, PointLayout
+
+XF_NONE, XF_AFFINE, XF_BITFIELD = 0, 1, 2
+
+
+@dataclass(frozen=True)
+class Transform:
+    """Closed-set stand-in for the reference's `transform_fn: Fn(T) -> T`; `datatype` is the closure's `T`."""
+    kind: int
+    datatype: PointAttributeDataType
+    scale: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    offset: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    shift: int = 0
+    mask: int = 0xFFFFFFFFFFFFFFFF
+
+    @staticmethod
+    def affine(datatype: PointAttributeDataType, scale: Sequence[float], offset: Sequence[float]) -> "Transform":
+        """|p| (p * scale) + offset per component, two roundings (raw_readers.rs:42-48); f32 types compute in f64 (:49-55)."""
+        s = tuple(float(x) for x in scale)
+        o = tuple(float(x) for x in offset)
+        if len(s) == 1:
+            s, o = s * 3, o * 3
+        return Transform(XF_AFFINE, datatype, s, o)
+
+    @staticmethod
+    def add_scalar(datatype: PointAttributeDataType, value: float) -> "Transform":
+        """|p| p.add_scalar(value) (buffer_conversion.rs:780-782): p*1.0 is exact, so this is affine with scale 1."""
+        return Transform.affine(datatype, (1.0, 1.0, 1.0), (value, value, value))
+
+    @staticmethod
+    def bitfield(datatype: PointAttributeDataType, shift: int, mask: int) -> "Transform":
+        """|v| (v >> shift) & mask on unsigned integers (raw_readers.rs:61-164)."""
+        return Transform(XF_BITFIELD, datatype, shift=shift, mask=mask)
+
+    def to_c(self) -> TransformStruct:
+        t = TransformStruct()
+        t.kind = self.kind
+        t.shift = self.shift
+        t.datatype = self.datatype.to_c()
+        t.scale[:] = list(self.scale)
+        t.offset[:] = list(self.offset)
+        t.mask = self.mask
+        return t
+
+
+@dataclass(frozen=True)
+class MappingInfo:
+    source: PointAttributeDefinition
+    target: PointAttributeDefinition
+    source_offset: int
+    target_offset: int
+    has_converter: bool
+    transform_kind: int
+    apply_to_source: bool
+
+
+class BufferLayoutConverter:
+    def __init__(self, from_layout: PointLayout, to_layout: PointLayout, with_default: bool):
+        assert from_layout.api is to_layout.api
+        self.api = from_layout.api
+        self.from_layout = from_layout
+        self.to_layout = to_layout
+        h = C.c_void_p()
+        self.api.converter_create(from_layout._h, to_layout._h, 1 if with_default else 0, C.byref(h))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.api.converter_destroy(self._h)
+        except Exception:
+            pass
+
+    @classmethod
+    def for_layouts(cls, from_layout: PointLayout, to_layout: PointLayout) -> "BufferLayoutConverter":  # :112-123
+        return cls(from_layout, to_layout, False)
+
+    @classmethod
+    def for_layouts_with_default(cls, from_layout: PointLayout, to_layout: PointLayout) -> "BufferLayoutConverter":  # :126-143
+        return cls(from_layout, to_layout, True)
+
+    def set_custom_mapping(self, from_attribute: PointAttributeDefinition, to_attribute: PointAttributeDefinition) -> None:  # :156-183
+        f, t = from_attribute.datatype().to_c(), to_attribute.datatype().to_c()
+        self.api.converter_set_custom_mapping(self._h, from_attribute.name().encode(), C.byref(f), to_attribute.name().encode(), C.byref(t))
+
+    def set_custom_mapping_with_transformation(self, from_attribute: PointAttributeDefinition, to_attribute: PointAttributeDefinition,
+                                               transform_fn: Transform, apply_to_source_attribute: bool) -> None:  # :194-234
+        if not isinstance(transform_fn, Transform):
+            raise _capi.PastureError(_capi.ERR_UNSUPPORTED_TRANSFORM,
+                                     "arbitrary closures cannot run on the device; describe the transformation with pasture_amd.Transform")
+        f, t = from_attribute.datatype().to_c(), to_attribute.datatype().to_c()
+        x = transform_fn.to_c()
+        self.api.converter_set_custom_mapping_with_transformation(self._h, from_attribute.name().encode(), C.byref(f),
+                                                                  to_attribute.name().encode(), C.byref(t), C.byref(x),
+                                                                  1 if apply_to_source_attribute else 0)
+
+    def mappings(self) -> List[MappingInfo]:
+        n = C.c_size_t()
+        self.api.converter_num_mappings(self._h, C.byref(n))
+        out = []
+        for i in range(n.value):
+            m = MappingInfoStruct()
+            self.api.converter_get_mapping(self._h, i, C.byref(m))
+            out.append(MappingInfo(PointAttributeDefinition(m.source_name.decode(), PointAttributeDataType.from_c(m.source_datatype)),
+                                   PointAttributeDefinition(m.target_name.decode(), PointAttributeDataType.from_c(m.target_datatype)),
+                                   m.source_offset, m.target_offset, bool(m.has_converter), m.transform_kind, bool(m.apply_to_source)))
+        return out
+
+    def convert(self, source_buffer: _Buffer, out_buffer_type: Type[_Buffer] = HashMapBuffer) -> _Buffer:  # :242-259
+        h = C.c_void_p()
+        self.api.converter_convert(self._h, source_buffer._h, out_buffer_type._storage, C.byref(h))
+        return out_buffer_type(h.value, self.api)
+
+    def convert_into(self, source_buffer: _Buffer, target_buffer: _Buffer) -> None:  # :268-283
+        n = source_buffer.len()
+        self.convert_into_range(source_buffer, range(0, n), target_buffer, range(0, n))
+
+    def convert_into_range(self, source_buffer: _Buffer, source_range: range, target_buffer: _Buffer, target_range: range) -> None:  # :292-359
+        self.api.converter_convert_into_range(self._h, source_buffer._h, source_range.start, source_range.stop, target_buffer._h,
+                                              target_range.start, target_range.stop)
+
+    # ---- device-only extras ---------------------------------------------------------------------------------
+    def convert_into_range_async(self, source_buffer, source_range, target_buffer, target_range) -> None:
+        self.api.converter_convert_into_range_async(self._h, source_buffer._h, source_range.start, source_range.stop, target_buffer._h,
+                                                    target_range.start, target_range.stop)
+
+    def convert_into_with_bounds(self, source_buffer, target_buffer, source_range: Optional[range] = None,
+                                 target_range: Optional[range] = None):
+        """convert_into_range + calculate_bounds(target range) in one pass over HBM.  Returns AABB or None."""
+        from .algorithms import AABB
+        n = source_buffer.len()
+        sr = source_range or range(0, n)
+        tr = target_range or range(0, n)
+        mn, mx, has = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int()
+        self.api.converter_convert_into_range_with_bounds(self._h, source_buffer._h, sr.start, sr.stop, target_buffer._h, tr.start, tr.stop,
+                                                          mn, mx, C.byref(has))
+        return AABB(tuple(mn), tuple(mx)) if has.value else None
+
+    def convert_into_with_bounds_async(self, source_buffer, target_buffer, device_out6_ptr: int, source_range=None, target_range=None) -> None:
+        n = source_buffer.len()
+        sr = source_range or range(0, n)
+        tr = target_range or range(0, n)
+        self.api.converter_convert_into_range_with_bounds_async(self._h, source_buffer._h, sr.start, sr.stop, target_buffer._h, tr.start,
+                                                                tr.stop, C.c_void_p(device_out6_ptr))

@@ -1,0 +1,344 @@
+// BufferLayoutConverter on the device: mapping construction (host), plan flattening, kernel selection.
+// Reference: pasture-core/src/layout/conversion/buffer_conversion.rs:98-663 and attribute_conversion.rs:184-271.
+#include <optional>
+
+#include "runtime.hpp"
+
+namespace pst {
+
+// The `as` table of attribute_conversion.rs:188-264: every ordered pair of distinct scalar primitives, and every
+// ordered pair of distinct Vec3 datatypes (Vec3 exists for u8,u16,i32,f32,f64 only).  Everything else — Vec4u8,
+// ByteArray, Custom, scalar<->Vec3 — panics with "Invalid conversion X -> Y" (:267-269).
+static bool convertible(const DataType& from, const DataType& to) {
+  if (from.is_scalar() && to.is_scalar()) return from.kind != to.kind;
+  if (from.is_vec3() && to.is_vec3()) return from.kind != to.kind;
+  return false;
+}
+static void require_convertible(const DataType& from, const DataType& to) {
+  if (!convertible(from, to)) throw Error(PST_ERR_INVALID_CONVERSION, "Invalid conversion " + from.display() + " -> " + to.display());
+}
+
+struct XfDesc {
+  uint32_t kind = PST_XF_NONE;
+  DataType datatype;
+  double scale[3] = {1, 1, 1};
+  double offset[3] = {0, 0, 0};
+  uint32_t shift = 0;
+  uint64_t mask = ~0ull;
+};
+
+// AttributeMapping, buffer_conversion.rs:41-55
+struct Mapping {
+  Member source, target;
+  bool has_converter = false;
+  std::optional<XfDesc> xf;
+  bool apply_to_source = false;
+};
+
+static Mapping make_default_mapping(const Member& from, const Member& to) {  // :368-396
+  Mapping m;
+  m.source = from;
+  m.target = to;
+  if (from.def.datatype != to.def.datatype) {
+    require_convertible(from.def.datatype, to.def.datatype);
+    m.has_converter = true;
+  }
+  return m;
+}
+
+// Which closures the kernels can evaluate (see pst_transform in include/pasture_amd.h)
+static void validate_transform(const XfDesc& x) {
+  const uint32_t k = x.datatype.kind;
+  if (x.kind == PST_XF_AFFINE) {
+    if (k == PST_F64 || k == PST_F32 || k == PST_VEC3F64 || k == PST_VEC3F32) return;
+  } else if (x.kind == PST_XF_BITFIELD) {
+    if ((k == PST_U8 || k == PST_U16 || k == PST_U32 || k == PST_U64) && x.shift < 64) return;
+  }
+  throw Error(PST_ERR_UNSUPPORTED_TRANSFORM,
+              "Unsupported transformation descriptor for datatype " + x.datatype.display() +
+                  ": only AFFINE on F32/F64/Vec3f32/Vec3f64 and BITFIELD on U8/U16/U32/U64 run on the device");
+}
+
+}  // namespace pst
+
+struct pst_converter {
+  pst::Layout from, to;
+  std::vector<pst::Mapping> mappings;
+};
+
+namespace pst {
+
+static PlanEntry entry_from_mapping(const Mapping& m) {
+  PlanEntry e = identity_entry(m.source, m.target);
+  e.dst_ct = (uint8_t)m.target.def.datatype.comp_type();
+  e.convert = m.has_converter ? 1u : 0u;
+  if (m.xf) {
+    e.xf_kind = (uint8_t)m.xf->kind;
+    e.xf_on_source = m.apply_to_source ? 1 : 0;
+    for (int c = 0; c < 3; ++c) { e.scale[c] = m.xf->scale[c]; e.offset[c] = m.xf->offset[c]; }
+    e.shift = m.xf->shift;
+    e.mask = m.xf->mask;
+  }
+  return e;
+}
+
+// LDS tile: as many records as fit in ~64 KiB (>= 2 resident blocks per CU), multiple of 64 points.
+static uint32_t pick_tile(bool src_aos, uint32_t src_stride, bool dst_aos, uint32_t dst_stride) {
+  const uint64_t per_point = (src_aos ? src_stride : 0) + (dst_aos ? dst_stride : 0);
+  if (per_point == 0) return 0;
+  const uint64_t budget = 64 * 1024 - 96;
+  uint64_t t = budget / per_point;
+  t = (t / 64) * 64;
+  if (t > 4096) t = 4096;
+  return (uint32_t)t;  // 0 => records too large for LDS staging
+}
+
+void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream) {
+  if (n == 0 || entries.empty()) return;
+  ensure_device();
+  const uint32_t tile = pick_tile(src_aos, src_stride, dst_aos, dst_stride);
+  const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 64;
+  for (size_t begin = 0; begin < entries.size(); begin += PST_PLAN_MAX_ENTRIES) {
+    const size_t cnt = std::min<size_t>(PST_PLAN_MAX_ENTRIES, entries.size() - begin);
+    ConvertPlan plan{};
+    plan.h.src_aos = src_base;
+    plan.h.dst_aos = dst_base;
+    plan.h.n = n;
+    plan.h.src_stride = src_stride;
+    plan.h.dst_stride = dst_stride;
+    plan.h.n_entries = (uint32_t)cnt;
+    plan.h.tile = tile;
+    std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
+    for (size_t i = 0; i < cnt; ++i) {
+      plan.e[i] = entries[begin + i];
+      if (dst_aos)
+        for (uint32_t b = 0; b < plan.e[i].dst_size; ++b) covered[plan.e[i].dst_off + b] = 1;
+    }
+    plan.h.dst_fully_covered = dst_aos && std::all_of(covered.begin(), covered.end(), [](uint8_t c) { return c != 0; });
+    if (!pstk::launch_convert(plan, src_aos, dst_aos, use_lds, stream))
+      throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+  }
+}
+
+// ---- convert_into_range, buffer_conversion.rs:292-359 -----------------------------------------------------
+// bounds_out6: when non-null, {min xyz, max xyz} of the TARGET's POSITION_3D over the target range is written there
+// (device-accessible memory), fused into the conversion pass when possible.
+static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1,
+                          double* bounds_out6, hipStream_t stream) {
+  if (src.layout != c.from) throw Error(PST_ERR_LAYOUT_MISMATCH, "assertion `left == right` failed: source_buffer.point_layout() != from_layout");
+  if (dst.layout != c.to) throw Error(PST_ERR_LAYOUT_MISMATCH, "assertion `left == right` failed: target_buffer.point_layout() != to_layout");
+  if (s1 < s0 || t1 < t0 || (s1 - s0) != (t1 - t0)) throw Error(PST_ERR_RANGE, "assertion failed: source_range.len() == target_range.len()");
+  if (s1 > src.len) throw Error(PST_ERR_RANGE, "assertion failed: source_range.end <= source_buffer.len()");
+  if (t1 > dst.len) throw Error(PST_ERR_RANGE, "assertion failed: target_range.end <= target_buffer.len()");
+  const uint64_t n = s1 - s0;
+  ensure_device();
+
+  // position attribute of the target for the fused / trailing bounds
+  int pos_slot = -1;
+  if (bounds_out6) {
+    const Member* pm = c.to.find_by_name("Position3D");
+    if (!pm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "target PointLayout has no Position3D attribute");
+    pos_slot = (int)(pm - c.to.members.data());
+  }
+  bool bounds_done = false;
+
+  std::vector<PlanEntry> generic;
+  if (!c.mappings.empty() && n > 0) {  // no mappings => silent no-op (:308-313)
+    for (const Mapping& m : c.mappings) {
+      PlanEntry e = entry_from_mapping(m);
+      const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
+      if (src.columnar) e.src_col = col_addr(src, (size_t)sslot, s0);
+      if (dst.columnar) e.dst_col = col_addr(dst, (size_t)tslot, t0);
+      if (src.columnar && dst.columnar) {
+        const bool same_type = !m.has_converter;
+        const bool vec3f64 = m.source.def.datatype.kind == PST_VEC3F64;
+        const bool want_bounds = bounds_out6 && tslot == pos_slot && vec3f64 && same_type;
+        const bool affine = m.xf && m.xf->kind == PST_XF_AFFINE;
+        const bool aligned = (e.src_col % 8 == 0) && (e.dst_col % 8 == 0) && (e.src_col % 16 == e.dst_col % 16);
+        if (same_type && vec3f64 && aligned && (affine || want_bounds)) {
+          // K2 fast path: one coalesced pass: copy (+ affine) (+ AABB)
+          Workspace& ws = workspace();
+          unsigned mode = 2u | (affine ? 1u : 0u) | (want_bounds ? 4u : 0u);
+          pstk::launch_vec3f64_stream((const double*)(uintptr_t)e.src_col, (double*)(uintptr_t)e.dst_col, n, e.scale, e.offset, mode,
+                                      (double*)ws.dev, bounds_out6, stream);
+          if (want_bounds) bounds_done = true;
+          continue;
+        }
+        if (same_type && !m.xf) {
+          // bulk column copy == set_attribute_range(copy_from_slice), buffer_conversion.rs:465-469
+          PST_HIP_CHECK(hipMemcpyAsync((void*)(uintptr_t)e.dst_col, (const void*)(uintptr_t)e.src_col, n * m.source.size,
+                                       hipMemcpyDeviceToDevice, stream));
+          continue;
+        }
+      }
+      generic.push_back(e);
+    }
+    if (!generic.empty())
+      execute_entries(!src.columnar, src.columnar ? 0 : aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar,
+                      dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, generic, true, stream);
+  }
+  PST_HIP_CHECK(hipGetLastError());
+  if (bounds_out6 && !bounds_done) {
+    bounds_of_range(dst, t0, n, bounds_out6, stream);
+  }
+}
+
+}  // namespace pst
+
+using namespace pst;
+
+static AttributeDef def_from(const char* name, const pst_datatype* dt) { return AttributeDef{not_null(name, "name"), DataType::from_c(dt)}; }
+
+static void install_mapping(pst_converter& c, Mapping&& m, const AttributeDef& to_attribute) {
+  for (auto& prev : c.mappings)
+    if (prev.target.def == to_attribute) { prev = std::move(m); return; }  // replace the mapping for this target (:168-176)
+  c.mappings.push_back(std::move(m));
+}
+
+extern "C" {
+
+int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_default, pst_converter** out) {
+  PST_API_BEGIN
+  auto c = std::make_unique<pst_converter>();
+  c->from = not_null(from, "from")->l;
+  c->to = not_null(to, "to")->l;
+  for (const Member& to_attr : c->to.members) {  // one default mapping per TARGET attribute, matched BY NAME (:112-143)
+    const Member* from_attr = c->from.find_by_name(to_attr.def.name);
+    if (!from_attr) {
+      if (with_default) continue;
+      throw Error(PST_ERR_MISSING_ATTRIBUTE,
+                  "Attribute not found in `from_layout`! When calling `BufferLayoutConverter::for_layouts`, the source PointLayout must "
+                  "contain all attributes from the target PointLayout. If you want to use default values for attributes that are not "
+                  "present in the source layout, use `BufferLayoutConverter::for_layouts_with_default` instead!");
+    }
+    c->mappings.push_back(make_default_mapping(*from_attr, to_attr));
+  }
+  *not_null(out, "out") = c.release();
+  PST_API_END
+}
+int pst_converter_destroy(pst_converter* c) { delete c; return PST_OK; }
+
+int pst_converter_set_custom_mapping(pst_converter* c, const char* from_name, const pst_datatype* from_dt, const char* to_name,
+                                     const pst_datatype* to_dt) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  const AttributeDef fa = def_from(from_name, from_dt), ta = def_from(to_name, to_dt);
+  const Member* fm = c->from.find(fa);
+  if (!fm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "from_attribute not found in source PointLayout");
+  const Member* tm = c->to.find(ta);
+  if (!tm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "to_attribute not found in target PointLayout");
+  install_mapping(*c, make_default_mapping(*fm, *tm), ta);
+  PST_API_END
+}
+int pst_converter_set_custom_mapping_with_transformation(pst_converter* c, const char* from_name, const pst_datatype* from_dt,
+                                                         const char* to_name, const pst_datatype* to_dt, const pst_transform* xf,
+                                                         int apply_to_source) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  not_null(xf, "transform");
+  const AttributeDef fa = def_from(from_name, from_dt), ta = def_from(to_name, to_dt);
+  const Member* fm = c->from.find(fa);
+  if (!fm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "from_attribute not found in source PointLayout");
+  const Member* tm = c->to.find(ta);
+  if (!tm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "to_attribute not found in target PointLayout");
+  XfDesc x;
+  x.kind = xf->kind;
+  x.datatype = DataType::from_c(&xf->datatype);
+  for (int i = 0; i < 3; ++i) { x.scale[i] = xf->scale[i]; x.offset[i] = xf->offset[i]; }
+  x.shift = xf->shift;
+  x.mask = xf->mask;
+  const DataType& expect = apply_to_source ? fm->def.datatype : tm->def.datatype;  // :209-213
+  if (x.datatype != expect)
+    throw Error(PST_ERR_TRANSFORM_TYPE_MISMATCH,
+                "assertion `left == right` failed: T::data_type() is " + x.datatype.display() + " but the attribute is " + expect.display());
+  Mapping m = make_default_mapping(*fm, *tm);
+  validate_transform(x);
+  m.xf = x;
+  m.apply_to_source = apply_to_source != 0;
+  install_mapping(*c, std::move(m), ta);
+  PST_API_END
+}
+int pst_converter_num_mappings(const pst_converter* c, size_t* out) { PST_API_BEGIN *not_null(out, "out") = not_null(c, "converter")->mappings.size(); PST_API_END }
+int pst_converter_get_mapping(const pst_converter* c, size_t index, pst_mapping_info* out) {
+  PST_API_BEGIN
+  const auto& ms = not_null(c, "converter")->mappings;
+  if (index >= ms.size()) throw Error(PST_ERR_RANGE, "index out of bounds");
+  const Mapping& m = ms[index];
+  not_null(out, "out")->source_name = m.source.def.name.c_str();
+  out->target_name = m.target.def.name.c_str();
+  out->source_datatype = m.source.def.datatype.to_c();
+  out->target_datatype = m.target.def.datatype.to_c();
+  out->source_offset = m.source.offset;
+  out->target_offset = m.target.offset;
+  out->has_converter = m.has_converter;
+  out->transform_kind = m.xf ? m.xf->kind : 0u;
+  out->apply_to_source = m.xf ? (int)m.apply_to_source : 0;
+  out->reserved = 0;
+  PST_API_END
+}
+
+int pst_converter_convert_into_range_async(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1) {
+  PST_API_BEGIN
+  convert_range(*not_null(c, "converter"), *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, nullptr, current_stream());
+  PST_API_END
+}
+int pst_converter_convert_into_range(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1) {
+  PST_API_BEGIN
+  convert_range(*not_null(c, "converter"), *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, nullptr, current_stream());
+  stream_sync(current_stream());
+  PST_API_END
+}
+
+// convert :242-259.  The reference zero-fills the whole target (`resize`) and then overwrites it; here only what no
+// mapping writes is zero-filled by resize — identical bytes, one write pass less... kept simple: resize zero-fills (async
+// memset on the same stream), the conversion overwrites.
+int pst_converter_convert(const pst_converter* c, pst_buffer* src, uint32_t out_storage, pst_buffer** out) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  not_null(src, "src");
+  pst_layout tl{c->to};
+  pst_buffer* target = nullptr;
+  int rc = pst_buffer_create(&tl, out_storage, PST_MEM_DEVICE, &target);
+  if (rc != PST_OK) return rc;
+  std::unique_ptr<pst_buffer> guard(target);
+  rc = pst_buffer_resize(target, src->len);
+  if (rc != PST_OK) return rc;
+  convert_range(*c, *src, 0, src->len, *target, 0, src->len, nullptr, current_stream());
+  stream_sync(current_stream());
+  *not_null(out, "out") = guard.release();
+  PST_API_END
+}
+
+int pst_converter_convert_into_range_with_bounds_async(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst,
+                                                       size_t t0, size_t t1, double* device_out6) {
+  PST_API_BEGIN
+  convert_range(*not_null(c, "converter"), *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, not_null(device_out6, "device_out6"),
+                current_stream());
+  PST_API_END
+}
+int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0,
+                                                 size_t t1, double out_min[3], double out_max[3], int* has_value) {
+  PST_API_BEGIN
+  not_null(dst, "dst");
+  not_null(has_value, "has_value");
+  Workspace& ws = workspace();
+  hipStream_t s = current_stream();
+  double* dev_rec = (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
+  double* host_rec = (double*)ws.pinned;
+  const bool has_pos = not_null(c, "converter")->to.find_by_name("Position3D") != nullptr;
+  convert_range(*c, *not_null(src, "src"), s0, s1, *dst, t0, t1, (has_pos && t1 > t0) ? dev_rec : nullptr, s);
+  // calculate_bounds(target): None for an empty range or a layout without Position3D (bounds.rs:12-21)
+  if (!has_pos || t1 <= t0) {
+    stream_sync(s);
+    *has_value = 0;
+    return PST_OK;
+  }
+  PST_HIP_CHECK(hipMemcpyAsync(host_rec, dev_rec, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  stream_sync(s);
+  check_bounds_record(host_rec, out_min, out_max);
+  *has_value = 1;
+  PST_API_END
+}
+
+}  // extern "C"

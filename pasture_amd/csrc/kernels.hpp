@@ -1,0 +1,40 @@
+// Host-callable launchers of the gfx950 kernels (implemented in *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.h"
+
+namespace pstk {
+
+// K2/K3/K3' generic conversion.  src_aos / dst_aos select the interleaved arms of buffer_conversion.rs:418-662.
+// use_lds: stage interleaved records through LDS tiles (plan.tile must be set); otherwise direct strided access.
+// Returns false when the launch (or the plan upload) failed; inspect hipGetLastError().
+bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream);
+int device_cus();
+
+// K1/K2 fast path: columnar Vec3f64 stream. mode bits: 1 = affine, 2 = write dst, 4 = bounds.
+// partials must hold stream_grid() * 6 doubles; out6 receives {min xyz, max xyz} when bounds are requested.
+int stream_grid();
+void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, const double scale[3], const double offset[3],
+                           unsigned mode, double* partials, double* out6, hipStream_t stream);
+
+// generic strided min/max over elements of `ncomp` components of component type `ct`.
+// acc_f64: accumulate in f64 after a Rust `as` cast (calculate_bounds_from_custom_positions) with +/-f64::MAX seeds;
+// otherwise accumulate in the component type with identity seeds.  out holds 2*ncomp accumulators {min.., max..}.
+int reduce_grid();
+void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials,
+                   void* out, hipStream_t stream);
+
+// deterministic synthetic fill of one attribute (see synth.hip)
+struct SynthAttr {
+  uint64_t base;    // address of the attribute of point 0
+  uint64_t stride;  // bytes between points
+  uint32_t size;    // attribute bytes
+  uint32_t slot;    // index of the attribute in the layout
+  uint32_t kind;    // PST_* datatype kind
+  uint32_t special; // 0 generic, 1 Position3D, 2 LASLocalPosition, 3 mask 7, 4 mask 1
+};
+void launch_synth(const SynthAttr& a, uint64_t n, uint64_t seed, uint64_t first_index, hipStream_t stream);
+
+}  // namespace pstk

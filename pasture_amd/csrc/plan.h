@@ -1,0 +1,64 @@
+// Kernel argument structures shared by the host runtime and the HIP kernels.
+// A ConvertPlan is the flattened form of the reference's Vec<AttributeMapping> (buffer_conversion.rs:41-55, 98-102)
+// for one convert_into_range call.
+#pragma once
+#include <stdint.h>
+
+#define PST_PLAN_MAX_ENTRIES 30
+
+struct PlanEntry {
+  uint64_t src_col;  // columnar source: device address of element 0 of the source RANGE; interleaved: unused
+  uint64_t dst_col;  // columnar target: device address of element 0 of the target RANGE
+  uint32_t src_off;  // interleaved source: attribute offset inside the point record
+  uint32_t dst_off;
+  uint32_t src_size;  // attribute size in bytes
+  uint32_t dst_size;
+  uint32_t ncomp;     // components per value: 1 scalar, 3 Vec3, size for opaque (byte-wise)
+  uint8_t src_ct;     // pst::CompType of one component
+  uint8_t dst_ct;
+  uint8_t xf_kind;    // PST_XF_*
+  uint8_t xf_on_source;
+  double scale[3];
+  double offset[3];
+  uint64_t mask;
+  uint32_t shift;
+  uint32_t convert;   // 1: datatypes differ => Rust `as` per component; 0: same type
+};
+
+// Header: passed BY VALUE (kernarg segment, statically indexed => plain s_load).  The entries live in a small device
+// buffer and are read through the constant address space (wave-uniform s_load, dynamic index).
+struct ConvertHeader {
+  uint64_t src_aos;  // interleaved source: device address of point s0
+  uint64_t dst_aos;  // interleaved target: device address of point t0
+  uint64_t n;        // points in the range
+  uint32_t src_stride;
+  uint32_t dst_stride;
+  uint32_t n_entries;
+  uint32_t tile;              // points per LDS tile (tile kernels)
+  uint32_t dst_fully_covered; // interleaved target: every byte of the record is written by some mapping
+  uint32_t reserved;
+};
+struct ConvertPlan {
+  ConvertHeader h;
+  PlanEntry e[PST_PLAN_MAX_ENTRIES];
+};
+
+// SoA Vec3f64 streaming kernel (copy / affine / bounds in one pass)
+struct StreamParams {
+  const double* src;   // first double of the source range (x of point s0)
+  double* dst;         // first double of the target range (may equal src for in-place)
+  uint64_t n_doubles;  // 3 * points
+  uint64_t vec_first;  // first double covered by the vector body (0 or 1)
+  uint64_t n_vec;      // number of W-wide vectors in the body
+  double scale[3];
+  double offset[3];
+  double* partials;    // [gridDim.x][6] = {min xyz, max xyz}
+};
+
+// generic strided min/max
+struct ReduceParams {
+  const uint8_t* base;  // address of component 0 of element 0
+  uint64_t stride;      // bytes between consecutive elements
+  uint64_t n;           // elements
+  void* partials;       // [gridDim.x][2*NCOMP] of ACC
+};

@@ -1,0 +1,62 @@
+// Internal host runtime declarations: device buffers, per-thread workspace, plan execution.
+#pragma once
+#include <vector>
+
+#include "core.hpp"
+#include "kernels.hpp"
+#include "plan.h"
+
+// Device-backed point buffer.  One struct serves the three reference buffer kinds:
+//   VectorBuffer          (point_buffer.rs:659-945)   columnar = false, owns = true
+//   HashMapBuffer         (point_buffer.rs:1031-1474) columnar = true,  owns = true   (one 256-B aligned column per attribute;
+//                          the per-point HashMap lookup of :1222-1235 becomes a pointer table indexed by layout slot)
+//   ExternalMemoryBuffer  (point_buffer.rs:1479-1708) owns = false (caller's device memory)
+struct pst_buffer {
+  pst::Layout layout;
+  bool columnar = false;
+  bool owns = true;
+  uint32_t memkind = PST_MEM_DEVICE;
+  size_t len = 0;       // points
+  size_t capacity = 0;  // points
+  uint8_t* data = nullptr;         // interleaved storage
+  std::vector<uint8_t*> columns;   // columnar storage, layout order
+  ~pst_buffer();
+};
+
+namespace pst {
+
+// per-thread scratch: device partials / result records + a pinned host mirror for small read-backs
+struct Workspace {
+  uint8_t* dev = nullptr;     // kWorkspaceBytes
+  uint8_t* pinned = nullptr;  // kPinnedBytes
+  static constexpr size_t kWorkspaceBytes = 1u << 20;
+  static constexpr size_t kPinnedBytes = 1u << 12;
+};
+Workspace& workspace();
+
+uint8_t* dev_alloc(size_t bytes, uint32_t memkind);
+void dev_free(uint8_t* p, uint32_t memkind);
+
+// address helpers
+inline uint64_t aos_addr(const pst_buffer& b, size_t point) { return (uint64_t)(uintptr_t)b.data + (uint64_t)point * b.layout.size; }
+inline uint64_t col_addr(const pst_buffer& b, size_t slot, size_t point) {
+  return (uint64_t)(uintptr_t)b.columns[slot] + (uint64_t)point * b.layout.members[slot].size;
+}
+
+// Plan execution: `entries` hold per-mapping descriptors with src_col/dst_col already resolved; the function splits them
+// into launches of <= PST_PLAN_MAX_ENTRIES, picks the LDS tile and the kernel body, and enqueues on `stream`.
+void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream);
+
+// identity (same datatype, no transformation) entry between two members
+PlanEntry identity_entry(const Member& src, const Member& dst);
+
+void stream_sync(hipStream_t s);
+
+// {min xyz, max xyz} of POSITION_3D over points [first, first+count) written to out6 (device-accessible); seeds
+// +/-f64::MAX (bounds.rs:31-32).  The buffer must have a Position3D attribute.
+void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* out6, hipStream_t stream);
+// AABB::from_min_max (math/bounds.rs:21-26): throws PST_ERR_BOUNDS_INVALID if min > max on any axis
+void check_bounds_record(const double r[6], double out_min[3], double out_max[3]);
+
+}  // namespace pst

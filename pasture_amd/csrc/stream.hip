@@ -1,0 +1,297 @@
+// K1 / K2 fast path — columnar Vec3f64 stream: copy | affine | AABB in ONE pass over HBM (gfx950).
+//
+// Replaces, for a columnar POSITION_3D (Vec3f64) attribute:
+//   * calculate_bounds_from_default_positions           pasture-algorithms/src/bounds.rs:30-54          (24 B/pt read)
+//   * convert_columnar_to_columnar same-type arm        buffer_conversion.rs:461-485 (memcpy + in-place
+//     transformation sweep = 2 passes in the reference)                                               (24 R + 24 W)
+//   * transform_attribute with the LAS affine closure   point_buffer.rs:391-404, raw_readers.rs:42-48   (24 R + 24 W)
+// and any combination of them (convert + transform + bounds of the result = 48 B/pt, the AABB rides for free).
+//
+// Memory mapping.  A Vec3f64 column is a flat f64 stream x0 y0 z0 x1 ...  Each lane moves 16-byte double2 vectors
+// (1 KiB per wave instruction, fully coalesced).  A block owns tiles of 6 x 256 vectors; lane t's j-th load of every
+// tile is vector  base + j*256 + t  with base = 0 (mod 3 vectors), so the xyz phase of (t, j) is LOOP-INVARIANT:
+// it is computed once, the per-phase scale/offset live in registers, and the running min/max are kept per
+// (j mod 3, half) — no per-element modulo, no divergence.  The phase is folded back to x/y/z once, after the loop.
+// Six independent 16-byte loads per lane are in flight before the first use.
+//
+// Reduction: wave64 shuffle -> LDS across the 4 waves -> one {min xyz, max xyz} record per block -> a one-block
+// finalize kernel.  Seeds are +/-f64::MAX like the reference; fmin/fmax never let a NaN win, exactly like the
+// reference's strict `<` / `>` compares.  HBM-bound: no MFMA, no LDS staging needed.
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+#include <algorithm>
+
+using namespace pstd;
+
+namespace {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kLoads = 6;                 // 16-byte loads in flight per lane
+constexpr int kTileVec = kLoads * kBlock;  // vectors per tile; multiple of 3 => phase invariance
+
+template <bool AFFINE, bool WRITE, bool BOUNDS>
+__global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamParams p) {
+  const uint32_t t = threadIdx.x;
+  const PST_AS_GLOBAL f64x2* __restrict__ src = (const PST_AS_GLOBAL f64x2*)(p.src + p.vec_first);
+  PST_AS_GLOBAL f64x2* __restrict__ dst = (PST_AS_GLOBAL f64x2*)(p.dst + p.vec_first);
+
+  // component of half h of lane t's j-th vector: (vec_first + 2*(j*256 + t) + h) mod 3, invariant over tiles
+  double sc[3][2], of[3][2];
+  uint32_t comp[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const uint32_t c = (uint32_t)((p.vec_first + 2ull * (uint64_t)(j * kBlock + t) + hh) % 3ull);
+      comp[j][hh] = c;
+      sc[j][hh] = pick3(c, p.scale[0], p.scale[1], p.scale[2]);
+      of[j][hh] = pick3(c, p.offset[0], p.offset[1], p.offset[2]);
+    }
+  }
+  double mn[3][2], mx[3][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    mn[j][0] = mn[j][1] = kF64Max;
+    mx[j][0] = mx[j][1] = -kF64Max;
+  }
+
+  auto body = [&](f64x2 v, int j) __attribute__((always_inline)) -> f64x2 {
+    const int jj = j % 3;
+    double a = v.x, b = v.y;
+    if constexpr (AFFINE) {
+#pragma clang fp contract(off)
+      a = a * sc[jj][0];
+      a = a + of[jj][0];
+      b = b * sc[jj][1];
+      b = b + of[jj][1];
+    }
+    if constexpr (BOUNDS) {
+      mn[jj][0] = __builtin_fmin(mn[jj][0], a);
+      mx[jj][0] = __builtin_fmax(mx[jj][0], a);
+      mn[jj][1] = __builtin_fmin(mn[jj][1], b);
+      mx[jj][1] = __builtin_fmax(mx[jj][1], b);
+    }
+    f64x2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+  };
+
+  const uint64_t n_tiles = (p.n_vec + kTileVec - 1) / kTileVec;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t base = tile * kTileVec + t;
+    if ((tile + 1) * (uint64_t)kTileVec <= p.n_vec) {
+      f64x2 v[kLoads];
+#pragma unroll
+      for (int j = 0; j < kLoads; ++j) v[j] = __builtin_nontemporal_load(&src[base + (uint64_t)j * kBlock]);
+#pragma unroll
+      for (int j = 0; j < kLoads; ++j) {
+        const f64x2 r = body(v[j], j);
+        if constexpr (WRITE) __builtin_nontemporal_store(r, &dst[base + (uint64_t)j * kBlock]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kLoads; ++j) {
+        const uint64_t i = base + (uint64_t)j * kBlock;
+        if (i < p.n_vec) {
+          const f64x2 r = body(src[i], j);
+          if constexpr (WRITE) dst[i] = r;
+        }
+      }
+    }
+  }
+
+  // fold the (phase, half) accumulators back to x / y / z
+  double bmn[3] = {kF64Max, kF64Max, kF64Max}, bmx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  if constexpr (BOUNDS) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+          const bool hit = comp[j][hh] == c;
+          bmn[c] = __builtin_fmin(bmn[c], hit ? mn[j][hh] : kF64Max);
+          bmx[c] = __builtin_fmax(bmx[c], hit ? mx[j][hh] : -kF64Max);
+        }
+      }
+    }
+  }
+
+  // ragged doubles outside the 16-byte aligned vector body (at most one in front, two behind): block 0, lanes 0..2
+  if (blockIdx.x == 0 && t < 3) {
+    const uint64_t tail_first = p.vec_first + 2 * p.n_vec;
+    uint64_t idx = ~0ull;
+    if (t == 0 && p.vec_first == 1) idx = 0;
+    if (t >= 1 && tail_first + (t - 1) < p.n_doubles) idx = tail_first + (t - 1);
+    if (idx != ~0ull) {
+      const uint32_t c = (uint32_t)(idx % 3ull);
+      double a = p.src[idx];
+      if constexpr (AFFINE) {
+#pragma clang fp contract(off)
+        a = a * pick3(c, p.scale[0], p.scale[1], p.scale[2]);
+        a = a + pick3(c, p.offset[0], p.offset[1], p.offset[2]);
+      }
+      if constexpr (WRITE) p.dst[idx] = a;
+      if constexpr (BOUNDS) {
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3; ++cc) {
+          bmn[cc] = __builtin_fmin(bmn[cc], cc == c ? a : kF64Max);
+          bmx[cc] = __builtin_fmax(bmx[cc], cc == c ? a : -kF64Max);
+        }
+      }
+    }
+  }
+
+  if constexpr (BOUNDS) {
+    __shared__ double scratch[(kBlock / 64) * 6];
+    block_reduce_minmax<double, 3>(bmn, bmx, scratch);
+    if (t == 0) {
+      double* out = p.partials + (uint64_t)blockIdx.x * 6;
+      out[0] = bmn[0]; out[1] = bmn[1]; out[2] = bmn[2];
+      out[3] = bmx[0]; out[4] = bmx[1]; out[5] = bmx[2];
+    }
+  }
+}
+
+// One block folds the per-block records: out[0..NV) = min, out[NV..2NV) = max.
+template <typename T, int NV>
+__global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __restrict__ partials, uint32_t n_records, T* __restrict__ out,
+                                                                 T seed_min, T seed_max) {
+  T mn[NV], mx[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { mn[i] = seed_min; mx[i] = seed_max; }
+  for (uint32_t r = threadIdx.x; r < n_records; r += kBlock) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      mn[i] = fold_min(mn[i], partials[(uint64_t)r * 2 * NV + i]);
+      mx[i] = fold_max(mx[i], partials[(uint64_t)r * 2 * NV + NV + i]);
+    }
+  }
+  __shared__ T scratch[(kBlock / 64) * 2 * NV];
+  block_reduce_minmax<T, NV>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { out[i] = mn[i]; out[NV + i] = mx[i]; }
+  }
+}
+
+// Generic strided min/max: element e lives at base + e*stride, NCOMP components of T.
+// ACC = double: Rust-`as` each component to f64 and fold with +/-f64::MAX seeds (calculate_bounds_from_custom_positions,
+// bounds.rs:56-85).  ACC = T: fold in the attribute's own type (minmax_attribute, minmax.rs:13-51).
+template <typename T, typename ACC, int NCOMP>
+__global__ __launch_bounds__(kBlock) void strided_minmax_kernel(const ReduceParams p, ACC seed_min, ACC seed_max) {
+  ACC mn[NCOMP], mx[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) { mn[c] = seed_min; mx[c] = seed_max; }
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  cgptr_t base = (cgptr_t)(uint64_t)p.base;
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < p.n; e += step) {
+    cgptr_t q = base + e * p.stride;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const ACC v = rust_as<ACC, T>(load_un<T>(q + c * sizeof(T)));
+      mn[c] = fold_min(mn[c], v);
+      mx[c] = fold_max(mx[c], v);
+    }
+  }
+  __shared__ ACC scratch[(kBlock / 64) * 2 * NCOMP];
+  block_reduce_minmax<ACC, NCOMP>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+    ACC* out = (ACC*)p.partials + (uint64_t)blockIdx.x * 2 * NCOMP;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) { out[c] = mn[c]; out[NCOMP + c] = mx[c]; }
+  }
+}
+
+template <typename T> struct Identity {
+  static T min_seed() {
+    if constexpr (std::is_floating_point<T>::value) return std::numeric_limits<T>::infinity();
+    else return std::numeric_limits<T>::max();
+  }
+  static T max_seed() {
+    if constexpr (std::is_floating_point<T>::value) return -std::numeric_limits<T>::infinity();
+    else return std::numeric_limits<T>::lowest();
+  }
+};
+
+template <typename T, int NCOMP>
+void launch_minmax_typed(const ReduceParams& p, bool acc_f64, void* out, unsigned grid, hipStream_t stream) {
+  if (acc_f64) {
+    hipLaunchKernelGGL((strided_minmax_kernel<T, double, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, kF64Max, -kF64Max);
+    hipLaunchKernelGGL((finalize_minmax_kernel<double, NCOMP>), dim3(1), dim3(kBlock), 0, stream, (const double*)p.partials, grid,
+                       (double*)out, kF64Max, -kF64Max);
+  } else {
+    hipLaunchKernelGGL((strided_minmax_kernel<T, T, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, Identity<T>::min_seed(),
+                       Identity<T>::max_seed());
+    hipLaunchKernelGGL((finalize_minmax_kernel<T, NCOMP>), dim3(1), dim3(kBlock), 0, stream, (const T*)p.partials, grid, (T*)out,
+                       Identity<T>::min_seed(), Identity<T>::max_seed());
+  }
+}
+
+}  // namespace
+
+namespace pstk {
+
+int stream_grid() { return device_cus() * 8; }
+int reduce_grid() { return device_cus() * 8; }
+
+void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, const double scale[3], const double offset[3], unsigned mode,
+                           double* partials, double* out6, hipStream_t stream) {
+  const bool affine = mode & 1u, write = mode & 2u, bounds = mode & 4u;
+  StreamParams p{};
+  p.src = src;
+  p.dst = write ? dst : const_cast<double*>(src);
+  p.n_doubles = 3 * n_points;
+  // 16-byte vectors need src and dst to share their alignment phase; otherwise run the body on scalars... the host
+  // only takes this path when (src - dst) % 16 == 0 (see converter.cpp), so only the phase of src matters.
+  p.vec_first = (((uintptr_t)src & 15u) != 0 && p.n_doubles > 0) ? 1 : 0;
+  p.n_vec = (p.n_doubles - p.vec_first) / 2;
+  for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
+  p.partials = partials;
+  const uint64_t n_tiles = std::max<uint64_t>(1, (p.n_vec + kTileVec - 1) / kTileVec);
+  const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
+#define PST_STREAM(A, W, B) hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B>), dim3(grid), dim3(kBlock), 0, stream, p)
+  switch (mode & 7u) {
+    case 1: case 0: break;  // nothing to do (affine without a sink is meaningless)
+    case 2: PST_STREAM(false, true, false); break;
+    case 3: PST_STREAM(true, true, false); break;
+    case 4: PST_STREAM(false, false, true); break;
+    case 5: PST_STREAM(true, false, true); break;
+    case 6: PST_STREAM(false, true, true); break;
+    case 7: PST_STREAM(true, true, true); break;
+  }
+#undef PST_STREAM
+  (void)affine;
+  if (bounds)
+    hipLaunchKernelGGL((finalize_minmax_kernel<double, 3>), dim3(1), dim3(kBlock), 0, stream, (const double*)partials, grid, out6, kF64Max,
+                       -kF64Max);
+}
+
+void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials, void* out,
+                   hipStream_t stream) {
+  ReduceParams p{base, stride, n, partials};
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)reduce_grid()));
+#define PST_MM(T)                                                             \
+  do {                                                                        \
+    if (ncomp == 3) launch_minmax_typed<T, 3>(p, acc_f64, out, grid, stream); \
+    else launch_minmax_typed<T, 1>(p, acc_f64, out, grid, stream);            \
+  } while (0)
+  switch (ct) {
+    case CT_U8: PST_MM(uint8_t); break;
+    case CT_I8: PST_MM(int8_t); break;
+    case CT_U16: PST_MM(uint16_t); break;
+    case CT_I16: PST_MM(int16_t); break;
+    case CT_U32: PST_MM(uint32_t); break;
+    case CT_I32: PST_MM(int32_t); break;
+    case CT_U64: PST_MM(uint64_t); break;
+    case CT_I64: PST_MM(int64_t); break;
+    case CT_F32: PST_MM(float); break;
+    default: PST_MM(double); break;
+  }
+#undef PST_MM
+}
+
+}  // namespace pstk

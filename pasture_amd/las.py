@@ -1,0 +1,162 @@
+"""The production caller's contract for the hot path: LAS point layouts and `get_default_las_converter`.
+
+Reference: pasture-io/src/las/las_layout.rs:37-125 (layouts), las_types.rs:10-601 (LasPointFormat0..10),
+raw_readers.rs:31-167 (converter construction).  File parsing (headers, VLRs, LAZ) is out of scope; a tiny reader
+for uncompressed point records exists only so the reference's fixtures can be used as golden vectors.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .conversion import BufferLayoutConverter, Transform
+from .layout import FieldAlignment, PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+
+# las_layout.rs:37-49
+ATTRIBUTE_BASIC_FLAGS = PointAttributeDefinition.custom("LASBasicFlags", T.U8)
+ATTRIBUTE_EXTENDED_FLAGS = PointAttributeDefinition.custom("LASExtendedFlags", T.U16)
+ATTRIBUTE_LOCAL_LAS_POSITION = PointAttributeDefinition.custom("LASLocalPosition", T.Vec3i32)
+
+
+@dataclass(frozen=True)
+class Format:
+    """las::point::Format (crate `las`, not vendored) restricted to what las_layout.rs reads from it."""
+    number: int
+
+    @property
+    def is_extended(self):
+        return self.number >= 6
+
+    @property
+    def has_gps_time(self):
+        return self.number in (1, 3, 4, 5) or self.number >= 6
+
+    @property
+    def has_color(self):
+        return self.number in (2, 3, 5, 7, 8, 10)
+
+    @property
+    def has_nir(self):
+        return self.number in (8, 10)
+
+    @property
+    def has_waveform(self):
+        return self.number in (4, 5, 9, 10)
+
+
+def point_layout_from_las_point_format(fmt: Format, exact_binary_representation: bool, api=None) -> PointLayout:
+    """las_layout.rs:64-125."""
+    if not 0 <= fmt.number <= 10:
+        raise ValueError(f"Unsupported LAS point format {fmt.number}")
+    P1 = FieldAlignment.Packed(1)
+    layout = PointLayout.default(api)
+    if exact_binary_representation:  # :70-107
+        layout.add_attribute(ATTRIBUTE_LOCAL_LAS_POSITION, P1)
+        layout.add_attribute(A.INTENSITY, P1)
+        layout.add_attribute(ATTRIBUTE_EXTENDED_FLAGS if fmt.is_extended else ATTRIBUTE_BASIC_FLAGS, P1)
+        layout.add_attribute(A.CLASSIFICATION, P1)
+        if fmt.is_extended:
+            layout.add_attribute(A.USER_DATA, P1)
+            layout.add_attribute(A.SCAN_ANGLE, P1)
+        else:
+            layout.add_attribute(A.SCAN_ANGLE_RANK, P1)
+            layout.add_attribute(A.USER_DATA, P1)
+        layout.add_attribute(A.POINT_SOURCE_ID, P1)
+    else:  # LasPointFormatN::layout(): repr(C, packed) structs, las_types.rs
+        layout.add_attribute(A.POSITION_3D, P1)
+        layout.add_attribute(A.INTENSITY, P1)
+        layout.add_attribute(A.RETURN_NUMBER, P1)
+        layout.add_attribute(A.NUMBER_OF_RETURNS, P1)
+        if fmt.is_extended:
+            layout.add_attribute(A.CLASSIFICATION_FLAGS, P1)
+            layout.add_attribute(A.SCANNER_CHANNEL, P1)
+        layout.add_attribute(A.SCAN_DIRECTION_FLAG, P1)
+        layout.add_attribute(A.EDGE_OF_FLIGHT_LINE, P1)
+        layout.add_attribute(A.CLASSIFICATION, P1)
+        if fmt.is_extended:
+            layout.add_attribute(A.USER_DATA, P1)
+            layout.add_attribute(A.SCAN_ANGLE, P1)
+        else:
+            layout.add_attribute(A.SCAN_ANGLE_RANK, P1)
+            layout.add_attribute(A.USER_DATA, P1)
+        layout.add_attribute(A.POINT_SOURCE_ID, P1)
+    if fmt.has_gps_time:
+        layout.add_attribute(A.GPS_TIME, P1)
+    if fmt.has_color:
+        layout.add_attribute(A.COLOR_RGB, P1)
+    if fmt.has_nir:
+        layout.add_attribute(A.NIR, P1)
+    if fmt.has_waveform:
+        layout.add_attribute(A.WAVE_PACKET_DESCRIPTOR_INDEX, P1)
+        layout.add_attribute(A.WAVEFORM_DATA_OFFSET, P1)
+        layout.add_attribute(A.WAVEFORM_PACKET_SIZE, P1)
+        layout.add_attribute(A.RETURN_POINT_WAVEFORM_LOCATION, P1)
+        layout.add_attribute(A.WAVEFORM_PARAMETERS, P1)
+    return layout
+
+
+def get_default_las_converter(raw_las_layout: PointLayout, target_layout: PointLayout, scale: Tuple[float, float, float],
+                              offset: Tuple[float, float, float]) -> BufferLayoutConverter:
+    """raw_readers.rs:31-167 with `las_header.transforms()` passed as (scale, offset)."""
+    converter = BufferLayoutConverter.for_layouts_with_default(raw_las_layout, target_layout)  # :36-37
+    pos = target_layout.get_attribute_by_name(A.POSITION_3D.name())
+    if pos is not None:  # :39-58
+        if pos.datatype() == T.Vec3f64:
+            converter.set_custom_mapping_with_transformation(ATTRIBUTE_LOCAL_LAS_POSITION, pos.attribute_definition(),
+                                                             Transform.affine(T.Vec3f64, scale, offset), False)
+        elif pos.datatype() == T.Vec3f32:
+            converter.set_custom_mapping_with_transformation(ATTRIBUTE_LOCAL_LAS_POSITION, pos.attribute_definition(),
+                                                             Transform.affine(T.Vec3f32, scale, offset), False)
+        else:
+            raise ValueError(f"Invalid datatype {pos.datatype()} for POSITION_3D attribute. Only Vec3f64 and Vec3f32 are supported!")
+
+    def bits(flags_attr, target_name, shift, mask):
+        t = target_layout.get_attribute_by_name(target_name)
+        if t is not None:
+            converter.set_custom_mapping_with_transformation(flags_attr, t.attribute_definition(),
+                                                             Transform.bitfield(flags_attr.datatype(), shift, mask), True)
+
+    if raw_las_layout.has_attribute(ATTRIBUTE_BASIC_FLAGS):  # :61-103
+        bits(ATTRIBUTE_BASIC_FLAGS, A.RETURN_NUMBER.name(), 0, 0b111)
+        bits(ATTRIBUTE_BASIC_FLAGS, A.NUMBER_OF_RETURNS.name(), 3, 0b111)
+        bits(ATTRIBUTE_BASIC_FLAGS, A.SCAN_DIRECTION_FLAG.name(), 6, 0b1)
+        bits(ATTRIBUTE_BASIC_FLAGS, A.EDGE_OF_FLIGHT_LINE.name(), 7, 0b1)
+    else:  # :104-164
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.RETURN_NUMBER.name(), 0, 0b1111)
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.NUMBER_OF_RETURNS.name(), 4, 0b1111)
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.CLASSIFICATION_FLAGS.name(), 8, 0b1111)
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.SCANNER_CHANNEL.name(), 12, 0b11)
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.SCAN_DIRECTION_FLAG.name(), 14, 0b1)
+        bits(ATTRIBUTE_EXTENDED_FLAGS, A.EDGE_OF_FLIGHT_LINE.name(), 15, 0b1)
+    return converter
+
+
+@dataclass
+class LasFile:
+    """Just enough of an uncompressed .las file to use the reference's fixtures as golden vectors."""
+    point_format: int
+    record_length: int
+    num_points: int
+    scale: Tuple[float, float, float]
+    offset: Tuple[float, float, float]
+    records: np.ndarray  # (num_points, record_length) uint8
+
+
+def read_las_records(path: str) -> LasFile:
+    """LAS 1.2-1.4 public header block (ASPRS LAS specification): offsets 94/96/104/105/107/131/155."""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"LASF"
+    minor = raw[25]
+    offset_to_points = struct.unpack_from("<I", raw, 96)[0]
+    fmt = raw[104] & 0x3F
+    rec_len = struct.unpack_from("<H", raw, 105)[0]
+    n_legacy = struct.unpack_from("<I", raw, 107)[0]
+    n = n_legacy
+    if minor >= 4 and n_legacy == 0:
+        n = struct.unpack_from("<Q", raw, 247)[0]
+    sx, sy, sz, ox, oy, oz = struct.unpack_from("<6d", raw, 131)
+    recs = np.frombuffer(raw, dtype=np.uint8, count=n * rec_len, offset=offset_to_points).reshape(n, rec_len).copy()
+    return LasFile(fmt, rec_len, n, (sx, sy, sz), (ox, oy, oz), recs)

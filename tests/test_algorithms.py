@@ -1,0 +1,185 @@
+"""calculate_bounds / minmax_attribute / transform_attribute / compute_normals — known answers of the reference's tests
+plus NaN / empty / seed semantics read from the source.  CPU suite pins the oracle, GPU suite the HIP path."""
+import numpy as np
+import pytest
+
+from harness import BUFFER_KINDS, make_buffer, random_records
+from pasture_amd._capi import PasturePanic
+from pasture_amd.algorithms import calculate_bounds, compute_normals, minmax_attribute, transform_attribute
+from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+from pasture_amd.conversion import Transform
+from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+
+KINDS = ["V", "H"]
+
+
+def positions_buffer(api, kind, pts, extra=False, dtype=T.Vec3f64):
+    pos = A.POSITION_3D.with_custom_datatype(dtype)
+    layout = PointLayout.from_attributes_packed([A.INTENSITY, pos] if extra else [pos], 1, api=api) if extra else \
+        PointLayout.from_attributes([pos], api=api)
+    buf = BUFFER_KINDS[kind].new_from_layout(layout)
+    pts = np.asarray(pts, dtype=dtype.numpy_dtype()).reshape(-1, 3)
+    buf.resize(pts.shape[0])
+    if pts.shape[0]:
+        buf.set_attribute_range(pos, range(0, pts.shape[0]), pts)
+    return buf
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_aabb_known_answer(api, kind):  # pasture-core/src/math/bounds.rs:305-315
+    b = calculate_bounds(positions_buffer(api, kind, [[0, 0, 0], [1, 1, 1], [-1, -1, -1]]))
+    assert b.min() == (-1.0, -1.0, -1.0) and b.max() == (1.0, 1.0, 1.0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 1535, 1536, 1537, 4096, 100003])
+def test_bounds_random(api, kind, n):  # aabb_bench.rs workload shape; sizes straddle the kernel's tile edges
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3)) * np.array([1000.0, 1000.0, 100.0]) - 250.0
+    b = calculate_bounds(positions_buffer(api, kind, pts, extra=(n % 2 == 1)))
+    assert b.min() == tuple(pts.min(axis=0)) and b.max() == tuple(pts.max(axis=0))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_bounds_none_cases(api, kind):  # bounds.rs:12-21
+    assert calculate_bounds(positions_buffer(api, kind, np.zeros((0, 3)))) is None
+    layout = PointLayout.from_attributes([A.INTENSITY], api=api)
+    buf = BUFFER_KINDS[kind].new_from_layout(layout)
+    buf.resize(5)
+    assert calculate_bounds(buf) is None
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_bounds_nan_semantics(api, kind):  # strict < / > from +-f64::MAX seeds: NaN never wins (bounds.rs:31-51)
+    nan = float("nan")
+    b = calculate_bounds(positions_buffer(api, kind, [[nan, 1, 2], [3, nan, 5], [4, 0, nan], [-1, 7, 9]]))
+    assert b.min() == (-1.0, 0.0, 2.0) and b.max() == (4.0, 7.0, 9.0)
+    with pytest.raises(PasturePanic) as e:  # a component that is NaN everywhere leaves min=MAX > max=MIN -> from_min_max panics
+        calculate_bounds(positions_buffer(api, kind, [[nan, 1, 2], [nan, 3, 4]]))
+    assert e.value.code == 10
+    inf = float("inf")
+    b = calculate_bounds(positions_buffer(api, kind, [[inf, -inf, 0], [inf, -inf, 1]]))  # inf < MAX is false: min.x stays f64::MAX
+    assert b.min() == (1.7976931348623157e308, -inf, 0.0) and b.max() == (inf, -1.7976931348623157e308, 1.0)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dtype", [T.Vec3f32, T.Vec3i32, T.Vec3u16, T.Vec3u8])
+def test_bounds_custom_position_datatype(api, kind, dtype):  # calculate_bounds_from_custom_positions bounds.rs:56-85
+    rng = np.random.default_rng(9)
+    npd = dtype.numpy_dtype()
+    pts = (rng.random((1000, 3)) * 200).astype(npd) if npd.kind != "f" else (rng.random((1000, 3)) * 200 - 100).astype(npd)
+    b = calculate_bounds(positions_buffer(api, kind, pts, dtype=dtype))
+    assert b.min() == tuple(pts.min(axis=0).astype(np.float64)) and b.max() == tuple(pts.max(axis=0).astype(np.float64))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_minmax_attribute(api, kind):
+    layout = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.SCAN_ANGLE_RANK, A.GPS_TIME, A.COLOR_RGB,
+                                                 A.WAVEFORM_PARAMETERS, A.POINT_ID], 1, api=api)
+    rec = random_records(layout, 10007, seed=17)
+    buf = make_buffer(kind, layout, rec)
+    for attr in (A.INTENSITY, A.SCAN_ANGLE_RANK, A.GPS_TIME, A.POINT_ID):
+        mn, mx = minmax_attribute(buf, attr)
+        assert mn == rec[attr.name()].min() and mx == rec[attr.name()].max()
+    for attr in (A.POSITION_3D, A.COLOR_RGB, A.WAVEFORM_PARAMETERS):
+        mn, mx = minmax_attribute(buf, attr)  # component-wise for Vec3 (math/minmax.rs:96-112)
+        assert np.array_equal(mn, rec[attr.name()].min(axis=0)) and np.array_equal(mx, rec[attr.name()].max(axis=0))
+    empty = BUFFER_KINDS[kind].new_from_layout(layout)
+    assert minmax_attribute(empty, A.INTENSITY) is None  # minmax.rs:28 -> None
+    with pytest.raises(PasturePanic):  # attribute name not in layout: minmax.rs:17-26
+        minmax_attribute(buf, A.CLASSIFICATION)
+    with pytest.raises(PasturePanic):  # T must be the stored datatype
+        minmax_attribute(buf, A.INTENSITY.with_custom_datatype(T.U32))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_minmax_nan_rule(api, kind):
+    """A NaN FIRST value seeds (NaN, NaN) and sticks; later NaNs are ignored (minmax.rs:30-33, math/minmax.rs:78-94)."""
+    layout = PointLayout.from_attributes([A.GPS_TIME], api=api)
+    nan = float("nan")
+
+    def run(vals):
+        b = BUFFER_KINDS[kind].new_from_layout(layout)
+        b.resize(len(vals))
+        b.set_attribute_range(A.GPS_TIME, range(0, len(vals)), np.array(vals))
+        return minmax_attribute(b, A.GPS_TIME)
+
+    mn, mx = run([1.0, nan, 0.5, 3.0, nan])
+    assert (mn, mx) == (0.5, 3.0)
+    mn, mx = run([nan, 1.0, 2.0])
+    assert np.isnan(mn) and np.isnan(mx)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_transform_attribute_affine(api, kind):
+    """transform_attribute(POSITION_3D, |_, p| p*scale+offset) in place (point_buffer.rs:391-404; loop shape of
+    reproject_point_cloud_within, reprojection.rs:132-146).  Two roundings per component, never an FMA."""
+    layout = PointLayout.from_attributes_packed([A.INTENSITY, A.POSITION_3D, A.CLASSIFICATION], 1, api=api)
+    rec = random_records(layout, 3001, seed=23)
+    rec["Position3D"] = rec["Position3D"] * 2e6
+    buf = make_buffer(kind, layout, rec)
+    scale, offset = np.array([0.001, 0.01, 0.0001]), np.array([500000.0, 5400000.0, 100.0])
+    transform_attribute(buf, A.POSITION_3D, Transform.affine(T.Vec3f64, scale, offset))
+    exp = (rec["Position3D"] * scale) + offset
+    assert buf.view_attribute(A.POSITION_3D).tobytes() == exp.tobytes()
+    assert np.array_equal(buf.view_attribute(A.INTENSITY), rec["Intensity"])
+    assert np.array_equal(buf.view_attribute(A.CLASSIFICATION), rec["Classification"])
+    with pytest.raises(PasturePanic):  # T::data_type() must equal the attribute's datatype
+        transform_attribute(buf, A.POSITION_3D, Transform.affine(T.Vec3f32, scale, offset))
+
+
+# ---- normal estimation: normal_estimation.rs:503-699 --------------------------------------------------------
+
+PLANAR4 = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [1.0, 1.0, 0.0], [-1.0, 0.0, 0.0]]
+
+
+def simple_point_buffer(api, kind, pts):
+    layout = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY], 1, api=api)  # SimplePoint :485-492
+    buf = BUFFER_KINDS[kind].new_from_layout(layout)
+    pts = np.asarray(pts, dtype=np.float64)
+    buf.resize(len(pts))
+    buf.set_attribute_range(A.POSITION_3D, range(0, len(pts)), pts)
+    return buf
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_compute_normal_planar(api, kind):  # test_compute_normal :580-610 (n = 4, k = 3)
+    normals, curv = compute_normals(simple_point_buffer(api, kind, PLANAR4), 3)
+    for i in range(4):
+        assert normals[i, 0] == 0.0 and normals[i, 1] == 0.0 and normals[i, 2] != 0.0 and curv[i] == 0.0
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_compute_normals_panics(api, kind):  # :612-698
+    with pytest.raises(PasturePanic) as e:
+        compute_normals(simple_point_buffer(api, kind, PLANAR4[:1]), 3)
+    assert e.value.code == 11 and "too small" in str(e.value)
+    with pytest.raises(PasturePanic):
+        compute_normals(simple_point_buffer(api, kind, PLANAR4[:2]), 3)
+    for k in (1, 2):
+        with pytest.raises(PasturePanic) as e:
+            compute_normals(simple_point_buffer(api, kind, PLANAR4), k)
+        assert e.value.code == 12 and "k nearest neigbors attribute is too small" in str(e.value)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_compute_normals_nan_neighbourhood(api, kind):  # test_covariance_error :552-578 via compute_normals' unwrap (:471)
+    nan = float("nan")
+    pts = [[nan, 0, 0], [0, 1, nan], [1, 1, nan], [-1, nan, 0]]
+    with pytest.raises(PasturePanic) as e:
+        compute_normals(simple_point_buffer(api, kind, pts), 4)
+    assert e.value.code == 13 and "not enough to span a plane" in str(e.value)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_compute_normals_plane_with_noise_free_grid(api, kind):
+    """Points on the plane z = 0.25x - 0.5y: every normal is parallel to (0.25, -0.5, -1), curvature ~ 0."""
+    rng = np.random.default_rng(3)
+    xy = rng.random((500, 2)) * 10
+    pts = np.column_stack([xy, 0.25 * xy[:, 0] - 0.5 * xy[:, 1]])
+    normals, curv = compute_normals(simple_point_buffer(api, kind, pts), 8)
+    ref = np.array([0.25, -0.5, -1.0])
+    ref /= np.linalg.norm(ref)
+    unit = normals / np.linalg.norm(normals, axis=1, keepdims=True)
+    assert np.allclose(np.abs(unit @ ref), 1.0, atol=1e-6)
+    assert np.all(curv < 1e-9)

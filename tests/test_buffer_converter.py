@@ -1,0 +1,215 @@
+"""BufferLayoutConverter — the reference's 5 scenarios x 4 buffer pairings (buffer_conversion.rs:684-930) with seeded
+inputs, plus what the reference lacks (ranges, unmapped-attribute defaults, padding preservation, error codes).
+Expectations are computed with numpy from the source records, never from the implementation under test."""
+import numpy as np
+import pytest
+
+from pasture_amd._capi import PastureError, PasturePanic
+from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+from pasture_amd.conversion import BufferLayoutConverter, Transform
+from pasture_amd.layout import FieldAlignment, PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+
+from harness import BUFFER_KINDS, PAIRINGS, custom_point_type_big, custom_point_type_small, make_buffer, random_records
+
+I16_INTENSITY = A.INTENSITY.with_custom_datatype(T.I16)
+SIZES = [16, 1, 257, 5000]
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+@pytest.mark.parametrize("n", SIZES)
+def test_buffer_converter_default(api, pair, n):  # :684-722
+    big = custom_point_type_big(api)
+    rec = random_records(big, n, seed=n)
+    src = make_buffer(pair[0], big, rec)
+    target_layout = custom_point_type_small(api)
+    conv = BufferLayoutConverter.for_layouts(src.point_layout(), target_layout)
+    out = conv.convert(src, BUFFER_KINDS[pair[1]])
+    assert out.point_layout() == target_layout and out.len() == n
+    assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"])
+    assert np.array_equal(out.view_attribute(A.CLASSIFICATION), rec["Classification"])
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_buffer_converter_multiple_attributes_from_one(api, pair):  # :724-762
+    big = custom_point_type_big(api)
+    rec = random_records(big, 16, seed=2)
+    src = make_buffer(pair[0], big, rec)
+    custom = PointLayout.from_attributes([A.CLASSIFICATION, A.RETURN_NUMBER], api=api)
+    conv = BufferLayoutConverter.for_layouts_with_default(src.point_layout(), custom)
+    conv.set_custom_mapping(A.CLASSIFICATION, A.RETURN_NUMBER)
+    out = conv.convert(src, BUFFER_KINDS[pair[1]])
+    assert out.point_layout() == custom
+    assert np.array_equal(out.view_attribute(A.CLASSIFICATION), rec["Classification"])
+    assert np.array_equal(out.view_attribute(A.RETURN_NUMBER), rec["Classification"])
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+@pytest.mark.parametrize("apply_to_source", [False, True])
+def test_buffer_converter_transformed_attribute(api, pair, apply_to_source):  # :764-846 (+42.0 post / pre)
+    big = custom_point_type_big(api)
+    rec = random_records(big, 16, seed=3)
+    src = make_buffer(pair[0], big, rec)
+    custom = PointLayout.from_attributes([A.POSITION_3D], api=api)
+    conv = BufferLayoutConverter.for_layouts_with_default(src.point_layout(), custom)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.add_scalar(T.Vec3f64, 42.0), apply_to_source)
+    out = conv.convert(src, BUFFER_KINDS[pair[1]])
+    assert out.point_layout() == custom
+    assert out.view_attribute(A.POSITION_3D).tobytes() == (rec["Position3D"] + 42.0).tobytes()
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_buffer_converter_identity(api, pair):  # :848-873
+    big = custom_point_type_big(api)
+    rec = random_records(big, 333, seed=4)
+    src = make_buffer(pair[0], big, rec)
+    conv = BufferLayoutConverter.for_layouts_with_default(src.point_layout(), src.point_layout())
+    out = conv.convert(src, BUFFER_KINDS[pair[1]])
+    assert out.get_point_range(range(0, 333)).tobytes() == rec.tobytes()
+
+
+def test_buffer_converter_mismatched_len(api):  # :912-930 should_panic
+    big = custom_point_type_big(api)
+    src = VectorBuffer.new_from_layout(big)
+    src.resize(16)
+    target = VectorBuffer.new_from_layout(big)
+    target.resize(8)
+    conv = BufferLayoutConverter.for_layouts_with_default(big, big)
+    with pytest.raises(PasturePanic):
+        conv.convert_into(src, target)
+
+
+# ---- beyond the reference's tests ----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_convert_into_range_offsets_and_untouched_points(api, pair):
+    """convert_into_range (buffer_conversion.rs:292-359): only target_range is written; everything else survives,
+    including target attributes without a mapping and alignment padding inside interleaved records."""
+    src_l = custom_point_type_big(api)
+    dst_l = PointLayout.from_attributes([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], api=api)  # repr(C): 32 B with 5 B padding
+    assert dst_l.size_of_point_entry() == 32
+    n_src, n_dst = 700, 900
+    src_rec = random_records(src_l, n_src, seed=7)
+    dst_rec = random_records(dst_l, n_dst, seed=8)
+    dst_bytes = dst_rec.view(np.uint8).reshape(n_dst, 32).copy()
+    dst_bytes[:, 27:32] = 0xCD  # trailing padding of the repr(C) record
+    dst_rec = dst_bytes.view(dst_l.numpy_record_dtype()).reshape(n_dst)  # a VIEW: numpy copies of padded records drop the padding
+    src = make_buffer(pair[0], src_l, src_rec)
+    dst = BUFFER_KINDS[pair[1]].from_numpy(dst_bytes, dst_l)
+    conv = BufferLayoutConverter.for_layouts_with_default(src_l, dst_l)
+    conv.set_custom_mapping(I16_INTENSITY, A.INTENSITY)  # I16 -> U16 by `as` (names match, default mapping would do the same)
+    s0, s1, t0 = 13, 613, 201
+    conv.convert_into_range(src, range(s0, s1), dst, range(t0, t0 + (s1 - s0)))
+    exp = {a.name(): dst_rec[a.name()].copy() for a in dst_l.attributes()}
+    exp["Position3D"][t0:t0 + 600] = src_rec["Position3D"][s0:s1]
+    exp["Intensity"][t0:t0 + 600] = src_rec["Intensity"][s0:s1].astype(np.uint16)
+    exp["Classification"][t0:t0 + 600] = src_rec["Classification"][s0:s1]
+    for a in (A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION):
+        assert dst.view_attribute(a).tobytes() == exp[a.name()].tobytes(), a.name()
+    if pair[1] == "V":  # padding bytes of interleaved records must be preserved
+        got = dst.get_point_range(range(0, n_dst))
+        assert np.array_equal(got[:, 27:32], dst_bytes[:, 27:32])
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_for_layouts_with_default_leaves_unmapped_zero(api, pair):
+    """Target attributes without a source stay at the resize() zero fill (for_layouts_with_default :126-143)."""
+    src_l = custom_point_type_small(api)
+    dst_l = PointLayout.from_attributes_packed([A.GPS_TIME, A.POSITION_3D, A.COLOR_RGB, A.CLASSIFICATION], 1, api=api)
+    rec = random_records(src_l, 100, seed=11)
+    src = make_buffer(pair[0], src_l, rec)
+    out = BufferLayoutConverter.for_layouts_with_default(src_l, dst_l).convert(src, BUFFER_KINDS[pair[1]])
+    assert not out.view_attribute(A.GPS_TIME).any() and not out.view_attribute(A.COLOR_RGB).any()
+    assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"])
+    with pytest.raises(PasturePanic):  # for_layouts: missing source attribute panics :112-123
+        BufferLayoutConverter.for_layouts(src_l, dst_l)
+
+
+def test_mapping_construction_rules(api):
+    """Order and replacement rules of set_custom_mapping (buffer_conversion.rs:156-234, make_default_mapping :368-396)."""
+    big, small = custom_point_type_big(api), custom_point_type_small(api)
+    conv = BufferLayoutConverter.for_layouts(big, small)
+    assert [(m.source.name(), m.target.name(), m.has_converter) for m in conv.mappings()] == [
+        ("Position3D", "Position3D", False), ("Classification", "Classification", False)]
+    custom = PointLayout.from_attributes([A.CLASSIFICATION, A.RETURN_NUMBER, A.POSITION_3D.with_custom_datatype(T.Vec3f32)], api=api)
+    conv = BufferLayoutConverter.for_layouts_with_default(big, custom)
+    assert [(m.target.name(), m.has_converter) for m in conv.mappings()] == [("Classification", False), ("Position3D", True)]
+    conv.set_custom_mapping(A.CLASSIFICATION, A.RETURN_NUMBER)  # appended
+    conv.set_custom_mapping(A.GPS_TIME.with_custom_datatype(T.F64), A.CLASSIFICATION)  # replaces the mapping whose target is Classification
+    ms = conv.mappings()
+    assert [(m.source.name(), m.target.name(), m.has_converter) for m in ms] == [
+        ("GpsTime", "Classification", True), ("Position3D", "Position3D", True), ("Classification", "ReturnNumber", False)]
+    with pytest.raises(PasturePanic):  # from_attribute must match name AND datatype (:161-164)
+        conv.set_custom_mapping(A.INTENSITY, A.RETURN_NUMBER)  # source Intensity is I16 here, not U16
+    with pytest.raises(PasturePanic):
+        conv.set_custom_mapping(A.CLASSIFICATION, A.USER_DATA)
+    # transformation type check :209-213
+    with pytest.raises(PasturePanic):
+        conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D.with_custom_datatype(T.Vec3f32),
+                                                    Transform.add_scalar(T.Vec3f64, 1.0), False)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D.with_custom_datatype(T.Vec3f32),
+                                                Transform.add_scalar(T.Vec3f64, 1.0), True)
+    m = [m for m in conv.mappings() if m.target.name() == "Position3D"][0]
+    assert m.apply_to_source and m.transform_kind != 0 and m.has_converter
+
+
+def test_layout_mismatch_panics(api):  # buffer_conversion.rs:302-306
+    big, small = custom_point_type_big(api), custom_point_type_small(api)
+    conv = BufferLayoutConverter.for_layouts(big, small)
+    src, dst = VectorBuffer.new_from_layout(small), HashMapBuffer.new_from_layout(small)
+    with pytest.raises(PasturePanic):
+        conv.convert_into(src, dst)
+    src2, dst2 = VectorBuffer.new_from_layout(big), HashMapBuffer.new_from_layout(big)
+    with pytest.raises(PasturePanic):
+        conv.convert_into(src2, dst2)
+    ok_src, ok_dst = VectorBuffer.new_from_layout(big), HashMapBuffer.new_from_layout(small)
+    conv.convert_into(ok_src, ok_dst)  # empty buffers: fine
+    with pytest.raises(PasturePanic):
+        conv.convert_into_range(ok_src, range(0, 1), ok_dst, range(0, 1))  # out of bounds
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_pre_vs_post_transform_with_type_change(api, pair):
+    """Pre-transform runs in the SOURCE type before `as`, post-transform in the TARGET type after it
+    (buffer_conversion.rs:446-456): with i32 -> f32 narrowing the two orders differ, the LAS reader uses both."""
+    sl = PointLayout.from_attributes_packed([PointAttributeDefinition("P", T.Vec3i32), PointAttributeDefinition("F", T.U16)], 1, api=api)
+    tl = PointLayout.from_attributes_packed([PointAttributeDefinition("P", T.Vec3f32), PointAttributeDefinition("A", T.U8),
+                                             PointAttributeDefinition("B", T.U8)], 1, api=api)
+    rec = random_records(sl, 513, seed=21)
+    src = make_buffer(pair[0], sl, rec)
+    conv = BufferLayoutConverter.for_layouts_with_default(sl, tl)
+    scale, offset = (0.001, 0.01, 0.1), (500000.0, 5400000.0, 100.0)
+    conv.set_custom_mapping_with_transformation(PointAttributeDefinition("P", T.Vec3i32), PointAttributeDefinition("P", T.Vec3f32),
+                                                Transform.affine(T.Vec3f32, scale, offset), False)
+    conv.set_custom_mapping_with_transformation(PointAttributeDefinition("F", T.U16), PointAttributeDefinition("A", T.U8),
+                                                Transform.bitfield(T.U16, 4, 0b1111), True)
+    conv.set_custom_mapping_with_transformation(PointAttributeDefinition("F", T.U16), PointAttributeDefinition("B", T.U8),
+                                                Transform.bitfield(T.U8, 1, 0b11), False)
+    out = conv.convert(src, BUFFER_KINDS[pair[1]])
+    p32 = rec["P"].astype(np.float32)  # i32 as f32 (RNE)
+    exp_p = ((p32.astype(np.float64) * np.array(scale)) + np.array(offset)).astype(np.float32)  # raw_readers.rs:49-55
+    assert out.view_attribute(PointAttributeDefinition("P", T.Vec3f32)).tobytes() == exp_p.tobytes()
+    assert np.array_equal(out.view_attribute(PointAttributeDefinition("A", T.U8)), ((rec["F"] >> 4) & 15).astype(np.uint8))
+    assert np.array_equal(out.view_attribute(PointAttributeDefinition("B", T.U8)), (((rec["F"] & 255).astype(np.uint8) >> 1) & 3))
+
+
+def test_unsupported_transform_descriptor(api):
+    sl = PointLayout.from_attributes([A.CLASSIFICATION], api=api)
+    conv = BufferLayoutConverter.for_layouts(sl, sl)
+    with pytest.raises(PastureError) as e:
+        conv.set_custom_mapping_with_transformation(A.CLASSIFICATION, A.CLASSIFICATION, Transform.affine(T.U8, (1, 1, 1), (0, 0, 0)), False)
+    assert e.value.code == 7
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_opaque_types_copy(api, pair):
+    """Vec4u8 / ByteArray attributes have no converter but same-type mappings copy them byte for byte."""
+    blob = PointAttributeDefinition("Blob", T.ByteArray(7))
+    rgba = PointAttributeDefinition("RGBA", T.Vec4u8)
+    sl = PointLayout.from_attributes_packed([A.CLASSIFICATION, blob, A.POSITION_3D, rgba], 1, api=api)
+    tl = PointLayout.from_attributes_packed([rgba, A.POSITION_3D, blob], 1, api=api)
+    rec = random_records(sl, 300, seed=31)
+    src = make_buffer(pair[0], sl, rec)
+    out = BufferLayoutConverter.for_layouts(sl, tl).convert(src, BUFFER_KINDS[pair[1]])
+    assert np.array_equal(out.view_attribute(blob), rec["Blob"])
+    assert np.array_equal(out.view_attribute(rgba), rec["RGBA"])
+    assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"])

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank owns an index-range shard (shard_range), computes its local AABB
+record (here with the ORACLE, the product path needs a GPU) and joins the single all-reduce the multi-GPU path uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, empty_rank, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import _load_oracle
+    from pasture_amd.algorithms import calculate_bounds
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.distributed import F64_MAX, allreduce_bounds_record, bounds_from_record, shard_range
+    from pasture_amd.layout import PointLayout, attributes as A
+    orc = _load_oracle()
+    r = shard_range(n, rank, world)
+    if rank == empty_rank:
+        r = range(0, 0)
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=orc))
+    buf.resize(len(r))
+    buf.synth_fill(42, r.start)  # every shard generates its own slice of the same global point set
+    local = calculate_bounds(buf)
+    rec = torch.tensor([F64_MAX] * 3 + [-F64_MAX] * 3, dtype=torch.float64)  # seeds = identities (bounds.rs:31-32)
+    if local is not None:
+        rec = torch.tensor(list(local.min()) + list(local.max()), dtype=torch.float64)
+    allreduce_bounds_record(rec)
+    q.put((rank, bounds_from_record(rec)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,empty_rank", [(100_001, None), (7, None), (1, 1), (0, None)])
+def test_sharded_bounds_allreduce_gloo(oracle, n, empty_rank):
+    from pasture_amd.algorithms import calculate_bounds
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.distributed import shard_range
+    from pasture_amd.layout import PointLayout, attributes as A
+    world = 2
+    assert [len(shard_range(n, r, world)) for r in range(world)] == [(n + 1) // 2, n // 2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, empty_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process answer over the points that were actually present
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=oracle))
+    covered = [shard_range(n, r, world) for r in range(world) if r != empty_rank]
+    total = sum(len(r) for r in covered)
+    if total == 0:
+        assert got[0] is None and got[1] is None
+        return
+    first = covered[0].start
+    buf.resize(total)
+    buf.synth_fill(42, first)
+    want = calculate_bounds(buf)
+    assert got[0] == got[1] == (want.min(), want.max())

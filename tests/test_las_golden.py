@@ -1,0 +1,136 @@
+"""Golden vectors: the reference's LAS fixtures (tests/golden/las, formats 0-10) pushed through
+`get_default_las_converter` (pasture-io/src/las/raw_readers.rs:31-167) exactly like `read_into_custom_layout`
+(:299-352) does — raw record layout -> user layout — and compared with the values the reference's own tests assert
+(pasture-io/src/las/test_util.rs:46-449; restated in las_expected.py).  CPU suite: pins the oracle.  GPU suite: HIP path."""
+import os
+
+import numpy as np
+import pytest
+
+import las_expected as E
+from harness import BUFFER_KINDS
+from pasture_amd import las
+from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+from pasture_amd.layout import PointAttributeDataType as T, PointLayout, attributes as A
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "las")
+
+
+def load(fmt, api):
+    f = las.read_las_records(os.path.join(GOLDEN, f"10_points_format_{fmt}.las"))
+    raw_layout = las.point_layout_from_las_point_format(las.Format(fmt), True, api=api)
+    assert f.point_format == fmt and f.num_points == 10 and f.record_length == raw_layout.size_of_point_entry()
+    assert f.scale == (1.0, 1.0, 1.0) and f.offset == (0.0, 0.0, 0.0)
+    return f, raw_layout
+
+
+def check_against_reference_data(points, fmt, rng=range(0, 10)):
+    """compare_to_reference_data_range, test_util.rs:190-449."""
+    F = las.Format(fmt)
+    s = slice(rng.start, rng.stop)
+
+    def col(attr):
+        return points.view_attribute(attr)
+
+    assert np.array_equal(col(A.POSITION_3D), E.POSITIONS[s])
+    assert np.array_equal(col(A.INTENSITY), E.INTENSITIES[s])
+    assert np.array_equal(col(A.RETURN_NUMBER), (E.RETURN_NUMBERS_EXTENDED if F.is_extended else E.RETURN_NUMBERS)[s])
+    assert np.array_equal(col(A.NUMBER_OF_RETURNS), (E.NUMBER_OF_RETURNS_EXTENDED if F.is_extended else E.NUMBER_OF_RETURNS)[s])
+    if F.is_extended:
+        assert np.array_equal(col(A.CLASSIFICATION_FLAGS), E.CLASSIFICATION_FLAGS[s])
+        assert np.array_equal(col(A.SCANNER_CHANNEL), E.SCANNER_CHANNELS[s])
+    assert np.array_equal(col(A.SCAN_DIRECTION_FLAG), E.SCAN_DIRECTION_FLAGS[s])
+    assert np.array_equal(col(A.EDGE_OF_FLIGHT_LINE), E.EDGE_OF_FLIGHT_LINES[s])
+    assert np.array_equal(col(A.CLASSIFICATION), E.CLASSIFICATIONS[s])
+    if F.is_extended:
+        assert np.array_equal(col(A.SCAN_ANGLE), E.SCAN_ANGLES_EXTENDED[s])
+    else:
+        assert np.array_equal(col(A.SCAN_ANGLE_RANK), E.SCAN_ANGLE_RANKS[s])
+    assert np.array_equal(col(A.USER_DATA), E.USER_DATA[s])
+    assert np.array_equal(col(A.POINT_SOURCE_ID), E.POINT_SOURCE_IDS[s])
+    if F.has_gps_time:
+        assert np.array_equal(col(A.GPS_TIME), E.GPS_TIMES[s])
+    if F.has_color:
+        assert np.array_equal(col(A.COLOR_RGB), E.COLORS[s])
+    if F.has_nir:
+        assert np.array_equal(col(A.NIR), E.NIRS[s])
+    if F.has_waveform:
+        assert np.array_equal(col(A.WAVE_PACKET_DESCRIPTOR_INDEX), E.WAVEPACKET_INDEX[s])
+        assert np.array_equal(col(A.WAVEFORM_DATA_OFFSET), E.WAVEPACKET_OFFSET[s])
+        assert np.array_equal(col(A.WAVEFORM_PACKET_SIZE), E.WAVEPACKET_SIZE[s])
+        assert np.array_equal(col(A.RETURN_POINT_WAVEFORM_LOCATION), E.WAVEPACKET_LOCATION[s])
+        assert np.array_equal(col(A.WAVEFORM_PARAMETERS), E.WAVEPACKET_PARAMETERS[s])
+
+
+@pytest.mark.parametrize("fmt", range(11))
+@pytest.mark.parametrize("target_kind", ["V", "H"])
+def test_read_into_default_layout(api, fmt, target_kind):
+    """raw_readers.rs test macro: read into the format's default (typed) layout, interleaved and columnar targets."""
+    f, raw_layout = load(fmt, api)
+    target_layout = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+    scratch = VectorBuffer.from_numpy(f.records, raw_layout)  # the reader's scratch buffer (:309-322)
+    conv = las.get_default_las_converter(raw_layout, target_layout, f.scale, f.offset)
+    target = BUFFER_KINDS[target_kind].new_from_layout(target_layout)
+    target.resize(10)
+    conv.convert_into_range(scratch, range(0, 10), target, range(0, 10))
+    check_against_reference_data(target, fmt)
+
+
+@pytest.mark.parametrize("fmt", [0, 3, 6, 10])
+def test_read_in_two_chunks(api, fmt):
+    """Chunked read (:333-349): two convert_into_range calls of 5 points into target ranges 0..5 and 5..10."""
+    f, raw_layout = load(fmt, api)
+    target_layout = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+    conv = las.get_default_las_converter(raw_layout, target_layout, f.scale, f.offset)
+    target = HashMapBuffer.new_from_layout(target_layout)
+    target.resize(10)
+    for c in range(2):
+        scratch = VectorBuffer.from_numpy(f.records[5 * c:5 * c + 5], raw_layout)
+        conv.convert_into_range(scratch, range(0, 5), target, range(5 * c, 5 * c + 5))
+    check_against_reference_data(target, fmt)
+
+
+@pytest.mark.parametrize("fmt", [0, 2, 7])
+@pytest.mark.parametrize("target_kind", ["V", "H"])
+def test_read_into_different_layout(api, fmt, target_kind):
+    """raw_readers.rs:820-905: positions as Vec3f32, classification as u32, colour as Vec3u8 (wraps), unmapped -> zero."""
+    f, raw_layout = load(fmt, api)
+    pos32 = A.POSITION_3D.with_custom_datatype(T.Vec3f32)
+    cls32 = A.CLASSIFICATION.with_custom_datatype(T.U32)
+    col8 = A.COLOR_RGB.with_custom_datatype(T.Vec3u8)
+    target_layout = PointLayout.from_attributes([pos32, cls32, col8, A.POINT_SOURCE_ID, A.WAVEFORM_PARAMETERS], api=api)
+    conv = las.get_default_las_converter(raw_layout, target_layout, f.scale, f.offset)
+    scratch = VectorBuffer.from_numpy(f.records, raw_layout)
+    target = BUFFER_KINDS[target_kind].new_from_layout(target_layout)
+    target.resize(10)
+    conv.convert_into(scratch, target)
+    assert np.array_equal(target.view_attribute(pos32), E.POSITIONS.astype(np.float32))
+    assert np.array_equal(target.view_attribute(cls32), E.CLASSIFICATIONS.astype(np.uint32))
+    exp_col = (E.COLORS & 255).astype(np.uint8) if las.Format(fmt).has_color else np.zeros((10, 3), np.uint8)
+    assert np.array_equal(target.view_attribute(col8), exp_col)
+    assert np.array_equal(target.view_attribute(A.POINT_SOURCE_ID), E.POINT_SOURCE_IDS)
+    assert not target.view_attribute(A.WAVEFORM_PARAMETERS).any()
+
+
+def test_fixture_bounds(api):
+    """test_util.rs:46-48: bounds of the fixture = [0,9]^3 (calculate_bounds on the converted buffer)."""
+    from pasture_amd.algorithms import calculate_bounds
+    f, raw_layout = load(0, api)
+    target_layout = las.point_layout_from_las_point_format(las.Format(0), False, api=api)
+    conv = las.get_default_las_converter(raw_layout, target_layout, f.scale, f.offset)
+    out = conv.convert(VectorBuffer.from_numpy(f.records, raw_layout), HashMapBuffer)
+    b = calculate_bounds(out)
+    assert (b.min(), b.max()) == E.BOUNDS
+
+
+def test_las_mapping_table(api):
+    """Appendix A: the 10 mappings of raw LAS-0 -> LasPointFormat0 (defaults in target order, customs replace/append)."""
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=api)
+    tgt = las.point_layout_from_las_point_format(las.Format(0), False, api=api)
+    conv = las.get_default_las_converter(raw, tgt, (0.001, 0.001, 0.001), (1.0, 2.0, 3.0))
+    got = [(m.source.name(), m.target.name(), m.has_converter, m.transform_kind != 0, m.apply_to_source) for m in conv.mappings()]
+    assert got == [("Intensity", "Intensity", False, False, False), ("Classification", "Classification", False, False, False),
+                   ("ScanAngleRank", "ScanAngleRank", False, False, False), ("UserData", "UserData", False, False, False),
+                   ("PointSourceID", "PointSourceID", False, False, False), ("LASLocalPosition", "Position3D", True, True, False),
+                   ("LASBasicFlags", "ReturnNumber", False, True, True), ("LASBasicFlags", "NumberOfReturns", False, True, True),
+                   ("LASBasicFlags", "ScanDirectionFlag", False, True, True), ("LASBasicFlags", "EdgeOfFlightLine", False, True, True)]
