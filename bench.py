@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on N GPUs of one node (one process per GPU).
+
+A "step" is one pass of the hot path over one batch of synthetic points already resident in HBM:
+
+  default workload `convert_affine_bounds` (BASELINE.json configs[1], the configuration the metric is quoted on):
+      10^8 points per GPU, columnar (HashMapBuffer) POSITION_3D Vec3f64
+      -> BufferLayoutConverter with the LAS affine transformation (p*scale)+offset -> columnar POSITION_3D
+      + calculate_bounds of the result, fused into ONE pass over HBM (24 B read + 24 B written per point).
+      N > 1: points shard by index range (weak scaling: 10^8 per GPU); the only exchange is one all-reduce (RCCL) of
+      the 6-double AABB record per step.
+  other workloads (`--workload`): bounds (AABB only, 24 B/pt), las0_to_columns (configs[2]: 35 B interleaved LAS-0 ->
+      10 columns, 70 B/pt), rawlas_to_columns (20 B raw records -> 10 columns with i32->f64 affine + bit fields, 55 B/pt).
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline` objects.
+The CPU baseline is the oracle (oracle/: faithful-shape single-thread restatement of the reference's Rust loops — the
+reference itself cannot be built offline) timed on the GPU box's host, rank 0, N = 1 only, on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+SCALE, OFFSET = (0.001, 0.001, 0.001), (500000.0, 5400000.0, 100.0)
+SEED = 42
+
+WORKLOADS = {
+    # name: (algorithmic bytes per point, description)
+    "convert_affine_bounds": (48, "SoA POSITION_3D f64 affine layout-conversion + AABB, fused (24 R + 24 W)"),
+    "bounds": (24, "SoA POSITION_3D f64 AABB (24 R)"),
+    "las0_to_columns": (70, "AoS LAS format-0 (35 B, 10 attrs, packed) -> 10 SoA columns (35 R + 35 W)"),
+    "rawlas_to_columns": (55, "raw LAS-0 records (20 B) -> 10 SoA columns, i32->f64 affine + bit fields (20 R + 35 W)"),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    p.add_argument("--workload", default="convert_affine_bounds", choices=sorted(WORKLOADS))
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-points", type=int, default=10_000_000)
+    return p.parse_args()
+
+
+def cpu_baseline(workload, sample_points):
+    """Oracle timed on one pinned host core.  Only the checker lives under oracle/; it is never the thing shipped."""
+    from pasture_amd._capi import CApi  # binding class only
+    lib_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib_path):
+        return None
+    lib = ctypes.CDLL(lib_path)
+    aff = None
+    try:
+        aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(aff)[0]})
+    except Exception:
+        pass
+    try:
+        reps = 5
+        secs = (ctypes.c_double * reps)()
+        bounds = (ctypes.c_double * 6)()
+        sc, of = (ctypes.c_double * 3)(*SCALE), (ctypes.c_double * 3)(*OFFSET)
+        lib.orc_bench_config2.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.orc_bench_config1.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        t0 = time.time()
+        rc = lib.orc_bench_config2(sample_points, reps, SEED, sc, of, secs, bounds)
+        if rc != 0:
+            return None
+        med = statistics.median(list(secs))
+        out = {
+            "value": round(sample_points / med / 1e6, 3), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_points} of the same synthetic points, same workload (columnar POSITION_3D affine convert + calculate_bounds), "
+                      f"median of {reps} runs, single thread pinned to one core; oracle = faithful-shape C++ restatement of the Rust "
+                      f"reference (g++ -O3 -march=x86-64-v2), the reference itself is not buildable offline",
+            "effective_GBps": round(48 * sample_points / med / 1e9, 3),
+            "bounds": list(bounds),
+        }
+        # BASELINE.json configs[0] exactly: 10^6 XYZ f64 points VectorBuffer -> HashMapBuffer + calculate_bounds, median of 10
+        reps1 = 10
+        secs1 = (ctypes.c_double * reps1)()
+        if lib.orc_bench_config1(1_000_000, reps1, SEED, secs1, bounds) == 0:
+            out["config0_1e6_aos_to_soa_plus_bounds_Mpoints_per_s"] = round(1.0 / statistics.median(list(secs1)), 3)
+        out["wall_s"] = round(time.time() - t0, 2)
+        try:
+            with open("/proc/cpuinfo") as f:
+                models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+            out["host_cpu"] = models[0] if models else "unknown"
+            out["host_logical_cores"] = os.cpu_count()
+        except Exception:
+            pass
+        return out
+    finally:
+        if aff is not None:
+            try:
+                os.sched_setaffinity(0, aff)
+            except Exception:
+                pass
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU: pasture_amd has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import pasture_amd as pa
+    from pasture_amd import las
+    from pasture_amd.distributed import allreduce_bounds_record, bounds_from_record
+    from pasture_amd.layout import PointAttributeDataType as T, attributes as A
+
+    api = pa.product_api()
+    api.set_device(local_rank)
+    stream = torch.cuda.current_stream()
+    api.set_stream(ctypes.c_void_p(stream.cuda_stream))  # kernels run on torch's current stream => torch events see them
+
+    n = args.points
+    first_index = rank * n  # weak scaling: every rank owns its own index range of one global synthetic cloud
+    bytes_per_point, desc = WORKLOADS[args.workload]
+    rec = torch.empty(6, dtype=torch.float64, device="cuda")
+
+    if args.workload in ("convert_affine_bounds", "bounds"):
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        if args.workload == "convert_affine_bounds":
+            dst = pa.HashMapBuffer.new_from_layout(layout)
+            dst.resize(n)
+            conv = pa.BufferLayoutConverter.for_layouts(layout, layout)
+            conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, pa.Transform.affine(T.Vec3f64, SCALE, OFFSET), False)
+
+            def step():
+                conv.convert_into_with_bounds_async(src, dst, rec.data_ptr())
+        else:
+            def step():
+                pa.calculate_bounds_async(src, rec.data_ptr())
+    else:
+        raw = args.workload == "rawlas_to_columns"
+        src_layout = las.point_layout_from_las_point_format(las.Format(0), raw)
+        dst_layout = las.point_layout_from_las_point_format(las.Format(0), False)
+        src = pa.VectorBuffer.new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.HashMapBuffer.new_from_layout(dst_layout)
+        dst.resize(n)
+        conv = las.get_default_las_converter(src_layout, dst_layout, SCALE, OFFSET) if raw else \
+            pa.BufferLayoutConverter.for_layouts(src_layout, dst_layout)
+
+        def step():
+            conv.convert_into_with_bounds_async(src, dst, rec.data_ptr())
+
+    def full_step():
+        step()
+        if distributed:
+            allreduce_bounds_record(rec)  # ONE all-reduce of 6 doubles (RCCL over xGMI)
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+        if distributed:
+            allreduce_bounds_record(rec)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    if distributed:
+        t = torch.tensor([kernel_ms_avg], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms_avg = float(t.item())
+
+    result = bounds_from_record(rec.cpu())
+    if rank == 0:
+        total_points = n * world * args.steps
+        value = total_points / elapsed / 1e6
+        achieved = bytes_per_point * n / (kernel_ms_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath)).get(args.workload)
+                if t and t.get("points") == n:
+                    traffic = t.get("bytes_per_launch")
+            except Exception:
+                pass
+        line = {
+            "metric": "Mpoints/sec + achieved HBM GB/s (% of peak), 10^8-pt POSITION_3D convert+AABB",
+            "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": n * world,
+                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds") else "LAS format 0",
+                       "parallelism": f"index-range shard x{world}, one all-reduce of the 6-f64 AABB" if distributed else "1 GPU",
+                       "seed": SEED, "bounds": result},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_point": bytes_per_point, "kernel_ms_avg": round(kernel_ms_avg, 4),
+                         "kernel_ms_min": round(min(kernel_ms), 4),
+                         "note": "HIP events around the fused conversion+AABB launch (stream kernel + 1-block finalize) on the launch stream"},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "convert_affine_bounds":
+            cb = cpu_baseline(args.workload, args.cpu_sample_points)
+            if cb is not None:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

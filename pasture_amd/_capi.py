@@ -171,5 +171,12 @@ def product_api() -> CApi:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C pasture_amd/csrc`).  pasture_amd has no CPU fallback.")
+        # One process must hold ONE HIP runtime: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's), and the
+        # first one loaded serves both.  Importing torch first makes torch's runtime the shared instance, so torch streams,
+        # events and allocations are valid handles inside this library (and torch keeps seeing the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # the C ABI itself does not need torch
+            pass
         _product_api = CApi(C.CDLL(LIB_PATH), "pst", product=True)
     return _product_api

@@ -145,8 +145,8 @@ class BufferLayoutConverter:
         """convert_into_range + calculate_bounds(target range) in one pass over HBM.  Returns AABB or None."""
         from .algorithms import AABB
         n = source_buffer.len()
-        sr = source_range or range(0, n)
-        tr = target_range or range(0, n)
+        sr = range(0, n) if source_range is None else source_range  # NB: an empty range is falsy
+        tr = range(0, n) if target_range is None else target_range
         mn, mx, has = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int()
         self.api.converter_convert_into_range_with_bounds(self._h, source_buffer._h, sr.start, sr.stop, target_buffer._h, tr.start, tr.stop,
                                                           mn, mx, C.byref(has))
@@ -154,7 +154,7 @@ class BufferLayoutConverter:
 
     def convert_into_with_bounds_async(self, source_buffer, target_buffer, device_out6_ptr: int, source_range=None, target_range=None) -> None:
         n = source_buffer.len()
-        sr = source_range or range(0, n)
-        tr = target_range or range(0, n)
+        sr = range(0, n) if source_range is None else source_range  # NB: an empty range is falsy
+        tr = range(0, n) if target_range is None else target_range
         self.api.converter_convert_into_range_with_bounds_async(self._h, source_buffer._h, sr.start, sr.stop, target_buffer._h, tr.start,
                                                                 tr.stop, C.c_void_p(device_out6_ptr))
