@@ -22,9 +22,11 @@ void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* ou
   const uint64_t stride = b.columnar ? pm->size : b.layout.size;
   if (b.columnar && dt.kind == PST_VEC3F64 && base % 8 == 0) {
     // K1: coalesced 16-byte stream over the column
-    pstk::launch_vec3f64_stream((const double*)(uintptr_t)base, nullptr, count, nullptr, nullptr, 4u, (double*)ws.dev, out6, stream);
+    pstk::launch_vec3f64_stream((const double*)(uintptr_t)base, nullptr, count, nullptr, nullptr, 4u,
+                                (double*)ws.partials(pstk::stream_partials_bytes(count, 4u)), out6, stream);
   } else {
-    pstk::launch_minmax((const uint8_t*)(uintptr_t)base, stride, count, dt.comp_type(), 3, /*acc_f64=*/true, ws.dev, out6, stream);
+    pstk::launch_minmax((const uint8_t*)(uintptr_t)base, stride, count, dt.comp_type(), 3, /*acc_f64=*/true,
+                        ws.partials(pstk::minmax_partials_bytes()), out6, stream);
   }
   PST_HIP_CHECK(hipGetLastError());
 }
@@ -89,7 +91,8 @@ int pst_minmax_attribute(const pst_buffer* b, const char* name, const pst_dataty
   const uint32_t ncomp = def.datatype.num_components();
   const size_t csize = m.size / ncomp;
   uint8_t* dev_rec = ws.dev + Workspace::kWorkspaceBytes - 64;  // 2 * ncomp * csize <= 48 bytes
-  pstk::launch_minmax((const uint8_t*)(uintptr_t)base, stride, b->len, def.datatype.comp_type(), ncomp, /*acc_f64=*/false, ws.dev, dev_rec, s);
+  pstk::launch_minmax((const uint8_t*)(uintptr_t)base, stride, b->len, def.datatype.comp_type(), ncomp, /*acc_f64=*/false,
+                      ws.partials(pstk::minmax_partials_bytes()), dev_rec, s);
   PST_HIP_CHECK(hipGetLastError());
   // record {min.., max..} + the FIRST value: a NaN first value seeds (NaN, NaN) and sticks (minmax.rs:30, math/minmax.rs:78-94)
   PST_HIP_CHECK(hipMemcpyAsync(ws.pinned, dev_rec, 2 * m.size, hipMemcpyDeviceToHost, s));
@@ -143,7 +146,7 @@ int pst_transform_attribute(pst_buffer* b, const char* name, const pst_datatype*
     if (k == PST_VEC3F64 && xf->kind == PST_XF_AFFINE && e.src_col % 8 == 0) {
       Workspace& ws = workspace();
       pstk::launch_vec3f64_stream((const double*)(uintptr_t)e.src_col, (double*)(uintptr_t)e.dst_col, b->len, e.scale, e.offset, 3u,
-                                  (double*)ws.dev, nullptr, s);
+                                  (double*)ws.partials(pstk::stream_partials_bytes(b->len, 3u)), nullptr, s);
     } else {
       execute_entries(false, 0, 0, false, 0, 0, b->len, {e}, false, s);
     }

@@ -34,6 +34,18 @@ Workspace& workspace() {
   return ws;
 }
 
+uint8_t* Workspace::partials(size_t bytes) {
+  if (bytes > partials_cap) {
+    if (partials_buf) (void)hipFree(partials_buf);  // implicit device synchronisation: nothing in flight uses it afterwards
+    partials_buf = nullptr;
+    partials_cap = 0;
+    const size_t want = std::max<size_t>(bytes, 8u << 20);
+    PST_HIP_CHECK(hipMalloc((void**)&partials_buf, want));
+    partials_cap = want;
+  }
+  return partials_buf;
+}
+
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind) {
   if (bytes == 0) return nullptr;
   ensure_device();

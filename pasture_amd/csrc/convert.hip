@@ -9,15 +9,20 @@
 // Two bodies:
 //  * convert_tile_kernel  — interleaved records are staged through LDS tiles with 16-byte coalesced global accesses;
 //    attributes are then picked out of / assembled in LDS at byte granularity (packed(1) layouts have no alignment).
+//    The columnar side is accessed in chunks of >= 4 bytes per lane (four u8 / two u16 values are packed into one
+//    dword), so a wave always moves >= 256 contiguous bytes per column instruction.
 //  * convert_direct_kernel — no LDS; flat per-component global accesses.  Used for columnar<->columnar (already
 //    coalesced: consecutive lanes touch consecutive components) and as the universal fall-back (huge records,
 //    in-place transform_attribute on interleaved buffers).
+// Entries flagged `.bounds` fold the Vec3f64 values they write into a per-block AABB record (fused calculate_bounds).
 //
 // HBM-bound integer/byte work: no MFMA.  Compiled with -ffp-contract=off (affine = two roundings).
 #include "device_common.hpp"
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstddef>
+#include <cstdlib>
 #include <mutex>
 
 using namespace pstd;
@@ -26,7 +31,6 @@ namespace {
 
 __device__ __forceinline__ uint32_t round_up16(uint32_t v) { return (v + 15u) & ~15u; }
 
-// One component: load S, optional pre-transform, `as` D, optional post-transform, store D.
 struct XfRegs {  // transformation parameters held in (scalar) registers for the duration of one mapping
   uint32_t kind, pre, shift;
   uint64_t mask;
@@ -39,14 +43,31 @@ __device__ __forceinline__ XfRegs load_xf(const PlanEntry& e) {
   x.o0 = e.offset[0]; x.o1 = e.offset[1]; x.o2 = e.offset[2];
   return x;
 }
-template <typename S, typename D, typename SP, typename DP>
-__device__ __forceinline__ void convert_component(SP sp, DP dp, uint32_t kind, uint32_t pre, double sc, double of, uint32_t shift,
-                                                  uint64_t mask) {
-  S v = load_un<S>(sp);
-  if (kind != 0 && pre != 0) v = apply_xf<S>(v, kind, sc, of, shift, mask);
+
+// per-thread AABB accumulators of the launch (only touched by `.bounds` entries)
+struct BoundsAcc {
+  double mn0, mn1, mn2, mx0, mx1, mx2;
+  __device__ __forceinline__ void init() { mn0 = mn1 = mn2 = kF64Max; mx0 = mx1 = mx2 = -kF64Max; }
+  __device__ __forceinline__ void fold2(uint32_t c, double lo, double hi) {
+    mn0 = __builtin_fmin(mn0, c == 0 ? lo : kF64Max);  mx0 = __builtin_fmax(mx0, c == 0 ? hi : -kF64Max);
+    mn1 = __builtin_fmin(mn1, c == 1 ? lo : kF64Max);  mx1 = __builtin_fmax(mx1, c == 1 ? hi : -kF64Max);
+    mn2 = __builtin_fmin(mn2, c == 2 ? lo : kF64Max);  mx2 = __builtin_fmax(mx2, c == 2 ? hi : -kF64Max);
+  }
+  __device__ __forceinline__ void fold(uint32_t c, double v) {
+    mn0 = __builtin_fmin(mn0, c == 0 ? v : kF64Max);  mx0 = __builtin_fmax(mx0, c == 0 ? v : -kF64Max);
+    mn1 = __builtin_fmin(mn1, c == 1 ? v : kF64Max);  mx1 = __builtin_fmax(mx1, c == 1 ? v : -kF64Max);
+    mn2 = __builtin_fmin(mn2, c == 2 ? v : kF64Max);  mx2 = __builtin_fmax(mx2, c == 2 ? v : -kF64Max);
+  }
+};
+
+// One value: optional pre-transform, `as` D, optional post-transform (buffer_conversion.rs:446-456)
+template <typename S, typename D>
+__device__ __forceinline__ D convert_value(S v, const XfRegs& x, uint32_t c) {
+  const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
+  if (x.kind != 0 && x.pre != 0) v = apply_xf<S>(v, x.kind, sc, of, x.shift, x.mask);
   D w = rust_as<D, S>(v);
-  if (kind != 0 && pre == 0) w = apply_xf<D>(w, kind, sc, of, shift, mask);
-  store_un<D>(dp, w);
+  if (x.kind != 0 && x.pre == 0) w = apply_xf<D>(w, x.kind, sc, of, x.shift, x.mask);
+  return w;
 }
 
 // Split a flat component index into (point, component).
@@ -72,11 +93,27 @@ __device__ __forceinline__ PlanEntry fetch_entry(const PlanEntry* entries, uint3
   return e;
 }
 
+template <typename T> struct ChunkOf { static constexpr uint32_t value = sizeof(T) >= 4 ? 1u : 4u / (uint32_t)sizeof(T); };
+
+// block-level write-out of the fused AABB record
+template <int BLK>
+__device__ __forceinline__ void flush_bounds(BoundsAcc& acc, uint64_t partials_addr) {
+  if (partials_addr == 0) return;
+  __shared__ double scratch[(BLK / 64) * 6];
+  double mn[3] = {acc.mn0, acc.mn1, acc.mn2}, mx[3] = {acc.mx0, acc.mx1, acc.mx2};
+  block_reduce_minmax<double, 3, BLK>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+    double* out = (double*)partials_addr + (uint64_t)blockIdx.x * 6;
+    out[0] = mn[0]; out[1] = mn[1]; out[2] = mn[2];
+    out[3] = mx[0]; out[4] = mx[1]; out[5] = mx[2];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // direct kernel
 // ------------------------------------------------------------------------------------------------------
 template <bool SRC_AOS, bool DST_AOS, typename S, typename D>
-__device__ __forceinline__ void run_direct(const ConvertHeader& h, const PlanEntry& e) {
+__device__ __forceinline__ void run_direct(const ConvertHeader& h, const PlanEntry& e, BoundsAcc& acc) {
   const uint64_t total = h.n * e.ncomp;
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   const XfRegs x = load_xf(e);
@@ -90,23 +127,30 @@ __device__ __forceinline__ void run_direct(const ConvertHeader& h, const PlanEnt
     else sp = as_global(e.src_col) + k * sizeof(S);
     if constexpr (DST_AOS) dp = as_global(h.dst_aos) + p * h.dst_stride + e.dst_off + c * sizeof(D);
     else dp = as_global(e.dst_col) + k * sizeof(D);
-    convert_component<S, D>(sp, dp, x.kind, x.pre, pick3(c, x.s0, x.s1, x.s2), pick3(c, x.o0, x.o1, x.o2), x.shift, x.mask);
+    const D w = convert_value<S, D>(load_un<S>(sp), x, c);
+    store_un<D>(dp, w);
+    if constexpr (std::is_same<D, double>::value) {
+      if (e.bounds) acc.fold(c, w);
+    }
   }
 }
 
 template <bool SRC_AOS, bool DST_AOS>
 __global__ __launch_bounds__(kBlock) void convert_direct_kernel(const ConvertHeader h, const PlanEntry* __restrict__ entries) {
+  BoundsAcc acc;
+  acc.init();
   for (uint32_t m = 0; m < h.n_entries; ++m) {
     const PlanEntry e = fetch_entry(entries, m);
     dispatch_ct(e.src_ct, [&](auto s) __attribute__((always_inline)) {
       using S = decltype(s);
       if (!e.convert) {
-        run_direct<SRC_AOS, DST_AOS, S, S>(h, e);
+        run_direct<SRC_AOS, DST_AOS, S, S>(h, e, acc);
       } else {
-        dispatch_ct(e.dst_ct, [&](auto d) __attribute__((always_inline)) { run_direct<SRC_AOS, DST_AOS, S, decltype(d)>(h, e); });
+        dispatch_ct(e.dst_ct, [&](auto d) __attribute__((always_inline)) { run_direct<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, acc); });
       }
     });
   }
+  flush_bounds<kBlock>(acc, h.bounds_partials);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -118,22 +162,30 @@ typedef const PST_AS_GLOBAL u32x4* cg4ptr_t;
 typedef PST_AS_LDS u32x4* l4ptr_t;
 typedef const PST_AS_LDS u32x4* cl4ptr_t;
 
-// Coalesced global -> LDS copy of the 16-byte aligned span [gbase, gbase + nbytes16).
+// Coalesced global -> LDS copy of the 16-byte aligned span [gbase, gbase + nbytes16) with LDS-DMA
+// (`global_load_lds_dwordx4`, gfx950): every lane names its own 16 global bytes, the wave's 1 KiB lands at the
+// wave-uniform LDS base + lane*16 without a VGPR round trip, so all of a wave's loads are in flight at once.
+// Completion is tracked by vmcnt: callers must `s_waitcnt vmcnt(0)` before the barrier that publishes the tile.
+template <int BLK>
 __device__ __forceinline__ void tile_load(lptr_t lds, cgptr_t gbase, uint32_t nbytes16) {
-  cg4ptr_t g = reinterpret_cast<cg4ptr_t>(gbase);
-  l4ptr_t l = reinterpret_cast<l4ptr_t>(lds);
   const uint32_t nvec = nbytes16 >> 4;
-  for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) l[i] = g[i];
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i = threadIdx.x; i < nvec; i += BLK) {
+    __builtin_amdgcn_global_load_lds((const PST_AS_GLOBAL void*)(gbase + (uint64_t)i * 16), (PST_AS_LDS void*)(lds + (i - lane) * 16u), 16, 0, 0);
+  }
 }
+__device__ __forceinline__ void wait_tile_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // LDS -> global copy of the bytes [mis, mis + nbytes) of the staged span; 16-byte stores for whole chunks, byte stores
 // on the two ragged edges so that no byte outside the target range is ever written.
+template <int BLK>
 __device__ __forceinline__ void tile_store(clptr_t lds, gptr_t gbase, uint32_t mis, uint32_t nbytes) {
   const uint32_t end = mis + nbytes;
   const uint32_t nvec = (end + 15u) >> 4;
-  for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) {
+  for (uint32_t i = threadIdx.x; i < nvec; i += BLK) {
     const uint32_t b0 = i << 4, b1 = b0 + 16;
     if (b0 >= mis && b1 <= end) {
-      reinterpret_cast<g4ptr_t>(gbase)[i] = reinterpret_cast<cl4ptr_t>(lds)[i];
+      __builtin_nontemporal_store(reinterpret_cast<cl4ptr_t>(lds)[i], &reinterpret_cast<g4ptr_t>(gbase)[i]);
     } else {
       const uint32_t lo = b0 > mis ? b0 : mis, hi = b1 < end ? b1 : end;
       for (uint32_t b = lo; b < hi; ++b) gbase[b] = lds[b];
@@ -141,37 +193,156 @@ __device__ __forceinline__ void tile_store(clptr_t lds, gptr_t gbase, uint32_t m
   }
 }
 
-template <bool SRC_AOS, bool DST_AOS, typename S, typename D>
-__device__ __forceinline__ void run_tile(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint64_t first,
-                                         uint32_t cnt) {
+// Which lanes work on an entry: all BLK lanes of the block, or (small entries) the 64 lanes of the one wave that owns it.
+struct LaneSpan { uint32_t first, step; };
+
+// interleaved (LDS) -> columnar (global): each lane produces one >= 4-byte chunk of the column
+template <typename S, typename D>
+__device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, uint64_t first, uint32_t cnt,
+                                                   LaneSpan span, BoundsAcc& acc) {
+  constexpr uint32_t E = ChunkOf<D>::value;
   const uint32_t total = cnt * e.ncomp;
-  const uint64_t kbase = first * e.ncomp;
   const XfRegs x = load_xf(e);
-  for (uint32_t k = threadIdx.x; k < total; k += kBlock) {
-    uint32_t p, c;
-    split_comp32(k, e.ncomp, p, c);
-    const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
-    if constexpr (SRC_AOS && DST_AOS) {
-      convert_component<S, D>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S)),
-                              lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), x.kind, x.pre, sc, of, x.shift, x.mask);
-    } else if constexpr (SRC_AOS) {
-      convert_component<S, D>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S)),
-                              as_global(e.dst_col) + (kbase + k) * sizeof(D), x.kind, x.pre, sc, of, x.shift, x.mask);
+  gptr_t col = as_global(e.dst_col) + first * e.ncomp * sizeof(D);
+  if constexpr (std::is_same<D, double>::value) {
+    if (e.bounds && e.ncomp == 3) {
+      // Vec3f64 with fused AABB: a lane's q advances by `step` (a multiple of 3 x step after three iterations), so the
+      // component of "slot r" = (first + r*step) mod 3 is fixed; three rotating min/max pairs need no per-value selects.
+      double lo[3] = {kF64Max, kF64Max, kF64Max}, hi[3] = {-kF64Max, -kF64Max, -kF64Max};
+      for (uint32_t q = span.first; q < total; q += 3 * span.step) {
+#pragma unroll
+        for (uint32_t r = 0; r < 3; ++r) {
+          const uint32_t k = q + r * span.step;
+          if (k < total) {
+            const uint32_t p = k / 3, c = k - 3 * p;
+            const double w = convert_value<S, double>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+            store_un<double>(col + (uint64_t)k * 8, w);
+            lo[r] = __builtin_fmin(lo[r], w);
+            hi[r] = __builtin_fmax(hi[r], w);
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < 3; ++r) acc.fold2((span.first + r * span.step) % 3u, lo[r], hi[r]);
+      return;
+    }
+  }
+  for (uint32_t q = span.first; q * E < total; q += span.step) {
+    const uint32_t k0 = q * E;
+    D vals[E];
+#pragma unroll
+    for (uint32_t i = 0; i < E; ++i) {
+      const uint32_t k = k0 + i < total ? k0 + i : total - 1;  // clamp: a ragged tail recomputes the last value, never stores it
+      uint32_t p, c;
+      split_comp32(k, e.ncomp, p, c);
+      vals[i] = convert_value<S, D>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+      if constexpr (std::is_same<D, double>::value) {
+        if (e.bounds) acc.fold(c, vals[i]);
+      }
+    }
+    if constexpr (E == 1) {
+      store_un<D>(col + (uint64_t)k0 * sizeof(D), vals[0]);
     } else {
-      convert_component<S, D>((cgptr_t)(as_global(e.src_col) + (kbase + k) * sizeof(S)),
-                              lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), x.kind, x.pre, sc, of, x.shift, x.mask);
+      if (k0 + E <= total) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) {
+          typename std::make_unsigned<D>::type u;
+          __builtin_memcpy(&u, &vals[i], sizeof(D));
+          packed |= (uint32_t)u << (8u * (uint32_t)sizeof(D) * i);
+        }
+        store_un<uint32_t>(col + (uint64_t)k0 * sizeof(D), packed);
+      } else {
+        for (uint32_t i = 0; k0 + i < total; ++i) store_un<D>(col + (uint64_t)(k0 + i) * sizeof(D), vals[i]);
+      }
     }
   }
 }
 
-template <bool SRC_AOS, bool DST_AOS>
-__global__ __launch_bounds__(kBlock) void convert_tile_kernel(const ConvertHeader h, const PlanEntry* __restrict__ entries) {
+// columnar (global) -> interleaved (LDS): each lane consumes one >= 4-byte chunk of the column
+template <typename S, typename D>
+__device__ __forceinline__ void run_tile_from_column(const ConvertHeader& h, const PlanEntry& e, lptr_t lds_dst, uint64_t first, uint32_t cnt,
+                                                     LaneSpan span, BoundsAcc& acc) {
+  constexpr uint32_t E = ChunkOf<S>::value;
+  const uint32_t total = cnt * e.ncomp;
+  const XfRegs x = load_xf(e);
+  cgptr_t col = as_global(e.src_col) + first * e.ncomp * sizeof(S);
+  for (uint32_t q = span.first; q * E < total; q += span.step) {
+    const uint32_t k0 = q * E;
+    S vals[E];
+    if constexpr (E == 1) {
+      vals[0] = load_un<S>(col + (uint64_t)k0 * sizeof(S));
+    } else {
+      if (k0 + E <= total) {
+        const uint32_t packed = load_un<uint32_t>(col + (uint64_t)k0 * sizeof(S));
+#pragma unroll
+        for (uint32_t i = 0; i < E; ++i) {
+          typename std::make_unsigned<S>::type u = (typename std::make_unsigned<S>::type)(packed >> (8u * (uint32_t)sizeof(S) * i));
+          __builtin_memcpy(&vals[i], &u, sizeof(S));
+        }
+      } else {
+        for (uint32_t i = 0; i < E; ++i) vals[i] = k0 + i < total ? load_un<S>(col + (uint64_t)(k0 + i) * sizeof(S)) : S{};
+      }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < E; ++i) {
+      if (k0 + i < total) {
+        uint32_t p, c;
+        split_comp32(k0 + i, e.ncomp, p, c);
+        const D w = convert_value<S, D>(vals[i], x, c);
+        store_un<D>(lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), w);
+        if constexpr (std::is_same<D, double>::value) {
+          if (e.bounds) acc.fold(c, w);
+        }
+      }
+    }
+  }
+}
+
+// interleaved (LDS) -> interleaved (LDS)
+template <typename S, typename D>
+__device__ __forceinline__ void run_tile_lds_to_lds(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint32_t cnt,
+                                                    LaneSpan span, BoundsAcc& acc) {
+  const uint32_t total = cnt * e.ncomp;
+  const XfRegs x = load_xf(e);
+  for (uint32_t k = span.first; k < total; k += span.step) {
+    uint32_t p, c;
+    split_comp32(k, e.ncomp, p, c);
+    const D w = convert_value<S, D>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+    store_un<D>(lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), w);
+    if constexpr (std::is_same<D, double>::value) {
+      if (e.bounds) acc.fold(c, w);
+    }
+  }
+}
+
+template <bool SRC_AOS, bool DST_AOS, typename S, typename D>
+__device__ __forceinline__ void run_tile(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint64_t first,
+                                         uint32_t cnt, LaneSpan span, BoundsAcc& acc) {
+  if constexpr (SRC_AOS && DST_AOS) run_tile_lds_to_lds<S, D>(h, e, lds_src, lds_dst, cnt, span, acc);
+  else if constexpr (SRC_AOS) run_tile_to_column<S, D>(h, e, lds_src, first, cnt, span, acc);
+  else run_tile_from_column<S, D>(h, e, lds_dst, first, cnt, span, acc);
+}
+
+// Entry scheduling inside a block.  Interpreting an entry (scalar fetch, type dispatch, loop set-up) costs every wave
+// that touches it a few hundred issue slots, whatever the entry's size.  Wide attributes are processed by all waves of
+// the block; narrow ones (<= 4 bytes per point on the columnar side) are each OWNED by one wave, which sweeps the whole
+// tile for that attribute.  The host stores, after the entries, masks[0] = entries handled by every wave and
+// masks[1 + w] = entries owned by wave w (w < 16).
+template <int BLK, bool SRC_AOS, bool DST_AOS>
+__global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h, const PlanEntry* __restrict__ entries) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   lptr_t lds = (lptr_t)lds_raw;
   const uint32_t T = h.tile;
   const uint32_t src_cap = SRC_AOS ? round_up16(T * h.src_stride + 32u) : 0u;
   lptr_t lds_s = lds;
   lptr_t lds_d = lds + src_cap;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const PST_AS_CONST uint32_t* masks = (const PST_AS_CONST uint32_t*)(entries + PST_PLAN_MAX_ENTRIES);
+  const uint32_t mask_all = masks[0];
+  const uint32_t mask_own = masks[1 + (wave & 15u)];
+  BoundsAcc acc;
+  acc.init();
   const uint64_t n_tiles = (h.n + T - 1) / T;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * T;
@@ -181,35 +352,40 @@ __global__ __launch_bounds__(kBlock) void convert_tile_kernel(const ConvertHeade
     if constexpr (SRC_AOS) {
       const uint64_t ga = h.src_aos + first * h.src_stride;
       s_mis = (uint32_t)(ga & 15u);
-      tile_load(lds_s, as_global(ga - s_mis), round_up16(s_mis + cnt * h.src_stride));
+      tile_load<BLK>(lds_s, as_global(ga - s_mis), round_up16(s_mis + cnt * h.src_stride));
     }
     if constexpr (DST_AOS) {
       const uint64_t ga = h.dst_aos + first * h.dst_stride;
       d_mis = (uint32_t)(ga & 15u);
       g_dst = as_global(ga - d_mis);
       // record bytes no mapping writes (unmapped attributes, padding) must survive: read-modify-write the tile
-      if (!h.dst_fully_covered) tile_load(lds_d, g_dst, round_up16(d_mis + cnt * h.dst_stride));
+      if (!h.dst_fully_covered) tile_load<BLK>(lds_d, g_dst, round_up16(d_mis + cnt * h.dst_stride));
     }
+    wait_tile_loads();
     __syncthreads();
-    for (uint32_t m = 0; m < h.n_entries; ++m) {
+    for (uint32_t bits = mask_all | mask_own; bits != 0; bits &= bits - 1) {
+      const uint32_t m = (uint32_t)__builtin_ctz(bits);
+      const bool shared_entry = (mask_all >> m) & 1u;
+      const LaneSpan span = shared_entry ? LaneSpan{threadIdx.x, (uint32_t)BLK} : LaneSpan{lane, 64u};
       const PlanEntry e = fetch_entry(entries, m);
       dispatch_ct(e.src_ct, [&](auto s) __attribute__((always_inline)) {
         using S = decltype(s);
         if (!e.convert) {
-          run_tile<SRC_AOS, DST_AOS, S, S>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt);
+          run_tile<SRC_AOS, DST_AOS, S, S>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt, span, acc);
         } else {
           dispatch_ct(e.dst_ct, [&](auto d) __attribute__((always_inline)) {
-            run_tile<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt);
+            run_tile<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt, span, acc);
           });
         }
       });
     }
     __syncthreads();
     if constexpr (DST_AOS) {
-      tile_store(lds_d, g_dst, d_mis, cnt * h.dst_stride);
+      tile_store<BLK>(lds_d, g_dst, d_mis, cnt * h.dst_stride);
       __syncthreads();
     }
   }
+  flush_bounds<BLK>(acc, h.bounds_partials);
 }
 
 }  // namespace
@@ -228,21 +404,51 @@ int device_cus() {
   return cus;
 }
 
+static long env_long(const char* name, long dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::strtol(v, nullptr, 10) : dflt;
+}
+
 // Plan entries are uploaded into a small ring of device slots; hipMemcpyAsync from pageable host memory stages the
 // bytes before returning, so the caller's ConvertPlan may die immediately.  Slot reuse is stream-ordered for the
 // common single-stream case and 256 launches deep otherwise.
 static const PlanEntry* upload_entries(const ConvertPlan& plan, hipStream_t stream) {
   constexpr int kSlots = 256;
-  static PlanEntry* ring = nullptr;
+  static uint8_t* ring = nullptr;
   static unsigned next = 0;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  constexpr size_t kSlotBytes = sizeof(plan.e) + sizeof(plan.masks);  // entries immediately followed by the wave masks
+  static_assert(offsetof(ConvertPlan, masks) == offsetof(ConvertPlan, e) + sizeof(plan.e), "masks must follow the entries");
   if (!ring) {
-    if (hipMalloc((void**)&ring, sizeof(PlanEntry) * PST_PLAN_MAX_ENTRIES * kSlots) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&ring, kSlotBytes * kSlots) != hipSuccess) return nullptr;
   }
-  PlanEntry* slot = ring + (size_t)(next++ % kSlots) * PST_PLAN_MAX_ENTRIES;
-  if (hipMemcpyAsync(slot, plan.e, sizeof(PlanEntry) * plan.h.n_entries, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
-  return slot;
+  uint8_t* slot = ring + (size_t)(next++ % kSlots) * kSlotBytes;
+  if (hipMemcpyAsync(slot, plan.e, kSlotBytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+  return (const PlanEntry*)slot;
+}
+
+static size_t tile_lds_bytes(const ConvertHeader& h, bool src_aos, bool dst_aos) {
+  size_t lds_bytes = 0;
+  if (src_aos) lds_bytes += ((size_t)h.tile * h.src_stride + 32 + 15) & ~(size_t)15;
+  if (dst_aos) lds_bytes += ((size_t)h.tile * h.dst_stride + 32 + 15) & ~(size_t)15;
+  return lds_bytes;
+}
+
+// grid of a conversion launch (the caller sizes the fused-bounds partials with it)
+unsigned convert_grid(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds) {
+  const ConvertHeader& h = plan.h;
+  const int cus = device_cus();
+  if (use_lds && (src_aos || dst_aos)) {
+    const uint64_t n_tiles = (h.n + h.tile - 1) / h.tile;
+    // one tile per block: staggered blocks keep HBM reads and writes interleaved (see stream.hip); cap for huge inputs
+    static const long cap = env_long("PST_TILE_GRID_CAP", 1 << 22);
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, (uint64_t)cap));
+  }
+  uint64_t max_comp = 1;
+  for (uint32_t m = 0; m < h.n_entries; ++m) max_comp = std::max<uint64_t>(max_comp, plan.e[m].ncomp);
+  const uint64_t work = h.n * max_comp;
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((work + kBlock - 1) / kBlock, (uint64_t)cus * 8));
 }
 
 bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream) {
@@ -250,33 +456,30 @@ bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool us
   if (h.n == 0 || h.n_entries == 0) return true;
   const PlanEntry* entries = upload_entries(plan, stream);
   if (!entries) return false;
-  const int cus = device_cus();
+  const unsigned grid = convert_grid(plan, src_aos, dst_aos, use_lds);
   if (use_lds && (src_aos || dst_aos)) {
-    const uint32_t T = h.tile;
-    const uint64_t n_tiles = (h.n + T - 1) / T;
-    size_t lds_bytes = 0;
-    if (src_aos) lds_bytes += ((size_t)T * h.src_stride + 32 + 15) & ~(size_t)15;
-    if (dst_aos) lds_bytes += ((size_t)T * h.dst_stride + 32 + 15) & ~(size_t)15;
-    // resident blocks per CU are LDS-limited (160 KiB / CU); a grid-stride loop covers the rest
-    const uint64_t per_cu = lds_bytes ? std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds_bytes)) : 8;
-    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, per_cu * cus);
-#define PST_LAUNCH_TILE(SA, DA)                                                                                \
+    const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
+    static const long blk = env_long("PST_TILE_BLOCK", 256);
+#define PST_LAUNCH_TILE_B(B, SA, DA)                                                                           \
   do {                                                                                                         \
-    auto kfn = convert_tile_kernel<SA, DA>;                                                                    \
+    auto kfn = convert_tile_kernel<B, SA, DA>;                                                                 \
     if (lds_bytes > 64 * 1024)                                                                                 \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kBlock), lds_bytes, stream, h, entries);                          \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(B), lds_bytes, stream, h, entries);                               \
+  } while (0)
+#define PST_LAUNCH_TILE(SA, DA)                                   \
+  do {                                                            \
+    if (blk == 512) PST_LAUNCH_TILE_B(512, SA, DA);               \
+    else if (blk == 1024) PST_LAUNCH_TILE_B(1024, SA, DA);        \
+    else PST_LAUNCH_TILE_B(256, SA, DA);                          \
   } while (0)
     if (src_aos && dst_aos) PST_LAUNCH_TILE(true, true);
     else if (src_aos) PST_LAUNCH_TILE(true, false);
     else PST_LAUNCH_TILE(false, true);
 #undef PST_LAUNCH_TILE
+#undef PST_LAUNCH_TILE_B
     return hipGetLastError() == hipSuccess;
   }
-  uint64_t max_comp = 1;
-  for (uint32_t m = 0; m < h.n_entries; ++m) max_comp = std::max<uint64_t>(max_comp, plan.e[m].ncomp);
-  const uint64_t work = h.n * max_comp;
-  const unsigned grid = (unsigned)std::min<uint64_t>((work + kBlock - 1) / kBlock, (uint64_t)cus * 8);
   if (src_aos && dst_aos) hipLaunchKernelGGL((convert_direct_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (src_aos) hipLaunchKernelGGL((convert_direct_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (dst_aos) hipLaunchKernelGGL((convert_direct_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);

@@ -1,5 +1,6 @@
 // BufferLayoutConverter on the device: mapping construction (host), plan flattening, kernel selection.
 // Reference: pasture-core/src/layout/conversion/buffer_conversion.rs:98-663 and attribute_conversion.rs:184-271.
+#include <cstdlib>
 #include <optional>
 
 #include "runtime.hpp"
@@ -82,23 +83,34 @@ static PlanEntry entry_from_mapping(const Mapping& m) {
   return e;
 }
 
-// LDS tile: as many records as fit in ~64 KiB (>= 2 resident blocks per CU), multiple of 64 points.
+// LDS tile: ~36 KiB of records per block (4 resident blocks per CU; measured best on MI355X: larger tiles amortise the
+// per-entry interpretation cost, smaller ones raise occupancy), multiple of 64 points.  PST_TILE_POINTS overrides (tuning).
 static uint32_t pick_tile(bool src_aos, uint32_t src_stride, bool dst_aos, uint32_t dst_stride) {
   const uint64_t per_point = (src_aos ? src_stride : 0) + (dst_aos ? dst_stride : 0);
   if (per_point == 0) return 0;
-  const uint64_t budget = 64 * 1024 - 96;
-  uint64_t t = budget / per_point;
-  t = (t / 64) * 64;
-  if (t > 4096) t = 4096;
+  static const long forced = [] { const char* v = std::getenv("PST_TILE_POINTS"); return v && *v ? std::strtol(v, nullptr, 10) : 0L; }();
+  static const long budget_env = [] { const char* v = std::getenv("PST_TILE_LDS_BYTES"); return v && *v ? std::strtol(v, nullptr, 10) : 0L; }();
+  const uint64_t hard_cap = 160 * 1024 - 256;
+  uint64_t t;
+  if (forced > 0) {
+    t = (uint64_t)forced;
+  } else {
+    const uint64_t budget = budget_env > 0 ? (uint64_t)budget_env : 36 * 1024;
+    t = budget / per_point;
+    t = (t / 64) * 64;
+    if (t < 64 && 64 * per_point <= hard_cap) t = 64;  // big records: fall back to the smallest tile that still fits
+    if (t > 4096) t = 4096;
+  }
+  if (t * per_point > hard_cap) t = 0;
   return (uint32_t)t;  // 0 => records too large for LDS staging
 }
 
 void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
-                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream) {
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6) {
   if (n == 0 || entries.empty()) return;
   ensure_device();
   const uint32_t tile = pick_tile(src_aos, src_stride, dst_aos, dst_stride);
-  const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 64;
+  const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 1;
   for (size_t begin = 0; begin < entries.size(); begin += PST_PLAN_MAX_ENTRIES) {
     const size_t cnt = std::min<size_t>(PST_PLAN_MAX_ENTRIES, entries.size() - begin);
     ConvertPlan plan{};
@@ -110,14 +122,40 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
     plan.h.n_entries = (uint32_t)cnt;
     plan.h.tile = tile;
     std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
+    bool wants_bounds = false;
     for (size_t i = 0; i < cnt; ++i) {
       plan.e[i] = entries[begin + i];
+      if (!bounds_out6) plan.e[i].bounds = 0;
+      wants_bounds = wants_bounds || plan.e[i].bounds;
       if (dst_aos)
         for (uint32_t b = 0; b < plan.e[i].dst_size; ++b) covered[plan.e[i].dst_off + b] = 1;
     }
     plan.h.dst_fully_covered = dst_aos && std::all_of(covered.begin(), covered.end(), [](uint8_t c) { return c != 0; });
+    // wave scheduling of the tile kernels (convert.hip): narrow attributes are owned by single waves, balanced by bytes
+    {
+      static const long nwaves = [] { const char* v = std::getenv("PST_TILE_BLOCK"); long b = v && *v ? std::strtol(v, nullptr, 10) : 256; return std::max(1L, b / 64); }();
+      static const long own_max = [] { const char* v = std::getenv("PST_TILE_OWN_MAX_BYTES"); return v && *v ? std::strtol(v, nullptr, 10) : 4L; }();
+      uint64_t load[16] = {0};
+      for (size_t i = 0; i < cnt; ++i) {
+        const uint32_t col_bytes = (src_aos && !dst_aos) ? plan.e[i].dst_size : (!src_aos && dst_aos) ? plan.e[i].src_size
+                                                                                                    : std::max(plan.e[i].src_size, plan.e[i].dst_size);
+        if ((long)col_bytes > own_max || plan.e[i].bounds || nwaves == 1) { plan.masks[0] |= 1u << i; continue; }
+        long best = 0;
+        for (long w = 1; w < nwaves; ++w) if (load[w] < load[best]) best = w;
+        load[best] += col_bytes + 2;  // + fixed interpretation cost
+        plan.masks[1 + best] |= 1u << i;
+      }
+    }
+    unsigned grid = 0;
+    double* partials = nullptr;
+    if (wants_bounds) {
+      grid = pstk::convert_grid(plan, src_aos, dst_aos, use_lds);
+      partials = (double*)workspace().partials(pstk::bounds_partials_bytes(grid));
+      plan.h.bounds_partials = (uint64_t)(uintptr_t)partials;
+    }
     if (!pstk::launch_convert(plan, src_aos, dst_aos, use_lds, stream))
       throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    if (wants_bounds) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
   }
 }
 
@@ -161,7 +199,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
           Workspace& ws = workspace();
           unsigned mode = 2u | (affine ? 1u : 0u) | (want_bounds ? 4u : 0u);
           pstk::launch_vec3f64_stream((const double*)(uintptr_t)e.src_col, (double*)(uintptr_t)e.dst_col, n, e.scale, e.offset, mode,
-                                      (double*)ws.dev, bounds_out6, stream);
+                                      (double*)ws.partials(pstk::stream_partials_bytes(n, mode)), bounds_out6, stream);
           if (want_bounds) bounds_done = true;
           continue;
         }
@@ -172,11 +210,15 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
           continue;
         }
       }
+      if (bounds_out6 && tslot == pos_slot && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done) {
+        e.bounds = 1;  // fused: the kernel folds the Vec3f64 values it writes into the AABB record
+        bounds_done = true;
+      }
       generic.push_back(e);
     }
     if (!generic.empty())
       execute_entries(!src.columnar, src.columnar ? 0 : aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar,
-                      dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, generic, true, stream);
+                      dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, generic, true, stream, bounds_out6);
   }
   PST_HIP_CHECK(hipGetLastError());
   if (bounds_out6 && !bounds_done) {

@@ -163,9 +163,9 @@ __device__ __forceinline__ T shfl_xor_any(T v, int mask) {
   }
 }
 
-// Block-wide (256 threads) reduction of NV min-values and NV max-values; result valid in thread 0.
+// Block-wide (BLK threads) reduction of NV min-values and NV max-values; result valid in thread 0.
 // `scratch` must hold 4 * 2 * NV elements of T.
-template <typename T, int NV>
+template <typename T, int NV, int BLK = kBlock>
 __device__ __forceinline__ void block_reduce_minmax(T (&mn)[NV], T (&mx)[NV], T* scratch) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ void block_reduce_minmax(T (&mn)[NV], T (&mx)[NV], T*
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int w = 1; w < kBlock / 64; ++w) {
+    for (int w = 1; w < BLK / 64; ++w) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         mn[i] = fold_min(mn[i], scratch[w * 2 * NV + i]);

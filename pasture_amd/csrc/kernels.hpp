@@ -11,11 +11,17 @@ namespace pstk {
 // use_lds: stage interleaved records through LDS tiles (plan.tile must be set); otherwise direct strided access.
 // Returns false when the launch (or the plan upload) failed; inspect hipGetLastError().
 bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream);
+// grid launch_convert will use: a plan with fused bounds needs convert_grid() records of 6 doubles (+ finalize room)
+unsigned convert_grid(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds);
+size_t bounds_partials_bytes(unsigned n_records);
+// fold n_records per-block {min xyz, max xyz} records into out6
+void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream);
 int device_cus();
 
 // K1/K2 fast path: columnar Vec3f64 stream. mode bits: 1 = affine, 2 = write dst, 4 = bounds.
-// partials must hold stream_grid() * 6 doubles; out6 receives {min xyz, max xyz} when bounds are requested.
+// partials must hold stream_partials_bytes(); out6 receives {min xyz, max xyz} when bounds are requested.
 int stream_grid();
+size_t stream_partials_bytes(uint64_t n_points, unsigned mode);  // bytes `partials` must hold for this launch
 void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, const double scale[3], const double offset[3],
                            unsigned mode, double* partials, double* out6, hipStream_t stream);
 
@@ -23,6 +29,7 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
 // acc_f64: accumulate in f64 after a Rust `as` cast (calculate_bounds_from_custom_positions) with +/-f64::MAX seeds;
 // otherwise accumulate in the component type with identity seeds.  out holds 2*ncomp accumulators {min.., max..}.
 int reduce_grid();
+size_t minmax_partials_bytes();
 void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials,
                    void* out, hipStream_t stream);
 

@@ -18,11 +18,12 @@ struct PlanEntry {
   uint8_t dst_ct;
   uint8_t xf_kind;    // PST_XF_*
   uint8_t xf_on_source;
-  double scale[3];
+  double scale[3];  // NB: keep 8-byte alignment: 4 x uint8 + ncomp precede
   double offset[3];
   uint64_t mask;
   uint32_t shift;
-  uint32_t convert;   // 1: datatypes differ => Rust `as` per component; 0: same type
+  uint16_t convert;   // 1: datatypes differ => Rust `as` per component; 0: same type
+  uint16_t bounds;    // 1: fold the written Vec3f64 values into the launch's AABB record (fused calculate_bounds)
 };
 
 // Header: passed BY VALUE (kernarg segment, statically indexed => plain s_load).  The entries live in a small device
@@ -37,10 +38,13 @@ struct ConvertHeader {
   uint32_t tile;              // points per LDS tile (tile kernels)
   uint32_t dst_fully_covered; // interleaved target: every byte of the record is written by some mapping
   uint32_t reserved;
+  uint64_t bounds_partials;   // 0, or device address of gridDim.x records {min xyz, max xyz} (f64) for entries with .bounds
 };
 struct ConvertPlan {
   ConvertHeader h;
   PlanEntry e[PST_PLAN_MAX_ENTRIES];
+  // tile kernels: masks[0] = entries every wave of a block works on; masks[1 + w] = entries owned by wave w (mod 16)
+  uint32_t masks[20];
 };
 
 // SoA Vec3f64 streaming kernel (copy / affine / bounds in one pass)

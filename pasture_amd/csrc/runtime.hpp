@@ -27,10 +27,14 @@ namespace pst {
 
 // per-thread scratch: device partials / result records + a pinned host mirror for small read-backs
 struct Workspace {
-  uint8_t* dev = nullptr;     // kWorkspaceBytes
+  uint8_t* dev = nullptr;     // kWorkspaceBytes: small result records
   uint8_t* pinned = nullptr;  // kPinnedBytes
+  uint8_t* partials_buf = nullptr;  // grow-only scratch for per-block reduction records
+  size_t partials_cap = 0;
   static constexpr size_t kWorkspaceBytes = 1u << 20;
   static constexpr size_t kPinnedBytes = 1u << 12;
+  // device scratch of at least `bytes` (grows by reallocation; growth synchronises the device once)
+  uint8_t* partials(size_t bytes);
 };
 Workspace& workspace();
 
@@ -45,8 +49,9 @@ inline uint64_t col_addr(const pst_buffer& b, size_t slot, size_t point) {
 
 // Plan execution: `entries` hold per-mapping descriptors with src_col/dst_col already resolved; the function splits them
 // into launches of <= PST_PLAN_MAX_ENTRIES, picks the LDS tile and the kernel body, and enqueues on `stream`.
+// If an entry has .bounds set, its AABB record {min xyz, max xyz} is written to bounds_out6 (device-accessible).
 void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
-                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream);
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6 = nullptr);
 
 // identity (same datatype, no transformation) entry between two members
 PlanEntry identity_entry(const Member& src, const Member& dst);

@@ -28,11 +28,13 @@ namespace {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kLoads = 6;                 // 16-byte loads in flight per lane
-constexpr int kTileVec = kLoads * kBlock;  // vectors per tile; multiple of 3 => phase invariance
-
-template <bool AFFINE, bool WRITE, bool BOUNDS>
+// KLOADS = 16-byte loads in flight per lane (multiple of 3 => a tile is a whole number of xyz periods => phase
+// invariance); NTL / NTS = non-temporal loads / stores (streaming data is touched once).
+template <bool AFFINE, bool WRITE, bool BOUNDS, int KLOADS, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamParams p) {
+  static_assert(KLOADS % 3 == 0, "tile must be a multiple of 3 vectors per lane");
+  constexpr int kLoads = KLOADS;
+  constexpr int kTileVec = kLoads * kBlock;
   const uint32_t t = threadIdx.x;
   const PST_AS_GLOBAL f64x2* __restrict__ src = (const PST_AS_GLOBAL f64x2*)(p.src + p.vec_first);
   PST_AS_GLOBAL f64x2* __restrict__ dst = (PST_AS_GLOBAL f64x2*)(p.dst + p.vec_first);
@@ -85,11 +87,17 @@ __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamPara
     if ((tile + 1) * (uint64_t)kTileVec <= p.n_vec) {
       f64x2 v[kLoads];
 #pragma unroll
-      for (int j = 0; j < kLoads; ++j) v[j] = __builtin_nontemporal_load(&src[base + (uint64_t)j * kBlock]);
+      for (int j = 0; j < kLoads; ++j) {
+        if constexpr (NTL) v[j] = __builtin_nontemporal_load(&src[base + (uint64_t)j * kBlock]);
+        else v[j] = src[base + (uint64_t)j * kBlock];
+      }
 #pragma unroll
       for (int j = 0; j < kLoads; ++j) {
         const f64x2 r = body(v[j], j);
-        if constexpr (WRITE) __builtin_nontemporal_store(r, &dst[base + (uint64_t)j * kBlock]);
+        if constexpr (WRITE) {
+          if constexpr (NTS) __builtin_nontemporal_store(r, &dst[base + (uint64_t)j * kBlock]);
+          else dst[base + (uint64_t)j * kBlock] = r;
+        }
       }
     } else {
 #pragma unroll
@@ -156,25 +164,47 @@ __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamPara
   }
 }
 
-// One block folds the per-block records: out[0..NV) = min, out[NV..2NV) = max.
+// Folds per-block records: block b reduces records [b*chunk, (b+1)*chunk) into out[b] = {min[NV], max[NV]}.
+// Launched with one block (chunk >= n_records) for the final fold, or as a first level when there are many records.
 template <typename T, int NV>
-__global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __restrict__ partials, uint32_t n_records, T* __restrict__ out,
-                                                                 T seed_min, T seed_max) {
+__global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __restrict__ partials, uint32_t n_records, uint32_t chunk,
+                                                                 T* __restrict__ out, T seed_min, T seed_max) {
   T mn[NV], mx[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) { mn[i] = seed_min; mx[i] = seed_max; }
-  for (uint32_t r = threadIdx.x; r < n_records; r += kBlock) {
+  const uint64_t first = (uint64_t)blockIdx.x * chunk;
+  const uint64_t last = first + chunk < n_records ? first + chunk : n_records;
+  for (uint64_t r = first + threadIdx.x; r < last; r += kBlock) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      mn[i] = fold_min(mn[i], partials[(uint64_t)r * 2 * NV + i]);
-      mx[i] = fold_max(mx[i], partials[(uint64_t)r * 2 * NV + NV + i]);
+      mn[i] = fold_min(mn[i], partials[r * 2 * NV + i]);
+      mx[i] = fold_max(mx[i], partials[r * 2 * NV + NV + i]);
     }
   }
   __shared__ T scratch[(kBlock / 64) * 2 * NV];
   block_reduce_minmax<T, NV>(mn, mx, scratch);
   if (threadIdx.x == 0) {
+    T* o = out + (uint64_t)blockIdx.x * 2 * NV;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { out[i] = mn[i]; out[NV + i] = mx[i]; }
+    for (int i = 0; i < NV; ++i) { o[i] = mn[i]; o[NV + i] = mx[i]; }
+  }
+}
+
+// two-level fold when there are many records (one-tile-per-block launches); `partials` must have room for
+// n_records + kFoldBlocks records
+constexpr uint32_t kFoldBlocks = 128;
+template <typename T, int NV>
+void launch_finalize(T* partials, uint32_t n_records, T* out, T seed_min, T seed_max, hipStream_t stream) {
+  if (n_records > 4096) {
+    const uint32_t chunk = (n_records + kFoldBlocks - 1) / kFoldBlocks;
+    T* level1 = partials + (uint64_t)n_records * 2 * NV;
+    hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(kFoldBlocks), dim3(kBlock), 0, stream, (const T*)partials, n_records, chunk, level1,
+                       seed_min, seed_max);
+    hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(1), dim3(kBlock), 0, stream, (const T*)level1, kFoldBlocks, kFoldBlocks, out,
+                       seed_min, seed_max);
+  } else {
+    hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(1), dim3(kBlock), 0, stream, (const T*)partials, n_records, n_records, out, seed_min,
+                       seed_max);
   }
 }
 
@@ -221,13 +251,11 @@ template <typename T, int NCOMP>
 void launch_minmax_typed(const ReduceParams& p, bool acc_f64, void* out, unsigned grid, hipStream_t stream) {
   if (acc_f64) {
     hipLaunchKernelGGL((strided_minmax_kernel<T, double, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, kF64Max, -kF64Max);
-    hipLaunchKernelGGL((finalize_minmax_kernel<double, NCOMP>), dim3(1), dim3(kBlock), 0, stream, (const double*)p.partials, grid,
-                       (double*)out, kF64Max, -kF64Max);
+    launch_finalize<double, NCOMP>((double*)p.partials, grid, (double*)out, kF64Max, -kF64Max, stream);
   } else {
     hipLaunchKernelGGL((strided_minmax_kernel<T, T, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, Identity<T>::min_seed(),
                        Identity<T>::max_seed());
-    hipLaunchKernelGGL((finalize_minmax_kernel<T, NCOMP>), dim3(1), dim3(kBlock), 0, stream, (const T*)p.partials, grid, (T*)out,
-                       Identity<T>::min_seed(), Identity<T>::max_seed());
+    launch_finalize<T, NCOMP>((T*)p.partials, grid, (T*)out, Identity<T>::min_seed(), Identity<T>::max_seed(), stream);
   }
 }
 
@@ -235,25 +263,41 @@ void launch_minmax_typed(const ReduceParams& p, bool acc_f64, void* out, unsigne
 
 namespace pstk {
 
-int stream_grid() { return device_cus() * 8; }
+// Launch geometry (measured on MI355X, tools/tune_stream*.hip, 10^8 points, random data):
+//  * read-only AABB: persistent grid of 4 blocks per CU, 6 loads in flight per lane  -> ~7.1 TB/s (8 blocks/CU: 6.0 TB/s)
+//  * any mode that writes: ONE tile per block (non-persistent)                       -> ~5.9 TB/s (persistent: 5.45 TB/s);
+//    staggered block start times keep reads and writes interleaved at the memory controllers.
+constexpr int kStreamLoads = 6;
+constexpr int kStreamTileVec = kStreamLoads * kBlock;
+int stream_grid() { return device_cus() * 4; }
 int reduce_grid() { return device_cus() * 8; }
+size_t minmax_partials_bytes() { return (size_t)(reduce_grid() + kFoldBlocks) * 6 * sizeof(double); }
+
+static uint64_t stream_launch_grid(uint64_t n_points, unsigned mode) {
+  const uint64_t n_vec = (3 * n_points) / 2;
+  const uint64_t n_tiles = std::max<uint64_t>(1, (n_vec + kStreamTileVec - 1) / kStreamTileVec);
+  return (mode & 2u) ? n_tiles : std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
+}
+size_t stream_partials_bytes(uint64_t n_points, unsigned mode) {
+  return (size_t)(stream_launch_grid(n_points, mode) + kFoldBlocks) * 6 * sizeof(double);
+}
 
 void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, const double scale[3], const double offset[3], unsigned mode,
                            double* partials, double* out6, hipStream_t stream) {
-  const bool affine = mode & 1u, write = mode & 2u, bounds = mode & 4u;
+  const bool write = mode & 2u, bounds = mode & 4u;
   StreamParams p{};
   p.src = src;
   p.dst = write ? dst : const_cast<double*>(src);
   p.n_doubles = 3 * n_points;
-  // 16-byte vectors need src and dst to share their alignment phase; otherwise run the body on scalars... the host
-  // only takes this path when (src - dst) % 16 == 0 (see converter.cpp), so only the phase of src matters.
+  // 16-byte vectors: src and dst must share their alignment phase — the host only takes this path when
+  // (src - dst) % 16 == 0 (converter.cpp), so only the phase of src matters.
   p.vec_first = (((uintptr_t)src & 15u) != 0 && p.n_doubles > 0) ? 1 : 0;
   p.n_vec = (p.n_doubles - p.vec_first) / 2;
   for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
   p.partials = partials;
-  const uint64_t n_tiles = std::max<uint64_t>(1, (p.n_vec + kTileVec - 1) / kTileVec);
-  const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
-#define PST_STREAM(A, W, B) hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B>), dim3(grid), dim3(kBlock), 0, stream, p)
+  const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
+#define PST_STREAM(A, W, B) \
+  hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p)
   switch (mode & 7u) {
     case 1: case 0: break;  // nothing to do (affine without a sink is meaningless)
     case 2: PST_STREAM(false, true, false); break;
@@ -264,10 +308,12 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
     case 7: PST_STREAM(true, true, true); break;
   }
 #undef PST_STREAM
-  (void)affine;
-  if (bounds)
-    hipLaunchKernelGGL((finalize_minmax_kernel<double, 3>), dim3(1), dim3(kBlock), 0, stream, (const double*)partials, grid, out6, kF64Max,
-                       -kF64Max);
+  if (bounds) launch_finalize<double, 3>(partials, grid, out6, kF64Max, -kF64Max, stream);
+}
+
+size_t bounds_partials_bytes(unsigned n_records) { return (size_t)(n_records + kFoldBlocks) * 6 * sizeof(double); }
+void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream) {
+  launch_finalize<double, 3>(partials, n_records, out6, kF64Max, -kF64Max, stream);
 }
 
 void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials, void* out,
