@@ -1119,6 +1119,7 @@ struct KdTree {
     const double* p = pts[nd.idx];
     double d0 = p[0] - q[0], d1 = p[1] - q[1], d2 = p[2] - q[2];
     double d = d0 * d0 + d1 * d1 + d2 * d2;
+    if (!(d == d)) d = INFINITY;  // a NaN coordinate never compares: such points rank last (tie order is the crate's, unpinned)
     if (heap.size() < k) { heap.push_back({d, nd.idx}); std::push_heap(heap.begin(), heap.end()); }
     else if (d < heap.front().first) { std::pop_heap(heap.begin(), heap.end()); heap.back() = {d, nd.idx}; std::push_heap(heap.begin(), heap.end()); }
     double delta = q[nd.axis] - p[nd.axis];

@@ -1,0 +1,563 @@
+// K4 — kNN normal estimation on the device (gfx950).
+//
+// Replaces compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130): per point the k nearest neighbours
+// (exact, f64 squared Euclidean distance, the point itself included, ascending distance — the contract of
+// kd-tree 0.3.0 `nearests`, normal_estimation.rs:103-108), the UN-normalised covariance of the neighbourhood
+// (:240-305), the closed-form eigen solve (:308-453) and the plane parameters (:456-467), reproduced quirk for quirk
+// (eigenvalues of the unscaled matrix multiplied by the scale again :441-443; the diagonal subtraction :446-449 that
+// has no effect; normal = largest of three row cross products, NOT normalised :395-426).
+//
+// Neighbour search: points are binned into a uniform grid whose cell edge is chosen so that a sphere of one cell edge
+// holds about k points; cells are addressed by a 63-bit Morton key, the points are radix-sorted by key (hipCUB) and an
+// open-addressing hash table maps occupied cells to their first sorted point.  One lane per query walks Chebyshev
+// shells of cells around its own cell, keeps the k best candidates SORTED IN REGISTERS (fully unrolled insertion, no
+// scratch), and stops as soon as the k-th best distance is inside the searched cube.  Queries run in Morton order, so
+// neighbouring lanes touch the same cells and the gathers hit L2.
+//
+// The reference allocates a HashMapBuffer per point and goes through DMatrix; none of that survives: the 3x3 moment
+// sums live in registers.  f64 throughout (sqrt / atan2 / cos / sin from the device math library); -ffp-contract=off.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+using namespace pstd;
+
+namespace {
+
+constexpr uint64_t kInvalidKey = ~0ull;
+constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
+
+struct GridParams {
+  double org[3];   // grid origin (min corner of the finite points)
+  double inv_h;    // 1 / cell edge
+  double h;        // cell edge
+  uint32_t dim[3]; // cells per axis (<= 2^21)
+};
+
+__device__ __forceinline__ uint64_t spread21(uint64_t v) {  // insert two zero bits between each of the low 21 bits
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x1F00000000FFFFull;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) { return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2); }
+
+__device__ __forceinline__ bool finite3(double x, double y, double z) {
+  return __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+}
+__device__ __forceinline__ uint32_t cell_coord(double v, double org, double inv_h, uint32_t dim) {
+  double c = __builtin_floor((v - org) * inv_h);
+  if (!(c > 0.0)) c = 0.0;
+  const double top = (double)(dim - 1);
+  if (c > top) c = top;
+  return (uint32_t)c;
+}
+
+// positions (any stride) -> packed xyz f64 + finite-only bounds partials
+__global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t* base, uint64_t stride, uint64_t n, double* __restrict__ xyz,
+                                                                  double* __restrict__ partials) {
+  double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    cgptr_t p = (cgptr_t)(uint64_t)base + i * stride;
+    const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
+    xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z;
+    if (finite3(x, y, z)) {
+      mn[0] = __builtin_fmin(mn[0], x); mx[0] = __builtin_fmax(mx[0], x);
+      mn[1] = __builtin_fmin(mn[1], y); mx[1] = __builtin_fmax(mx[1], y);
+      mn[2] = __builtin_fmin(mn[2], z); mx[2] = __builtin_fmax(mx[2], z);
+    }
+  }
+  __shared__ double scratch[(kBlock / 64) * 6];
+  block_reduce_minmax<double, 3>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+    double* o = partials + (uint64_t)blockIdx.x * 6;
+    o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite) {
+  unsigned long long local = 0;
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    uint64_t key = kInvalidKey;
+    if (finite3(x, y, z)) {
+      key = morton3(cell_coord(x, g.org[0], g.inv_h, g.dim[0]), cell_coord(y, g.org[1], g.inv_h, g.dim[1]), cell_coord(z, g.org[2], g.inv_h, g.dim[2]));
+      local += 1;
+    }
+    keys[i] = key;
+    idx[i] = (uint32_t)i;
+  }
+  if (local) atomicAdd(n_finite, local);  // the compiler folds this to one atomic per wave
+}
+
+__global__ __launch_bounds__(kBlock) void reorder_kernel(const double* __restrict__ xyz, const uint32_t* __restrict__ idx, uint64_t n,
+                                                         double* __restrict__ sorted_xyz) {
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += step) {
+    const uint64_t i = idx[j];
+    sorted_xyz[3 * j] = xyz[3 * i]; sorted_xyz[3 * j + 1] = xyz[3 * i + 1]; sorted_xyz[3 * j + 2] = xyz[3 * i + 2];
+  }
+}
+
+// ---- cell hash table: key -> first sorted point of the cell -------------------------------------------------
+struct CellTable {
+  uint64_t* keys;    // kInvalidKey = empty
+  uint32_t* starts;
+  uint32_t mask;     // capacity - 1 (power of two)
+};
+__device__ __forceinline__ uint32_t hash_key(uint64_t k, uint32_t mask) {
+  k *= 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(k >> 32) & mask;
+}
+__global__ __launch_bounds__(kBlock) void count_cells_kernel(const uint64_t* __restrict__ keys, uint64_t nf, unsigned long long* __restrict__ n_cells) {
+  unsigned long long local = 0;
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < nf; j += step)
+    if (j == 0 || keys[j] != keys[j - 1]) local += 1;
+  if (local) atomicAdd(n_cells, local);
+}
+__global__ __launch_bounds__(kBlock) void build_table_kernel(const uint64_t* __restrict__ keys, uint64_t nf, CellTable t) {
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < nf; j += step) {
+    const uint64_t k = keys[j];
+    if (j != 0 && k == keys[j - 1]) continue;
+    uint32_t slot = hash_key(k, t.mask);
+    while (true) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)&t.keys[slot], (unsigned long long)kInvalidKey, (unsigned long long)k);
+      if (prev == kInvalidKey) { t.starts[slot] = (uint32_t)j; break; }
+      slot = (slot + 1) & t.mask;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t lookup_cell(const CellTable& t, uint64_t k) {
+  uint32_t slot = hash_key(k, t.mask);
+  while (true) {
+    const uint64_t kk = t.keys[slot];
+    if (kk == k) return t.starts[slot];
+    if (kk == kInvalidKey) return kNoIndex;
+    slot = (slot + 1) & t.mask;
+  }
+}
+
+// ---- k-best list, sorted ascending, fully in registers --------------------------------------------------------
+template <int K>
+struct KBest {
+  double d[K];
+  uint32_t i[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < K; ++t) { d[t] = __builtin_inf(); i[t] = kNoIndex; }
+  }
+  // Insert (dist, index) keeping ascending order; an equal distance goes AFTER the existing ones (first found wins).
+  __device__ __forceinline__ void insert(double dist, uint32_t index) {
+    if (!(dist < d[K - 1])) return;
+#pragma unroll
+    for (int t = K - 1; t >= 0; --t) {
+      const bool keep = d[t] <= dist;                       // element t is not displaced
+      const bool here = t == 0 ? true : (d[t - 1] <= dist); // the new element lands exactly at t (if t is displaced)
+      const double nd = keep ? d[t] : (here ? dist : d[t > 0 ? t - 1 : 0]);
+      const uint32_t ni = keep ? i[t] : (here ? index : i[t > 0 ? t - 1 : 0]);
+      d[t] = nd;
+      i[t] = ni;
+    }
+  }
+  __device__ __forceinline__ double kth(uint32_t k) const {  // d[k-1] without dynamic register indexing
+    double v = d[K - 1];
+#pragma unroll
+    for (int t = 0; t < K; ++t) v = (uint32_t)t == k - 1 ? d[t] : v;
+    return v;
+  }
+};
+
+// ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
+struct Fit { double nx, ny, nz, curvature; int ok; };
+
+template <typename GetPoint>
+__device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
+  Fit f{0, 0, 0, 0, 1};
+  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points)
+  bool dense = true;
+  for (uint32_t t = 0; t < m; ++t) {
+    double x, y, z; get(t, x, y, z);
+    if (x != x || y != y || z != z) dense = false;
+  }
+  // compute_centroid :198-237
+  double sx = 0, sy = 0, sz = 0;
+  long long cnt = 0;
+  for (uint32_t t = 0; t < m; ++t) {
+    double x, y, z; get(t, x, y, z);
+    if (dense || finite3(x, y, z)) { sx += x; sy += y; sz += z; cnt += 1; }
+  }
+  const double div = dense ? (double)m : (double)cnt;
+  const double cx = sx / div, cy = sy / div, cz = sz / div;
+  // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  long long used = 0;
+  for (uint32_t t = 0; t < m; ++t) {
+    double x, y, z; get(t, x, y, z);
+    if (!dense && !finite3(x, y, z)) continue;
+    double d0 = x - cx, d1 = y - cy, d2 = z - cz;
+    c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+    const double dx = d0;
+    d0 *= dx; d1 *= dx; d2 *= dx;
+    c00 += d0; c01 += d1; c02 += d2;
+    used += 1;
+  }
+  if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
+  const double c10 = c01, c20 = c02, c21 = c12;
+  // eigen_3x3 :429-453
+  double scale = __builtin_fabs(c00);  // covariance_matrix.abs().max(), column-major order
+  {
+    const double a[8] = {c10, c20, c01, c11, c21, c02, c12, c22};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const double v = __builtin_fabs(a[q]); if (v > scale) scale = v; }
+  }
+  const double s00 = c00 / scale, s01 = c01 / scale, s02 = c02 / scale, s10 = c10 / scale, s11 = c11 / scale, s12 = c12 / scale,
+               s20 = c20 / scale, s21 = c21 / scale, s22 = c22 / scale;
+  // solve_polynomial on the UNSCALED matrix :328-392
+  double ev0, ev1, ev2;
+  {
+    const double k0 = c00 * c11 * c22 + 2.0 * c01 * c02 * c12 - c00 * c12 * c12 - c11 * c02 * c02 - c22 * c01 * c01;
+    const double k1 = c00 * c11 - c01 * c01 + c00 * c22 - c02 * c02 + c11 * c22 - c12 * c12;
+    const double k2 = c00 + c11 + c22;
+    auto quadratic = [&]() {  // :308-325
+      ev0 = 0.0;
+      double delta = k2 * k2 - 4.0 * k1;
+      if (delta < 0.0) delta = 0.0;
+      const double sd = __builtin_sqrt(delta);
+      ev2 = 0.5 * (k2 + sd);
+      ev1 = 0.5 * (k2 - sd);
+    };
+    if (__builtin_fabs(k0) < 2.220446049250313e-16) {
+      quadratic();
+    } else {
+      const double one_third = 1.0 / 3.0;
+      const double sqrt_3 = __builtin_sqrt(3.0);
+      const double k2_third = k2 * one_third;
+      double alpha_third = (k1 - k2 * k2_third) * one_third;
+      if (alpha_third > 0.0) alpha_third = 0.0;
+      const double half_beta = 0.5 * (k0 + k2_third * (2.0 * k2_third * k2_third - k1));
+      double q = half_beta * half_beta + alpha_third * alpha_third * alpha_third;
+      if (q > 0.0) q = 0.0;
+      const double rho = __builtin_sqrt(-alpha_third);
+      const double theta = ::atan2(__builtin_sqrt(-q), half_beta) * one_third;
+      const double ct = ::cos(theta), st = ::sin(theta);
+      double a = k2_third + 2.0 * rho * ct;
+      double b = k2_third - rho * (ct + sqrt_3 * st);
+      double c = k2_third - rho * (ct - sqrt_3 * st);
+      // sort ascending (:384-386)
+      if (b < a) { const double t = a; a = b; b = t; }
+      if (c < b) { const double t = b; b = c; c = t; }
+      if (b < a) { const double t = a; a = b; b = t; }
+      ev0 = a; ev1 = b; ev2 = c;
+      if (ev0 <= 0.0) quadratic();
+    }
+    (void)ev1; (void)ev2;
+  }
+  const double eigen_value = ev0 * scale;  // "undo scale" :443 (sic)
+  // :446-449 subtracts ev0 from a COPY of the diagonal: no effect on the scaled matrix
+  // get_largest_eigen_vector :395-426: rows r0 x r1, r0 x r2, r1 x r2; first maximum of the L2 norm wins
+  const double a0 = s01 * s12 - s02 * s11, a1 = s02 * s10 - s00 * s12, a2 = s00 * s11 - s01 * s10;
+  const double b0 = s01 * s22 - s02 * s21, b1 = s02 * s20 - s00 * s22, b2 = s00 * s21 - s01 * s20;
+  const double d0 = s11 * s22 - s12 * s21, d1 = s12 * s20 - s10 * s22, d2 = s10 * s21 - s11 * s20;
+  const double na = __builtin_sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = __builtin_sqrt(b0 * b0 + b1 * b1 + b2 * b2),
+               nd = __builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  f.nx = a0; f.ny = a1; f.nz = a2;
+  double best = na;
+  if (nb > best) { f.nx = b0; f.ny = b1; f.nz = b2; best = nb; }
+  if (nd > best) { f.nx = d0; f.ny = d1; f.nz = d2; }
+  // solve_plane_parameter :456-467
+  const double eigen_sum = c00 + c11 + c22;
+  f.curvature = eigen_sum != 0.0 ? __builtin_fabs(eigen_value / eigen_sum) : 0.0;
+  return f;
+}
+
+struct NormalsOut {
+  double* normals_f64;    // [n][3] or null
+  double* curvature_f64;  // [n] or null
+  long long* knn;         // [n][k] or null
+  uint64_t normal_attr;   // device address of the NORMAL (Vec3f32) attribute of point 0, or 0
+  uint64_t normal_stride;
+  uint64_t curv_attr;     // device address of the Curvature (F64) attribute of point 0, or 0
+  uint64_t curv_stride;
+  int* error_count;       // neighbourhoods with fewer than 3 usable points
+};
+
+__device__ __forceinline__ void write_result(const NormalsOut& o, uint64_t orig, const Fit& f) {
+  if (!f.ok) { atomicAdd(o.error_count, 1); return; }
+  if (o.normals_f64) { o.normals_f64[3 * orig] = f.nx; o.normals_f64[3 * orig + 1] = f.ny; o.normals_f64[3 * orig + 2] = f.nz; }
+  if (o.curvature_f64) o.curvature_f64[orig] = f.curvature;
+  if (o.normal_attr) {  // f64 -> f32 narrowing of the normal = Rust `as` (RNE, overflow -> inf)
+    gptr_t p = as_global(o.normal_attr) + orig * o.normal_stride;
+    store_un<float>(p, (float)f.nx); store_un<float>(p + 4, (float)f.ny); store_un<float>(p + 8, (float)f.nz);
+  }
+  if (o.curv_attr) store_un<double>(as_global(o.curv_attr) + orig * o.curv_stride, f.curvature);
+}
+
+// ---- brute force (tiny inputs, NaN-heavy inputs): exact, distance NaN counts as +inf, ties -> lower index first --
+template <int K>
+__global__ __launch_bounds__(kBlock) void knn_bruteforce_kernel(const double* __restrict__ xyz, uint32_t n, uint32_t k, NormalsOut out) {
+  const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n) return;
+  const double qx = xyz[3 * q], qy = xyz[3 * q + 1], qz = xyz[3 * q + 2];
+  KBest<K> best;
+  best.init();
+  uint32_t filled = 0;
+  // the query itself first (distance 0 when finite), then every other point in index order
+  for (uint32_t pass = 0; pass < 2; ++pass) {
+    for (uint32_t j = (pass == 0 ? q : 0); j < (pass == 0 ? q + 1 : n); ++j) {
+      if (pass == 1 && j == q) continue;
+      const double dx = xyz[3 * j] - qx, dy = xyz[3 * j + 1] - qy, dz = xyz[3 * j + 2] - qz;
+      double d = dx * dx + dy * dy + dz * dz;
+      if (d != d) d = __builtin_inf();
+      if (d == __builtin_inf()) {  // +inf never wins `<`: take them only while the list is not full
+        if (filled < k) {
+          // append at the first free slot (slots beyond `filled` hold +inf / kNoIndex)
+#pragma unroll
+          for (int t = 0; t < K; ++t) if ((uint32_t)t == filled) best.i[t] = j;
+          filled += 1;
+        }
+      } else {
+        const double kth = best.kth(k);
+        if (d < kth) {
+          // drop the k-th entry by inserting into a list limited to k: entries >= k are never read
+          best.insert(d, j);
+          if (filled < k) filled += 1;
+        }
+      }
+    }
+  }
+  const uint32_t m = n < k ? n : k;
+  if (out.knn)
+    for (uint32_t t = 0; t < k; ++t) {
+      long long v = -1;
+#pragma unroll
+      for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = (long long)best.i[u];
+      out.knn[(uint64_t)q * k + t] = v;
+    }
+  const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
+    uint32_t j = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) if ((uint32_t)u == t) j = best.i[u];
+    x = xyz[3 * j]; y = xyz[3 * j + 1]; z = xyz[3 * j + 2];
+  });
+  write_result(out, q, f);
+}
+
+// ---- grid search ----------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys,
+                                                          const uint32_t* __restrict__ sidx, uint32_t nf, uint32_t k, GridParams g, CellTable table,
+                                                          NormalsOut out) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= nf) return;
+  const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+  const int cx = (int)cell_coord(qx, g.org[0], g.inv_h, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
+            cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+  KBest<K> best;
+  best.init();
+  const int max_r = (int)max(g.dim[0], max(g.dim[1], g.dim[2]));
+  for (int r = 0; r <= max_r; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= (int)g.dim[2]) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= (int)g.dim[1]) continue;
+        const bool face = (dz == -r || dz == r || dy == -r || dy == r);
+        const int xstep = face ? 1 : (2 * r > 0 ? 2 * r : 1);  // interior rows of the shell: only the two end cells
+        for (int dx = -r; dx <= r; dx += xstep) {
+          const int x = cx + dx;
+          if (x < 0 || x >= (int)g.dim[0]) continue;
+          const uint64_t key = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
+          uint32_t p = lookup_cell(table, key);
+          if (p == kNoIndex) continue;
+          for (; p < nf && skeys[p] == key; ++p) {
+            const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
+            const double d = ddx * ddx + ddy * ddy + ddz * ddz;
+            best.insert(d, p);
+          }
+        }
+      }
+    }
+    // searched cube = cells [c - r, c + r]^3.  Anything outside is at least `margin` away; a side that already reaches
+    // the grid boundary has nothing beyond it.  The slack absorbs the rounding of the cell assignment.
+    double margin = __builtin_inf();
+    const double qa[3] = {qx, qy, qz};
+    const int ca[3] = {cx, cy, cz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (ca[a] - r > 0) margin = __builtin_fmin(margin, qa[a] - (g.org[a] + (double)(ca[a] - r) * g.h));
+      if (ca[a] + r < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + r + 1) * g.h) - qa[a]);
+    }
+    if (margin == __builtin_inf()) break;  // the cube covers the whole grid
+    margin = margin * (1.0 - 1e-12) - 1e-300;
+    const double kth = best.kth(k);
+    if (margin > 0.0 && kth <= margin * margin) break;
+  }
+  const uint32_t m = nf < k ? nf : k;
+  const uint64_t orig = sidx[j];
+  if (out.knn)
+    for (uint32_t t = 0; t < k; ++t) {
+      long long v = -1;
+#pragma unroll
+      for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = (long long)sidx[best.i[u]];
+      out.knn[orig * k + t] = v;
+    }
+  const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int u = 0; u < K; ++u) if ((uint32_t)u == t) p = best.i[u];
+    x = sxyz[3 * (uint64_t)p]; y = sxyz[3 * (uint64_t)p + 1]; z = sxyz[3 * (uint64_t)p + 2];
+  });
+  write_result(out, orig, f);
+}
+
+// non-finite query points (sorted positions [nf, n)): neighbourhood = itself + the first k-1 finite points
+__global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __restrict__ xyz, const double* __restrict__ sxyz,
+                                                               const uint32_t* __restrict__ sidx, uint32_t nf, uint32_t n, uint32_t k, NormalsOut out) {
+  const uint32_t j = nf + blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n) return;
+  const uint64_t orig = sidx[j];
+  const uint32_t m = (nf + 1 < k) ? nf + 1 : k;
+  if (out.knn)
+    for (uint32_t t = 0; t < k; ++t) out.knn[orig * k + t] = t == 0 ? (long long)orig : (t < m ? (long long)sidx[t - 1] : -1);
+  const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
+    if (t == 0) { x = xyz[3 * orig]; y = xyz[3 * orig + 1]; z = xyz[3 * orig + 2]; }
+    else { x = sxyz[3 * (uint64_t)(t - 1)]; y = sxyz[3 * (uint64_t)(t - 1) + 1]; z = sxyz[3 * (uint64_t)(t - 1) + 2]; }
+  });
+  write_result(out, orig, f);
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+namespace pstk {
+
+// Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), or the number of degenerate neighbourhoods (> 0).
+long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
+                      long long* out_knn_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride,
+                      hipStream_t stream) {
+#define NCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+  const unsigned cus = (unsigned)device_cus();
+  const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
+  DevBuf xyz, partials, counters;
+  NCK(xyz.alloc(n * 24));
+  NCK(partials.alloc((size_t)sgrid * 48));
+  NCK(counters.alloc(64));
+  NCK(hipMemsetAsync(counters.p, 0, 64, stream));
+  hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, xyz.as<double>(), partials.as<double>());
+  std::vector<double> hp((size_t)sgrid * 6);
+  NCK(hipMemcpyAsync(hp.data(), partials.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
+  NCK(hipStreamSynchronize(stream));
+  double mn[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, mx[3] = {-mn[0], -mn[0], -mn[0]};
+  for (unsigned b = 0; b < sgrid; ++b)
+    for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hp[b * 6 + c]); mx[c] = std::fmax(mx[c], hp[b * 6 + 3 + c]); }
+
+  NormalsOut out{};
+  out.normals_f64 = out_normals_dev; out.curvature_f64 = out_curv_dev; out.knn = out_knn_dev;
+  out.normal_attr = normal_attr; out.normal_stride = normal_stride; out.curv_attr = curv_attr; out.curv_stride = curv_stride;
+  out.error_count = (int*)((uint8_t*)counters.p + 32);
+
+  const bool any_finite = mn[0] <= mx[0];
+  const bool brute = n <= 2048 || !any_finite;
+#define KNN_DISPATCH(KERNEL, GRID, ...)                                                                        \
+  do {                                                                                                        \
+    if (k <= 8) hipLaunchKernelGGL((KERNEL<8>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);           \
+    else if (k <= 16) hipLaunchKernelGGL((KERNEL<16>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);    \
+    else if (k <= 32) hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);    \
+    else hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);                 \
+  } while (0)
+  if (brute) {
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    KNN_DISPATCH(knn_bruteforce_kernel, grid, xyz.as<double>(), (uint32_t)n, k, out);
+  } else {
+    // cell edge: a sphere of radius h should hold about k points  =>  (4/3 pi) h^3 * density ~ k
+    double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    double maxext = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
+    if (!(maxext > 0.0)) maxext = 1.0;
+    // treat flat axes (extent < 1e-6 of the largest) as thickness-free: density is per area / per length then
+    double vol = 1.0;
+    int dims_used = 0;
+    for (int c = 0; c < 3; ++c) if (ext[c] > maxext * 1e-9) { vol *= ext[c]; dims_used += 1; }
+    const double per_cell = std::fmax(1.0, (double)k / 3.0);
+    double h = dims_used ? std::pow(vol * per_cell / (double)n, 1.0 / dims_used) : maxext;
+    if (const char* e = std::getenv("PST_KNN_CELL")) { const double v = std::atof(e); if (v > 0) h = v; }
+    const double min_h = maxext / 2000000.0;  // <= 2^21 cells per axis
+    if (!(h > min_h)) h = min_h;
+    GridParams g{};
+    for (int c = 0; c < 3; ++c) {
+      g.org[c] = mn[c];
+      double d = std::floor(ext[c] / h) + 1.0;
+      if (d > 2097151.0) d = 2097151.0;
+      g.dim[c] = (uint32_t)d;
+    }
+    g.h = h;
+    g.inv_h = 1.0 / h;
+    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp;
+    NCK(keys.alloc(n * 8)); NCK(keys2.alloc(n * 8)); NCK(idx.alloc(n * 4)); NCK(idx2.alloc(n * 4)); NCK(sorted_xyz.alloc(n * 24));
+    unsigned long long* n_finite = (unsigned long long*)counters.p;
+    unsigned long long* n_cells = n_finite + 1;
+    hipLaunchKernelGGL(keys_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+    size_t tmp_bytes = 0;
+    NCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
+                                           (int)n, 0, 64, stream));
+    NCK(tmp.alloc(tmp_bytes));
+    NCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
+                                           (int)n, 0, 64, stream));
+    hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
+    unsigned long long h_counts[2] = {0, 0};
+    NCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
+    NCK(hipStreamSynchronize(stream));
+    const uint64_t nf = h_counts[0];
+    hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
+    NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
+    NCK(hipStreamSynchronize(stream));
+    uint64_t cap = 64;
+    while (cap < 2 * h_counts[1]) cap <<= 1;
+    DevBuf tkeys, tstarts;
+    NCK(tkeys.alloc(cap * 8)); NCK(tstarts.alloc(cap * 4));
+    NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
+    CellTable table{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
+    hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
+    if (nf) {
+      const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
+      KNN_DISPATCH(knn_grid_kernel, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table, out);
+    }
+    if (nf < n) {
+      // non-finite query points: every distance is NaN (-> +inf), so "the k nearest" is the reference's kd-tree tie order
+      // (unpinned).  Chosen here: the point itself, then the first k-1 finite points in Morton order.
+      const unsigned grid = (unsigned)((n - nf + kBlock - 1) / kBlock);
+      hipLaunchKernelGGL(knn_nonfinite_kernel, dim3(grid), dim3(kBlock), 0, stream, xyz.as<double>(), sorted_xyz.as<double>(), idx2.as<uint32_t>(),
+                         (uint32_t)nf, (uint32_t)n, k, out);
+    }
+    NCK(hipGetLastError());
+    NCK(hipStreamSynchronize(stream));  // temporaries die here
+  }
+  NCK(hipGetLastError());
+  int errors = 0;
+  NCK(hipMemcpyAsync(&errors, out.error_count, 4, hipMemcpyDeviceToHost, stream));
+  NCK(hipStreamSynchronize(stream));
+#undef KNN_DISPATCH
+#undef NCK
+  return errors;
+}
+
+}  // namespace pstk

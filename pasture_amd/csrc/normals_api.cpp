@@ -1,0 +1,91 @@
+// compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130) — argument checks + host/device plumbing; the
+// neighbour search and the plane fit run in normals.hip.
+#include "runtime.hpp"
+
+using namespace pst;
+
+namespace {
+
+struct TempDev {
+  uint8_t* p = nullptr;
+  explicit TempDev(size_t bytes) { p = dev_alloc(bytes, PST_MEM_DEVICE); }
+  ~TempDev() { dev_free(p, PST_MEM_DEVICE); }
+};
+
+const Member& checked_position(const pst_buffer& b, size_t k) {
+  if (b.len < 3)  // :86-88
+    throw Error(PST_ERR_TOO_FEW_POINTS, "The point cloud is too small. Please use a point cloud that has 3 or more points!");
+  if (k < 3) throw Error(PST_ERR_K_TOO_SMALL, "The k nearest neigbors attribute is too small!");  // :89-91
+  AttributeDef pos{"Position3D", DataType{}};
+  pos.datatype.kind = PST_VEC3F64;
+  const Member* m = b.layout.find(pos);  // view_attribute::<Vector3<f64>>(&POSITION_3D): exact (name, datatype) :97
+  if (!m) throw Error(PST_ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  if (k > 64) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: k > 64 is not supported by the register-resident k-best list");
+  if (b.len >= (1ull << 31)) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: more than 2^31-1 points per call");
+  return *m;
+}
+
+void raise_degenerate(long long rc) {
+  if (rc < 0) throw Error(PST_ERR_HIP, std::string("normal estimation failed: ") + hipGetErrorString(hipGetLastError()));
+  if (rc > 0)  // compute_covariance_matrix Err(..) :293-295, unwrapped at :471
+    throw Error(PST_ERR_NOT_ENOUGH_NEIGHBOURS,
+                "called `Result::unwrap()` on an `Err` value: \"The number of valid (finite and non-NaN values) points in a k nearest "
+                "neighborhood is not enough to span a plane!\" (" + std::to_string(rc) + " neighbourhoods)");
+}
+
+}  // namespace
+
+extern "C" {
+
+int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  const Member& pm = checked_position(*b, k);
+  ensure_device();
+  hipStream_t s = current_stream();
+  const size_t n = b->len;
+  const size_t slot = (size_t)(&pm - b->layout.members.data());
+  const uint64_t base = b->columnar ? col_addr(*b, slot, 0) : aos_addr(*b, 0) + pm.offset;
+  const uint64_t stride = b->columnar ? pm.size : b->layout.size;
+  TempDev d_normals(n * 24), d_curv(n * 8), d_knn(out_knn ? n * k * 8 : 0);
+  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, n, (uint32_t)k, (double*)d_normals.p, (double*)d_curv.p,
+                                     (long long*)d_knn.p, 0, 0, 0, 0, s));
+  PST_HIP_CHECK(hipMemcpyAsync(not_null(out_normals, "out_normals"), d_normals.p, n * 24, hipMemcpyDeviceToHost, s));
+  PST_HIP_CHECK(hipMemcpyAsync(not_null(out_curvature, "out_curvature"), d_curv.p, n * 8, hipMemcpyDeviceToHost, s));
+  if (out_knn) PST_HIP_CHECK(hipMemcpyAsync(out_knn, d_knn.p, n * k * 8, hipMemcpyDeviceToHost, s));
+  stream_sync(s);
+  PST_API_END
+}
+
+// Device-resident: NORMAL (Vec3f32, point_layout.rs:594-597) receives the f64 normal narrowed with `as`; an F64 attribute
+// named "Curvature" receives the curvature.  Either attribute may be absent from `dst`; at least one must be present.
+int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  not_null(dst, "dst");
+  const Member& pm = checked_position(*b, k);
+  if (dst->len != b->len) throw Error(PST_ERR_RANGE, "target buffer length must equal the point cloud length");
+  AttributeDef nd{"Normal", DataType{}}, cd{"Curvature", DataType{}};
+  nd.datatype.kind = PST_VEC3F32;
+  cd.datatype.kind = PST_F64;
+  const int ns = dst->layout.index_of(nd), cs = dst->layout.index_of(cd);
+  if (ns < 0 && cs < 0) throw Error(PST_ERR_MISSING_ATTRIBUTE, "target PointLayout has neither Normal (Vec3f32) nor Curvature (F64)");
+  ensure_device();
+  hipStream_t s = current_stream();
+  const size_t slot = (size_t)(&pm - b->layout.members.data());
+  const uint64_t base = b->columnar ? col_addr(*b, slot, 0) : aos_addr(*b, 0) + pm.offset;
+  const uint64_t stride = b->columnar ? pm.size : b->layout.size;
+  auto attr_addr = [&](int sl, uint64_t& addr, uint64_t& st) {
+    if (sl < 0) { addr = 0; st = 0; return; }
+    const Member& m = dst->layout.members[(size_t)sl];
+    addr = dst->columnar ? col_addr(*dst, (size_t)sl, 0) : aos_addr(*dst, 0) + m.offset;
+    st = dst->columnar ? m.size : dst->layout.size;
+  };
+  uint64_t na, nst, ca, cst;
+  attr_addr(ns, na, nst);
+  attr_addr(cs, ca, cst);
+  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, b->len, (uint32_t)k, nullptr, nullptr, nullptr, na, nst, ca, cst, s));
+  PST_API_END
+}
+
+}  // extern "C"

@@ -189,3 +189,83 @@ def test_full_size_1e8_interleaved_las0_round_trip(hip):
     back = conv.convert(cols, VectorBuffer)
     assert torch.equal(_torch_view(back.points_ptr(), n * 35), _torch_view(src.points_ptr(), n * 35))
     assert calculate_bounds(src) == calculate_bounds(cols) == calculate_bounds(back)
+
+
+# ---- kNN normal estimation (configs[4]) ------------------------------------------------------------------------
+
+def _normals_inputs(n, seed, shape):
+    rng = np.random.default_rng(seed)
+    if shape == "volume":  # uniform in a box: no exact distance ties w.h.p.
+        return rng.random((n, 3)) * np.array([1000.0, 1000.0, 100.0])
+    if shape == "surface":  # a noisy terrain-like sheet: the LiDAR case (2-D manifold in a 3-D box)
+        xy = rng.random((n, 2)) * 500.0
+        z = 20.0 * np.sin(xy[:, 0] / 40.0) * np.cos(xy[:, 1] / 55.0) + rng.normal(0, 0.05, n)
+        return np.column_stack([xy, z])
+    raise ValueError(shape)
+
+
+def _compare_normals(hn, hc, on, oc, rel=1e-9):
+    """<= 1e-9 relative (BASELINE.json).  Documented tie window: the normal is the largest of three cross products
+    (normal_estimation.rs:395-426); when two candidates have norms within 1e-9 of each other the winner may differ."""
+    scale = np.maximum(np.linalg.norm(on, axis=1), 1e-300)
+    err = np.linalg.norm(hn - on, axis=1) / scale
+    bad = err > rel
+    cerr = np.abs(hc - oc) > rel * np.maximum(np.abs(oc), 1e-300) + 1e-18
+    return bad, cerr
+
+
+@pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5)])
+@pytest.mark.parametrize("kind", ["V", "H"])
+def test_compute_normals_vs_oracle(hip, oracle, shape, n, k, kind):
+    from pasture_amd.algorithms import compute_normals
+    pts = _normals_inputs(n, 11 + n, shape)
+
+    def run(api):
+        layout = PointLayout.from_attributes_packed([A.INTENSITY, A.POSITION_3D], 1, api=api)
+        buf = BUFFER_KINDS[kind].new_from_layout(layout)
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    assert np.array_equal(hk, ok), "k-nearest-neighbour indices (ascending distance) differ from the oracle"
+    bad, cbad = _compare_normals(hn, hc, on, oc)
+    assert bad.sum() == 0 and cbad.sum() == 0, f"{bad.sum()} normals / {cbad.sum()} curvatures beyond 1e-9 relative; worst {np.nanmax(np.linalg.norm(hn - on, axis=1))}"
+
+
+def test_compute_normals_into_device_columns(hip, oracle):
+    """north star: f64 -> f32 attribute narrowing of the normal into the NORMAL (Vec3f32) attribute, curvature as F64."""
+    from pasture_amd.algorithms import compute_normals, compute_normals_into
+    n, k = 25_000, 16
+    pts = _normals_inputs(n, 5, "surface")
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    buf = HashMapBuffer.new_from_layout(layout)
+    buf.resize(n)
+    buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+    curv = PointAttributeDefinition("Curvature", T.F64)
+    for kind in ("V", "H"):
+        out = BUFFER_KINDS[kind].new_from_layout(PointLayout.from_attributes_packed([A.CLASSIFICATION, A.NORMAL, curv], 1, api=hip))
+        out.resize(n)
+        compute_normals_into(buf, k, out)
+        hn, hc = compute_normals(buf, k)
+        assert out.view_attribute(A.NORMAL).tobytes() == hn.astype(np.float32).tobytes()
+        assert out.view_attribute(curv).tobytes() == hc.tobytes()
+        assert not out.view_attribute(A.CLASSIFICATION).any()
+
+
+def test_compute_normals_1e6_properties(hip):
+    """Scale check (10^6 points, k = 16) through properties: every point is its own nearest neighbour, neighbour lists are
+    sorted by distance, and brute-force verification of a random sample of queries against numpy."""
+    from pasture_amd.algorithms import compute_normals
+    n, k = 1_000_000, 16
+    pts = _normals_inputs(n, 77, "surface")
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    buf.resize(n)
+    buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+    normals, curv, knn = compute_normals(buf, k, return_knn=True)
+    assert np.array_equal(knn[:, 0], np.arange(n))
+    assert np.isfinite(normals).all() and np.isfinite(curv).all() and (curv >= 0).all()
+    rng = np.random.default_rng(1)
+    for q in rng.integers(0, n, 200):
+        d = ((pts - pts[q]) ** 2).sum(axis=1)
+        want = np.argsort(d, kind="stable")[:k]
+        assert np.array_equal(knn[q], want)
