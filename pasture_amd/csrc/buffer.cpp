@@ -1,6 +1,7 @@
 // Device-backed buffers + their C ABI.
 // Reference: pasture-core/src/containers/point_buffer.rs (VectorBuffer :659-945, HashMapBuffer :1031-1474,
 // ExternalMemoryBuffer :1479-1708) — storage shape and accessor semantics (resize zero-fills, ranges are checked).
+#include <cstdlib>
 #include <mutex>
 
 #include "runtime.hpp"
@@ -46,17 +47,38 @@ uint8_t* Workspace::partials(size_t bytes) {
   return partials_buf;
 }
 
+// Device memory comes from HIP's stream-ordered pool (hipMallocAsync): hipMalloc / hipFree of multi-GB buffers cost
+// ~100 ms each on this platform, which would dominate `convert()` (allocate + convert + return).  The pool keeps freed
+// blocks (release threshold = never), so steady-state allocations are sub-microsecond and stream-ordered.
+static bool pool_ready() {
+  static int state = [] {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int supported = 0;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) != hipSuccess || !supported) return 0;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) return 0;
+    uint64_t keep = ~0ull;
+    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) return 0;
+    return 1;
+  }();
+  if (std::getenv("PST_NO_POOL")) return false;
+  return state == 1;
+}
+
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind) {
   if (bytes == 0) return nullptr;
   ensure_device();
   void* p = nullptr;
   if (memkind == PST_MEM_PINNED_HOST) PST_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  else if (pool_ready()) PST_HIP_CHECK(hipMallocAsync(&p, bytes, current_stream()));
   else PST_HIP_CHECK(hipMalloc(&p, bytes));
   return (uint8_t*)p;
 }
 void dev_free(uint8_t* p, uint32_t memkind) {
   if (!p) return;
   if (memkind == PST_MEM_PINNED_HOST) (void)hipHostFree(p);
+  else if (pool_ready()) (void)hipFreeAsync(p, current_stream());
   else (void)hipFree(p);
 }
 
@@ -85,7 +107,7 @@ static size_t slot_of(const pst_buffer& b, const char* name, const pst_datatype*
 }
 
 // grow storage to `count` points (contents preserved, new points zero-filled: Vec::resize(_, 0))
-static void resize_buffer(pst_buffer& b, size_t count) {
+void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
   if (!b.owns) {
     if (count != b.len) throw Error(PST_ERR_UNSUPPORTED, "ExternalMemoryBuffer is not an OwningBuffer: it cannot be resized");
     return;
@@ -111,7 +133,7 @@ static void resize_buffer(pst_buffer& b, size_t count) {
     }
     b.capacity = count;
   }
-  if (count > b.len) {
+  if (count > b.len && zero_fill) {
     const size_t extra = count - b.len;
     if (b.columnar) {
       for (size_t a = 0; a < b.columns.size(); ++a) {
@@ -200,7 +222,7 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
 }
 int pst_buffer_destroy(pst_buffer* b) { delete b; return PST_OK; }
 int pst_buffer_len(const pst_buffer* b, size_t* out) { PST_API_BEGIN *not_null(out, "out") = not_null(b, "buffer")->len; PST_API_END }
-int pst_buffer_resize(pst_buffer* b, size_t count) { PST_API_BEGIN resize_buffer(*not_null(b, "buffer"), count); PST_API_END }
+int pst_buffer_resize(pst_buffer* b, size_t count) { PST_API_BEGIN resize_buffer(*not_null(b, "buffer"), count, true); PST_API_END }
 int pst_buffer_is_columnar(const pst_buffer* b, int* out) { PST_API_BEGIN *not_null(out, "out") = not_null(b, "buffer")->columnar; PST_API_END }
 int pst_buffer_layout(const pst_buffer* b, pst_layout** out_clone) { PST_API_BEGIN *not_null(out_clone, "out") = new pst_layout{not_null(b, "buffer")->layout}; PST_API_END }
 int pst_buffer_points_ptr(const pst_buffer* b, void** out) {

@@ -203,12 +203,22 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
           if (want_bounds) bounds_done = true;
           continue;
         }
-        if (same_type && !m.xf) {
-          // bulk column copy == set_attribute_range(copy_from_slice), buffer_conversion.rs:465-469
-          PST_HIP_CHECK(hipMemcpyAsync((void*)(uintptr_t)e.dst_col, (const void*)(uintptr_t)e.src_col, n * m.source.size,
-                                       hipMemcpyDeviceToDevice, stream));
-          continue;
+        // every other columnar -> columnar mapping is its own wide-vector launch (columns.hip): plain copies move raw
+        // bytes (== set_attribute_range / copy_from_slice, buffer_conversion.rs:465-469), the rest converts per component
+        const bool fuse_bounds = bounds_out6 && tslot == pos_slot && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done;
+        double* partials = nullptr;
+        unsigned grid = 0;
+        if (fuse_bounds) {
+          grid = pstk::column_launch_grid(e, n, true);
+          partials = (double*)workspace().partials(pstk::bounds_partials_bytes(grid));
         }
+        if (!pstk::launch_column(e, n, partials, stream))
+          throw Error(PST_ERR_HIP, std::string("column conversion launch failed: ") + hipGetErrorString(hipGetLastError()));
+        if (fuse_bounds) {
+          pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
+          bounds_done = true;
+        }
+        continue;
       }
       if (bounds_out6 && tslot == pos_slot && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done) {
         e.bounds = 1;  // fused: the kernel folds the Vec3f64 values it writes into the AABB record
@@ -332,22 +342,39 @@ int pst_converter_convert_into_range(const pst_converter* c, pst_buffer* src, si
   PST_API_END
 }
 
-// convert :242-259.  The reference zero-fills the whole target (`resize`) and then overwrites it; here only what no
-// mapping writes is zero-filled by resize — identical bytes, one write pass less... kept simple: resize zero-fills (async
-// memset on the same stream), the conversion overwrites.
+// convert :242-259.  The reference zero-fills the whole target (`resize`) and then overwrites most of it.  Here only the
+// bytes NO mapping writes are zero-filled (unmapped columns; interleaved records that are not fully covered) — the
+// resulting buffer is byte-identical, one full write pass over the target cheaper.
 int pst_converter_convert(const pst_converter* c, pst_buffer* src, uint32_t out_storage, pst_buffer** out) {
   PST_API_BEGIN
   not_null(c, "converter");
   not_null(src, "src");
+  if (src->layout != c->from) throw Error(PST_ERR_LAYOUT_MISMATCH, "assertion `left == right` failed: source_buffer.point_layout() != from_layout");
   pst_layout tl{c->to};
   pst_buffer* target = nullptr;
   int rc = pst_buffer_create(&tl, out_storage, PST_MEM_DEVICE, &target);
   if (rc != PST_OK) return rc;
   std::unique_ptr<pst_buffer> guard(target);
-  rc = pst_buffer_resize(target, src->len);
-  if (rc != PST_OK) return rc;
-  convert_range(*c, *src, 0, src->len, *target, 0, src->len, nullptr, current_stream());
-  stream_sync(current_stream());
+  const size_t n = src->len;
+  if (n > 0) {
+    resize_buffer(*target, n, /*zero_fill=*/false);
+    hipStream_t s = current_stream();
+    if (target->columnar) {
+      for (size_t a = 0; a < c->to.members.size(); ++a) {
+        bool written = false;
+        for (const Mapping& m : c->mappings) written = written || (m.target.def == c->to.members[a].def);
+        if (!written && c->to.members[a].size) PST_HIP_CHECK(hipMemsetAsync(target->columns[a], 0, n * c->to.members[a].size, s));
+      }
+    } else {
+      std::vector<uint8_t> covered(c->to.size, 0);
+      for (const Mapping& m : c->mappings)
+        for (uint64_t b = 0; b < m.target.size; ++b) covered[m.target.offset + b] = 1;
+      const bool full = std::all_of(covered.begin(), covered.end(), [](uint8_t v) { return v != 0; });
+      if (!full && c->to.size) PST_HIP_CHECK(hipMemsetAsync(target->data, 0, n * c->to.size, s));
+    }
+    convert_range(*c, *src, 0, n, *target, 0, n, nullptr, s);
+    stream_sync(s);
+  }
   *not_null(out, "out") = guard.release();
   PST_API_END
 }

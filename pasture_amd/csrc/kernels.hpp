@@ -44,6 +44,11 @@ struct SynthAttr {
 };
 void launch_synth(const SynthAttr& a, uint64_t n, uint64_t seed, uint64_t first_index, hipStream_t stream);
 
+// columnar -> columnar conversion of one attribute (columns.hip): e.src_col / e.dst_col are the range starts.
+// With bounds_partials != nullptr (Vec3f64 target) the written values are folded into column_launch_grid() records.
+unsigned column_launch_grid(const PlanEntry& e, uint64_t n, bool with_bounds);
+bool launch_column(const PlanEntry& e, uint64_t n, double* bounds_partials, hipStream_t stream);
+
 // K4 kNN normal estimation (normals.hip).  Positions: Vec3f64 at pos_base + i*pos_stride.  Outputs (all optional, device
 // addresses): normals f64 [n][3], curvature f64 [n], knn int64 [n][k], NORMAL attribute (Vec3f32) and Curvature attribute (F64)
 // of a target buffer.  Returns 0, -1 on a HIP failure, or the number of neighbourhoods with < 3 usable points.

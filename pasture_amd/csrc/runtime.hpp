@@ -57,6 +57,8 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
 PlanEntry identity_entry(const Member& src, const Member& dst);
 
 void stream_sync(hipStream_t s);
+// OwningBuffer::resize; zero_fill = false leaves new points uninitialised (callers that overwrite every byte)
+void resize_buffer(pst_buffer& b, size_t count, bool zero_fill);
 
 // {min xyz, max xyz} of POSITION_3D over points [first, first+count) written to out6 (device-accessible); seeds
 // +/-f64::MAX (bounds.rs:31-32).  The buffer must have a Position3D attribute.
