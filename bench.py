@@ -119,7 +119,8 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: pasture_amd has no CPU fallback"
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # torchrun with one rank (or PASTURE_FORCE_DIST=1) still exercises the RCCL path: init, all-reduce, barrier
+    distributed = world > 1 or (os.environ.get("PASTURE_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
