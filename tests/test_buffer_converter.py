@@ -213,3 +213,59 @@ def test_opaque_types_copy(api, pair):
     assert np.array_equal(out.view_attribute(blob), rec["Blob"])
     assert np.array_equal(out.view_attribute(rgba), rec["RGBA"])
     assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"])
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_many_attributes_more_than_one_plan(api, pair):
+    """45 mappings (the device plan holds 30 entries per launch): mixed datatypes, shuffled order, a few `as` casts."""
+    kinds = [T.U8, T.I16, T.F32, T.U64, T.Vec3u8, T.F64, T.Vec3f32, T.I8, T.U16, T.Vec3f64, T.I32, T.Vec3u16, T.U32, T.I64, T.Vec3i32]
+    src_attrs = [PointAttributeDefinition(f"f{i}", kinds[i % len(kinds)]) for i in range(45)]
+    cast = {T.U8: T.U32, T.F32: T.F64, T.Vec3u8: T.Vec3u16, T.I16: T.I64, T.Vec3f64: T.Vec3f32}
+    dst_attrs = [PointAttributeDefinition(a.name(), cast.get(a.datatype(), a.datatype()) if i % 3 == 0 else a.datatype())
+                 for i, a in reversed(list(enumerate(src_attrs)))]
+    sl = PointLayout.from_attributes_packed(src_attrs, 1, api=api)
+    tl = PointLayout.from_attributes(dst_attrs, api=api)  # repr(C) target: padding between attributes
+    rec = random_records(sl, 777, seed=41)
+    src = make_buffer(pair[0], sl, rec)
+    out = BufferLayoutConverter.for_layouts(sl, tl).convert(src, BUFFER_KINDS[pair[1]])
+    for s_attr, d_attr in zip(reversed(src_attrs), dst_attrs):
+        want = rec[s_attr.name()]
+        if d_attr.datatype() != s_attr.datatype():
+            want = want.astype(d_attr.datatype().numpy_dtype())  # all chosen casts are value-preserving widenings or f64->f32 RNE
+        assert out.view_attribute(d_attr).tobytes() == want.tobytes(), d_attr.name()
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_huge_records_fall_back_to_direct_path(api, pair):
+    """Records too large for an LDS tile (200 KB each) take the strided direct kernel."""
+    blob = PointAttributeDefinition("Blob", T.ByteArray(200_000))
+    sl = PointLayout.from_attributes_packed([A.CLASSIFICATION, blob, A.POSITION_3D], 1, api=api)
+    tl = PointLayout.from_attributes_packed([A.POSITION_3D, blob], 1, api=api)
+    rec = random_records(sl, 5, seed=43)
+    src = make_buffer(pair[0], sl, rec)
+    out = BufferLayoutConverter.for_layouts(sl, tl).convert(src, BUFFER_KINDS[pair[1]])
+    assert np.array_equal(out.view_attribute(blob), rec["Blob"])
+    assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"])
+
+
+@pytest.mark.parametrize("pair", PAIRINGS)
+def test_empty_and_single_point(api, pair):
+    big, small = custom_point_type_big(api), custom_point_type_small(api)
+    conv = BufferLayoutConverter.for_layouts(big, small)
+    empty = BUFFER_KINDS[pair[0]].new_from_layout(big)
+    out = conv.convert(empty, BUFFER_KINDS[pair[1]])
+    assert out.len() == 0 and out.point_layout() == small
+    rec = random_records(big, 1, seed=47)
+    one = conv.convert(make_buffer(pair[0], big, rec), BUFFER_KINDS[pair[1]])
+    assert np.array_equal(one.view_attribute(A.POSITION_3D), rec["Position3D"])
+
+
+def test_empty_layout_converter(api):
+    """A target layout without attributes: no mappings => convert_into_range is a silent no-op (buffer_conversion.rs:308-313)."""
+    big = custom_point_type_big(api)
+    empty_layout = PointLayout.default(api)
+    conv = BufferLayoutConverter.for_layouts(big, empty_layout)
+    assert conv.mappings() == []
+    src = make_buffer("V", big, random_records(big, 10, seed=1))
+    out = conv.convert(src, VectorBuffer)
+    assert out.len() == 10 and out.point_layout().size_of_point_entry() == 0
