@@ -62,12 +62,17 @@ struct BoundsAcc {
 
 // One value: optional pre-transform, `as` D, optional post-transform (buffer_conversion.rs:446-456)
 template <typename S, typename D>
-__device__ __forceinline__ D convert_value(S v, const XfRegs& x, uint32_t c) {
-  const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
-  if (x.kind != 0 && x.pre != 0) v = apply_xf<S>(v, x.kind, sc, of, x.shift, x.mask);
+__device__ __forceinline__ D convert_value_sc(S v, const XfRegs& x, double sc, double of) {
+  if (x.kind == 0) return rust_as<D, S>(v);  // wave-uniform: the common untransformed mapping pays nothing
+  if (x.pre != 0) v = apply_xf<S>(v, x.kind, sc, of, x.shift, x.mask);
   D w = rust_as<D, S>(v);
-  if (x.kind != 0 && x.pre == 0) w = apply_xf<D>(w, x.kind, sc, of, x.shift, x.mask);
+  if (x.pre == 0) w = apply_xf<D>(w, x.kind, sc, of, x.shift, x.mask);
   return w;
+}
+template <typename S, typename D>
+__device__ __forceinline__ D convert_value(S v, const XfRegs& x, uint32_t c) {
+  if (x.kind == 0) return rust_as<D, S>(v);
+  return convert_value_sc<S, D>(v, x, pick3(c, x.s0, x.s1, x.s2), pick3(c, x.o0, x.o1, x.o2));
 }
 
 // Split a flat component index into (point, component).
@@ -204,28 +209,59 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
   const uint32_t total = cnt * e.ncomp;
   const XfRegs x = load_xf(e);
   gptr_t col = as_global(e.dst_col) + first * e.ncomp * sizeof(D);
-  if constexpr (std::is_same<D, double>::value) {
-    if (e.bounds && e.ncomp == 3) {
-      // Vec3f64 with fused AABB: a lane's q advances by `step` (a multiple of 3 x step after three iterations), so the
-      // component of "slot r" = (first + r*step) mod 3 is fixed; three rotating min/max pairs need no per-value selects.
-      double lo[3] = {kF64Max, kF64Max, kF64Max}, hi[3] = {-kF64Max, -kF64Max, -kF64Max};
-      for (uint32_t q = span.first; q < total; q += 3 * span.step) {
-#pragma unroll
-        for (uint32_t r = 0; r < 3; ++r) {
-          const uint32_t k = q + r * span.step;
-          if (k < total) {
-            const uint32_t p = k / 3, c = k - 3 * p;
-            const double w = convert_value<S, double>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
-            store_un<double>(col + (uint64_t)k * 8, w);
-            lo[r] = __builtin_fmin(lo[r], w);
-            hi[r] = __builtin_fmax(hi[r], w);
+  if constexpr (E == 1) {
+    if (e.ncomp == 3) {
+      // Vec3 values with >= 4-byte components: use step - step%3 lanes so that a lane's component index c = lane % 3 NEVER
+      // changes: no division, no per-value selects; scale / offset / AABB slot are per-lane constants; the LDS and column
+      // addresses advance by constants.  (255 of 256 lanes work on a shared entry.)
+      const uint32_t lanes = span.step - span.step % 3u;
+      if (span.first < lanes) {
+        const uint32_t c = span.first % 3u, p0 = span.first / 3u, ppi = lanes / 3u;
+        const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
+        uint32_t la = p0 * h.src_stride + e.src_off + c * (uint32_t)sizeof(S);
+        uint32_t ga = span.first * (uint32_t)sizeof(D);
+        const uint32_t la_step = ppi * h.src_stride, ga_step = lanes * (uint32_t)sizeof(D);
+        double lo = kF64Max, hi = -kF64Max;
+        for (uint32_t pp = p0; pp < cnt; pp += ppi, la += la_step, ga += ga_step) {
+          const D w = convert_value_sc<S, D>(load_un<S>(lds_src + la), x, sc, of);
+          store_un<D>(col + ga, w);
+          if constexpr (std::is_same<D, double>::value) {
+            lo = __builtin_fmin(lo, w);
+            hi = __builtin_fmax(hi, w);
           }
         }
+        if constexpr (std::is_same<D, double>::value) {
+          if (e.bounds) acc.fold2(c, lo, hi);
+        }
       }
-#pragma unroll
-      for (uint32_t r = 0; r < 3; ++r) acc.fold2((span.first + r * span.step) % 3u, lo[r], hi[r]);
       return;
     }
+  }
+  if (e.ncomp == 1) {
+    // scalar attributes: a lane produces E consecutive points (one >= 4-byte chunk); addresses advance by constants
+    const uint32_t la_step = span.step * E * h.src_stride;
+    uint32_t la = span.first * E * h.src_stride + e.src_off;
+    for (uint32_t k0 = span.first * E; k0 < cnt; k0 += span.step * E, la += la_step) {
+      if (k0 + E <= cnt) {
+        if constexpr (E == 1) {
+          store_un<D>(col + (uint64_t)k0 * sizeof(D), convert_value_sc<S, D>(load_un<S>(lds_src + la), x, x.s0, x.o0));
+        } else {
+          uint32_t packed = 0;
+#pragma unroll
+          for (uint32_t i = 0; i < E; ++i) {
+            const D w = convert_value_sc<S, D>(load_un<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0);
+            typename std::make_unsigned<D>::type u;
+            __builtin_memcpy(&u, &w, sizeof(D));
+            packed |= (uint32_t)u << (8u * (uint32_t)sizeof(D) * i);
+          }
+          store_un<uint32_t>(col + (uint64_t)k0 * sizeof(D), packed);
+        }
+      } else {
+        for (uint32_t i = 0; k0 + i < cnt; ++i)
+          store_un<D>(col + (uint64_t)(k0 + i) * sizeof(D), convert_value_sc<S, D>(load_un<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0));
+      }
+    }
+    return;
   }
   for (uint32_t q = span.first; q * E < total; q += span.step) {
     const uint32_t k0 = q * E;
@@ -267,6 +303,55 @@ __device__ __forceinline__ void run_tile_from_column(const ConvertHeader& h, con
   const uint32_t total = cnt * e.ncomp;
   const XfRegs x = load_xf(e);
   cgptr_t col = as_global(e.src_col) + first * e.ncomp * sizeof(S);
+  if constexpr (E == 1) {
+    if (e.ncomp == 3) {  // lane-fixed component index, see run_tile_to_column
+      const uint32_t lanes = span.step - span.step % 3u;
+      if (span.first < lanes) {
+        const uint32_t c = span.first % 3u, p0 = span.first / 3u, ppi = lanes / 3u;
+        const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
+        uint32_t la = p0 * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D);
+        uint32_t ga = span.first * (uint32_t)sizeof(S);
+        const uint32_t la_step = ppi * h.dst_stride, ga_step = lanes * (uint32_t)sizeof(S);
+        double lo = kF64Max, hi = -kF64Max;
+        for (uint32_t pp = p0; pp < cnt; pp += ppi, la += la_step, ga += ga_step) {
+          const D w = convert_value_sc<S, D>(load_un<S>(col + ga), x, sc, of);
+          store_un<D>(lds_dst + la, w);
+          if constexpr (std::is_same<D, double>::value) {
+            lo = __builtin_fmin(lo, w);
+            hi = __builtin_fmax(hi, w);
+          }
+        }
+        if constexpr (std::is_same<D, double>::value) {
+          if (e.bounds) acc.fold2(c, lo, hi);
+        }
+      }
+      return;
+    }
+  }
+  if (e.ncomp == 1) {
+    const uint32_t la_step = span.step * E * h.dst_stride;
+    uint32_t la = span.first * E * h.dst_stride + e.dst_off;
+    for (uint32_t k0 = span.first * E; k0 < cnt; k0 += span.step * E, la += la_step) {
+      if (k0 + E <= cnt) {
+        if constexpr (E == 1) {
+          store_un<D>(lds_dst + la, convert_value_sc<S, D>(load_un<S>(col + (uint64_t)k0 * sizeof(S)), x, x.s0, x.o0));
+        } else {
+          const uint32_t packed = load_un<uint32_t>(col + (uint64_t)k0 * sizeof(S));
+#pragma unroll
+          for (uint32_t i = 0; i < E; ++i) {
+            typename std::make_unsigned<S>::type u = (typename std::make_unsigned<S>::type)(packed >> (8u * (uint32_t)sizeof(S) * i));
+            S v;
+            __builtin_memcpy(&v, &u, sizeof(S));
+            store_un<D>(lds_dst + (la + i * h.dst_stride), convert_value_sc<S, D>(v, x, x.s0, x.o0));
+          }
+        }
+      } else {
+        for (uint32_t i = 0; k0 + i < cnt; ++i)
+          store_un<D>(lds_dst + (la + i * h.dst_stride), convert_value_sc<S, D>(load_un<S>(col + (uint64_t)(k0 + i) * sizeof(S)), x, x.s0, x.o0));
+      }
+    }
+    return;
+  }
   for (uint32_t q = span.first; q * E < total; q += span.step) {
     const uint32_t k0 = q * E;
     S vals[E];
@@ -337,7 +422,9 @@ __global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h
   const uint32_t src_cap = SRC_AOS ? round_up16(T * h.src_stride + 32u) : 0u;
   lptr_t lds_s = lds;
   lptr_t lds_d = lds + src_cap;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  // readfirstlane: the wave index is wave-uniform by construction, but the compiler only knows it derives from threadIdx;
+  // without it every entry field lands in VGPRs and the type dispatch becomes exec-mask control flow.
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
   const PST_AS_CONST uint32_t* masks = (const PST_AS_CONST uint32_t*)(entries + PST_PLAN_MAX_ENTRIES);
   const uint32_t mask_all = masks[0];
   const uint32_t mask_own = masks[1 + (wave & 15u)];
