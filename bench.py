@@ -35,8 +35,12 @@ WORKLOADS = {
     # name: (algorithmic bytes per point, description)
     "convert_affine_bounds": (48, "SoA POSITION_3D f64 affine layout-conversion + AABB, fused (24 R + 24 W)"),
     "bounds": (24, "SoA POSITION_3D f64 AABB (24 R)"),
-    "las0_to_columns": (70, "AoS LAS format-0 (35 B, 10 attrs, packed) -> 10 SoA columns (35 R + 35 W)"),
+    "las0_to_columns": (70, "configs[2]: AoS LAS format-0 (35 B, 10 attrs, packed) -> 10 SoA columns (35 R + 35 W)"),
+    "las0_to_columns_bounds": (70, "AoS LAS format-0 -> 10 SoA columns + AABB of the result, fused (35 R + 35 W)"),
     "rawlas_to_columns": (55, "raw LAS-0 records (20 B) -> 10 SoA columns, i32->f64 affine + bit fields (20 R + 35 W)"),
+    "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
+    "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
+    "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
 }
 
 
@@ -156,8 +160,34 @@ def main():
         else:
             def step():
                 pa.calculate_bounds_async(src, rec.data_ptr())
+    elif args.workload == "narrow_f64_f32":
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        layout32 = pa.PointLayout.from_attributes([A.POSITION_3D.with_custom_datatype(T.Vec3f32)])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.HashMapBuffer.new_from_layout(layout32)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(layout, layout32)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload == "columns_to_las0":
+        layout = las.point_layout_from_las_point_format(las.Format(0), False)
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.VectorBuffer.new_from_layout(layout)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(layout, layout)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
     else:
-        raw = args.workload == "rawlas_to_columns"
+        raw = args.workload.startswith("rawlas")
+        with_bounds = args.workload.endswith("_bounds")
         src_layout = las.point_layout_from_las_point_format(las.Format(0), raw)
         dst_layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.VectorBuffer.new_from_layout(src_layout)
@@ -167,13 +197,21 @@ def main():
         dst.resize(n)
         conv = las.get_default_las_converter(src_layout, dst_layout, SCALE, OFFSET) if raw else \
             pa.BufferLayoutConverter.for_layouts(src_layout, dst_layout)
+        if with_bounds:
+            def step():
+                conv.convert_into_with_bounds_async(src, dst, rec.data_ptr())
+        else:
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+            pa.calculate_bounds_async(dst, rec.data_ptr())  # reported once in config.bounds; not part of the timed step
 
-        def step():
-            conv.convert_into_with_bounds_async(src, dst, rec.data_ptr())
+            def step():
+                conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+
+    has_reduction = args.workload in ("convert_affine_bounds", "bounds") or args.workload.endswith("_bounds")
 
     def full_step():
         step()
-        if distributed:
+        if distributed and has_reduction:
             allreduce_bounds_record(rec)  # ONE all-reduce of 6 doubles (RCCL over xGMI)
 
     for _ in range(args.warmup):
@@ -189,7 +227,7 @@ def main():
         ev[i][0].record(stream)
         step()
         ev[i][1].record(stream)
-        if distributed:
+        if distributed and has_reduction:
             allreduce_bounds_record(rec)
     torch.cuda.synchronize()
     if distributed:
@@ -228,14 +266,14 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": n * world,
-                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds") else "LAS format 0",
+                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32") else "LAS format 0",
                        "parallelism": f"index-range shard x{world}, one all-reduce of the 6-f64 AABB" if distributed else "1 GPU",
                        "seed": SEED, "bounds": result},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_point": bytes_per_point, "kernel_ms_avg": round(kernel_ms_avg, 4),
                          "kernel_ms_min": round(min(kernel_ms), 4),
-                         "note": "HIP events around the fused conversion+AABB launch (stream kernel + 1-block finalize) on the launch stream"},
+                         "note": "HIP events around one step's launches on the launch stream (conversion kernel + the AABB fold kernels where fused)"},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "convert_affine_bounds":
             cb = cpu_baseline(args.workload, args.cpu_sample_points)

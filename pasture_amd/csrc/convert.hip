@@ -186,16 +186,22 @@ __device__ __forceinline__ void wait_tile_loads() { asm volatile("s_waitcnt vmcn
 template <int BLK>
 __device__ __forceinline__ void tile_store(clptr_t lds, gptr_t gbase, uint32_t mis, uint32_t nbytes) {
   const uint32_t end = mis + nbytes;
-  const uint32_t nvec = (end + 15u) >> 4;
-  for (uint32_t i = threadIdx.x; i < nvec; i += BLK) {
-    const uint32_t b0 = i << 4, b1 = b0 + 16;
-    if (b0 >= mis && b1 <= end) {
-      __builtin_nontemporal_store(reinterpret_cast<cl4ptr_t>(lds)[i], &reinterpret_cast<g4ptr_t>(gbase)[i]);
-    } else {
-      const uint32_t lo = b0 > mis ? b0 : mis, hi = b1 < end ? b1 : end;
-      for (uint32_t b = lo; b < hi; ++b) gbase[b] = lds[b];
-    }
+  const uint32_t v_first = (mis + 15u) >> 4, v_last = end >> 4;  // whole 16-byte chunks [v_first, v_last)
+  cl4ptr_t l = reinterpret_cast<cl4ptr_t>(lds);
+  g4ptr_t g = reinterpret_cast<g4ptr_t>(gbase);
+  constexpr uint32_t kBatch = 4;  // LDS reads in flight per lane before the first store
+  for (uint32_t i0 = v_first + threadIdx.x; i0 < v_last; i0 += kBatch * BLK) {
+    u32x4 v[kBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) if (i0 + u * BLK < v_last) v[u] = l[i0 + u * BLK];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) if (i0 + u * BLK < v_last) __builtin_nontemporal_store(v[u], &g[i0 + u * BLK]);
   }
+  // ragged edges: bytes [mis, v_first*16) and [v_last*16, end) — never touch a byte outside the target range
+  const uint32_t head_end = v_first * 16u < end ? v_first * 16u : end;
+  for (uint32_t b = mis + threadIdx.x; b < head_end; b += BLK) gbase[b] = lds[b];
+  const uint32_t tail_begin = v_last * 16u > head_end ? v_last * 16u : head_end;
+  for (uint32_t b = tail_begin + threadIdx.x; b < end; b += BLK) gbase[b] = lds[b];
 }
 
 // Which lanes work on an entry: all BLK lanes of the block, or (small entries) the 64 lanes of the one wave that owns it.
@@ -222,12 +228,21 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
         uint32_t ga = span.first * (uint32_t)sizeof(D);
         const uint32_t la_step = ppi * h.src_stride, ga_step = lanes * (uint32_t)sizeof(D);
         double lo = kF64Max, hi = -kF64Max;
-        for (uint32_t pp = p0; pp < cnt; pp += ppi, la += la_step, ga += ga_step) {
-          const D w = convert_value_sc<S, D>(load_un<S>(lds_src + la), x, sc, of);
-          store_un<D>(col + ga, w);
-          if constexpr (std::is_same<D, double>::value) {
-            lo = __builtin_fmin(lo, w);
-            hi = __builtin_fmax(hi, w);
+        constexpr uint32_t kBatch = 4;  // LDS reads in flight per lane
+        for (uint32_t pp = p0; pp < cnt; pp += kBatch * ppi, la += kBatch * la_step, ga += kBatch * ga_step) {
+          S v[kBatch];
+#pragma unroll
+          for (uint32_t u = 0; u < kBatch; ++u) v[u] = pp + u * ppi < cnt ? load_un<S>(lds_src + (la + u * la_step)) : S{};
+#pragma unroll
+          for (uint32_t u = 0; u < kBatch; ++u) {
+            if (pp + u * ppi < cnt) {
+              const D w = convert_value_sc<S, D>(v[u], x, sc, of);
+              store_un<D>(col + (ga + u * ga_step), w);
+              if constexpr (std::is_same<D, double>::value) {
+                lo = __builtin_fmin(lo, w);
+                hi = __builtin_fmax(hi, w);
+              }
+            }
           }
         }
         if constexpr (std::is_same<D, double>::value) {
@@ -313,12 +328,23 @@ __device__ __forceinline__ void run_tile_from_column(const ConvertHeader& h, con
         uint32_t ga = span.first * (uint32_t)sizeof(S);
         const uint32_t la_step = ppi * h.dst_stride, ga_step = lanes * (uint32_t)sizeof(S);
         double lo = kF64Max, hi = -kF64Max;
-        for (uint32_t pp = p0; pp < cnt; pp += ppi, la += la_step, ga += ga_step) {
-          const D w = convert_value_sc<S, D>(load_un<S>(col + ga), x, sc, of);
-          store_un<D>(lds_dst + la, w);
-          if constexpr (std::is_same<D, double>::value) {
-            lo = __builtin_fmin(lo, w);
-            hi = __builtin_fmax(hi, w);
+        // batches of kBatch global loads in flight per lane (a dependent load -> LDS-store chain per iteration would expose
+        // the full HBM latency every time)
+        constexpr uint32_t kBatch = 4;
+        for (uint32_t pp = p0; pp < cnt; pp += kBatch * ppi, la += kBatch * la_step, ga += kBatch * ga_step) {
+          S v[kBatch];
+#pragma unroll
+          for (uint32_t u = 0; u < kBatch; ++u) v[u] = pp + u * ppi < cnt ? load_un<S>(col + (ga + u * ga_step)) : S{};
+#pragma unroll
+          for (uint32_t u = 0; u < kBatch; ++u) {
+            if (pp + u * ppi < cnt) {
+              const D w = convert_value_sc<S, D>(v[u], x, sc, of);
+              store_un<D>(lds_dst + (la + u * la_step), w);
+              if constexpr (std::is_same<D, double>::value) {
+                lo = __builtin_fmin(lo, w);
+                hi = __builtin_fmax(hi, w);
+              }
+            }
           }
         }
         if constexpr (std::is_same<D, double>::value) {
@@ -329,25 +355,37 @@ __device__ __forceinline__ void run_tile_from_column(const ConvertHeader& h, con
     }
   }
   if (e.ncomp == 1) {
-    const uint32_t la_step = span.step * E * h.dst_stride;
+    const uint32_t la_step = span.step * E * h.dst_stride, k_step = span.step * E;
     uint32_t la = span.first * E * h.dst_stride + e.dst_off;
-    for (uint32_t k0 = span.first * E; k0 < cnt; k0 += span.step * E, la += la_step) {
-      if (k0 + E <= cnt) {
-        if constexpr (E == 1) {
-          store_un<D>(lds_dst + la, convert_value_sc<S, D>(load_un<S>(col + (uint64_t)k0 * sizeof(S)), x, x.s0, x.o0));
-        } else {
-          const uint32_t packed = load_un<uint32_t>(col + (uint64_t)k0 * sizeof(S));
+    constexpr uint32_t kBatch = 4;
+    typedef typename std::conditional<(E > 1), uint32_t, S>::type chunk_t;  // E narrow values travel as one dword
+    for (uint32_t k0 = span.first * E; k0 < cnt; k0 += kBatch * k_step, la += kBatch * la_step) {
+      chunk_t chunk[kBatch];
 #pragma unroll
-          for (uint32_t i = 0; i < E; ++i) {
-            typename std::make_unsigned<S>::type u = (typename std::make_unsigned<S>::type)(packed >> (8u * (uint32_t)sizeof(S) * i));
-            S v;
-            __builtin_memcpy(&v, &u, sizeof(S));
-            store_un<D>(lds_dst + (la + i * h.dst_stride), convert_value_sc<S, D>(v, x, x.s0, x.o0));
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t k = k0 + u * k_step;
+        chunk[u] = chunk_t{};
+        if (k + E <= cnt) chunk[u] = load_un<chunk_t>(col + (uint64_t)k * sizeof(S));
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < kBatch; ++u) {
+        const uint32_t k = k0 + u * k_step, lau = la + u * la_step;
+        if (k + E <= cnt) {
+          if constexpr (E == 1) {
+            store_un<D>(lds_dst + lau, convert_value_sc<S, D>(chunk[u], x, x.s0, x.o0));
+          } else {
+#pragma unroll
+            for (uint32_t i = 0; i < E; ++i) {
+              typename std::make_unsigned<S>::type bits = (typename std::make_unsigned<S>::type)(chunk[u] >> (8u * (uint32_t)sizeof(S) * i));
+              S v;
+              __builtin_memcpy(&v, &bits, sizeof(S));
+              store_un<D>(lds_dst + (lau + i * h.dst_stride), convert_value_sc<S, D>(v, x, x.s0, x.o0));
+            }
           }
+        } else if (k < cnt) {  // ragged tail of the tile
+          for (uint32_t i = 0; k + i < cnt; ++i)
+            store_un<D>(lds_dst + (lau + i * h.dst_stride), convert_value_sc<S, D>(load_un<S>(col + (uint64_t)(k + i) * sizeof(S)), x, x.s0, x.o0));
         }
-      } else {
-        for (uint32_t i = 0; k0 + i < cnt; ++i)
-          store_un<D>(lds_dst + (la + i * h.dst_stride), convert_value_sc<S, D>(load_un<S>(col + (uint64_t)(k0 + i) * sizeof(S)), x, x.s0, x.o0));
       }
     }
     return;
@@ -546,7 +584,7 @@ bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool us
   const unsigned grid = convert_grid(plan, src_aos, dst_aos, use_lds);
   if (use_lds && (src_aos || dst_aos)) {
     const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
-    static const long blk = env_long("PST_TILE_BLOCK", 256);
+    // 256-thread blocks: 512 / 1024 measured 15-60 % slower (per-wave interpretation cost is amortised over fewer points)
 #define PST_LAUNCH_TILE_B(B, SA, DA)                                                                           \
   do {                                                                                                         \
     auto kfn = convert_tile_kernel<B, SA, DA>;                                                                 \
@@ -554,12 +592,7 @@ bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool us
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(B), lds_bytes, stream, h, entries);                               \
   } while (0)
-#define PST_LAUNCH_TILE(SA, DA)                                   \
-  do {                                                            \
-    if (blk == 512) PST_LAUNCH_TILE_B(512, SA, DA);               \
-    else if (blk == 1024) PST_LAUNCH_TILE_B(1024, SA, DA);        \
-    else PST_LAUNCH_TILE_B(256, SA, DA);                          \
-  } while (0)
+#define PST_LAUNCH_TILE(SA, DA) PST_LAUNCH_TILE_B(256, SA, DA)
     if (src_aos && dst_aos) PST_LAUNCH_TILE(true, true);
     else if (src_aos) PST_LAUNCH_TILE(true, false);
     else PST_LAUNCH_TILE(false, true);

@@ -133,7 +133,7 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
     plan.h.dst_fully_covered = dst_aos && std::all_of(covered.begin(), covered.end(), [](uint8_t c) { return c != 0; });
     // wave scheduling of the tile kernels (convert.hip): narrow attributes are owned by single waves, balanced by bytes
     {
-      static const long nwaves = [] { const char* v = std::getenv("PST_TILE_BLOCK"); long b = v && *v ? std::strtol(v, nullptr, 10) : 256; return std::max(1L, b / 64); }();
+      const long nwaves = 4;  // convert_tile_kernel runs 256-thread blocks
       static const long own_max = [] { const char* v = std::getenv("PST_TILE_OWN_MAX_BYTES"); return v && *v ? std::strtol(v, nullptr, 10) : 4L; }();
       uint64_t load[16] = {0};
       for (size_t i = 0; i < cnt; ++i) {

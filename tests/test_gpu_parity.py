@@ -269,3 +269,56 @@ def test_compute_normals_1e6_properties(hip):
         d = ((pts - pts[q]) ** 2).sum(axis=1)
         want = np.argsort(d, kind="stable")[:k]
         assert np.array_equal(knn[q], want)
+
+
+# ---- buffer kinds of the boundary: external memory, pinned host memory, explicit stream --------------------------
+
+def test_external_memory_buffers_over_torch_tensors(hip):
+    """ExternalMemoryBuffer<T: AsRef<[u8]>> (point_buffer.rs:1479-1708, 'for mmap or GPU buffers'): the library works on
+    caller-owned device memory (torch tensors) without copying, on the caller's stream."""
+    import torch
+    from pasture_amd.buffers import ExternalColumnsBuffer, ExternalMemoryBuffer
+    n = 100_003
+    layout = las.point_layout_from_las_point_format(las.Format(0), False)
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, size=(n, 35), dtype=np.uint8)
+    raw[:, :24] = (rng.random((n, 3)) * 1000).view(np.uint8).reshape(n, 24)
+    t_src = torch.from_numpy(raw.copy()).cuda()
+    src = ExternalMemoryBuffer(t_src, layout)
+    assert src.len() == n and src.as_interleaved() is not None
+    cols = [torch.empty(n * a.size(), dtype=torch.uint8, device="cuda") for a in layout.attributes()]
+    dst = ExternalColumnsBuffer(cols, layout, n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())  # t_src's H2D copy ran on the current stream
+    import ctypes
+    hip.set_stream(ctypes.c_void_p(side.cuda_stream))
+    try:
+        BufferLayoutConverter.for_layouts(layout, layout).convert_into(src, dst)
+        b = calculate_bounds(dst)
+    finally:
+        hip.set_stream(None)
+    for a, c in zip(layout.attributes(), cols):
+        assert np.array_equal(c.cpu().numpy().reshape(n, a.size()), raw[:, a.offset():a.offset() + a.size()]), a.name()
+    pos = raw[:, :24].copy().view(np.float64).reshape(n, 3)
+    assert b.min() == tuple(pos.min(axis=0)) and b.max() == tuple(pos.max(axis=0))
+    with pytest.raises(Exception):  # not an OwningBuffer: cannot be resized
+        src.resize(n + 1)
+    with pytest.raises(Exception):  # byte size must be a multiple of the point size (point_buffer.rs:1488-1497)
+        ExternalMemoryBuffer(t_src.view(-1)[:-1], layout)
+
+
+def test_pinned_host_buffers(hip, oracle):
+    """Buffers backed by pinned host memory (device-accessible): same results, data stays readable from the host."""
+    from pasture_amd.buffers import MEM_PINNED_HOST
+    n = 20_001
+    layout = las.point_layout_from_las_point_format(las.Format(3), False)
+
+    def run(api, memkind):
+        src = VectorBuffer.new_from_layout(layout.clone() if api is hip else las.point_layout_from_las_point_format(las.Format(3), False, api=api), memkind)
+        src.resize(n)
+        src.synth_fill(9, 0)
+        out = BufferLayoutConverter.for_layouts(src.point_layout(), src.point_layout()).convert(src, HashMapBuffer)
+        return out.get_point_range(range(0, n)), calculate_bounds(src)
+    hp, hb = run(hip, MEM_PINNED_HOST)
+    op, ob = run(oracle, 0)
+    assert hp.tobytes() == op.tobytes() and hb == ob
