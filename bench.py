@@ -41,6 +41,8 @@ WORKLOADS = {
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
+    "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
+                          "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
 }
 
 
@@ -173,6 +175,18 @@ def main():
 
         def step():
             conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload == "normals_knn16":
+        from pasture_amd.layout import PointAttributeDefinition
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.NORMAL, PointAttributeDefinition("Curvature", T.F64)]))
+        dst.resize(n)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            pa.compute_normals_into(src, 16, dst)
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)
@@ -266,7 +280,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": n * world,
-                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32") else "LAS format 0",
+                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16") else "LAS format 0",
                        "parallelism": f"index-range shard x{world}, one all-reduce of the 6-f64 AABB" if distributed else "1 GPU",
                        "seed": SEED, "bounds": result},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
