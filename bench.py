@@ -40,6 +40,7 @@ WORKLOADS = {
     "rawlas_to_columns": (55, "raw LAS-0 records (20 B) -> 10 SoA columns, i32->f64 affine + bit fields (20 R + 35 W)"),
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
+    "las0_encode": (55, "LAS writer: 10 SoA columns (typed LAS-0) -> raw LAS-0 records + header AABB + per-return counts, fused (35 R + 20 W)"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
@@ -187,6 +188,17 @@ def main():
 
         def step():
             pa.compute_normals_into(src, 16, dst)
+    elif args.workload == "las0_encode":
+        layout = las.point_layout_from_las_point_format(las.Format(0), False)
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.VectorBuffer.new_from_layout(las.point_layout_from_las_point_format(las.Format(0), True))
+        dst.resize(n)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            las.encode_points(src, 0, (0.001, 0.001, 0.001), (0.0, 0.0, 0.0), dst)
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)

@@ -184,6 +184,18 @@ int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, doub
  * and an F64 "Curvature" attribute of `dst` (columnar or interleaved, same length) without leaving HBM. */
 int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst);
 
+/* ---- LAS record encoder (the writer side of the hot path) ---------------------------- */
+/* RawLASWriter::write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 (+ write_helpers.rs:10-55):
+ * `src` holds points in the DEFAULT typed layout of `point_format` (LasPointFormatN::layout(), las_types.rs; interleaved or
+ * columnar), `dst` is an interleaved buffer in the exact-binary record layout (las_layout.rs:70-107); records are written
+ * to dst[dst_first .. dst_first + len(src)).  X,Y,Z = (((p - offset) / scale) as i64) checked into i32 — a position outside
+ * the i32 range is PST_ERR_RANGE ("Position is out of bounds given the current LAS offset and scale!"), like the expect().
+ * Header side effects: bounds_inout = {min xyz, max xyz} of the header, updated with strict compares (:28-48; the writer
+ * starts from f64::MAX / f64::MIN); points_by_return[r-1] += number of points whose return number is r, 1 <= r <= max_return
+ * (5 for legacy headers, 15 with the large_file block, :220-229). */
+int pst_las_encode_points(const pst_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], pst_buffer* dst,
+                          size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,22 @@ template <typename T> static T* need(T* p, const char* what) {
   return p;
 }
 
+namespace {
+struct LasFmt { bool ext, gps, color, nir, wave; };
+LasFmt las_fmt(uint32_t n) {  // las::point::Format::new(n) (crate `las`, not vendored) restricted to the flags the writer reads
+  return LasFmt{n >= 6, n == 1 || n == 3 || n == 4 || n == 5 || n >= 6, n == 2 || n == 3 || n == 5 || n == 7 || n == 8 || n == 10, n == 8 || n == 10,
+                n == 4 || n == 5 || n == 9 || n == 10};
+}
+struct Cursor {  // std::io::Cursor + byteorder reads (native = little endian here)
+  const uint8_t* p;
+  template <typename T> T read() { T v; std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+};
+struct Writer {
+  uint8_t* p;
+  template <typename T> void write(T v) { std::memcpy(p, &v, sizeof(T)); p += sizeof(T); }
+};
+}  // namespace
+
 extern "C" {
 
 const char* orc_last_error(void) { return g_last_error.c_str(); }
@@ -294,6 +310,86 @@ int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype*
 int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn) {
   ORC_TRY
   compute_normals(*need(b, "buffer")->b, k, out_normals, out_curvature, out_knn);
+  ORC_CATCH
+}
+
+// ---- LAS writer: write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 ---------------------------------
+
+int orc_las_encode_points(const orc_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], orc_buffer* dst,
+                          size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return) {
+  ORC_TRY
+  const Buffer& points = *need(src, "src")->b;
+  Buffer& out = *need(dst, "dst")->b;
+  if (point_format > 10) throw Panic(ERR_INVALID_ARGUMENT, "Unsupported LAS point format");
+  const LasFmt f = las_fmt(point_format);
+  InterleavedBuffer* ob = out.as_interleaved();
+  if (!ob) throw Panic(ERR_LAYOUT_MISMATCH, "target must be interleaved");
+  const size_t n = points.len();
+  if (dst_first + n > out.len()) throw Panic(ERR_RANGE, "target range out of bounds");
+  if (n == 0) return OK;  // :207-209
+  const size_t size_of_single_point = points.point_layout().size_of_point_entry();
+  const size_t raw_size = out.point_layout().size_of_point_entry();
+  // the default-layout writer is only reached when points.point_layout() == the format's default layout (:185-201)
+  const size_t typed_size = (f.ext ? 38 : 35) + (f.gps ? 8 : 0) + (f.color ? 6 : 0) + (f.nir ? 2 : 0) + (f.wave ? 29 : 0);
+  if (size_of_single_point != typed_size) throw Panic(ERR_LAYOUT_MISMATCH, "source layout is not the default layout of the LAS point format");
+  const size_t num_points_in_chunk = 50000;  // :214
+  const size_t num_chunks = (n + (num_points_in_chunk - 1)) / num_points_in_chunk;
+  std::vector<uint8_t> chunk_buffer(num_points_in_chunk * size_of_single_point, 0);
+  std::unordered_map<uint8_t, uint64_t> by_return;  // :220-229
+  for (uint32_t r = 1; r <= max_return; ++r) by_return[(uint8_t)r] = 0;
+  Writer w{ob->get_point_range_mut({dst_first, dst_first + n})};
+  for (size_t chunk_index = 0; chunk_index < num_chunks; ++chunk_index) {
+    const size_t in_chunk = std::min(num_points_in_chunk, n - chunk_index * num_points_in_chunk);
+    const size_t start = chunk_index * num_points_in_chunk;
+    // points.get_point_range(start..start+in_chunk, &mut chunk_buffer) :236-239
+    for (auto& a : points.point_layout().attributes)
+      for (size_t i = 0; i < in_chunk; ++i) points.get_attribute_unchecked(a, start + i, chunk_buffer.data() + i * size_of_single_point + a.offset);
+    Cursor rd{chunk_buffer.data()};
+    for (size_t i = 0; i < in_chunk; ++i) {
+      const uint8_t* record_start = w.p;
+      double pos[3] = {rd.read<double>(), rd.read<double>(), rd.read<double>()};
+      for (int c = 0; c < 3; ++c) {  // write_position_as_las_position, write_helpers.rs:10-23
+        const double local = (pos[c] - offset[c]) / scale[c];
+        const int64_t as_i64 = rust_as<int64_t, double>(local);
+        if (as_i64 > INT32_MAX || as_i64 < INT32_MIN)
+          throw Panic(ERR_RANGE, "write_position_as_las_position: Position is out of bounds given the current LAS offset and scale!");
+        w.write<int32_t>((int32_t)as_i64);
+      }
+      for (int c = 0; c < 3; ++c) {  // update_bounds_in_las_header :28-48
+        if (pos[c] < bounds_inout[c]) bounds_inout[c] = pos[c];
+        if (pos[c] > bounds_inout[3 + c]) bounds_inout[3 + c] = pos[c];
+      }
+      w.write<uint16_t>(rd.read<uint16_t>());  // intensity
+      if (f.ext) {  // :253-273 + write_las_bit_attributes (Extended) write_helpers.rs:39-49
+        const uint8_t rn = rd.read<uint8_t>();
+        auto it = by_return.find(rn);
+        if (it != by_return.end()) it->second += 1;
+        const uint8_t nr = rd.read<uint8_t>(), cf = rd.read<uint8_t>(), sc = rd.read<uint8_t>(), sd = rd.read<uint8_t>(), eof = rd.read<uint8_t>();
+        w.write<uint8_t>((uint8_t)((rn & 0b1111) | (uint8_t)((nr & 0b1111) << 4)));
+        w.write<uint8_t>((uint8_t)((cf & 0b1111) | (uint8_t)((sc & 0b11) << 4) | (uint8_t)((sd & 0b1) << 6) | (uint8_t)((eof & 0b1) << 7)));
+      } else {  // :274-289 + Regular write_helpers.rs:32-38
+        const uint8_t rn = rd.read<uint8_t>();
+        auto it = by_return.find(rn);
+        if (it != by_return.end()) it->second += 1;
+        const uint8_t nr = rd.read<uint8_t>(), sd = rd.read<uint8_t>(), eof = rd.read<uint8_t>();
+        w.write<uint8_t>((uint8_t)((rn & 0b111) | (uint8_t)((nr & 0b111) << 3) | (uint8_t)((sd & 0b1) << 6) | (uint8_t)((eof & 0b1) << 7)));
+      }
+      w.write<uint8_t>(rd.read<uint8_t>());  // classification
+      if (f.ext) { w.write<uint8_t>(rd.read<uint8_t>()); w.write<int16_t>(rd.read<int16_t>()); }  // user data, scan angle :296-301
+      else { w.write<int8_t>(rd.read<int8_t>()); w.write<uint8_t>(rd.read<uint8_t>()); }          // scan angle rank, user data :302-308
+      w.write<uint16_t>(rd.read<uint16_t>());  // point source id
+      if (f.gps) w.write<double>(rd.read<double>());
+      if (f.color) for (int c = 0; c < 3; ++c) w.write<uint16_t>(rd.read<uint16_t>());
+      if (f.nir) w.write<uint16_t>(rd.read<uint16_t>());
+      if (f.wave) {
+        w.write<uint8_t>(rd.read<uint8_t>()); w.write<uint64_t>(rd.read<uint64_t>()); w.write<uint32_t>(rd.read<uint32_t>());
+        w.write<float>(rd.read<float>());
+        for (int c = 0; c < 3; ++c) w.write<float>(rd.read<float>());
+      }
+      if ((size_t)(w.p - record_start) != raw_size) throw Panic(ERR_LAYOUT_MISMATCH, "raw record size does not match the target layout");
+    }
+  }
+  for (uint32_t r = 1; r <= max_return; ++r) points_by_return[r - 1] += by_return[(uint8_t)r];  // update_point_counts_in_las_header :50-82
   ORC_CATCH
 }
 

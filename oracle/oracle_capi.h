@@ -97,6 +97,10 @@ int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_dataty
 int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf);
 int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);
 
+/* RawLASWriter::write_points_default_layout (pasture-io/src/las/raw_writers.rs:203-363); same contract as pst_las_encode_points */
+int orc_las_encode_points(const orc_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], orc_buffer* dst,
+                          size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return);
+
 /* single value through the `as` table (attribute_conversion.rs:184-271); ERR_INVALID_CONVERSION if unlisted */
 int orc_as_convert(uint32_t from_kind, uint32_t to_kind, const void* in, void* out);
 /* helpers of normal_estimation.rs exposed for the known-answer tests (:503-550) */

@@ -109,6 +109,7 @@ _SHARED_SIGNATURES = {
     "minmax_attribute": [_P, C.c_char_p, _DT, _P, _P, C.POINTER(C.c_int)],
     "transform_attribute": [_P, C.c_char_p, _DT, C.POINTER(TransformStruct)],
     "compute_normals": [_P, _SZ, _D3, _D3, C.POINTER(C.c_int64)],
+    "las_encode_points": [_P, C.c_uint32, _D3, _D3, _P, _SZ, _D3, C.POINTER(C.c_uint64), C.c_uint32],
 }
 
 # entry points only the HIP library has

@@ -1,0 +1,101 @@
+// pst_las_encode_points: argument checks + plumbing for the LAS record encoder (las_encode.hip).
+// Reference: pasture-io/src/las/raw_writers.rs:203-363, 606-613; las_layout.rs:64-125; las_types.rs.
+#include "runtime.hpp"
+
+using namespace pst;
+
+namespace {
+
+struct Fmt { bool ext, gps, color, nir, wave; };
+Fmt fmt_of(uint32_t n) {
+  return Fmt{n >= 6, n == 1 || n == 3 || n == 4 || n == 5 || n >= 6, n == 2 || n == 3 || n == 5 || n == 7 || n == 8 || n == 10, n == 8 || n == 10,
+             n == 4 || n == 5 || n == 9 || n == 10};
+}
+AttributeDef def(const char* name, uint32_t kind) {
+  AttributeDef d{name, DataType{}};
+  d.datatype.kind = kind;
+  return d;
+}
+// LasPointFormatN::layout(): #[repr(C, packed)] structs of las_types.rs, field order = attribute order
+Layout typed_layout(uint32_t format) {
+  const Fmt f = fmt_of(format);
+  Layout l;
+  auto add = [&](const char* n, uint32_t k) { l.add_attribute(def(n, k), true, 1); };
+  add("Position3D", PST_VEC3F64); add("Intensity", PST_U16); add("ReturnNumber", PST_U8); add("NumberOfReturns", PST_U8);
+  if (f.ext) { add("ClassificationFlags", PST_U8); add("ScannerChannel", PST_U8); }
+  add("ScanDirectionFlag", PST_U8); add("EdgeOfFlightLine", PST_U8); add("Classification", PST_U8);
+  if (f.ext) { add("UserData", PST_U8); add("ScanAngle", PST_I16); } else { add("ScanAngleRank", PST_I8); add("UserData", PST_U8); }
+  add("PointSourceID", PST_U16);
+  if (f.gps) add("GpsTime", PST_F64);
+  if (f.color) add("ColorRGB", PST_VEC3U16);
+  if (f.nir) add("NIR", PST_U16);
+  if (f.wave) {
+    add("WavePacketDescriptorIndex", PST_U8); add("WaveformDataOffset", PST_U64); add("WaveformPacketSize", PST_U32);
+    add("ReturnPointWaveformLocation", PST_F32); add("WaveformParameters", PST_VEC3F32);
+  }
+  return l;
+}
+// point_layout_from_las_point_format(format, exact_binary_representation = true), las_layout.rs:70-107
+Layout raw_layout(uint32_t format) {
+  const Fmt f = fmt_of(format);
+  Layout l;
+  auto add = [&](const char* n, uint32_t k) { l.add_attribute(def(n, k), true, 1); };
+  add("LASLocalPosition", PST_VEC3I32); add("Intensity", PST_U16);
+  if (f.ext) add("LASExtendedFlags", PST_U16); else add("LASBasicFlags", PST_U8);
+  add("Classification", PST_U8);
+  if (f.ext) { add("UserData", PST_U8); add("ScanAngle", PST_I16); } else { add("ScanAngleRank", PST_I8); add("UserData", PST_U8); }
+  add("PointSourceID", PST_U16);
+  if (f.gps) add("GpsTime", PST_F64);
+  if (f.color) add("ColorRGB", PST_VEC3U16);
+  if (f.nir) add("NIR", PST_U16);
+  if (f.wave) {
+    add("WavePacketDescriptorIndex", PST_U8); add("WaveformDataOffset", PST_U64); add("WaveformPacketSize", PST_U32);
+    add("ReturnPointWaveformLocation", PST_F32); add("WaveformParameters", PST_VEC3F32);
+  }
+  return l;
+}
+
+}  // namespace
+
+extern "C" int pst_las_encode_points(const pst_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], pst_buffer* dst,
+                                     size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return) {
+  PST_API_BEGIN
+  not_null(src, "src"); not_null(dst, "dst"); not_null(scale, "scale"); not_null(offset, "offset");
+  not_null(bounds_inout, "bounds_inout"); not_null(points_by_return, "points_by_return");
+  if (point_format > 10) throw Error(PST_ERR_INVALID_ARGUMENT, "Unsupported LAS point format " + std::to_string(point_format));
+  if (max_return == 0 || max_return > 15) throw Error(PST_ERR_INVALID_ARGUMENT, "max_return must be 5 (legacy header) or 15 (large_file)");
+  const Layout typed = typed_layout(point_format), raw = raw_layout(point_format);
+  if (src->layout != typed)  // raw_writers.rs:607-613: only the default layout takes this path
+    throw Error(PST_ERR_LAYOUT_MISMATCH, "source PointLayout is not the default layout of LAS point format " + std::to_string(point_format));
+  if (dst->layout != raw || dst->columnar)
+    throw Error(PST_ERR_LAYOUT_MISMATCH, "target must be an interleaved buffer in the exact-binary LAS record layout of the format");
+  const size_t n = src->len;
+  if (dst_first + n < dst_first || dst_first + n > dst->len) throw Error(PST_ERR_RANGE, "target range out of bounds");
+  if (n == 0) return PST_OK;  // :207-209
+  ensure_device();
+  hipStream_t s = current_stream();
+  uint64_t base[24];
+  uint32_t stride[24];
+  const size_t na = typed.members.size();
+  for (size_t a = 0; a < na; ++a) {
+    base[a] = src->columnar ? col_addr(*src, a, 0) : aos_addr(*src, 0) + typed.members[a].offset;
+    stride[a] = (uint32_t)(src->columnar ? typed.members[a].size : typed.size);
+  }
+  Workspace& ws = workspace();
+  uint8_t* scratch = ws.partials(pstk::las_encode_workspace_bytes());
+  double* dev_bounds = (double*)(ws.dev + 1024);
+  unsigned long long* dev_counts = (unsigned long long*)(ws.dev + 1024 + 64);
+  if (!pstk::launch_las_encode((int)point_format, base, stride, (int)na, aos_addr(*dst, dst_first), n, scale, offset, bounds_inout, max_return, scratch,
+                               dev_bounds, dev_counts, s))
+    throw Error(PST_ERR_HIP, std::string("LAS encode launch failed: ") + hipGetErrorString(hipGetLastError()));
+  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 256, dev_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 512, dev_counts, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  stream_sync(s);
+  const unsigned long long* counts = (const unsigned long long*)(ws.pinned + 512);
+  if (counts[0] != 0)  // write_helpers.rs:15-17 .expect(...)
+    throw Error(PST_ERR_RANGE, "write_position_as_las_position: Position is out of bounds given the current LAS offset and scale! (" +
+                                   std::to_string(counts[0]) + " positions)");
+  std::memcpy(bounds_inout, ws.pinned + 256, 6 * sizeof(double));
+  for (uint32_t r = 1; r <= max_return; ++r) points_by_return[r - 1] += counts[r];
+  PST_API_END
+}

@@ -134,6 +134,19 @@ def get_default_las_converter(raw_las_layout: PointLayout, target_layout: PointL
     return converter
 
 
+def encode_points(points, point_format: int, scale, offset, target, target_first: int = 0, header_bounds=None, max_return: int = 15):
+    """RawLASWriter::write_points_default_layout (pasture-io/src/las/raw_writers.rs:203-363): typed LAS points in the format's
+    default layout -> exact-binary records in `target[target_first:]`.  Returns (bounds, points_by_return): the header's
+    updated {min xyz, max xyz} (starting from `header_bounds`, default f64::MAX / f64::MIN like the writer) and the number of
+    points per return number 1..max_return."""
+    import ctypes as C
+    b = (C.c_double * 6)(*(header_bounds if header_bounds is not None else [1.7976931348623157e308] * 3 + [-1.7976931348623157e308] * 3))
+    counts = (C.c_uint64 * 15)()
+    sc, of = (C.c_double * 3)(*scale), (C.c_double * 3)(*offset)
+    points.api.las_encode_points(points._h, point_format, sc, of, target._h, target_first, b, counts, max_return)
+    return (tuple(b[:3]), tuple(b[3:])), list(counts)[:max_return]
+
+
 @dataclass
 class LasFile:
     """Just enough of an uncompressed .las file to use the reference's fixtures as golden vectors."""

@@ -322,3 +322,63 @@ def test_pinned_host_buffers(hip, oracle):
     hp, hb = run(hip, MEM_PINNED_HOST)
     op, ob = run(oracle, 0)
     assert hp.tobytes() == op.tobytes() and hb == ob
+
+
+@pytest.mark.parametrize("fmt", range(11))
+@pytest.mark.parametrize("kind", ["V", "H"])
+def test_las_encode_vs_oracle(hip, oracle, fmt, kind):
+    """RawLASWriter::write_points_default_layout (raw_writers.rs:203-363) on synthetic typed points: records, header bounds
+    and per-return counts identical to the oracle's (multi-tile, ragged target offset, positions with NaN/Inf-free synth data)."""
+    n, first = 200_003, 11
+    scale, offset = (0.01, 0.01, 0.01), (-1000.0, 2000.0, 0.5)
+
+    def run(api):
+        F = las.Format(fmt)
+        typed = las.point_layout_from_las_point_format(F, False, api=api)
+        raw = las.point_layout_from_las_point_format(F, True, api=api)
+        src = BUFFER_KINDS[kind].new_from_layout(typed)
+        src.resize(n)
+        src.synth_fill(900 + fmt, 5)
+        dst = VectorBuffer.new_from_layout(raw)
+        dst.resize(n + 2 * first)
+        bounds, counts = las.encode_points(src, fmt, scale, offset, dst, target_first=first, header_bounds=[1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+        return dst.get_point_range(range(0, n + 2 * first)).tobytes(), bounds, counts
+    (hb, hbounds, hcounts), (ob, obounds, ocounts) = both(run, hip, oracle)
+    assert hbounds == obounds and hcounts == ocounts
+    assert hb == ob
+
+
+def test_full_size_1e8_las_encode_then_decode_round_trip(hip):
+    """Full-size property: encode 10^8 typed LAS-0 points, decode with get_default_las_converter; every non-position field
+    is identical and positions come back within one grid step (truncation toward zero in write_position_as_las_position)."""
+    import torch
+    n = 100_000_000
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=hip)
+    src = HashMapBuffer.new_from_layout(typed)
+    src.resize(n)
+    src.synth_fill(77, 0)
+    # synth flags are arbitrary bytes; mask them to the widths the record holds so that the round trip is lossless
+    for a, m in [(A.RETURN_NUMBER, 7), (A.NUMBER_OF_RETURNS, 7), (A.SCAN_DIRECTION_FLAG, 1), (A.EDGE_OF_FLIGHT_LINE, 1)]:
+        _torch_view(src.column_ptr(a), n).bitwise_and_(m)
+    dst = VectorBuffer.new_from_layout(raw)
+    dst.resize(n)
+    b = calculate_bounds(src)
+    scale = (0.001, 0.001, 0.001)
+    offset = tuple(b.min())
+    bounds, counts = las.encode_points(src, 0, scale, offset, dst)
+    assert bounds == (b.min(), b.max())
+    rn = _torch_view(src.column_ptr(A.RETURN_NUMBER), n)
+    assert counts[:7] == [int((rn == r).sum()) for r in range(1, 8)] and sum(counts[7:]) == 0
+    back = HashMapBuffer.new_from_layout(typed)
+    back.resize(n)
+    las.get_default_las_converter(raw, typed, scale, offset).convert_into(dst, back)
+    for a in typed.attributes():
+        d = a.attribute_definition()
+        nbytes = n * a.size()
+        x, y = _torch_view(src.column_ptr(d), nbytes), _torch_view(back.column_ptr(d), nbytes)
+        if a.name() == A.POSITION_3D.name():
+            diff = (x.view(torch.float64) - y.view(torch.float64)).abs().max().item()
+            assert diff <= 0.001 * (1 + 1e-9)
+        else:
+            assert torch.equal(x, y), a.name()
