@@ -75,17 +75,18 @@ extern "C" int pst_las_encode_points(const pst_buffer* src, uint32_t point_forma
   ensure_device();
   hipStream_t s = current_stream();
   uint64_t base[24];
-  uint32_t stride[24];
+  uint32_t stride[24], esize[24];
   const size_t na = typed.members.size();
   for (size_t a = 0; a < na; ++a) {
     base[a] = src->columnar ? col_addr(*src, a, 0) : aos_addr(*src, 0) + typed.members[a].offset;
     stride[a] = (uint32_t)(src->columnar ? typed.members[a].size : typed.size);
+    esize[a] = (uint32_t)typed.members[a].size;
   }
   Workspace& ws = workspace();
   uint8_t* scratch = ws.partials(pstk::las_encode_workspace_bytes());
   double* dev_bounds = (double*)(ws.dev + 1024);
   unsigned long long* dev_counts = (unsigned long long*)(ws.dev + 1024 + 64);
-  if (!pstk::launch_las_encode((int)point_format, base, stride, (int)na, aos_addr(*dst, dst_first), n, scale, offset, bounds_inout, max_return, scratch,
+  if (!pstk::launch_las_encode((int)point_format, base, stride, esize, (int)na, aos_addr(*dst, dst_first), n, scale, offset, bounds_inout, max_return, scratch,
                                dev_bounds, dev_counts, s))
     throw Error(PST_ERR_HIP, std::string("LAS encode launch failed: ") + hipGetErrorString(hipGetLastError()));
   PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 256, dev_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -55,7 +55,254 @@ __device__ __forceinline__ T src_load(const EncodeArgs& a, int slot, uint64_t i)
   return load_un<T>((cgptr_t)(as_global(a.attr_base[slot]) + i * a.attr_stride[slot]));
 }
 
+// One point, one lane: typed attributes read where they live (any stride), record assembled at `rec` in LDS.
 template <int FORMAT>
+__device__ __forceinline__ void encode_point(const EncodeArgs& a, uint64_t i, lptr_t rec, double (&mn)[3], double (&mx)[3], unsigned int* hist) {
+  constexpr Fmt F = fmt_of(FORMAT);
+  int s = 0;       // typed slot cursor (LasPointFormatN field order, las_types.rs)
+  uint32_t o = 0;  // raw record cursor
+  // position: write_position_as_las_position, write_helpers.rs:10-23
+  {
+    cgptr_t pp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double w = load_un<double>(pp + 8 * c);
+      const double local = (w - a.offset[c]) / a.scale[c];  // two roundings, like the Rust expression
+      // `as i64` saturates and maps NaN to 0; try_into::<i32>() then fails outside [i32::MIN, i32::MAX]
+      const long long t = rust_as<long long, double>(local);
+      if (t > 2147483647ll || t < -2147483648ll) bad = true;
+      store_un<int32_t>(rec + o, (int32_t)t);
+      o += 4;
+      mn[c] = __builtin_fmin(mn[c], w);  // update_bounds_in_las_header: strict compares, NaN never wins
+      mx[c] = __builtin_fmax(mx[c], w);
+    }
+    if (bad) atomicAdd(&hist[0], 1u);
+    s += 1;
+  }
+  store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // intensity
+  {
+    const uint32_t rn = src_load<uint8_t>(a, s, i), nr = src_load<uint8_t>(a, s + 1, i);
+    s += 2;
+    if (rn >= 1 && rn <= a.max_return) atomicAdd(&hist[rn], 1u);  // points_by_return.get_mut(&return_number)
+    if constexpr (F.ext) {
+      const uint32_t cf = src_load<uint8_t>(a, s, i), sc = src_load<uint8_t>(a, s + 1, i), sd = src_load<uint8_t>(a, s + 2, i),
+                     eof = src_load<uint8_t>(a, s + 3, i);
+      s += 4;
+      store_un<uint8_t>(rec + o, (uint8_t)((rn & 15u) | ((nr & 15u) << 4)));
+      store_un<uint8_t>(rec + o + 1, (uint8_t)((cf & 15u) | ((sc & 3u) << 4) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
+      o += 2;
+    } else {
+      const uint32_t sd = src_load<uint8_t>(a, s, i), eof = src_load<uint8_t>(a, s + 1, i);
+      s += 2;
+      store_un<uint8_t>(rec + o, (uint8_t)((rn & 7u) | ((nr & 7u) << 3) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
+      o += 1;
+    }
+  }
+  store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;  // classification
+  if constexpr (F.ext) {
+    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
+    store_un<int16_t>(rec + o, src_load<int16_t>(a, s, i)); o += 2; s += 1;    // scan angle
+  } else {
+    store_un<int8_t>(rec + o, src_load<int8_t>(a, s, i)); o += 1; s += 1;      // scan angle rank
+    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
+  }
+  store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // point source id
+  if constexpr (F.gps) { store_un<double>(rec + o, src_load<double>(a, s, i)); o += 8; s += 1; }
+  if constexpr (F.color) {
+    cgptr_t cp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) store_un<uint16_t>(rec + o + 2 * c, load_un<uint16_t>(cp + 2 * c));
+    o += 6; s += 1;
+  }
+  if constexpr (F.nir) { store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1; }
+  if constexpr (F.wave) {
+    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;
+    store_un<uint64_t>(rec + o, src_load<uint64_t>(a, s, i)); o += 8; s += 1;
+    store_un<uint32_t>(rec + o, src_load<uint32_t>(a, s, i)); o += 4; s += 1;
+    store_un<float>(rec + o, src_load<float>(a, s, i)); o += 4; s += 1;
+    cgptr_t wp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) store_un<float>(rec + o + 4 * c, load_un<float>(wp + 4 * c));
+    o += 12; s += 1;
+  }
+}
+
+// ---- columnar fast path: four consecutive points per lane ------------------------------------------------------------
+// A column of B-byte values is read as one 4*B-byte vector per lane (wave = 256 consecutive points, fully coalesced);
+// the words are then cut apart with compile-time shifts.  QuadCol<B>::w holds the 4 values of this lane's points.
+template <int B>
+struct QuadCol {
+  uint32_t w[B + 2];  // 4 * B bytes + two zero words so that bytes_at() needs no guards
+  __device__ __forceinline__ void load(cgptr_t p) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    w[B] = 0; w[B + 1] = 0;
+    constexpr int K4 = B / 4 * 4, K2 = K4 + ((B - K4) >= 2 ? 2 : 0);
+#pragma unroll
+    for (int k = 0; k < K4; k += 4) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<u32x4>::type*>(p + 4 * k));
+      w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+    }
+    if constexpr (K2 > K4) {
+      const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<u32x2>::type*>(p + 4 * K4));
+      w[K4] = v.x; w[K4 + 1] = v.y;
+    }
+    if constexpr (B > K2) w[K2] = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<uint32_t>::type*>(p + 4 * K2));
+  }
+  // up to 8 bytes starting at byte `off` of the 4*B-byte vector (compile-time `off` after unrolling)
+  __device__ __forceinline__ uint64_t bytes_at(int off) const {
+    const int wi = off >> 2, sh = (off & 3) * 8;
+    const uint64_t lo = w[wi], mid = w[wi + 1], hi = w[wi + 2];
+    const uint64_t v = lo | (mid << 32);
+    return sh == 0 ? v : ((v >> sh) | (hi << (64 - sh)));
+  }
+  __device__ __forceinline__ uint64_t value(int t) const {  // point t's B bytes (B <= 8), zero-extended
+    const uint64_t v = bytes_at(t * B);
+    return B >= 8 ? v : (v & ((1ull << (8 * (B & 7))) - 1ull));
+  }
+};
+
+// The non-position bytes of one record, assembled in registers at compile-time offsets and written with word stores.
+template <int NB>
+struct RecTail {
+  uint32_t w[(NB + 3) / 4] = {};
+  __device__ __forceinline__ void put(int off, int nbytes, uint64_t v) {  // v zero-extended to 8 bytes
+    const int wi = off >> 2, sh = (off & 3) * 8;
+    w[wi] |= (uint32_t)(v << sh);
+    if (sh + 8 * nbytes > 32) w[wi + 1] |= (uint32_t)(sh == 0 ? (v >> 32) : (v >> (32 - sh)));
+    if (sh + 8 * nbytes > 64) w[wi + 2] |= (uint32_t)(v >> (64 - sh));
+  }
+  __device__ __forceinline__ void store(lptr_t p) const {
+    int k = 0;
+#pragma unroll
+    for (; 4 * k + 4 <= NB; ++k) store_un<uint32_t>(p + 4 * k, w[k]);
+    if (NB - 4 * k >= 2) { store_un<uint16_t>(p + 4 * k, (uint16_t)w[k]); if (NB - 4 * k == 3) store_un<uint8_t>(p + 4 * k + 2, (uint8_t)(w[k] >> 16)); }
+    else if (NB - 4 * k == 1) store_un<uint8_t>(p + 4 * k, (uint8_t)w[k]);
+  }
+};
+
+constexpr uint32_t kQuadTile = 4 * kBlock;  // points per tile of the columnar path
+
+// One full tile of kQuadTile points starting at `first`; records staged at lds + mis.
+template <int FORMAT>
+__device__ __forceinline__ void encode_quad_tile(const EncodeArgs& a, uint64_t first, lptr_t lds, uint32_t mis, double (&mn)[3], double (&mx)[3],
+                                                 unsigned int* hist) {
+  constexpr Fmt F = fmt_of(FORMAT);
+  constexpr uint32_t RS = raw_size(F);
+  const uint32_t tid = threadIdx.x;
+  const uint64_t p0 = first + 4u * tid;  // this lane's four points (byte / short / tail columns)
+  int s = 0;
+  // ---- issue every load of the tile before the first use ----
+  // positions: the tile's 3 * kQuadTile doubles as 16-byte chunks, lane-contiguous (chunk = tid + kBlock * j)
+  u32x4 pc[6];
+  {
+    cgptr_t pb = (cgptr_t)(as_global(a.attr_base[0]) + first * 24u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      pc[j] = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<u32x4>::type*>(pb + 16u * (tid + (uint32_t)kBlock * j)));
+    s = 1;
+  }
+  auto col = [&](int slot, uint32_t bytes) -> cgptr_t { return (cgptr_t)(as_global(a.attr_base[slot]) + p0 * bytes); };
+  QuadCol<2> intensity; intensity.load(col(s, 2)); s += 1;
+  QuadCol<1> rn, nr, cf, sc, sd, eof, cls, sar, ud;
+  QuadCol<2> sa, psid, nir;
+  QuadCol<8> gps, woff;
+  QuadCol<6> color;
+  QuadCol<1> widx;
+  QuadCol<4> wsize, wloc;
+  QuadCol<12> wpar;
+  rn.load(col(s, 1)); nr.load(col(s + 1, 1)); s += 2;
+  if constexpr (F.ext) { cf.load(col(s, 1)); sc.load(col(s + 1, 1)); s += 2; }
+  sd.load(col(s, 1)); eof.load(col(s + 1, 1)); cls.load(col(s + 2, 1)); s += 3;
+  if constexpr (F.ext) { ud.load(col(s, 1)); sa.load(col(s + 1, 2)); s += 2; }
+  else { sar.load(col(s, 1)); ud.load(col(s + 1, 1)); s += 2; }
+  psid.load(col(s, 2)); s += 1;
+  if constexpr (F.gps) { gps.load(col(s, 8)); s += 1; }
+  if constexpr (F.color) { color.load(col(s, 6)); s += 1; }
+  if constexpr (F.nir) { nir.load(col(s, 2)); s += 1; }
+  if constexpr (F.wave) {
+    widx.load(col(s, 1)); woff.load(col(s + 1, 8)); wsize.load(col(s + 2, 4)); wloc.load(col(s + 3, 4)); wpar.load(col(s + 4, 12));
+    s += 5;
+  }
+
+  // ---- positions: double d = 2*tid + 512*j + e of the tile belongs to point d/3, component d%3 ----
+  // c0 = (2*tid) % 3 is fixed per lane, so the component of (j, e) is (c0 + (512*j + e) % 3) % 3: accumulators and
+  // scale/offset are kept "rotated by c0" and indexed with compile-time r; the rotation is undone once at the end.
+  {
+    const uint32_t d0 = 2u * tid, q0 = d0 / 3u, c0 = d0 - 3u * q0;
+    double sc_r[3], of_r[3], rmn[3], rmx[3];
+#pragma unroll
+    for (uint32_t r = 0; r < 3; ++r) {
+      const uint32_t c = c0 + r >= 3u ? c0 + r - 3u : c0 + r;
+      sc_r[r] = pick3(c, a.scale[0], a.scale[1], a.scale[2]);
+      of_r[r] = pick3(c, a.offset[0], a.offset[1], a.offset[2]);
+      rmn[r] = pick3(c, mn[0], mn[1], mn[2]);
+      rmx[r] = pick3(c, mx[0], mx[1], mx[2]);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t k = 512u * j + e, A = k / 3u, r = k % 3u;  // compile-time
+        const uint64_t bits = (uint64_t)(e ? pc[j].z : pc[j].x) | ((uint64_t)(e ? pc[j].w : pc[j].y) << 32);
+        const double w = __builtin_bit_cast(double, bits);
+        const double local = (w - of_r[r]) / sc_r[r];
+        if (local >= 2147483648.0 || local <= -2147483649.0) bad = true;  // == (local as i64) does not fit an i32 (NaN -> 0 fits)
+        const int32_t v = rust_as<int32_t, double>(local);
+        const bool wrap = c0 + r >= 3u;
+        const uint32_t c = wrap ? c0 + r - 3u : c0 + r, q = q0 + A + (wrap ? 1u : 0u);
+        store_un<int32_t>(lds + (mis + q * RS + 4u * c), v);
+        rmn[r] = __builtin_fmin(rmn[r], w);
+        rmx[r] = __builtin_fmax(rmx[r], w);
+      }
+    }
+    if (bad) atomicAdd(&hist[0], 1u);
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+      const uint32_t r = c >= c0 ? c - c0 : c + 3u - c0;
+      mn[c] = pick3(r, rmn[0], rmn[1], rmn[2]);
+      mx[c] = pick3(r, rmx[0], rmx[1], rmx[2]);
+    }
+  }
+
+  // ---- flags (write_las_bit_attributes, write_helpers.rs:32-49) for four points at once, then the record tails ----
+  QuadCol<1> f0, f1;
+  if constexpr (F.ext) {
+    f0.w[1] = f0.w[2] = f1.w[1] = f1.w[2] = 0;
+    f0.w[0] = (rn.w[0] & 0x0F0F0F0Fu) | ((nr.w[0] & 0x0F0F0F0Fu) << 4);
+    f1.w[0] = (cf.w[0] & 0x0F0F0F0Fu) | ((sc.w[0] & 0x03030303u) << 4) | ((sd.w[0] & 0x01010101u) << 6) | ((eof.w[0] & 0x01010101u) << 7);
+  } else {
+    f0.w[1] = f0.w[2] = 0;
+    f0.w[0] = (rn.w[0] & 0x07070707u) | ((nr.w[0] & 0x07070707u) << 3) | ((sd.w[0] & 0x01010101u) << 6) | ((eof.w[0] & 0x01010101u) << 7);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint32_t r = (rn.w[0] >> (8 * t)) & 255u;
+    if (r >= 1 && r <= a.max_return) atomicAdd(&hist[r], 1u);  // points_by_return.get_mut(&return_number)
+    RecTail<RS - 12> rec;
+    int o = 0;
+    rec.put(o, 2, intensity.value(t)); o += 2;
+    rec.put(o, 1, f0.value(t)); o += 1;
+    if constexpr (F.ext) { rec.put(o, 1, f1.value(t)); o += 1; }
+    rec.put(o, 1, cls.value(t)); o += 1;
+    if constexpr (F.ext) { rec.put(o, 1, ud.value(t)); rec.put(o + 1, 2, sa.value(t)); o += 3; }
+    else { rec.put(o, 1, sar.value(t)); rec.put(o + 1, 1, ud.value(t)); o += 2; }
+    rec.put(o, 2, psid.value(t)); o += 2;
+    if constexpr (F.gps) { rec.put(o, 8, gps.value(t)); o += 8; }
+    if constexpr (F.color) { rec.put(o, 6, color.value(t)); o += 6; }
+    if constexpr (F.nir) { rec.put(o, 2, nir.value(t)); o += 2; }
+    if constexpr (F.wave) {
+      rec.put(o, 1, widx.value(t)); rec.put(o + 1, 8, woff.value(t)); rec.put(o + 9, 4, wsize.value(t)); rec.put(o + 13, 4, wloc.value(t));
+      rec.put(o + 17, 8, wpar.bytes_at(12 * t)); rec.put(o + 25, 4, wpar.bytes_at(12 * t + 8) & 0xFFFFFFFFull);
+      o += 29;
+    }
+    rec.store(lds + (mis + (4u * tid + t) * RS + 12u));
+  }
+}
+
+// QUAD = every typed attribute is a dense column (stride == element size): full tiles take the four-points-per-lane path.
+template <int FORMAT, bool QUAD>
 __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) {
   constexpr Fmt F = fmt_of(FORMAT);
   constexpr uint32_t RS = raw_size(F);
@@ -64,7 +311,6 @@ __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) 
   __shared__ unsigned int hist[kReturnSlots];
   if (threadIdx.x < kReturnSlots) hist[threadIdx.x] = 0;
   double mn[3] = {a.seed_min[0], a.seed_min[1], a.seed_min[2]}, mx[3] = {a.seed_max[0], a.seed_max[1], a.seed_max[2]};
-  unsigned long long counts_acc = 0;  // lane r < 16 accumulates hist[r] across tiles
   __syncthreads();
 
   const uint64_t n_tiles = (a.n + a.tile - 1) / a.tile;
@@ -73,76 +319,10 @@ __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) 
     const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
     const uint64_t ga = a.dst + first * RS;
     const uint32_t mis = (uint32_t)(ga & 15u);
-    for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock) {
-      const uint64_t i = first + lp;
-      lptr_t rec = lds + (mis + lp * RS);
-      int s = 0;  // typed slot cursor (LasPointFormatN field order, las_types.rs)
-      uint32_t o = 0;  // raw record cursor
-      // position: write_position_as_las_position, write_helpers.rs:10-23
-      {
-        cgptr_t pp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
-        bool bad = false;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const double w = load_un<double>(pp + 8 * c);
-          const double local = (w - a.offset[c]) / a.scale[c];  // two roundings, like the Rust expression
-          // `as i64` saturates and maps NaN to 0; try_into::<i32>() then fails outside [i32::MIN, i32::MAX]
-          const long long t = rust_as<long long, double>(local);
-          if (t > 2147483647ll || t < -2147483648ll) bad = true;
-          store_un<int32_t>(rec + o, (int32_t)t);
-          o += 4;
-          mn[c] = __builtin_fmin(mn[c], w);  // update_bounds_in_las_header: strict compares, NaN never wins
-          mx[c] = __builtin_fmax(mx[c], w);
-        }
-        if (bad) atomicAdd(&hist[0], 1u);
-        s += 1;
-      }
-      store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // intensity
-      {
-        const uint32_t rn = src_load<uint8_t>(a, s, i), nr = src_load<uint8_t>(a, s + 1, i);
-        s += 2;
-        if (rn >= 1 && rn <= a.max_return) atomicAdd(&hist[rn], 1u);  // points_by_return.get_mut(&return_number)
-        if constexpr (F.ext) {
-          const uint32_t cf = src_load<uint8_t>(a, s, i), sc = src_load<uint8_t>(a, s + 1, i), sd = src_load<uint8_t>(a, s + 2, i),
-                         eof = src_load<uint8_t>(a, s + 3, i);
-          s += 4;
-          store_un<uint8_t>(rec + o, (uint8_t)((rn & 15u) | ((nr & 15u) << 4)));
-          store_un<uint8_t>(rec + o + 1, (uint8_t)((cf & 15u) | ((sc & 3u) << 4) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
-          o += 2;
-        } else {
-          const uint32_t sd = src_load<uint8_t>(a, s, i), eof = src_load<uint8_t>(a, s + 1, i);
-          s += 2;
-          store_un<uint8_t>(rec + o, (uint8_t)((rn & 7u) | ((nr & 7u) << 3) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
-          o += 1;
-        }
-      }
-      store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;  // classification
-      if constexpr (F.ext) {
-        store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
-        store_un<int16_t>(rec + o, src_load<int16_t>(a, s, i)); o += 2; s += 1;    // scan angle
-      } else {
-        store_un<int8_t>(rec + o, src_load<int8_t>(a, s, i)); o += 1; s += 1;      // scan angle rank
-        store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
-      }
-      store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // point source id
-      if constexpr (F.gps) { store_un<double>(rec + o, src_load<double>(a, s, i)); o += 8; s += 1; }
-      if constexpr (F.color) {
-        cgptr_t cp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) store_un<uint16_t>(rec + o + 2 * c, load_un<uint16_t>(cp + 2 * c));
-        o += 6; s += 1;
-      }
-      if constexpr (F.nir) { store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1; }
-      if constexpr (F.wave) {
-        store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;
-        store_un<uint64_t>(rec + o, src_load<uint64_t>(a, s, i)); o += 8; s += 1;
-        store_un<uint32_t>(rec + o, src_load<uint32_t>(a, s, i)); o += 4; s += 1;
-        store_un<float>(rec + o, src_load<float>(a, s, i)); o += 4; s += 1;
-        cgptr_t wp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) store_un<float>(rec + o + 4 * c, load_un<float>(wp + 4 * c));
-        o += 12; s += 1;
-      }
+    if (QUAD && cnt == kQuadTile) {
+      encode_quad_tile<FORMAT>(a, first, lds, mis, mn, mx, hist);
+    } else {
+      for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock) encode_point<FORMAT>(a, first + lp, lds + (mis + lp * RS), mn, mx, hist);
     }
     __syncthreads();
     tile_store<kBlock>(lds, as_global(ga - mis), mis, cnt * RS);
@@ -156,16 +336,16 @@ __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) 
     double* o = a.partial_bounds + (uint64_t)blockIdx.x * 6;
     o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
   }
-  (void)counts_acc;
   if (threadIdx.x < kReturnSlots) a.partial_counts[(uint64_t)blockIdx.x * kReturnSlots + threadIdx.x] = hist[threadIdx.x];
 }
 
+// Folds partials [0, n_in) into one record per block (block b takes b, b + gridDim.x, ...).
 __global__ __launch_bounds__(kBlock) void las_encode_fold_kernel(const double* __restrict__ partial_bounds,
-                                                                 const unsigned long long* __restrict__ partial_counts, uint32_t n_blocks,
+                                                                 const unsigned long long* __restrict__ partial_counts, uint32_t n_in,
                                                                  double* __restrict__ out_bounds, unsigned long long* __restrict__ out_counts,
                                                                  double s0, double s1, double s2, double t0, double t1, double t2) {
   double mn[3] = {s0, s1, s2}, mx[3] = {t0, t1, t2};
-  for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) {
+  for (uint32_t b = blockIdx.x + gridDim.x * threadIdx.x; b < n_in; b += gridDim.x * kBlock) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       mn[c] = __builtin_fmin(mn[c], partial_bounds[(uint64_t)b * 6 + c]);
@@ -175,18 +355,19 @@ __global__ __launch_bounds__(kBlock) void las_encode_fold_kernel(const double* _
   __shared__ double scratch[(kBlock / 64) * 6];
   block_reduce_minmax<double, 3>(mn, mx, scratch);
   if (threadIdx.x == 0) {
-    out_bounds[0] = mn[0]; out_bounds[1] = mn[1]; out_bounds[2] = mn[2];
-    out_bounds[3] = mx[0]; out_bounds[4] = mx[1]; out_bounds[5] = mx[2];
+    double* o = out_bounds + (uint64_t)blockIdx.x * 6;
+    o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
   }
   __shared__ unsigned long long csum[kReturnSlots];
   if (threadIdx.x < kReturnSlots) csum[threadIdx.x] = 0;
   __syncthreads();
-  // 16 lanes per counter row: lane l handles counter (l & 15) of blocks l/16, l/16 + 16, ...
+  // 16 lanes per counter row: lane l handles counter (l & 15) of this block's rows l/16, l/16 + 16, ...
   unsigned long long local = 0;
-  for (uint32_t b = threadIdx.x >> 4; b < n_blocks; b += kBlock / 16) local += partial_counts[(uint64_t)b * kReturnSlots + (threadIdx.x & 15u)];
+  for (uint32_t b = blockIdx.x + gridDim.x * (threadIdx.x >> 4); b < n_in; b += gridDim.x * (kBlock / 16))
+    local += partial_counts[(uint64_t)b * kReturnSlots + (threadIdx.x & 15u)];
   atomicAdd(&csum[threadIdx.x & 15u], local);
   __syncthreads();
-  if (threadIdx.x < kReturnSlots) out_counts[threadIdx.x] = csum[threadIdx.x];
+  if (threadIdx.x < kReturnSlots) out_counts[(uint64_t)blockIdx.x * kReturnSlots + threadIdx.x] = csum[threadIdx.x];
 }
 
 }  // namespace
@@ -197,33 +378,62 @@ uint32_t las_raw_record_size(int format) { return raw_size(fmt_of(format)); }
 
 // attr_base / attr_stride: typed attributes in LasPointFormatN field order.  out_bounds (6 doubles) and out_counts (16 u64)
 // are device-accessible.  workspace must hold las_encode_workspace_bytes().
-size_t las_encode_workspace_bytes() { return (size_t)16384 * (6 * sizeof(double) + kReturnSlots * sizeof(unsigned long long)); }
+constexpr uint32_t kMaxGrid = 16384, kFoldGrid = 64;
+size_t las_encode_workspace_bytes() { return (size_t)(kMaxGrid + kFoldGrid) * (6 * sizeof(double) + kReturnSlots * sizeof(unsigned long long)); }
 
-bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, int n_attrs, uint64_t dst, uint64_t n,
-                       const double scale[3], const double offset[3], const double bounds_in[6], uint32_t max_return, uint8_t* workspace,
+bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, uint64_t dst,
+                       uint64_t n, const double scale[3], const double offset[3], const double bounds_in[6], uint32_t max_return, uint8_t* workspace,
                        double* out_bounds, unsigned long long* out_counts, hipStream_t stream) {
   EncodeArgs a{};
-  for (int i = 0; i < n_attrs && i < kMaxAttrs; ++i) { a.attr_base[i] = attr_base[i]; a.attr_stride[i] = attr_stride[i]; }
+  bool dense = true;
+  for (int i = 0; i < n_attrs && i < kMaxAttrs; ++i) {
+    a.attr_base[i] = attr_base[i];
+    a.attr_stride[i] = attr_stride[i];
+    dense = dense && attr_stride[i] == attr_size[i];
+  }
   a.dst = dst;
   a.n = n;
   for (int c = 0; c < 3; ++c) { a.scale[c] = scale[c]; a.offset[c] = offset[c]; a.seed_min[c] = bounds_in[c]; a.seed_max[c] = bounds_in[3 + c]; }
   a.max_return = max_return;
   const uint32_t rs = las_raw_record_size(format);
-  a.tile = std::max<uint32_t>(kBlock, ((32u * 1024u) / rs) / kBlock * kBlock);  // ~32 KiB of records per tile
+  // columnar sources: tiles of kQuadTile points (four per lane); otherwise ~32 KiB of records per tile
+  a.tile = dense ? kQuadTile : std::max<uint32_t>(kBlock, ((32u * 1024u) / rs) / kBlock * kBlock);
   const uint64_t n_tiles = std::max<uint64_t>(1, (n + a.tile - 1) / a.tile);
-  const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, 16384);
-  a.partial_bounds = (double*)workspace;
-  a.partial_counts = (unsigned long long*)(workspace + (size_t)16384 * 6 * sizeof(double));
+  const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, kMaxGrid);
+  double* pb = (double*)workspace;
+  unsigned long long* pc = (unsigned long long*)(workspace + (size_t)(kMaxGrid + kFoldGrid) * 6 * sizeof(double));
+  a.partial_bounds = pb;
+  a.partial_counts = pc;
   const size_t lds_bytes = (size_t)a.tile * rs + 32;
-#define PST_ENC(N) case N: hipLaunchKernelGGL((las_encode_kernel<N>), dim3(grid), dim3(kBlock), lds_bytes, stream, a); break;
+#define PST_ENC(N)                                                                                                                  \
+  case N: {                                                                                                                         \
+    if (dense) {                                                                                                                    \
+      static const hipError_t attr = hipFuncSetAttribute((const void*)las_encode_kernel<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                         (int)(kQuadTile * raw_size(fmt_of(N)) + 32));                             \
+      (void)attr;                                                                                                                   \
+      hipLaunchKernelGGL((las_encode_kernel<N, true>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                            \
+    } else {                                                                                                                        \
+      hipLaunchKernelGGL((las_encode_kernel<N, false>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                           \
+    }                                                                                                                               \
+    break;                                                                                                                          \
+  }
   switch (format) {
     PST_ENC(0) PST_ENC(1) PST_ENC(2) PST_ENC(3) PST_ENC(4) PST_ENC(5) PST_ENC(6) PST_ENC(7) PST_ENC(8) PST_ENC(9) PST_ENC(10)
     default: return false;
   }
 #undef PST_ENC
-  hipLaunchKernelGGL(las_encode_fold_kernel, dim3(1), dim3(kBlock), 0, stream, (const double*)a.partial_bounds,
-                     (const unsigned long long*)a.partial_counts, grid, out_bounds, out_counts, bounds_in[0], bounds_in[1], bounds_in[2], bounds_in[3],
-                     bounds_in[4], bounds_in[5]);
+  uint32_t n_in = grid;
+  const double* in_b = pb;
+  const unsigned long long* in_c = pc;
+  if (n_in > 4 * kFoldGrid) {  // two-level fold: 64 blocks first
+    hipLaunchKernelGGL(las_encode_fold_kernel, dim3(kFoldGrid), dim3(kBlock), 0, stream, in_b, in_c, n_in, pb + (size_t)kMaxGrid * 6,
+                       pc + (size_t)kMaxGrid * kReturnSlots, bounds_in[0], bounds_in[1], bounds_in[2], bounds_in[3], bounds_in[4], bounds_in[5]);
+    in_b = pb + (size_t)kMaxGrid * 6;
+    in_c = pc + (size_t)kMaxGrid * kReturnSlots;
+    n_in = kFoldGrid;
+  }
+  hipLaunchKernelGGL(las_encode_fold_kernel, dim3(1), dim3(kBlock), 0, stream, in_b, in_c, n_in, out_bounds, out_counts, bounds_in[0], bounds_in[1],
+                     bounds_in[2], bounds_in[3], bounds_in[4], bounds_in[5]);
   return hipGetLastError() == hipSuccess;
 }
 
