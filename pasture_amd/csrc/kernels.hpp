@@ -59,8 +59,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
 // LAS record encoder (las_encode.hip)
 uint32_t las_raw_record_size(int format);
 size_t las_encode_workspace_bytes();
-bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, uint64_t dst,
-                       uint64_t n,
+bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, bool interleaved,
+                       uint64_t dst, uint64_t n,
                        const double scale[3], const double offset[3], const double bounds_in[6], uint32_t max_return, uint8_t* workspace,
                        double* out_bounds, unsigned long long* out_counts, hipStream_t stream);
 

@@ -86,7 +86,7 @@ extern "C" int pst_las_encode_points(const pst_buffer* src, uint32_t point_forma
   uint8_t* scratch = ws.partials(pstk::las_encode_workspace_bytes());
   double* dev_bounds = (double*)(ws.dev + 1024);
   unsigned long long* dev_counts = (unsigned long long*)(ws.dev + 1024 + 64);
-  if (!pstk::launch_las_encode((int)point_format, base, stride, esize, (int)na, aos_addr(*dst, dst_first), n, scale, offset, bounds_inout, max_return, scratch,
+  if (!pstk::launch_las_encode((int)point_format, base, stride, esize, (int)na, !src->columnar, aos_addr(*dst, dst_first), n, scale, offset, bounds_inout, max_return, scratch,
                                dev_bounds, dev_counts, s))
     throw Error(PST_ERR_HIP, std::string("LAS encode launch failed: ") + hipGetErrorString(hipGetLastError()));
   PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 256, dev_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -50,24 +50,75 @@ __host__ __device__ constexpr uint32_t raw_size(Fmt f) {
   return (f.ext ? 30u : 20u) + (f.gps && !f.ext ? 8u : 0u) + (f.color ? 6u : 0u) + (f.nir ? 2u : 0u) + (f.wave ? 29u : 0u);
 }
 
-template <typename T>
-__device__ __forceinline__ T src_load(const EncodeArgs& a, int slot, uint64_t i) {
-  return load_un<T>((cgptr_t)(as_global(a.attr_base[slot]) + i * a.attr_stride[slot]));
+// Where one point's typed attributes are read from: HBM at any per-attribute stride, or a record staged in LDS.
+struct GlobalSrc {
+  const EncodeArgs& a;
+  uint64_t i;
+  template <typename T>
+  __device__ __forceinline__ T get(int slot, uint32_t off = 0) const {
+    return load_un<T>((cgptr_t)(as_global(a.attr_base[slot]) + i * a.attr_stride[slot] + off));
+  }
+};
+// LasPointFormatN::layout() is packed in field order (las_types.rs), so slot offsets are prefix sums of the field sizes.
+__host__ __device__ constexpr uint32_t typed_slot_offset(Fmt f, int slot) {
+  uint32_t sizes[kMaxAttrs] = {};
+  int n = 0;
+  sizes[n++] = 24; sizes[n++] = 2; sizes[n++] = 1; sizes[n++] = 1;
+  if (f.ext) { sizes[n++] = 1; sizes[n++] = 1; }
+  sizes[n++] = 1; sizes[n++] = 1; sizes[n++] = 1;
+  if (f.ext) { sizes[n++] = 1; sizes[n++] = 2; } else { sizes[n++] = 1; sizes[n++] = 1; }
+  sizes[n++] = 2;
+  if (f.gps) sizes[n++] = 8;
+  if (f.color) sizes[n++] = 6;
+  if (f.nir) sizes[n++] = 2;
+  if (f.wave) { sizes[n++] = 1; sizes[n++] = 8; sizes[n++] = 4; sizes[n++] = 4; sizes[n++] = 12; }
+  uint32_t o = 0;
+  for (int i = 0; i < slot && i < n; ++i) o += sizes[i];
+  return o;
 }
+__host__ __device__ constexpr uint32_t typed_size(Fmt f) { return typed_slot_offset(f, kMaxAttrs); }
+
+// One interleaved typed record staged in LDS at ANY byte alignment: read as aligned dwords and re-aligned in registers
+// with v_alignbyte (unaligned ds accesses stall the LDS pipe: records of odd size make 3 of 4 lanes unaligned).
+template <int FORMAT>
+struct RecordSrc {
+  static constexpr uint32_t TS = typed_size(fmt_of(FORMAT)), NW = (TS + 3) / 4;
+  uint32_t r[NW + 2];
+  __device__ __forceinline__ explicit RecordSrc(clptr_t rec) {
+    const uint32_t addr = (uint32_t)(uintptr_t)rec, m = addr & 3u;
+    const PST_AS_LDS uint32_t* p = (const PST_AS_LDS uint32_t*)(rec - m);
+    uint32_t d[NW + 1];
+#pragma unroll
+    for (uint32_t k = 0; k <= NW; ++k) d[k] = p[k];
+#pragma unroll
+    for (uint32_t k = 0; k < NW; ++k) r[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], m);
+    r[NW] = 0; r[NW + 1] = 0;
+  }
+  template <typename T>
+  __device__ __forceinline__ T get(int slot, uint32_t off = 0) const {
+    const uint32_t b = typed_slot_offset(fmt_of(FORMAT), slot) + off, wi = b >> 2, sh = (b & 3u) * 8u;
+    const uint64_t lo = r[wi], mid = r[wi + 1], hi = r[wi + 2];
+    uint64_t v = lo | (mid << 32);
+    if (sh != 0) v = (v >> sh) | (hi << (64 - sh));
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, v);
+    else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, (uint32_t)v);
+    else if constexpr (sizeof(T) == 2) return __builtin_bit_cast(T, (uint16_t)v);
+    else return __builtin_bit_cast(T, (uint8_t)v);
+  }
+};
 
 // One point, one lane: typed attributes read where they live (any stride), record assembled at `rec` in LDS.
-template <int FORMAT>
-__device__ __forceinline__ void encode_point(const EncodeArgs& a, uint64_t i, lptr_t rec, double (&mn)[3], double (&mx)[3], unsigned int* hist) {
+template <int FORMAT, typename Src>
+__device__ __forceinline__ void encode_point(const EncodeArgs& a, const Src& src, lptr_t rec, double (&mn)[3], double (&mx)[3], unsigned int* hist) {
   constexpr Fmt F = fmt_of(FORMAT);
   int s = 0;       // typed slot cursor (LasPointFormatN field order, las_types.rs)
   uint32_t o = 0;  // raw record cursor
   // position: write_position_as_las_position, write_helpers.rs:10-23
   {
-    cgptr_t pp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const double w = load_un<double>(pp + 8 * c);
+      const double w = src.template get<double>(s, 8 * c);
       const double local = (w - a.offset[c]) / a.scale[c];  // two roundings, like the Rust expression
       // `as i64` saturates and maps NaN to 0; try_into::<i32>() then fails outside [i32::MIN, i32::MAX]
       const long long t = rust_as<long long, double>(local);
@@ -80,50 +131,48 @@ __device__ __forceinline__ void encode_point(const EncodeArgs& a, uint64_t i, lp
     if (bad) atomicAdd(&hist[0], 1u);
     s += 1;
   }
-  store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // intensity
+  store_un<uint16_t>(rec + o, src.template get<uint16_t>(s)); o += 2; s += 1;  // intensity
   {
-    const uint32_t rn = src_load<uint8_t>(a, s, i), nr = src_load<uint8_t>(a, s + 1, i);
+    const uint32_t rn = src.template get<uint8_t>(s), nr = src.template get<uint8_t>(s + 1);
     s += 2;
     if (rn >= 1 && rn <= a.max_return) atomicAdd(&hist[rn], 1u);  // points_by_return.get_mut(&return_number)
     if constexpr (F.ext) {
-      const uint32_t cf = src_load<uint8_t>(a, s, i), sc = src_load<uint8_t>(a, s + 1, i), sd = src_load<uint8_t>(a, s + 2, i),
-                     eof = src_load<uint8_t>(a, s + 3, i);
+      const uint32_t cf = src.template get<uint8_t>(s), sc = src.template get<uint8_t>(s + 1), sd = src.template get<uint8_t>(s + 2),
+                     eof = src.template get<uint8_t>(s + 3);
       s += 4;
       store_un<uint8_t>(rec + o, (uint8_t)((rn & 15u) | ((nr & 15u) << 4)));
       store_un<uint8_t>(rec + o + 1, (uint8_t)((cf & 15u) | ((sc & 3u) << 4) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
       o += 2;
     } else {
-      const uint32_t sd = src_load<uint8_t>(a, s, i), eof = src_load<uint8_t>(a, s + 1, i);
+      const uint32_t sd = src.template get<uint8_t>(s), eof = src.template get<uint8_t>(s + 1);
       s += 2;
       store_un<uint8_t>(rec + o, (uint8_t)((rn & 7u) | ((nr & 7u) << 3) | ((sd & 1u) << 6) | ((eof & 1u) << 7)));
       o += 1;
     }
   }
-  store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;  // classification
+  store_un<uint8_t>(rec + o, src.template get<uint8_t>(s)); o += 1; s += 1;  // classification
   if constexpr (F.ext) {
-    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
-    store_un<int16_t>(rec + o, src_load<int16_t>(a, s, i)); o += 2; s += 1;    // scan angle
+    store_un<uint8_t>(rec + o, src.template get<uint8_t>(s)); o += 1; s += 1;    // user data
+    store_un<int16_t>(rec + o, src.template get<int16_t>(s)); o += 2; s += 1;    // scan angle
   } else {
-    store_un<int8_t>(rec + o, src_load<int8_t>(a, s, i)); o += 1; s += 1;      // scan angle rank
-    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;    // user data
+    store_un<int8_t>(rec + o, src.template get<int8_t>(s)); o += 1; s += 1;      // scan angle rank
+    store_un<uint8_t>(rec + o, src.template get<uint8_t>(s)); o += 1; s += 1;    // user data
   }
-  store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1;  // point source id
-  if constexpr (F.gps) { store_un<double>(rec + o, src_load<double>(a, s, i)); o += 8; s += 1; }
+  store_un<uint16_t>(rec + o, src.template get<uint16_t>(s)); o += 2; s += 1;  // point source id
+  if constexpr (F.gps) { store_un<double>(rec + o, src.template get<double>(s)); o += 8; s += 1; }
   if constexpr (F.color) {
-    cgptr_t cp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) store_un<uint16_t>(rec + o + 2 * c, load_un<uint16_t>(cp + 2 * c));
+    for (int c = 0; c < 3; ++c) store_un<uint16_t>(rec + o + 2 * c, src.template get<uint16_t>(s, 2 * c));
     o += 6; s += 1;
   }
-  if constexpr (F.nir) { store_un<uint16_t>(rec + o, src_load<uint16_t>(a, s, i)); o += 2; s += 1; }
+  if constexpr (F.nir) { store_un<uint16_t>(rec + o, src.template get<uint16_t>(s)); o += 2; s += 1; }
   if constexpr (F.wave) {
-    store_un<uint8_t>(rec + o, src_load<uint8_t>(a, s, i)); o += 1; s += 1;
-    store_un<uint64_t>(rec + o, src_load<uint64_t>(a, s, i)); o += 8; s += 1;
-    store_un<uint32_t>(rec + o, src_load<uint32_t>(a, s, i)); o += 4; s += 1;
-    store_un<float>(rec + o, src_load<float>(a, s, i)); o += 4; s += 1;
-    cgptr_t wp = (cgptr_t)(as_global(a.attr_base[s]) + i * a.attr_stride[s]);
+    store_un<uint8_t>(rec + o, src.template get<uint8_t>(s)); o += 1; s += 1;
+    store_un<uint64_t>(rec + o, src.template get<uint64_t>(s)); o += 8; s += 1;
+    store_un<uint32_t>(rec + o, src.template get<uint32_t>(s)); o += 4; s += 1;
+    store_un<float>(rec + o, src.template get<float>(s)); o += 4; s += 1;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) store_un<float>(rec + o + 4 * c, load_un<float>(wp + 4 * c));
+    for (int c = 0; c < 3; ++c) store_un<float>(rec + o + 4 * c, src.template get<float>(s, 4 * c));
     o += 12; s += 1;
   }
 }
@@ -301,8 +350,14 @@ __device__ __forceinline__ void encode_quad_tile(const EncodeArgs& a, uint64_t f
   }
 }
 
-// QUAD = every typed attribute is a dense column (stride == element size): full tiles take the four-points-per-lane path.
-template <int FORMAT, bool QUAD>
+// MODE_QUAD: every typed attribute is a dense column (stride == element size): full tiles take the four-points-per-lane path.
+// MODE_STAGED: interleaved typed records: the tile's source bytes are staged in LDS with LDS-DMA, then read per point.
+// MODE_STRIDED: any per-attribute base / stride, read from HBM per point.
+enum { MODE_STRIDED = 0, MODE_QUAD = 1, MODE_STAGED = 2 };
+
+__device__ __forceinline__ uint32_t round_up16(uint32_t v) { return (v + 15u) & ~15u; }
+
+template <int FORMAT, int MODE>
 __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) {
   constexpr Fmt F = fmt_of(FORMAT);
   constexpr uint32_t RS = raw_size(F);
@@ -313,16 +368,27 @@ __global__ __launch_bounds__(kBlock) void las_encode_kernel(const EncodeArgs a) 
   double mn[3] = {a.seed_min[0], a.seed_min[1], a.seed_min[2]}, mx[3] = {a.seed_max[0], a.seed_max[1], a.seed_max[2]};
   __syncthreads();
 
+  const uint32_t TS = a.attr_stride[0];                     // MODE_STAGED: typed record size
+  lptr_t lds_src = lds + round_up16(a.tile * RS + 16u);     // MODE_STAGED: staged source records
   const uint64_t n_tiles = (a.n + a.tile - 1) / a.tile;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * a.tile;
     const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
     const uint64_t ga = a.dst + first * RS;
     const uint32_t mis = (uint32_t)(ga & 15u);
-    if (QUAD && cnt == kQuadTile) {
+    if (MODE == MODE_QUAD && cnt == kQuadTile) {
       encode_quad_tile<FORMAT>(a, first, lds, mis, mn, mx, hist);
+    } else if (MODE == MODE_STAGED) {
+      const uint64_t sa = a.attr_base[0] + first * TS;
+      const uint32_t smis = (uint32_t)(sa & 15u);
+      tile_load<kBlock>(lds_src, as_global(sa - smis), round_up16(smis + cnt * TS));
+      wait_tile_loads();
+      __syncthreads();
+      for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock)
+        encode_point<FORMAT>(a, RecordSrc<FORMAT>(lds_src + (smis + lp * TS)), lds + (mis + lp * RS), mn, mx, hist);
     } else {
-      for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock) encode_point<FORMAT>(a, first + lp, lds + (mis + lp * RS), mn, mx, hist);
+      for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock)
+        encode_point<FORMAT>(a, GlobalSrc{a, first + lp}, lds + (mis + lp * RS), mn, mx, hist);
     }
     __syncthreads();
     tile_store<kBlock>(lds, as_global(ga - mis), mis, cnt * RS);
@@ -381,8 +447,8 @@ uint32_t las_raw_record_size(int format) { return raw_size(fmt_of(format)); }
 constexpr uint32_t kMaxGrid = 16384, kFoldGrid = 64;
 size_t las_encode_workspace_bytes() { return (size_t)(kMaxGrid + kFoldGrid) * (6 * sizeof(double) + kReturnSlots * sizeof(unsigned long long)); }
 
-bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, uint64_t dst,
-                       uint64_t n, const double scale[3], const double offset[3], const double bounds_in[6], uint32_t max_return, uint8_t* workspace,
+bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, bool interleaved,
+                       uint64_t dst, uint64_t n, const double scale[3], const double offset[3], const double bounds_in[6], uint32_t max_return, uint8_t* workspace,
                        double* out_bounds, unsigned long long* out_counts, hipStream_t stream) {
   EncodeArgs a{};
   bool dense = true;
@@ -396,32 +462,37 @@ bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* at
   for (int c = 0; c < 3; ++c) { a.scale[c] = scale[c]; a.offset[c] = offset[c]; a.seed_min[c] = bounds_in[c]; a.seed_max[c] = bounds_in[3 + c]; }
   a.max_return = max_return;
   const uint32_t rs = las_raw_record_size(format);
-  // columnar sources: tiles of kQuadTile points (four per lane); otherwise ~32 KiB of records per tile
-  a.tile = dense ? kQuadTile : std::max<uint32_t>(kBlock, ((32u * 1024u) / rs) / kBlock * kBlock);
+  const uint32_t ts = attr_stride[0];
+  // columnar sources: tiles of kQuadTile points (four per lane); interleaved: source + records in <= 48 KiB; otherwise ~32 KiB of records
+  const int mode = dense ? MODE_QUAD : (interleaved ? MODE_STAGED : MODE_STRIDED);
+  if (mode == MODE_QUAD) a.tile = kQuadTile;
+  else if (mode == MODE_STAGED) a.tile = std::max<uint32_t>(kBlock, ((48u * 1024u) / (rs + ts)) / kBlock * kBlock);
+  else a.tile = std::max<uint32_t>(kBlock, ((32u * 1024u) / rs) / kBlock * kBlock);
   const uint64_t n_tiles = std::max<uint64_t>(1, (n + a.tile - 1) / a.tile);
   const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, kMaxGrid);
   double* pb = (double*)workspace;
   unsigned long long* pc = (unsigned long long*)(workspace + (size_t)(kMaxGrid + kFoldGrid) * 6 * sizeof(double));
   a.partial_bounds = pb;
   a.partial_counts = pc;
-  const size_t lds_bytes = (size_t)a.tile * rs + 32;
-#define PST_ENC(N)                                                                                                                  \
-  case N: {                                                                                                                         \
-    if (dense) {                                                                                                                    \
-      static const hipError_t attr = hipFuncSetAttribute((const void*)las_encode_kernel<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                         (int)(kQuadTile * raw_size(fmt_of(N)) + 32));                             \
-      (void)attr;                                                                                                                   \
-      hipLaunchKernelGGL((las_encode_kernel<N, true>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                            \
-    } else {                                                                                                                        \
-      hipLaunchKernelGGL((las_encode_kernel<N, false>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                           \
-    }                                                                                                                               \
-    break;                                                                                                                          \
+  const size_t lds_bytes = (((size_t)a.tile * rs + 16 + 15) & ~(size_t)15) + (mode == MODE_STAGED ? (size_t)a.tile * ts + 48 : 16);
+#define PST_ENC_MODE(N, M)                                                                                                         \
+  {                                                                                                                                 \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)las_encode_kernel<N, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    (void)attr;                                                                                                                     \
+    hipLaunchKernelGGL((las_encode_kernel<N, M>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                                 \
   }
+#define PST_ENC(N)                                                                                                                  \
+  case N:                                                                                                                           \
+    if (mode == MODE_QUAD) PST_ENC_MODE(N, MODE_QUAD)                                                                               \
+    else if (mode == MODE_STAGED) PST_ENC_MODE(N, MODE_STAGED)                                                                      \
+    else PST_ENC_MODE(N, MODE_STRIDED)                                                                                              \
+    break;
   switch (format) {
     PST_ENC(0) PST_ENC(1) PST_ENC(2) PST_ENC(3) PST_ENC(4) PST_ENC(5) PST_ENC(6) PST_ENC(7) PST_ENC(8) PST_ENC(9) PST_ENC(10)
     default: return false;
   }
 #undef PST_ENC
+#undef PST_ENC_MODE
   uint32_t n_in = grid;
   const double* in_b = pb;
   const unsigned long long* in_c = pc;
