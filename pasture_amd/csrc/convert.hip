@@ -190,7 +190,7 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
         for (uint32_t pp = p0; pp < cnt; pp += kBatch * ppi, la += kBatch * la_step, ga += kBatch * ga_step) {
           S v[kBatch];
 #pragma unroll
-          for (uint32_t u = 0; u < kBatch; ++u) v[u] = pp + u * ppi < cnt ? load_un<S>(lds_src + (la + u * la_step)) : S{};
+          for (uint32_t u = 0; u < kBatch; ++u) v[u] = pp + u * ppi < cnt ? lds_load<S>(lds_src + (la + u * la_step)) : S{};
 #pragma unroll
           for (uint32_t u = 0; u < kBatch; ++u) {
             if (pp + u * ppi < cnt) {
@@ -217,12 +217,12 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
     for (uint32_t k0 = span.first * E; k0 < cnt; k0 += span.step * E, la += la_step) {
       if (k0 + E <= cnt) {
         if constexpr (E == 1) {
-          store_un<D>(col + (uint64_t)k0 * sizeof(D), convert_value_sc<S, D>(load_un<S>(lds_src + la), x, x.s0, x.o0));
+          store_un<D>(col + (uint64_t)k0 * sizeof(D), convert_value_sc<S, D>(lds_load<S>(lds_src + la), x, x.s0, x.o0));
         } else {
           uint32_t packed = 0;
 #pragma unroll
           for (uint32_t i = 0; i < E; ++i) {
-            const D w = convert_value_sc<S, D>(load_un<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0);
+            const D w = convert_value_sc<S, D>(lds_load<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0);
             typename std::make_unsigned<D>::type u;
             __builtin_memcpy(&u, &w, sizeof(D));
             packed |= (uint32_t)u << (8u * (uint32_t)sizeof(D) * i);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
         }
       } else {
         for (uint32_t i = 0; k0 + i < cnt; ++i)
-          store_un<D>(col + (uint64_t)(k0 + i) * sizeof(D), convert_value_sc<S, D>(load_un<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0));
+          store_un<D>(col + (uint64_t)(k0 + i) * sizeof(D), convert_value_sc<S, D>(lds_load<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0));
       }
     }
     return;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const
       const uint32_t k = k0 + i < total ? k0 + i : total - 1;  // clamp: a ragged tail recomputes the last value, never stores it
       uint32_t p, c;
       split_comp32(k, e.ncomp, p, c);
-      vals[i] = convert_value<S, D>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+      vals[i] = convert_value<S, D>(lds_load<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
       if constexpr (std::is_same<D, double>::value) {
         if (e.bounds) acc.fold(c, vals[i]);
       }
@@ -389,8 +389,8 @@ __device__ __forceinline__ void run_tile_lds_to_lds(const ConvertHeader& h, cons
   for (uint32_t k = span.first; k < total; k += span.step) {
     uint32_t p, c;
     split_comp32(k, e.ncomp, p, c);
-    const D w = convert_value<S, D>(load_un<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
-    store_un<D>(lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), w);
+    const D w = convert_value<S, D>(lds_load<S>(lds_src + (p * h.src_stride + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+    lds_store<D>(lds_dst + (p * h.dst_stride + e.dst_off + c * (uint32_t)sizeof(D)), w);
     if constexpr (std::is_same<D, double>::value) {
       if (e.bounds) acc.fold(c, w);
     }

@@ -67,6 +67,57 @@ __device__ __forceinline__ void store_un(lptr_t p, T v) {
   *reinterpret_cast<PST_AS_LDS typename Unaligned<T>::type*>(p) = v;
 }
 
+// LDS accesses to packed(1) records.  gfx950 executes unaligned ds_read/ds_write, but an access that is not naturally aligned
+// stalls the LDS pipe for tens of cycles (measured: a 35-byte-stride record tile read with unaligned b64 accesses ran the
+// whole kernel at 3.3 TB/s, the same reads as aligned dwords + v_alignbyte at 5.2 TB/s).  So: read the covering aligned
+// dwords and re-align in registers; split stores by alignment class into naturally aligned pieces.
+// lds_load may read up to 7 bytes past the value (tiles carry 32 bytes of slack).
+template <typename T>
+__device__ __forceinline__ T lds_load(clptr_t p) {
+  if constexpr (sizeof(T) == 1) {
+    return load_un<T>(p);
+  } else {
+    const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
+    const PST_AS_LDS uint32_t* q = (const PST_AS_LDS uint32_t*)(p - m);
+    const uint32_t d0 = q[0], d1 = q[1];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, m);
+    if constexpr (sizeof(T) == 8) {
+      const uint32_t d2 = q[2];
+      const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, m);
+      return __builtin_bit_cast(T, (uint64_t)lo | ((uint64_t)hi << 32));
+    } else if constexpr (sizeof(T) == 4) {
+      return __builtin_bit_cast(T, lo);
+    } else {
+      return __builtin_bit_cast(T, (uint16_t)lo);
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void lds_store(lptr_t p, T v) {
+  typedef PST_AS_LDS uint8_t* p8;
+  typedef PST_AS_LDS uint16_t* p16;
+  typedef PST_AS_LDS uint32_t* p32;
+  if constexpr (sizeof(T) == 1) {
+    store_un<T>(p, v);
+  } else if constexpr (sizeof(T) == 2) {
+    const uint16_t b = __builtin_bit_cast(uint16_t, v);
+    if (((uint32_t)(uintptr_t)p & 1u) == 0) *(p16)p = b;
+    else { *(p8)p = (uint8_t)b; *(p8)(p + 1) = (uint8_t)(b >> 8); }
+  } else if constexpr (sizeof(T) == 4) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v), m = (uint32_t)(uintptr_t)p & 3u;
+    if (m == 0) *(p32)p = b;
+    else if (m == 2) { *(p16)p = (uint16_t)b; *(p16)(p + 2) = (uint16_t)(b >> 16); }
+    else { *(p8)p = (uint8_t)b; *(p16)(p + 1) = (uint16_t)(b >> 8); *(p8)(p + 3) = (uint8_t)(b >> 24); }
+  } else {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
+    if (m == 0) { *(p32)p = (uint32_t)b; *(p32)(p + 4) = (uint32_t)(b >> 32); }
+    else if (m == 2) { *(p16)p = (uint16_t)b; *(p32)(p + 2) = (uint32_t)(b >> 16); *(p16)(p + 6) = (uint16_t)(b >> 48); }
+    else if (m == 1) { *(p8)p = (uint8_t)b; *(p16)(p + 1) = (uint16_t)(b >> 8); *(p32)(p + 3) = (uint32_t)(b >> 24); *(p8)(p + 7) = (uint8_t)(b >> 56); }
+    else { *(p8)p = (uint8_t)b; *(p32)(p + 1) = (uint32_t)(b >> 8); *(p16)(p + 5) = (uint16_t)(b >> 40); *(p8)(p + 7) = (uint8_t)(b >> 56); }
+  }
+}
+
 // Rust `as` (attribute_conversion.rs:310-343 via num_traits::AsPrimitive):
 //   int->int   two's complement truncate / sign- or zero-extend
 //   int->float round to nearest even
