@@ -41,6 +41,9 @@ WORKLOADS = {
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
     "las0_encode": (55, "LAS writer: 10 SoA columns (typed LAS-0) -> raw LAS-0 records + header AABB + per-return counts, fused (35 R + 20 W)"),
+    "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
+                                  "resident in HBM (2 mask reads + 41 R + 20.5 W per input point)"),
+    "filter_big_interleaved": (63.5, "buffer_filter_bench: HashMapBuffer::filter_into, CustomPointTypeBig columnar -> VectorBuffer, density 0.5"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
@@ -199,6 +202,21 @@ def main():
 
         def step():
             las.encode_points(src, 0, (0.001, 0.001, 0.001), (0.0, 0.0, 0.0), dst)
+    elif args.workload.startswith("filter_big"):
+        big = pa.PointLayout.from_attributes_packed([A.GPS_TIME, A.COLOR_RGB, A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY.with_custom_datatype(T.I16)], 1)
+        src = pa.HashMapBuffer.new_from_layout(big)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(SEED + rank)
+        mask = (torch.rand(n, device="cuda", generator=g) < 0.5).to(torch.uint8)
+        k = int(mask.sum().item())
+        dst = (pa.VectorBuffer if args.workload.endswith("interleaved") else pa.HashMapBuffer).new_from_layout(big)
+        dst.resize(k)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            src.filter_into(dst, (mask.data_ptr(), "device"), k)
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)

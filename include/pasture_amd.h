@@ -145,6 +145,20 @@ int pst_buffer_read_attribute(const pst_buffer* b, const char* name, const pst_d
 /* deterministic synthetic points generated on the device (DESIGN.md "Synthetic inputs") */
 int pst_buffer_synth_fill(pst_buffer* b, uint64_t seed, uint64_t first_index);
 
+/* OwningBufferExt::append (point_buffer.rs:419-489): appends every point of `other`; the layouts must be equal
+ * (PST_ERR_LAYOUT_MISMATCH = the assert_eq! of :420).  Capacity grows geometrically like Vec. */
+int pst_buffer_append(pst_buffer* self, const pst_buffer* other);
+/* HashMapBuffer::filter_into (point_buffer.rs:1082-1136): order-preserving compaction of the points whose predicate holds into
+ * dst[0, matches).  The predicate `Fn(usize) -> bool` is passed as a byte mask of src->len entries (mask[i] != 0 keeps
+ * point i; benches/buffer_filter_bench.rs:62-64); mask_memkind = PST_MEM_DEVICE for a device pointer, anything else = host.
+ * num_matches_hint < 0 = None.  Panics of the reference: layouts differ -> PST_ERR_LAYOUT_MISMATCH; dst shorter than
+ * num_matches -> PST_ERR_RANGE; more matches than the hint -> PST_ERR_RANGE (slice index out of range).
+ * *out_matches (optional) = number of mask hits. */
+int pst_buffer_filter_into(const pst_buffer* src, pst_buffer* dst, const uint8_t* mask, uint32_t mask_memkind, int64_t num_matches_hint,
+                           size_t* out_matches);
+/* HashMapBuffer::filter::<B, _> (point_buffer.rs:1064-1076): new buffer of out_storage holding exactly the matching points */
+int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, pst_buffer** out);
+
 /* ---- BufferLayoutConverter ------------------------------------------------------------------------- */
 int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_default, pst_converter** out); /* for_layouts :112 / for_layouts_with_default :126 */
 int pst_converter_destroy(pst_converter* c);

@@ -123,6 +123,108 @@ int orc_buffer_resize(orc_buffer* b, size_t count) { ORC_TRY need(b, "buffer")->
 int orc_buffer_is_columnar(const orc_buffer* b, int* out) { ORC_TRY *need(out, "out") = need(b, "buffer")->b->as_columnar() != nullptr; ORC_CATCH }
 int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone) { ORC_TRY *need(out_clone, "out") = new orc_layout{need(b, "buffer")->b->point_layout()}; ORC_CATCH }
 
+// OwningBufferExt::append — point_buffer.rs:419-489
+int orc_buffer_append(orc_buffer* self_, const orc_buffer* other_) {
+  ORC_TRY
+  Buffer& self = *need(self_, "self")->b;
+  Buffer& other = *need(other_, "other")->b;
+  if (!(self.point_layout() == other.point_layout())) throw Panic(ERR_LAYOUT_MISMATCH, "assertion failed: self.point_layout() == other.point_layout()");
+  const size_t old_self_len = self.len(), new_self_len = old_self_len + other.len();
+  const size_t point_size = self.point_layout().size_of_point_entry();
+  InterleavedBuffer* si = self.as_interleaved();
+  InterleavedBuffer* oi = other.as_interleaved();
+  if (si && oi) {  // :430-439 push_points == Vec::extend_from_slice
+    self.resize(new_self_len);
+    std::memcpy(si->get_point_range_mut({old_self_len, new_self_len}), oi->get_point_range_ref({0, other.len()}), other.len() * point_size);
+    return OK;
+  }
+  self.resize(new_self_len);  // :441-443
+  if (si) {  // :445-450 other.get_point(index, new_point)
+    uint8_t* new_points = si->get_point_range_mut({old_self_len, new_self_len});
+    for (size_t index = 0; index < other.len(); ++index)
+      for (auto& a : other.point_layout().attributes) other.get_attribute_unchecked(a, index, new_points + index * point_size + a.offset);
+  } else if (ColumnarBuffer* sc = self.as_columnar()) {
+    if (ColumnarBuffer* oc = other.as_columnar()) {  // :452-465
+      for (auto& a : other.point_layout().attributes)
+        sc->set_attribute_range(a.def, {old_self_len, new_self_len}, oc->get_attribute_range_ref(a.def, {0, oc->len()}));
+    } else {  // :466-479
+      for (auto& a : other.point_layout().attributes) {
+        uint8_t* new_attributes = sc->get_attribute_range_mut(a.def, {old_self_len, new_self_len});
+        for (size_t index = 0; index < other.len(); ++index) other.get_attribute_unchecked(a, index, new_attributes + index * a.size);
+      }
+    }
+  }
+  ORC_CATCH
+}
+
+// HashMapBuffer::filter_into — point_buffer.rs:1082-1136
+static size_t filter_into_impl(Buffer& self, Buffer& buffer, const uint8_t* mask, int64_t num_matches_hint) {
+  ColumnarBuffer* sc = self.as_columnar();
+  if (!sc) throw Panic(ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
+  if (!(buffer.point_layout() == self.point_layout())) throw Panic(ERR_LAYOUT_MISMATCH, "PointLayouts must match");
+  auto predicate = [&](size_t idx) { return mask[idx] != 0; };
+  size_t num_matches = 0;
+  if (num_matches_hint >= 0) num_matches = (size_t)num_matches_hint;
+  else for (size_t i = 0; i < self.len(); ++i) num_matches += predicate(i);
+  if (buffer.len() < num_matches) throw Panic(ERR_RANGE, "buffer.len() must be at least as large as the number of predicate matches");
+  if (ColumnarBuffer* dc = buffer.as_columnar()) {
+    for (auto& attribute : self.point_layout().attributes) {
+      const uint8_t* src_attribute_data = sc->get_attribute_range_ref(attribute.def, {0, self.len()});
+      uint8_t* dst_attribute_data = dc->get_attribute_range_mut(attribute.def, {0, num_matches});
+      const size_t stride = attribute.size;
+      size_t dst_index = 0;
+      for (size_t src_index = 0; src_index < self.len(); ++src_index) {
+        if (!predicate(src_index)) continue;
+        if (dst_index >= num_matches) throw Panic(ERR_RANGE, "range end index out of range for slice (more matches than num_matches_hint)");
+        std::memcpy(dst_attribute_data + dst_index * stride, src_attribute_data + src_index * stride, stride);
+        ++dst_index;
+      }
+    }
+  } else if (InterleavedBuffer* di = buffer.as_interleaved()) {
+    uint8_t* dst_data = di->get_point_range_mut({0, num_matches});
+    for (auto& attribute : self.point_layout().attributes) {
+      const uint8_t* src_attribute_data = sc->get_attribute_range_ref(attribute.def, {0, self.len()});
+      const size_t src_stride = attribute.size, dst_offset = attribute.offset, dst_stride = self.point_layout().size_of_point_entry();
+      size_t dst_index = 0;
+      for (size_t src_index = 0; src_index < self.len(); ++src_index) {
+        if (!predicate(src_index)) continue;
+        if (dst_index >= num_matches) throw Panic(ERR_RANGE, "range end index out of range for slice (more matches than num_matches_hint)");
+        std::memcpy(dst_data + dst_offset + dst_index * dst_stride, src_attribute_data + src_index * src_stride, src_stride);
+        ++dst_index;
+      }
+    }
+  }
+  size_t real = 0;
+  for (size_t i = 0; i < self.len(); ++i) real += predicate(i);
+  return real;
+}
+int orc_buffer_filter_into(const orc_buffer* src, orc_buffer* dst, const uint8_t* mask, uint32_t, int64_t num_matches_hint, size_t* out_matches) {
+  ORC_TRY
+  Buffer& self = *need(src, "src")->b;
+  if (self.len() && !mask) throw Panic(ERR_INVALID_ARGUMENT, "mask is null");
+  const size_t m = filter_into_impl(self, *need(dst, "dst")->b, mask, num_matches_hint);
+  if (out_matches) *out_matches = m;
+  ORC_CATCH
+}
+// HashMapBuffer::filter — point_buffer.rs:1064-1076
+int orc_buffer_filter(const orc_buffer* src, const uint8_t* mask, uint32_t, uint32_t out_storage, orc_buffer** out) {
+  ORC_TRY
+  Buffer& self = *need(src, "src")->b;
+  if (self.len() && !mask) throw Panic(ERR_INVALID_ARGUMENT, "mask is null");
+  if (!self.as_columnar()) throw Panic(ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
+  size_t num_matches = 0;
+  for (size_t i = 0; i < self.len(); ++i) num_matches += mask[i] != 0;
+  auto* b = new orc_buffer();
+  if (out_storage == 0) b->b = std::make_unique<VectorBuffer>(self.point_layout());
+  else if (out_storage == 1) b->b = std::make_unique<HashMapBuffer>(self.point_layout());
+  else { delete b; throw Panic(ERR_INVALID_ARGUMENT, "invalid storage kind"); }
+  std::unique_ptr<orc_buffer> guard(b);
+  b->b->resize(num_matches);
+  filter_into_impl(self, *b->b, mask, (int64_t)num_matches);
+  *need(out, "out") = guard.release();
+  ORC_CATCH
+}
+
 // set_point_range / get_point_range — point_buffer.rs:792-795 (AoS memcpy), :1294-1315 / :1194-1211 (SoA per attribute x per point)
 int orc_buffer_write_points(orc_buffer* b, size_t first, size_t count, const void* src) {
   ORC_TRY

@@ -79,6 +79,12 @@ int orc_buffer_read_points(const orc_buffer* b, size_t first, size_t count, void
 int orc_buffer_write_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, const void* src);
 int orc_buffer_read_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, size_t first, size_t count, void* dst);
 int orc_buffer_synth_fill(orc_buffer* b, uint64_t seed, uint64_t first_index);
+/* OwningBufferExt::append, point_buffer.rs:419-489 */
+int orc_buffer_append(orc_buffer* self, const orc_buffer* other);
+/* HashMapBuffer::filter_into / filter, point_buffer.rs:1064-1136; predicate = mask[idx] != 0; mask_memkind ignored (host) */
+int orc_buffer_filter_into(const orc_buffer* src, orc_buffer* dst, const uint8_t* mask, uint32_t mask_memkind, int64_t num_matches_hint,
+                           size_t* out_matches);
+int orc_buffer_filter(const orc_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, orc_buffer** out);
 
 int orc_converter_create(const orc_layout* from, const orc_layout* to, int with_default, orc_converter** out);
 int orc_converter_destroy(orc_converter* c);

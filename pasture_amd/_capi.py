@@ -109,6 +109,9 @@ _SHARED_SIGNATURES = {
     "minmax_attribute": [_P, C.c_char_p, _DT, _P, _P, C.POINTER(C.c_int)],
     "transform_attribute": [_P, C.c_char_p, _DT, C.POINTER(TransformStruct)],
     "compute_normals": [_P, _SZ, _D3, _D3, C.POINTER(C.c_int64)],
+    "buffer_append": [_P, _P],
+    "buffer_filter_into": [_P, _P, _P, C.c_uint32, C.c_int64, C.POINTER(C.c_size_t)],
+    "buffer_filter": [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)],
     "las_encode_points": [_P, C.c_uint32, _D3, _D3, _P, _SZ, _D3, C.POINTER(C.c_uint64), C.c_uint32],
 }
 

@@ -139,6 +139,35 @@ class _Buffer:
     def clear(self) -> None:  # :266
         self.resize(0)
 
+    def append(self, other: "_Buffer") -> None:  # OwningBufferExt::append :419-489
+        self.api.buffer_append(self._h, other._h)
+        self._keepalive = getattr(self, "_keepalive", None)
+
+    @staticmethod
+    def _mask_arg(predicate, n: int):
+        """The reference's predicate is `Fn(usize) -> bool`; here: a bool/uint8 numpy array, a callable evaluated on the
+        host into such an array, or a (device_pointer, 'device') pair for a mask that already lives in HBM."""
+        if isinstance(predicate, tuple) and len(predicate) == 2 and predicate[1] == "device":
+            return C.c_void_p(int(predicate[0])), MEM_DEVICE, None
+        if callable(predicate):
+            predicate = np.fromiter((bool(predicate(i)) for i in range(n)), dtype=np.bool_, count=n)
+        m = np.ascontiguousarray(np.asarray(predicate)).astype(np.uint8, copy=False)
+        if m.shape != (n,):
+            raise ValueError(f"mask must have {n} entries")
+        return m.ctypes.data_as(C.c_void_p), 1, m
+
+    def filter(self, out_buffer_type, predicate):  # HashMapBuffer::filter :1064-1076
+        ptr, kind, keep = self._mask_arg(predicate, self.len())
+        h = C.c_void_p()
+        self.api.buffer_filter(self._h, ptr, kind, out_buffer_type._storage, C.byref(h))
+        return out_buffer_type(h.value, self.api)
+
+    def filter_into(self, buffer: "_Buffer", predicate, num_matches_hint: Optional[int] = None) -> int:  # :1082-1136
+        ptr, kind, keep = self._mask_arg(predicate, self.len())
+        n = C.c_size_t()
+        self.api.buffer_filter_into(self._h, buffer._h, ptr, kind, -1 if num_matches_hint is None else num_matches_hint, C.byref(n))
+        return n.value
+
     # device-side helpers ---------------------------------------------------------------------------------
     def synth_fill(self, seed: int, first_index: int = 0) -> None:
         self.api.buffer_synth_fill(self._h, seed, first_index)

@@ -1,0 +1,312 @@
+// Predicate compaction for gfx950: HashMapBuffer::filter_into / filter
+// (pasture-core/src/containers/point_buffer.rs:1064-1136) with the predicate given as a byte mask
+// (benches/buffer_filter_bench.rs:62-64: `|idx| random_matches[idx]`).
+//
+// The reference walks the matching indices once per attribute; here the order-preserving rank of every selected point is
+// computed once (count per tile -> exclusive scan of the tile counts -> ranks inside the tile) and every attribute of the
+// tile's selected points is copied in the same launch:
+//
+//   mask_count_kernel     one tile of the mask per block: number of non-zero bytes                (1 B/pt read)
+//   tile_scan_kernel      exclusive scan of the tile counts (one block; <= 10^5 values)           (negligible)
+//   filter_scatter_kernel per tile: selected local indices compacted into LDS (order preserved), then attribute by
+//                         attribute: gather from the source columns, store to the tile's contiguous output span —
+//                         columnar targets directly (coalesced, narrow values packed four/two per dword), interleaved
+//                         targets through an LDS record tile and 16-byte stores.
+// HBM-bound gather/scatter: no MFMA.
+#include "device_common.hpp"
+#include "kernels.hpp"
+#include "tile_io.hpp"
+
+#include <algorithm>
+
+using namespace pstd;
+
+namespace {
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {  // number of non-zero bytes of a dword
+  const uint32_t t = (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+  return (uint32_t)__builtin_popcount(t);
+}
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+  if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t s = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) s += scratch[w];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __restrict__ mask, uint64_t n, uint32_t tile, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t scratch[kBlock / 64];
+  const uint64_t first = (uint64_t)blockIdx.x * tile;
+  const uint32_t cnt = (uint32_t)((n - first) < tile ? (n - first) : tile);
+  cgptr_t m = (cgptr_t)((uint64_t)(uintptr_t)mask + first);
+  uint32_t c = 0;
+  const uint32_t nvec = cnt >> 4;
+  for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) {
+    const u32x4 v = load_un<u32x4>(m + 16u * i);
+    c += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+  }
+  for (uint32_t i = (nvec << 4) + threadIdx.x; i < cnt; i += kBlock) c += m[i] != 0;
+  const uint32_t total = block_sum(c, scratch);
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+// offsets[t] = sum of counts[0..t); offsets[n_tiles] = total
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets) {
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < n_tiles; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const unsigned long long v = i < n_tiles ? counts[i] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+      if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long before = carry_s;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    if (i < n_tiles) offsets[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n_tiles] = carry_s;
+}
+
+constexpr int kMaxFilterAttrs = 32;
+
+struct FilterAttr {
+  uint64_t src;         // address of the attribute of source point 0
+  uint64_t dst;         // columnar target: address of the attribute of target point 0; interleaved: unused
+  uint32_t src_stride;  // bytes between consecutive source points
+  uint32_t dst_off;     // interleaved target: offset inside the record
+  uint32_t unit;        // copy granule: largest of 16/8/4/2/1 dividing the attribute size
+  uint32_t cnt;         // granules per value
+};
+
+struct FilterArgs {
+  const uint8_t* mask;
+  const uint32_t* counts;
+  const unsigned long long* offsets;
+  uint64_t n;
+  uint64_t limit;       // never write target points >= limit (num_matches of the reference)
+  uint64_t dst_aos;     // interleaved target: address of record 0
+  uint32_t dst_stride;  // interleaved target: record size
+  uint32_t tile;
+  uint32_t n_attrs;
+  uint32_t dst_covered;  // interleaved target: attributes cover every byte of the record (no read-modify-write needed)
+  FilterAttr attrs[kMaxFilterAttrs];
+};
+
+template <typename U>
+__device__ __forceinline__ void copy_granules(const FilterAttr& a, const uint16_t* sel, uint64_t first, uint64_t out0, uint32_t m, bool dst_aos, lptr_t lds,
+                                              uint32_t mis, uint32_t dst_stride) {
+  constexpr uint32_t kBatch = 4;
+  const uint32_t total = m * a.cnt;
+  cgptr_t src = (cgptr_t)as_global(a.src);
+  gptr_t dst = as_global(a.dst) + out0 * a.cnt * sizeof(U);
+  constexpr uint32_t PACK = sizeof(U) >= 4 ? 1u : 4u / (uint32_t)sizeof(U);  // narrow granules travel four / two per dword
+  if constexpr (PACK > 1) if (!dst_aos) {
+    // columnar target, 1- or 2-byte granules: each lane produces one dword of PACK consecutive granules
+    const uint32_t head = (uint32_t)((0u - (uint32_t)(uintptr_t)dst) & 3u) / (uint32_t)sizeof(U);  // granules before the first aligned dword
+    const uint32_t h = head < total ? head : total;
+    auto fetch = [&](uint32_t k) -> U {
+      uint32_t j, c;
+      if (a.cnt == 1) { j = k; c = 0; } else if (a.cnt == 3) { j = (k * 43691u) >> 17; c = k - 3u * j; } else { j = k / a.cnt; c = k - j * a.cnt; }
+      return load_un<U>(src + ((first + sel[j]) * a.src_stride + c * (uint32_t)sizeof(U)));
+    };
+    if (threadIdx.x < h) store_un<U>(dst + threadIdx.x * sizeof(U), fetch(threadIdx.x));
+    const uint32_t nd = (total - h) / PACK;
+    for (uint32_t q = threadIdx.x; q < nd; q += kBlock) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < PACK; ++i) packed |= (uint32_t)fetch(h + q * PACK + i) << (8u * (uint32_t)sizeof(U) * i);
+      store_un<uint32_t>(dst + (h + q * PACK) * sizeof(U), packed);
+    }
+    for (uint32_t k = h + nd * PACK + threadIdx.x; k < total; k += kBlock) store_un<U>(dst + k * sizeof(U), fetch(k));
+    return;
+  }
+  for (uint32_t k0 = threadIdx.x; k0 < total; k0 += kBatch * kBlock) {
+    U v[kBatch];
+    uint32_t jj[kBatch], cc[kBatch];
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) {
+      const uint32_t k = k0 + u * kBlock;
+      uint32_t j = 0, c = 0;
+      if (k < total) {
+        if (a.cnt == 1) { j = k; } else if (a.cnt == 3) { j = (k * 43691u) >> 17; c = k - 3u * j; } else { j = k / a.cnt; c = k - j * a.cnt; }
+        v[u] = load_un<U>(src + ((first + sel[j]) * a.src_stride + c * (uint32_t)sizeof(U)));
+      }
+      jj[u] = j; cc[u] = c;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kBatch; ++u) {
+      const uint32_t k = k0 + u * kBlock;
+      if (k < total) {
+        if (dst_aos) store_un<U>(lds + (mis + jj[u] * dst_stride + a.dst_off + cc[u] * (uint32_t)sizeof(U)), v[u]);
+        else store_un<U>(dst + (uint64_t)k * sizeof(U), v[u]);
+      }
+    }
+  }
+}
+
+template <int PPL, bool DST_AOS>
+__global__ __launch_bounds__(kBlock) void filter_scatter_kernel(const FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  uint16_t* sel = (uint16_t*)lds_raw;                         // [tile] local indices of the selected points, ascending
+  lptr_t lds = (lptr_t)lds_raw + ((a.tile * 2u + 15u) & ~15u);  // interleaved target: record tile
+  __shared__ uint32_t wave_tot[kBlock / 64];
+
+  const uint64_t first = (uint64_t)blockIdx.x * a.tile;
+  const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
+  const uint64_t out0 = a.offsets[blockIdx.x];
+  uint32_t m = a.counts[blockIdx.x];
+  if (m == 0 || out0 >= a.limit) return;
+
+  // ranks: lane t owns the PPL consecutive points t*PPL ..
+  const uint32_t p0 = threadIdx.x * PPL;
+  uint8_t mb[PPL];
+  cgptr_t mp = (cgptr_t)((uint64_t)(uintptr_t)a.mask + first);
+  if (p0 + PPL <= cnt) {
+    if constexpr (PPL == 8) { const uint64_t w = load_un<uint64_t>(mp + p0); for (int i = 0; i < 8; ++i) mb[i] = (uint8_t)(w >> (8 * i)); }
+    else if constexpr (PPL == 4) { const uint32_t w = load_un<uint32_t>(mp + p0); for (int i = 0; i < 4; ++i) mb[i] = (uint8_t)(w >> (8 * i)); }
+    else if constexpr (PPL == 2) { const uint16_t w = load_un<uint16_t>(mp + p0); mb[0] = (uint8_t)w; mb[1] = (uint8_t)(w >> 8); }
+    else mb[0] = mp[p0];
+  } else {
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) mb[i] = p0 + i < cnt ? mp[p0 + i] : (uint8_t)0;
+  }
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) c += mb[i] != 0;
+  uint32_t incl = c;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t r = incl - c;
+  for (uint32_t w = 0; w < wave; ++w) r += wave_tot[w];
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) if (mb[i] != 0) sel[r++] = (uint16_t)(p0 + i);
+
+  if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);  // more matches than num_matches: the host raises the panic
+  uint32_t mis = 0;
+  uint64_t ga = 0;
+  if constexpr (DST_AOS) {
+    ga = a.dst_aos + out0 * a.dst_stride;
+    mis = (uint32_t)(ga & 15u);
+    if (!a.dst_covered) {  // padding bytes of the target records must survive
+      tile_load<kBlock>(lds, as_global(ga - mis), (mis + m * a.dst_stride + 15u) & ~15u);
+      wait_tile_loads();
+    }
+  }
+  __syncthreads();
+
+  for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+    const FilterAttr& at = a.attrs[ai];
+    switch (at.unit) {
+      case 16: copy_granules<u32x4>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
+      case 8: copy_granules<uint64_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
+      case 4: copy_granules<uint32_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
+      case 2: copy_granules<uint16_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
+      default: copy_granules<uint8_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
+    }
+  }
+  if constexpr (DST_AOS) {
+    __syncthreads();
+    tile_store<kBlock>(lds, as_global(ga - mis), mis, m * a.dst_stride);
+  }
+}
+
+}  // namespace
+
+namespace pstk {
+
+size_t filter_workspace_bytes(uint64_t n) {
+  const uint64_t max_tiles = (n + 255) / 256 + 1;
+  return (size_t)(max_tiles * (sizeof(uint32_t) + sizeof(unsigned long long)) + 64);
+}
+
+// Points per tile: columnar targets 2048; interleaved targets as many records as fit ~40 KiB of LDS (a power of two >= 256).
+uint32_t filter_tile(bool dst_aos, uint32_t dst_stride) {
+  if (!dst_aos) return 2048;
+  uint32_t t = 2048;
+  while (t > 256 && (uint64_t)t * dst_stride > 40u * 1024u) t >>= 1;
+  return t;
+}
+
+// Phase 1: counts + offsets (offsets[n_tiles] = number of matches), device memory inside `workspace`.
+void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
+                         hipStream_t stream) {
+  const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+  unsigned long long* offsets = (unsigned long long*)workspace;
+  uint32_t* counts = (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
+  hipLaunchKernelGGL(mask_count_kernel, dim3(n_tiles), dim3(kBlock), 0, stream, mask_dev, n, tile, counts);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)counts, n_tiles, offsets);
+  *out_total_dev = offsets + n_tiles;
+}
+
+// Phase 2: attribute copies.  attrs: all attributes of the layout (launched in groups of kMaxFilterAttrs).
+bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, uint64_t limit, const uint64_t* src_addr,
+                           const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_off, const uint32_t* size, int n_attrs,
+                           bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream) {
+  const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+  FilterArgs a{};
+  a.mask = mask_dev;
+  a.offsets = (const unsigned long long*)workspace;
+  a.counts = (const uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
+  a.n = n;
+  a.limit = limit;
+  a.dst_aos = dst_aos_base;
+  a.dst_stride = dst_stride;
+  a.tile = tile;
+  const size_t lds_bytes = (((size_t)tile * 2 + 15) & ~(size_t)15) + (dst_aos ? (size_t)tile * dst_stride + 48 : 0);
+  for (int g = 0; g < n_attrs; g += kMaxFilterAttrs) {
+    const int ng = std::min(kMaxFilterAttrs, n_attrs - g);
+    a.n_attrs = (uint32_t)ng;
+    // read-modify-write of the record tile is needed unless this launch writes every byte of the records
+    a.dst_covered = (dst_covered && n_attrs <= kMaxFilterAttrs) ? 1u : 0u;
+    for (int i = 0; i < ng; ++i) {
+      FilterAttr& f = a.attrs[i];
+      f.src = src_addr[g + i];
+      f.dst = dst_aos ? 0 : dst_addr[g + i];
+      f.src_stride = src_stride[g + i];
+      f.dst_off = dst_off[g + i];
+      const uint32_t sz = size[g + i];
+      f.unit = sz % 16 == 0 ? 16u : sz % 8 == 0 ? 8u : sz % 4 == 0 ? 4u : sz % 2 == 0 ? 2u : 1u;
+      f.cnt = sz / f.unit;
+    }
+#define PST_FILTER(PPL, AOS)                                                                                                            \
+  {                                                                                                                                     \
+    if (lds_bytes > 64 * 1024)                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)filter_scatter_kernel<PPL, AOS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    hipLaunchKernelGGL((filter_scatter_kernel<PPL, AOS>), dim3(n_tiles), dim3(kBlock), lds_bytes, stream, a);                          \
+  }
+    switch (tile / kBlock) {
+      case 8: if (dst_aos) PST_FILTER(8, true) else PST_FILTER(8, false) break;
+      case 4: if (dst_aos) PST_FILTER(4, true) else PST_FILTER(4, false) break;
+      case 2: if (dst_aos) PST_FILTER(2, true) else PST_FILTER(2, false) break;
+      case 1: if (dst_aos) PST_FILTER(1, true) else PST_FILTER(1, false) break;
+      default: return false;
+    }
+#undef PST_FILTER
+  }
+  return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace pstk

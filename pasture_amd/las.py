@@ -147,6 +147,23 @@ def encode_points(points, point_format: int, scale, offset, target, target_first
     return (tuple(b[:3]), tuple(b[3:])), list(counts)[:max_return]
 
 
+def write_points(points, point_format: int, scale, offset, target, target_first: int = 0, header_bounds=None, max_return: int = 15):
+    """RawLASWriter::write (raw_writers.rs:606-613): the format's default layout takes `encode_points` directly; any other
+    layout takes write_points_custom_layout (:365-603), whose per-attribute readers (read_helpers.rs:302-345: same datatype ->
+    copy, other datatype -> the `as` converter, attribute missing -> Default::default()) are exactly a
+    `BufferLayoutConverter::for_layouts_with_default(source layout, default layout)`; the records are then encoded from the
+    converted (device-resident, columnar) points.  Reference quirk kept: the custom-layout writer never increments its
+    points-by-return map (:379-387 vs :256-258), so the counts it adds to the header are all zero."""
+    from .buffers import HashMapBuffer
+    default_layout = point_layout_from_las_point_format(Format(point_format), False, api=points.api)
+    if points.point_layout() == default_layout:
+        return encode_points(points, point_format, scale, offset, target, target_first, header_bounds, max_return)
+    converter = BufferLayoutConverter.for_layouts_with_default(points.point_layout(), default_layout)
+    staged = converter.convert(points, HashMapBuffer)
+    bounds, counts = encode_points(staged, point_format, scale, offset, target, target_first, header_bounds, max_return)
+    return bounds, [0] * len(counts)
+
+
 @dataclass
 class LasFile:
     """Just enough of an uncompressed .las file to use the reference's fixtures as golden vectors."""

@@ -382,3 +382,68 @@ def test_full_size_1e8_las_encode_then_decode_round_trip(hip):
             assert diff <= 0.001 * (1 + 1e-9)
         else:
             assert torch.equal(x, y), a.name()
+
+
+@pytest.mark.parametrize("out_kind", ["V", "H"])
+@pytest.mark.parametrize("density", [0.5, 0.02])
+def test_filter_vs_oracle(hip, oracle, out_kind, density):
+    """HashMapBuffer::filter (point_buffer.rs:1064-1136) on synthetic LAS-3 points (14 attributes incl. GPS time and colour):
+    byte-identical output for both target kinds (multi-tile, ragged last tile)."""
+    n = 300_007
+    mask = np.random.default_rng(17).random(n) < density
+
+    def run(api):
+        layout = las.point_layout_from_las_point_format(las.Format(3), False, api=api)
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(31, 1000)
+        out = src.filter(BUFFER_KINDS[out_kind], mask)
+        return out.len(), out.get_point_range(range(0, out.len())).tobytes()
+    (hn, hb), (on, ob) = both(run, hip, oracle)
+    assert hn == on == int(mask.sum())
+    assert hb == ob
+
+
+@pytest.mark.parametrize("self_kind,other_kind", PAIRINGS)
+def test_append_vs_oracle(hip, oracle, self_kind, other_kind):
+    def run(api):
+        layout = las.point_layout_from_las_point_format(las.Format(1), False, api=api)
+        buf = BUFFER_KINDS[self_kind].new_from_layout(layout)
+        for i, n in enumerate((1000, 70_001, 3)):
+            other = BUFFER_KINDS[other_kind].new_from_layout(layout)
+            other.resize(n)
+            other.synth_fill(5 + i, 0)
+            buf.append(other)
+        return buf.len(), buf.get_point_range(range(0, buf.len())).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h == o
+
+
+def test_full_size_1e8_filter_properties(hip):
+    """Full-size compaction: 10^8 LAS-0 points, random device mask.  The output columns equal torch's boolean indexing of the
+    source columns (an independent compaction), and filtering with the complement partitions the cloud (counts add up)."""
+    import torch
+    n = 100_000_000
+    layout = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(11, 0)
+    mask = torch.rand(n, device="cuda") < 0.37
+    m8 = mask.to(torch.uint8)
+    k = int(mask.sum().item())
+    dst = HashMapBuffer.new_from_layout(layout)
+    dst.resize(k)
+    assert src.filter_into(dst, (m8.data_ptr(), "device")) == k
+    for a in layout.attributes():
+        d = a.attribute_definition()
+        x = _torch_view(src.column_ptr(d), n * a.size()).view(n, a.size())
+        y = _torch_view(dst.column_ptr(d), k * a.size()).view(k, a.size())
+        assert torch.equal(x[mask], y), a.name()
+    rest = src.filter(HashMapBuffer, ((1 - m8).data_ptr(), "device"))
+    assert rest.len() == n - k
+    out_v = src.filter(VectorBuffer, (m8.data_ptr(), "device"))
+    recs = _torch_view(out_v.points_ptr(), k * 35).view(k, 35)
+    pos = _torch_view(dst.column_ptr(A.POSITION_3D), k * 24).view(k, 24)
+    assert torch.equal(recs[:, :24], pos)
+    psid = _torch_view(dst.column_ptr(A.POINT_SOURCE_ID), k * 2).view(k, 2)
+    assert torch.equal(recs[:, 33:35], psid)

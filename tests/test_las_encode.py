@@ -202,3 +202,40 @@ def test_wrong_layouts_and_ranges(api):
     empty = VectorBuffer.new_from_layout(typed)
     b, c = las.encode_points(empty, 1, (1, 1, 1), (0, 0, 0), dst)
     assert b == ((F64_MAX,) * 3, (-F64_MAX,) * 3) and c == [0] * 15
+
+
+@pytest.mark.parametrize("fmt", [0, 3, 7])
+@pytest.mark.parametrize("src_kind", ["V", "H"])
+def test_write_points_custom_layout(api, fmt, src_kind):
+    """write_points_custom_layout (raw_writers.rs:365-603): positions as Vec3f32, classification as u32 (wraps through `as`),
+    intensity present, everything else missing -> Default::default(); points-by-return stay zero (reference quirk)."""
+    from pasture_amd.layout import PointAttributeDataType as T, PointLayout
+    typed, raw = layouts(fmt, api)
+    n = 1000
+    pos32 = A.POSITION_3D.with_custom_datatype(T.Vec3f32)
+    cls32 = A.CLASSIFICATION.with_custom_datatype(T.U32)
+    custom = PointLayout.from_attributes([cls32, pos32, A.INTENSITY, A.RETURN_NUMBER, A.NORMAL], api=api)
+    rng = np.random.default_rng(5)
+    rec = np.zeros(n, dtype=custom.numpy_record_dtype())
+    rec[pos32.name()] = rng.uniform(-100, 100, size=(n, 3)).astype(np.float32)
+    rec[cls32.name()] = rng.integers(0, 2**32, size=n, dtype=np.uint32)
+    rec[A.INTENSITY.name()] = rng.integers(0, 65536, size=n, dtype=np.uint16)
+    rec[A.RETURN_NUMBER.name()] = rng.integers(0, 8, size=n, dtype=np.uint8)
+    src = BUFFER_KINDS[src_kind].from_numpy(rec, custom)
+    dst = VectorBuffer.new_from_layout(raw)
+    dst.resize(n)
+    scale, offset = (0.01, 0.01, 0.01), (0.0, 0.0, 0.0)
+    bounds, counts = las.write_points(src, fmt, scale, offset, dst)
+    exp = np.zeros(n, dtype=typed.numpy_record_dtype())
+    exp[A.POSITION_3D.name()] = rec[pos32.name()].astype(np.float64)
+    exp[A.CLASSIFICATION.name()] = rec[cls32.name()].astype(np.uint8)
+    exp[A.INTENSITY.name()] = rec[A.INTENSITY.name()]
+    exp[A.RETURN_NUMBER.name()] = rec[A.RETURN_NUMBER.name()]
+    assert np.array_equal(raw_bytes(dst), numpy_encode(exp, fmt, scale, offset))
+    p = exp[A.POSITION_3D.name()]
+    assert bounds == (tuple(p.min(axis=0)), tuple(p.max(axis=0)))
+    assert counts == [0] * 15
+    # the default layout dispatches to the default-layout writer (counts are kept there)
+    d = BUFFER_KINDS[src_kind].from_numpy(exp, typed)
+    _, counts2 = las.write_points(d, fmt, scale, offset, dst)
+    assert counts2[:7] == [int((exp[A.RETURN_NUMBER.name()] == r).sum()) for r in range(1, 8)]
