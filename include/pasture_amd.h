@@ -42,6 +42,7 @@ typedef enum pst_status {
   PST_ERR_TOO_FEW_POINTS = 11,         /* normal_estimation.rs:86-88 */
   PST_ERR_K_TOO_SMALL = 12,            /* normal_estimation.rs:89-91 */
   PST_ERR_NOT_ENOUGH_NEIGHBOURS = 13,  /* normal_estimation.rs:471 unwrap on Err */
+  PST_ERR_UNSUPPORTED_ATTRIBUTE = 14,  /* voxel_grid.rs:475 "Waveform data currently not supported!", :683 non-standard attribute */
   PST_ERR_HIP = 20,
   PST_ERR_NO_DEVICE = 21,
   PST_ERR_OUT_OF_MEMORY = 22,
@@ -197,6 +198,14 @@ int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, doub
 /* device-resident variant: writes the NORMAL attribute (Vec3f32, point_layout.rs:594-597; f64 -> f32 `as` narrowing)
  * and an F64 "Curvature" attribute of `dst` (columnar or interleaved, same length) without leaving HBM. */
 int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst);
+/* voxelgrid_filter, pasture-algorithms/src/voxel_grid.rs:109-166: one centroid point per occupied voxel (cells centred on the
+ * axis markers min + k*leafsize, find_leaf :21-52), appended to `filtered` in (x, y, z) voxel order.  Reductions per attribute
+ * of filtered's layout (set_all_attributes :459-689): average (Position3D, ColorRGB, Normal, Intensity, NIR; sequential f64
+ * sums in point order), most common (return fields, classification, scan angle, user data, point source id; ties: smallest
+ * value — the reference's HashMap order is random), max-pool from 0.0 (ClassificationFlags, GpsTime, PointID).
+ * Panics: no Position3D -> PST_ERR_MISSING_ATTRIBUTE; empty buffer -> PST_ERR_BOUNDS_INVALID (unwrap on None); waveform or
+ * non-standard attribute in filtered's layout -> PST_ERR_UNSUPPORTED_ATTRIBUTE; attribute missing in `buffer` -> PST_ERR_MISSING_ATTRIBUTE. */
+int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, pst_buffer* filtered);
 
 /* ---- LAS record encoder (the writer side of the hot path) ---------------------------- */
 /* RawLASWriter::write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 (+ write_helpers.rs:10-55):

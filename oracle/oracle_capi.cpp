@@ -417,6 +417,12 @@ int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, doub
 
 // ---- LAS writer: write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 ---------------------------------
 
+int orc_voxelgrid_filter(const orc_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, orc_buffer* filtered) {
+  ORC_TRY
+  voxelgrid_filter(*need(buffer, "buffer")->b, leafsize_x, leafsize_y, leafsize_z, *need(filtered, "filtered")->b);
+  ORC_CATCH
+}
+
 int orc_las_encode_points(const orc_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], orc_buffer* dst,
                           size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return) {
   ORC_TRY

@@ -103,6 +103,9 @@ int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_dataty
 int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf);
 int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);
 
+/* voxelgrid_filter (pasture-algorithms/src/voxel_grid.rs:109-166): appends one centroid point per occupied voxel to `filtered` */
+int orc_voxelgrid_filter(const orc_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, orc_buffer* filtered);
+
 /* RawLASWriter::write_points_default_layout (pasture-io/src/las/raw_writers.rs:203-363); same contract as pst_las_encode_points */
 int orc_las_encode_points(const orc_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], orc_buffer* dst,
                           size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return);

@@ -63,6 +63,7 @@ enum Status : int {
   ERR_TOO_FEW_POINTS = 11,
   ERR_K_TOO_SMALL = 12,
   ERR_NOT_ENOUGH_NEIGHBOURS = 13,
+  ERR_UNSUPPORTED_ATTRIBUTE = 14,
 };
 
 struct Panic : std::runtime_error {
@@ -878,6 +879,163 @@ inline std::optional<AABB> calculate_bounds(const Buffer& buffer) {
     }
   }
   return AABB::from_min_max(pos_min, pos_max);
+}
+
+// ----------------------------------------------------------------------------------
+// voxelgrid_filter — pasture-algorithms/src/voxel_grid.rs:21-689
+// ----------------------------------------------------------------------------------
+namespace voxel {
+
+enum Reduce { AVG_VEC = 1, AVG_NUM = 2, MOST_COMMON = 3, MOST_COMMON_BOOL = 4, MAX_POOL = 5 };
+struct Rule { const char* name; Kind kind; Reduce reduce; };
+// set_all_attributes :459-689: name AND datatype must equal the builtin definition
+static const Rule kRules[] = {
+    {"Position3D", Vec3f64, AVG_VEC},      {"Intensity", U16, AVG_NUM},           {"ReturnNumber", U8, MOST_COMMON},
+    {"NumberOfReturns", U8, MOST_COMMON},  {"ClassificationFlags", U8, MAX_POOL}, {"ScannerChannel", U8, MOST_COMMON},
+    {"ScanDirectionFlag", U8, MOST_COMMON_BOOL}, {"EdgeOfFlightLine", U8, MOST_COMMON_BOOL}, {"Classification", U8, MOST_COMMON},
+    {"ScanAngleRank", I8, MOST_COMMON},    {"ScanAngle", I16, MOST_COMMON},       {"UserData", U8, MOST_COMMON},
+    {"PointSourceID", U16, MOST_COMMON},   {"ColorRGB", Vec3u16, AVG_VEC},        {"GpsTime", F64, MAX_POOL},
+    {"NIR", U16, AVG_NUM},                 {"PointID", U64, MAX_POOL},            {"Normal", Vec3f32, AVG_VEC},
+};
+static const char* kWaveform[] = {"WaveformDataOffset", "WaveformPacketSize", "WaveformParameters", "WavePacketDescriptorIndex",
+                                  "ReturnPointWaveformLocation"};
+
+template <typename T> inline double scalar_as_f64(const uint8_t* p) { T v; std::memcpy(&v, p, sizeof(T)); return rust_as<double, T>(v); }
+inline double component_as_f64(Kind scalar, const uint8_t* p) {
+  switch (scalar) {
+    case U8: return scalar_as_f64<uint8_t>(p);   case I8: return scalar_as_f64<int8_t>(p);
+    case U16: return scalar_as_f64<uint16_t>(p); case I16: return scalar_as_f64<int16_t>(p);
+    case U32: return scalar_as_f64<uint32_t>(p); case I32: return scalar_as_f64<int32_t>(p);
+    case U64: return scalar_as_f64<uint64_t>(p); case I64: return scalar_as_f64<int64_t>(p);
+    case F32: return scalar_as_f64<float>(p);    default: return scalar_as_f64<double>(p);
+  }
+}
+inline int64_t scalar_as_isize(Kind k, const uint8_t* p) {  // to_string().parse::<isize>() of an integer value
+  switch (k) {
+    case U8: { uint8_t v; std::memcpy(&v, p, 1); return v; }   case I8: { int8_t v; std::memcpy(&v, p, 1); return v; }
+    case U16: { uint16_t v; std::memcpy(&v, p, 2); return v; } default: { int16_t v; std::memcpy(&v, p, 2); return v; }
+  }
+}
+
+// find_leaf :21-52
+inline size_t find_leaf_axis(double p, const std::vector<double>& markers) {
+  size_t index = 0;
+  while (!markers.empty() && markers[index] < p) index += 1;
+  if (index > 0 && p - markers[index - 1] < markers[index] - p) index -= 1;  // clamp to the better fitting marker
+  return index;
+}
+// create_markers_for_axis :55-83
+inline std::vector<double> create_markers(double mn, double mx, double leafsize) {
+  std::vector<double> m;
+  double curr = mn;
+  while (curr < mx) {
+    const double next = curr + leafsize;
+    if (!(next > curr)) throw Panic(ERR_INVALID_ARGUMENT, "voxelgrid_filter: leaf size does not advance the marker (the reference loops forever)");
+    curr = next;
+    m.push_back(curr);
+  }
+  return m;
+}
+
+}  // namespace voxel
+
+// voxelgrid_filter :109-166.  Ties of centroid_most_common are broken by HashMap iteration order in the reference (random per
+// process, :319-327); the restatement picks the smallest value among the most frequent ones.
+inline void voxelgrid_filter(const Buffer& buffer, double leafsize_x, double leafsize_y, double leafsize_z, Buffer& filtered_buffer) {
+  using namespace voxel;
+  const AttributeMember* pos = buffer.point_layout().get_attribute(POSITION_3D);
+  if (!pos)  // :116-122
+    throw Panic(ERR_MISSING_ATTRIBUTE, "The PointBuffer does not have the attribute attributes::POSITION_3D which is needed for the creation of the voxel grid.");
+  std::optional<AABB> aabb = calculate_bounds(buffer);  // :125
+  if (!aabb) throw Panic(ERR_BOUNDS_INVALID, "called `Option::unwrap()` on a `None` value");
+  const std::vector<double> mx = create_markers(aabb->min[0], aabb->max[0], leafsize_x), my = create_markers(aabb->min[1], aabb->max[1], leafsize_y),
+                            mz = create_markers(aabb->min[2], aabb->max[2], leafsize_z);
+  // :131-152: Vec<Voxel> kept sorted by pos with binary_search + insert; points pushed in index order == an ordered map
+  std::map<std::tuple<size_t, size_t, size_t>, std::vector<size_t>> voxels;
+  for (size_t i = 0; i < buffer.len(); ++i) {
+    double p[3];
+    buffer.get_attribute_unchecked(*pos, i, (uint8_t*)p);
+    voxels[{find_leaf_axis(p[0], mx), find_leaf_axis(p[1], my), find_leaf_axis(p[2], mz)}].push_back(i);
+  }
+  const PointLayout& layout = filtered_buffer.point_layout();
+  // set_all_attributes :459-476
+  for (const char* w : kWaveform)
+    if (layout.get_attribute_by_name(w)) throw Panic(ERR_UNSUPPORTED_ATTRIBUTE, "Waveform data currently not supported!");
+  struct Plan { const AttributeMember* dst; const AttributeMember* src; const Rule* rule; };
+  std::vector<Plan> plan;
+  for (auto& a : layout.attributes) {
+    const Rule* rule = nullptr;
+    for (auto& r : kRules)
+      if (a.def.name == r.name && a.def.datatype == DataType::of(r.kind)) rule = &r;
+    if (!rule) throw Panic(ERR_UNSUPPORTED_ATTRIBUTE, "attribute is non-standard which is not supported currently: " + a.def.display());
+    const AttributeMember* src = buffer.point_layout().get_attribute(a.def);  // view_attribute::<T>(&attributes::X)
+    if (!src) throw Panic(ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+    plan.push_back({&a, src, rule});
+  }
+  const size_t point_size = layout.size_of_point_entry();
+  std::vector<uint8_t> centroid(point_size), value(32);
+  for (auto& kv : voxels) {
+    const std::vector<size_t>& points = kv.second;
+    std::fill(centroid.begin(), centroid.end(), 0);  // UntypedPointBuffer::new: vec![0; size]
+    for (auto& pl : plan) {
+      uint8_t* out = centroid.data() + pl.dst->offset;
+      const Kind kind = pl.rule->kind;
+      switch (pl.rule->reduce) {
+        case AVG_VEC: {  // centroid_average_vec :332-385: sequential f64 sums in point order
+          const Kind sk = kind == Vec3f64 ? F64 : kind == Vec3f32 ? F32 : kind == Vec3u16 ? U16 : U8;
+          const size_t cs = DataType::of(sk).size();
+          double sum[3] = {0.0, 0.0, 0.0};
+          for (size_t p : points) {
+            buffer.get_attribute_unchecked(*pl.src, p, value.data());
+            for (int c = 0; c < 3; ++c) sum[c] += component_as_f64(sk, value.data() + c * cs);
+          }
+          const double n = (double)points.size();
+          for (int c = 0; c < 3; ++c) {
+            const double avg = sum[c] / n;
+            if (kind == Vec3f64) std::memcpy(out + 8 * c, &avg, 8);
+            else if (kind == Vec3u16) { uint16_t v = rust_as<uint16_t, double>(avg); std::memcpy(out + 2 * c, &v, 2); }  // :626
+            else { float v = rust_as<float, double>(avg); std::memcpy(out + 4 * c, &v, 4); }                              // :676
+          }
+          break;
+        }
+        case AVG_NUM: {  // centroid_average_num :389-440, `as u16` :489, :638
+          double sum = 0.0;
+          for (size_t p : points) { buffer.get_attribute_unchecked(*pl.src, p, value.data()); sum += component_as_f64(kind, value.data()); }
+          const uint16_t v = rust_as<uint16_t, double>(sum / (double)points.size());
+          std::memcpy(out, &v, 2);
+          break;
+        }
+        case MAX_POOL: {  // centroid_max_pool :169-219: starts at 0.0, strict >
+          double curr_max = 0.0;
+          for (size_t p : points) {
+            buffer.get_attribute_unchecked(*pl.src, p, value.data());
+            const double v = component_as_f64(kind, value.data());
+            if (v > curr_max) curr_max = v;
+          }
+          if (kind == F64) std::memcpy(out, &curr_max, 8);
+          else if (kind == U64) { uint64_t v = rust_as<uint64_t, double>(curr_max); std::memcpy(out, &v, 8); }
+          else { uint8_t v = rust_as<uint8_t, double>(curr_max); std::memcpy(out, &v, 1); }
+          break;
+        }
+        case MOST_COMMON:
+        case MOST_COMMON_BOOL: {  // centroid_most_common :222-329
+          std::map<int64_t, size_t> counts;
+          for (size_t p : points) { buffer.get_attribute_unchecked(*pl.src, p, value.data()); counts[scalar_as_isize(kind, value.data())] += 1; }
+          size_t highest_count = 0;
+          int64_t curr_key = 0;
+          for (auto& c : counts) if (c.second > highest_count) { highest_count = c.second; curr_key = c.first; }  // ascending keys: smallest wins ties
+          if (pl.rule->reduce == MOST_COMMON_BOOL) { uint8_t v = curr_key != 0; std::memcpy(out, &v, 1); }
+          else if (kind == U8 || kind == I8) { uint8_t v = (uint8_t)curr_key; std::memcpy(out, &v, 1); }
+          else { uint16_t v = (uint16_t)curr_key; std::memcpy(out, &v, 2); }
+          break;
+        }
+      }
+    }
+    // filtered_buffer.push_points(centroid) :161-164
+    const size_t at = filtered_buffer.len();
+    filtered_buffer.resize(at + 1);
+    for (auto& a : layout.attributes) filtered_buffer.set_attribute(a.def, at, centroid.data() + a.offset);
+  }
 }
 
 // ----------------------------------------------------------------------------------

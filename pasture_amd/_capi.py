@@ -28,6 +28,7 @@ ERR_BOUNDS_INVALID = 10
 ERR_TOO_FEW_POINTS = 11
 ERR_K_TOO_SMALL = 12
 ERR_NOT_ENOUGH_NEIGHBOURS = 13
+ERR_UNSUPPORTED_ATTRIBUTE = 14
 ERR_HIP = 20
 ERR_NO_DEVICE = 21
 ERR_OUT_OF_MEMORY = 22
@@ -44,7 +45,7 @@ class PastureError(RuntimeError):
 
 
 class PasturePanic(PastureError):
-    """Status codes 2..13: conditions on which the Rust reference panics (assert!/expect/panic!)."""
+    """Status codes 2..14: conditions on which the Rust reference panics (assert!/expect/panic!)."""
 
 
 class DataTypeStruct(C.Structure):
@@ -112,6 +113,7 @@ _SHARED_SIGNATURES = {
     "buffer_append": [_P, _P],
     "buffer_filter_into": [_P, _P, _P, C.c_uint32, C.c_int64, C.POINTER(C.c_size_t)],
     "buffer_filter": [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)],
+    "voxelgrid_filter": [_P, C.c_double, C.c_double, C.c_double, _P],
     "las_encode_points": [_P, C.c_uint32, _D3, _D3, _P, _SZ, _D3, C.POINTER(C.c_uint64), C.c_uint32],
 }
 
@@ -157,7 +159,7 @@ class CApi:
             rc = fn(*args)
             if rc != OK:
                 msg = (self._last_error() or b"").decode("utf-8", "replace")
-                cls = PasturePanic if 2 <= rc <= 13 else PastureError
+                cls = PasturePanic if 2 <= rc <= 14 else PastureError
                 raise cls(rc, msg)
             return rc
 

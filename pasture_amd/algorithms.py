@@ -85,3 +85,9 @@ def compute_normals(point_cloud: _Buffer, k_nn: int, return_knn: bool = False):
 def compute_normals_into(point_cloud: _Buffer, k_nn: int, target: _Buffer) -> None:
     """Device-resident: writes NORMAL (Vec3f32) and "Curvature" (F64) attributes of `target`."""
     point_cloud.api.compute_normals_into(point_cloud._h, k_nn, target._h)
+
+
+def voxelgrid_filter(buffer: _Buffer, leafsize_x: float, leafsize_y: float, leafsize_z: float, filtered_buffer: _Buffer) -> None:
+    """voxel_grid.rs:109-166: down-samples `buffer` to one centroid per occupied voxel (cells centred on the axis markers),
+    appended to `filtered_buffer` in (x, y, z) voxel order; per-attribute reductions of set_all_attributes (:459-689)."""
+    buffer.api.voxelgrid_filter(buffer._h, leafsize_x, leafsize_y, leafsize_z, filtered_buffer._h)

@@ -1,0 +1,370 @@
+// Voxel-grid down-sampling for gfx950: voxelgrid_filter, pasture-algorithms/src/voxel_grid.rs:109-689.
+//
+// The reference keeps a Vec<Voxel> sorted by (x, y, z) leaf position with binary-search inserts (O(n * voxels)) and then
+// reduces every attribute of every voxel with per-point view lookups and String-keyed HashMaps.  Here:
+//
+//   voxel_keys_kernel    per point: find_leaf (:21-52) = lower_bound over the axis markers + "better fitting marker" step;
+//                        key = x << 42 | y << 21 | z (lexicographic == the reference's tuple order)
+//   hipCUB radix sort    (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library)
+//   hipCUB run-length    unique keys -> points per voxel; exclusive sum -> voxel starts                         (library)
+//   voxel_reduce_kernel  one wave per voxel, attribute by attribute (set_all_attributes :459-689):
+//                          average:     64 values fetched in parallel, then ONE sequential f64 addition chain in point order
+//                                       (v_readlane + v_add_f64) so the sums round exactly like the reference's loop
+//                          max-pool:    per-lane strict '>' from 0.0, wave max (order-independent, NaN never wins)
+//                          most common: <= 64 points: match-any by 16 ballots; <= kMidVoxel points: readlane compare loops;
+//                                       larger voxels: voxel_mode_big_kernel (one block per voxel, 65536-bin histogram)
+//                                       ties -> smallest value (the reference's HashMap iteration order is random)
+// Gather-bound (points of a voxel are scattered in the source) + sort-bound: no MFMA.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "device_common.hpp"
+#include "kernels.hpp"
+
+using namespace pstd;
+
+namespace {
+
+constexpr uint32_t kMidVoxel = 2048;   // up to here the wave counts matches itself
+constexpr uint32_t kBigBlocks = 128;   // blocks (and 256 KiB histograms) of the big-voxel pass
+constexpr int kMaxVoxelAttrs = 24;
+
+struct VoxelAttr {
+  uint64_t src, dst;               // attribute of source point 0 / of target point 0
+  uint32_t src_stride, dst_stride;
+  uint32_t reduce;                 // pstk::VX_*
+  uint32_t kind;                   // datatype kind of the attribute (PST_U8 ...)
+};
+struct VoxelArgs {
+  const uint32_t* sorted_idx;            // point indices sorted by voxel key
+  const unsigned long long* starts;      // [n_voxels + 1] offsets into sorted_idx
+  uint64_t n_voxels;
+  uint64_t dst_first;                    // first new point of the target buffer
+  uint32_t* big_list;                    // voxels with more than kMidVoxel points ...
+  unsigned int* big_count;               // ... and how many
+  uint32_t n_attrs;
+  VoxelAttr attrs[kMaxVoxelAttrs];
+};
+
+// find_leaf :21-52 for one axis.  markers[0..n) strictly increasing.
+__device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __restrict__ markers, uint32_t n) {
+  if (n == 0) return 0;
+  // first index with !(markers[i] < p); the reference's scan never passes the last marker (it is >= max >= p); NaN -> 0
+  uint32_t lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (markers[mid] < p) lo = mid + 1; else hi = mid;
+  }
+  uint32_t index = lo;
+  if (index > 0 && p - markers[index - 1] < markers[index] - p) index -= 1;
+  return index;
+}
+
+__global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n,
+                                                            const double* __restrict__ mx, uint32_t nx, const double* __restrict__ my, uint32_t ny,
+                                                            const double* __restrict__ mz, uint32_t nz, uint64_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ idx) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
+    const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
+    const uint64_t kx = find_leaf_axis(x, mx, nx), ky = find_leaf_axis(y, my, ny), kz = find_leaf_axis(z, mz, nz);
+    keys[i] = (kx << 42) | (ky << 21) | kz;
+    idx[i] = (uint32_t)i;
+  }
+}
+
+__device__ __forceinline__ double wave_bcast_f64(double v, uint32_t lane) {  // lane is wave-uniform
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)lane);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+
+// component `c` of the attribute of point `i` as f64 (`as f64` of voxel_grid.rs:178-209, :344-376, :401-431)
+__device__ __forceinline__ double load_as_f64(const VoxelAttr& a, uint32_t scalar_kind, uint64_t i, uint32_t c) {
+  cgptr_t p = (cgptr_t)as_global(a.src) + i * a.src_stride;
+  switch (scalar_kind) {
+    case CT_U8: return (double)load_un<uint8_t>(p + c);
+    case CT_I8: return (double)load_un<int8_t>(p + c);
+    case CT_U16: return (double)load_un<uint16_t>(p + 2 * c);
+    case CT_I16: return (double)load_un<int16_t>(p + 2 * c);
+    case CT_U32: return (double)load_un<uint32_t>(p + 4 * c);
+    case CT_I32: return (double)load_un<int32_t>(p + 4 * c);
+    case CT_U64: return (double)load_un<uint64_t>(p + 8 * c);
+    case CT_I64: return (double)load_un<int64_t>(p + 8 * c);
+    case CT_F32: return (double)load_un<float>(p + 4 * c);
+    default: return load_un<double>(p + 8 * c);
+  }
+}
+__device__ __forceinline__ int32_t load_as_int(const VoxelAttr& a, uint64_t i) {  // most-common attributes: u8 / i8 / u16 / i16
+  cgptr_t p = (cgptr_t)as_global(a.src) + i * a.src_stride;
+  switch (a.kind) {
+    case 0: return load_un<uint8_t>(p);
+    case 1: return load_un<int8_t>(p);
+    case 2: return load_un<uint16_t>(p);
+    default: return load_un<int16_t>(p);
+  }
+}
+// scalar component type of a datatype kind (PST_* order: U8 I8 U16 I16 U32 I32 U64 I64 F32 F64 Vec3u8 Vec3u16 Vec3f32 Vec3i32 Vec3f64)
+__device__ __forceinline__ uint32_t scalar_of(uint32_t kind) {
+  switch (kind) {
+    case 10: return CT_U8;
+    case 11: return CT_U16;
+    case 12: return CT_F32;
+    case 13: return CT_I32;
+    case 14: return CT_F64;
+    default: return kind;
+  }
+}
+
+__device__ __forceinline__ void store_mode(const VoxelAttr& a, uint64_t out_point, int32_t value) {
+  gptr_t d = as_global(a.dst) + out_point * a.dst_stride;
+  if (a.reduce == pstk::VX_MOST_COMMON_BOOL) store_un<uint8_t>(d, (uint8_t)(value != 0));  // `!= 0` then bytes_of(bool) :548, :563
+  else if (a.kind <= 1) store_un<uint8_t>(d, (uint8_t)value);
+  else store_un<uint16_t>(d, (uint16_t)value);
+}
+
+// (count, value) -> key whose maximum is: highest count, then smallest value
+__device__ __forceinline__ uint64_t mode_key(uint32_t count, int32_t value) { return ((uint64_t)count << 32) | (uint32_t)(0x7FFFFFFF - (value + 32768)); }
+__device__ __forceinline__ int32_t mode_value(uint64_t key) { return (int32_t)(0x7FFFFFFF - (uint32_t)key) - 32768; }
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint64_t o = shfl_xor_any(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
+  for (uint64_t v = wave0; v < a.n_voxels; v += n_waves) {
+    const uint64_t s = a.starts[v];
+    const uint64_t m64 = a.starts[v + 1] - s;
+    const uint32_t m = (uint32_t)m64;  // n < 2^32
+    const uint32_t* idx = a.sorted_idx + s;
+    const uint64_t out = a.dst_first + v;
+    if (m > kMidVoxel && lane == 0) a.big_list[atomicAdd(a.big_count, 1u)] = (uint32_t)v;
+    for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+      const VoxelAttr& at = a.attrs[ai];
+      if (at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM) {
+        const uint32_t nc = at.reduce == pstk::VX_AVG_VEC ? 3u : 1u, sk = scalar_of(at.kind);
+        double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0;
+        for (uint32_t b = 0; b < m; b += 64) {
+          const uint32_t cnt = m - b < 64u ? m - b : 64u;
+          double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+          if (lane < cnt) {
+            const uint64_t i = idx[b + lane];
+            x0 = load_as_f64(at, sk, i, 0);
+            if (nc == 3) { x1 = load_as_f64(at, sk, i, 1); x2 = load_as_f64(at, sk, i, 2); }
+          }
+          // the reference's loop: x_sum += v.x; ... one point after the other (:343-376, :400-431)
+          if (nc == 3) {
+            for (uint32_t j = 0; j < cnt; ++j) { sum0 += wave_bcast_f64(x0, j); sum1 += wave_bcast_f64(x1, j); sum2 += wave_bcast_f64(x2, j); }
+          } else {
+            for (uint32_t j = 0; j < cnt; ++j) sum0 += wave_bcast_f64(x0, j);
+          }
+        }
+        if (lane == 0) {
+          const double np = (double)m;
+          gptr_t d = as_global(at.dst) + out * at.dst_stride;
+          const double a0 = sum0 / np, a1 = sum1 / np, a2 = sum2 / np;
+          if (at.reduce == pstk::VX_AVG_NUM) {
+            store_un<uint16_t>(d, rust_as<uint16_t, double>(a0));  // `as u16` :489, :638
+          } else if (at.kind == 14) {
+            store_un<double>(d, a0); store_un<double>(d + 8, a1); store_un<double>(d + 16, a2);
+          } else if (at.kind == 11) {  // ColorRGB :626
+            store_un<uint16_t>(d, rust_as<uint16_t, double>(a0)); store_un<uint16_t>(d + 2, rust_as<uint16_t, double>(a1));
+            store_un<uint16_t>(d + 4, rust_as<uint16_t, double>(a2));
+          } else {  // Normal :676
+            store_un<float>(d, (float)a0); store_un<float>(d + 4, (float)a1); store_un<float>(d + 8, (float)a2);
+          }
+        }
+      } else if (at.reduce == pstk::VX_MAX_POOL) {
+        const uint32_t sk = scalar_of(at.kind);
+        double cur = 0.0;  // :175
+        for (uint32_t j = lane; j < m; j += 64) {
+          const double x = load_as_f64(at, sk, idx[j], 0);
+          if (x > cur) cur = x;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const double o = shfl_xor_any(cur, off);
+          if (o > cur) cur = o;
+        }
+        if (lane == 0) {
+          gptr_t d = as_global(at.dst) + out * at.dst_stride;
+          if (at.kind == 9) store_un<double>(d, cur);
+          else if (at.kind == 6) store_un<uint64_t>(d, rust_as<uint64_t, double>(cur));
+          else store_un<uint8_t>(d, rust_as<uint8_t, double>(cur));
+        }
+      } else {  // most common
+        if (m > kMidVoxel) continue;  // voxel_mode_big_kernel
+        uint64_t best = 0;
+        if (m <= 64) {
+          const bool valid = lane < m;
+          const int32_t x = valid ? load_as_int(at, idx[lane]) : 0;
+          const uint64_t vmask = __ballot(valid);
+          uint64_t same = vmask;
+          const uint32_t ux = (uint32_t)(x + 32768);
+#pragma unroll
+          for (int bit = 0; bit < 17; ++bit) {
+            const bool b1 = (ux >> bit) & 1u;
+            const uint64_t bal = __ballot(b1);
+            same &= b1 ? bal : ~bal;
+          }
+          if (valid) best = mode_key((uint32_t)__builtin_popcountll(same & vmask), x);
+        } else {
+          for (uint32_t ca = 0; ca < m; ca += 64) {  // candidates
+            const bool valid = ca + lane < m;
+            const int32_t x = valid ? load_as_int(at, idx[ca + lane]) : 0;
+            uint32_t count = 0;
+            for (uint32_t cb = 0; cb < m; cb += 64) {
+              const uint32_t cnt = m - cb < 64u ? m - cb : 64u;
+              const int32_t w = cb + lane < m ? load_as_int(at, idx[cb + lane]) : 0;
+              for (uint32_t j = 0; j < cnt; ++j) count += (x == __builtin_amdgcn_readlane(w, (int)j)) ? 1u : 0u;
+            }
+            if (valid) { const uint64_t k = mode_key(count, x); best = k > best ? k : best; }
+          }
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) store_mode(at, out, mode_value(best));
+      }
+    }
+  }
+}
+
+// One block per voxel with more than kMidVoxel points: 65536-bin histogram (ascending bins are ascending values) in the block's private global scratch.
+__global__ __launch_bounds__(kBlock) void voxel_mode_big_kernel(const VoxelArgs a, uint32_t* __restrict__ hist_all) {
+  uint32_t* hist = hist_all + (size_t)blockIdx.x * 65536u;
+  __shared__ unsigned long long best_s[kBlock / 64];
+  const uint32_t n_big = *a.big_count;
+  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    const uint64_t v = a.big_list[bi];
+    const uint64_t s = a.starts[v];
+    const uint32_t m = (uint32_t)(a.starts[v + 1] - s);
+    const uint32_t* idx = a.sorted_idx + s;
+    for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+      const VoxelAttr& at = a.attrs[ai];
+      if (at.reduce != pstk::VX_MOST_COMMON && at.reduce != pstk::VX_MOST_COMMON_BOOL) continue;
+      for (uint32_t b = threadIdx.x; b < 65536u; b += kBlock) hist[b] = 0;
+      __syncthreads();
+      const int32_t bias = (at.kind == 1 || at.kind == 3) ? 32768 : 0;  // signed kinds: bin = value + 32768
+      for (uint32_t j = threadIdx.x; j < m; j += kBlock) atomicAdd(&hist[(uint32_t)(load_as_int(at, idx[j]) + bias)], 1u);
+      __syncthreads();
+      uint64_t best = 0;
+      for (uint32_t b = threadIdx.x; b < 65536u; b += kBlock) {
+        const uint32_t c = hist[b];
+        if (c) { const uint64_t k = mode_key(c, (int32_t)b - bias); best = k > best ? k : best; }
+      }
+      best = wave_max_u64(best);
+      if ((threadIdx.x & 63u) == 0) best_s[threadIdx.x >> 6] = best;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) best = best_s[w] > best ? best_s[w] : best;
+        store_mode(at, a.dst_first + v, mode_value(best));
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+namespace pstk {
+
+struct VoxelGridState {
+  DevBuf keys, keys2, idx, idx2, tmp, markers, unique, counts, starts, nruns, big_list, big_count, hist;
+  uint64_t n = 0, n_voxels = 0;
+};
+
+// Phase 1: keys, sort, voxel segmentation.  Returns the number of voxels (>= 1), or -1 on a HIP failure.
+long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
+                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, hipStream_t stream) {
+#define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+  st = new VoxelGridState();
+  st->n = n;
+  VCK(st->keys.alloc(n * 8)); VCK(st->keys2.alloc(n * 8)); VCK(st->idx.alloc(n * 4)); VCK(st->idx2.alloc(n * 4));
+  VCK(st->markers.alloc(((size_t)nx + ny + nz + 1) * 8));
+  double* dm = st->markers.as<double>();
+  if (nx) VCK(hipMemcpyAsync(dm, markers_x, (size_t)nx * 8, hipMemcpyHostToDevice, stream));
+  if (ny) VCK(hipMemcpyAsync(dm + nx, markers_y, (size_t)ny * 8, hipMemcpyHostToDevice, stream));
+  if (nz) VCK(hipMemcpyAsync(dm + nx + ny, markers_z, (size_t)nz * 8, hipMemcpyHostToDevice, stream));
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)device_cus() * 16));
+  hipLaunchKernelGGL(voxel_keys_kernel, dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, (const double*)dm, nx, (const double*)(dm + nx), ny,
+                     (const double*)(dm + nx + ny), nz, st->keys.as<uint64_t>(), st->idx.as<uint32_t>());
+  size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
+  VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
+                                         st->idx2.as<uint32_t>(), (int)n, 0, 63, stream));
+  // unique/counts reuse the unsorted key / index arrays after the sort (n entries each)
+  VCK(st->nruns.alloc(16));
+  VCK(st->starts.alloc((n + 1) * 8));
+  VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
+                                            st->nruns.as<uint32_t>(), (int)n, stream));
+  VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n, stream));
+  VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan))));
+  VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
+                                         st->idx2.as<uint32_t>(), (int)n, 0, 63, stream));
+  VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
+                                            st->nruns.as<uint32_t>(), (int)n, stream));
+  uint32_t runs = 0;
+  VCK(hipMemcpyAsync(&runs, st->nruns.p, 4, hipMemcpyDeviceToHost, stream));
+  VCK(hipStreamSynchronize(stream));
+  st->n_voxels = runs;
+  // starts[v] = exclusive sum of counts; starts[n_voxels] = n
+  VCK(hipcub::DeviceScan::ExclusiveSum(st->tmp.p, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)runs, stream));
+  const unsigned long long total = n;
+  VCK(hipMemcpyAsync(st->starts.as<unsigned long long>() + runs, &total, 8, hipMemcpyHostToDevice, stream));
+  VCK(hipStreamSynchronize(stream));
+  return (long long)runs;
+#undef VCK
+}
+
+// Phase 2: reductions into target points [dst_first, dst_first + n_voxels).
+bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_stride,
+                       const uint32_t* reduce, const uint32_t* kind, int n_attrs, uint64_t dst_first, hipStream_t stream) {
+  if (n_attrs > kMaxVoxelAttrs) return false;
+  VoxelArgs a{};
+  a.sorted_idx = st->idx2.as<uint32_t>();
+  a.starts = st->starts.as<unsigned long long>();
+  a.n_voxels = st->n_voxels;
+  a.dst_first = dst_first;
+  const size_t max_big = (size_t)(st->n / kMidVoxel) + 1;
+  if (st->big_list.alloc(max_big * 4) != hipSuccess || st->big_count.alloc(16) != hipSuccess) return false;
+  if (hipMemsetAsync(st->big_count.p, 0, 16, stream) != hipSuccess) return false;
+  a.big_list = st->big_list.as<uint32_t>();
+  a.big_count = st->big_count.as<unsigned int>();
+  a.n_attrs = (uint32_t)n_attrs;
+  bool any_mode = false;
+  for (int i = 0; i < n_attrs; ++i) {
+    a.attrs[i] = VoxelAttr{src_addr[i], dst_addr[i], src_stride[i], dst_stride[i], reduce[i], kind[i]};
+    any_mode = any_mode || reduce[i] == VX_MOST_COMMON || reduce[i] == VX_MOST_COMMON_BOOL;
+  }
+  const uint64_t waves_needed = st->n_voxels;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, (uint64_t)device_cus() * 32));
+  hipLaunchKernelGGL(voxel_reduce_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+  if (any_mode && st->n > kMidVoxel) {
+    unsigned int n_big = 0;
+    if (hipMemcpyAsync(&n_big, st->big_count.p, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(stream) != hipSuccess) return false;
+    if (n_big) {
+      const unsigned bgrid = std::min<unsigned>(n_big, kBigBlocks);
+      if (st->hist.alloc((size_t)bgrid * 65536u * 4u) != hipSuccess) return false;
+      hipLaunchKernelGGL(voxel_mode_big_kernel, dim3(bgrid), dim3(kBlock), 0, stream, a, st->hist.as<uint32_t>());
+    }
+  }
+  return hipGetLastError() == hipSuccess;
+}
+
+void voxel_grid_free(VoxelGridState* st) { delete st; }
+
+}  // namespace pstk

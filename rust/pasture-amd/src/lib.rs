@@ -15,7 +15,7 @@ use std::ffi::{CStr, CString};
 use std::ops::Range;
 use std::os::raw::c_int;
 
-/// Status codes 2..=13 are the conditions on which pasture itself panics; re-raise them as panics.
+/// Status codes 2..=14 are the conditions on which pasture itself panics; re-raise them as panics.
 fn check(rc: c_int) {
     if rc != PST_OK {
         let msg = unsafe { CStr::from_ptr(pst_last_error()) }.to_string_lossy().into_owned();
