@@ -44,6 +44,8 @@ WORKLOADS = {
     "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
                                   "resident in HBM (2 mask reads + 41 R + 20.5 W per input point)"),
     "filter_big_interleaved": (63.5, "buffer_filter_bench: HashMapBuffer::filter_into, CustomPointTypeBig columnar -> VectorBuffer, density 0.5"),
+    "voxelgrid_xyz": (24, "voxelgrid_filter, columnar POSITION_3D, leaf 2.5 (about 15 points per voxel): keys + radix sort + run-length + "
+                          "per-voxel sequential centroid sums (sort-bound; 24 B/pt is only the unavoidable read)"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
@@ -217,6 +219,16 @@ def main():
 
         def step():
             src.filter_into(dst, (mask.data_ptr(), "device"), k)
+    elif args.workload == "voxelgrid_xyz":
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            out = pa.HashMapBuffer.new_from_layout(layout)
+            pa.voxelgrid_filter(src, 2.5, 2.5, 2.5, out)
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)

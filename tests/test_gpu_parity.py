@@ -472,3 +472,42 @@ def test_voxelgrid_filter_vs_oracle(hip, oracle, kinds, leaf):
     (hn, hb), (on, ob) = both(run, hip, oracle)
     assert hn == on
     assert hb == ob
+
+
+def test_full_size_1e8_voxelgrid_properties(hip):
+    """Full size: 10^8 XYZ points, leaf 2.5 (about 15 points per voxel).  An independent torch restatement of find_leaf gives the
+    set of occupied voxels: the filter must return exactly one centroid per occupied voxel, in ascending (x, y, z) voxel order,
+    and every centroid must fall into its own voxel (cells are convex)."""
+    import torch
+    from pasture_amd.algorithms import voxelgrid_filter
+    n = 100_000_000
+    leaf = (2.5, 2.5, 2.5)
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(42, 0)
+    out = HashMapBuffer.new_from_layout(layout)
+    voxelgrid_filter(src, *leaf, out)
+    b = calculate_bounds(src)
+
+    def leaf_index(p, c):
+        markers = []
+        cur = b.min()[c]
+        while cur < b.max()[c]:
+            cur += leaf[c]
+            markers.append(cur)
+        m = torch.tensor(markers, dtype=torch.float64, device="cuda")
+        i = torch.searchsorted(m, p, right=False)  # first marker >= p
+        prev = m[torch.clamp(i - 1, min=0)]
+        back = (i > 0) & (p - prev < m[i] - p)
+        return i - back.to(i.dtype)
+
+    def keys_of(ptr, count):
+        xyz = _torch_view(ptr, count * 24).view(torch.float64).view(count, 3)
+        k = torch.zeros(count, dtype=torch.int64, device="cuda")
+        for c in range(3):
+            k = (k << 21) | leaf_index(xyz[:, c].contiguous(), c)
+        return k
+    occupied = torch.unique(keys_of(src.column_ptr(A.POSITION_3D), n))  # sorted
+    assert out.len() == occupied.numel()
+    assert torch.equal(keys_of(out.column_ptr(A.POSITION_3D), out.len()), occupied)
