@@ -56,32 +56,39 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __res
   if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 
-// offsets[t] = sum of counts[0..t); offsets[n_tiles] = total
+// offsets[t] = sum of counts[0..t); offsets[n_tiles] = total.  One block; every thread takes four consecutive counts per round
+// (one 16-byte load), so 10^8 points (48,829 tiles) need 12 rounds of a 1024-thread scan.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets) {
-  __shared__ unsigned long long wave_tot[16];
-  __shared__ unsigned long long carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
+  __shared__ unsigned long long wave_tot[2][16];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  for (uint32_t base = 0; base < n_tiles; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const unsigned long long v = i < n_tiles ? counts[i] : 0ull;
+  unsigned long long carry = 0;
+  uint32_t round = 0;
+  for (uint32_t base = 0; base < n_tiles; base += 4096, ++round) {
+    const uint32_t i0 = base + threadIdx.x * 4u;
+    uint32_t c[4] = {0, 0, 0, 0};
+    if (i0 + 4 <= n_tiles) {
+      const u32x4 v = load_un<u32x4>((cgptr_t)(counts + i0));
+      c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+    } else {
+      for (uint32_t k = 0; k < 4; ++k) if (i0 + k < n_tiles) c[k] = counts[i0 + k];
+    }
+    const unsigned long long v = (unsigned long long)c[0] + c[1] + c[2] + c[3];
     unsigned long long incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
-      if ((int)lane >= off) incl += ((unsigned long long)hi << 32) | lo;
+      const uint32_t l = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), h = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+      if ((int)lane >= off) incl += ((unsigned long long)h << 32) | l;
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    unsigned long long (&tot)[16] = wave_tot[round & 1u];  // double-buffered: one barrier per round
+    if (lane == 63) tot[wave] = incl;
     __syncthreads();
-    unsigned long long before = carry_s;
-    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
-    if (i < n_tiles) offsets[i] = before + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = before + incl;
-    __syncthreads();
+    unsigned long long before = carry + incl - v, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += tot[w]; all += tot[w]; }
+    for (uint32_t k = 0; k < 4; ++k) { if (i0 + k < n_tiles) offsets[i0 + k] = before; before += c[k]; }
+    carry += all;
   }
-  if (threadIdx.x == 0) offsets[n_tiles] = carry_s;
+  if (threadIdx.x == 0) offsets[n_tiles] = carry;
 }
 
 constexpr int kMaxFilterAttrs = 32;

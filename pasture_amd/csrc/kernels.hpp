@@ -79,7 +79,8 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
 enum : uint32_t { VX_AVG_VEC = 1, VX_AVG_NUM = 2, VX_MOST_COMMON = 3, VX_MOST_COMMON_BOOL = 4, VX_MAX_POOL = 5 };
 struct VoxelGridState;
 long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
-                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, hipStream_t stream);
+                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, const double origin[3], const double leaf[3],
+                           hipStream_t stream);
 bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_stride,
                        const uint32_t* reduce, const uint32_t* kind, int n_attrs, uint64_t dst_first, hipStream_t stream);
 void voxel_grid_free(VoxelGridState* st);

@@ -4,7 +4,7 @@
 // reduces every attribute of every voxel with per-point view lookups and String-keyed HashMaps.  Here:
 //
 //   voxel_keys_kernel    per point: find_leaf (:21-52) = lower_bound over the axis markers + "better fitting marker" step;
-//                        key = x << 42 | y << 21 | z (lexicographic == the reference's tuple order)
+//                        key = x | y | z packed x-major in as few bits as the marker counts need (fewer radix passes)
 //   hipCUB radix sort    (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library)
 //   hipCUB run-length    unique keys -> points per voxel; exclusive sum -> voxel starts                         (library)
 //   voxel_reduce_kernel  one wave per voxel, attribute by attribute (set_all_attributes :459-689):
@@ -48,29 +48,29 @@ struct VoxelArgs {
   VoxelAttr attrs[kMaxVoxelAttrs];
 };
 
-// find_leaf :21-52 for one axis.  markers[0..n) strictly increasing.
-__device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __restrict__ markers, uint32_t n) {
+// find_leaf :21-52 for one axis.  markers[0..n) strictly increasing, markers[i] ~ origin + (i + 1) * leaf (accumulated sums, so
+// the arithmetic guess is only a starting point; the two fix-up loops make the result exactly the reference's linear scan).
+__device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __restrict__ markers, uint32_t n, double origin, double inv_leaf) {
   if (n == 0) return 0;
+  const double t = (p - origin) * inv_leaf;
+  uint32_t index = t >= 1.0 ? (t < (double)(n - 1) ? (uint32_t)t : n - 1) : 0u;  // NaN -> 0
   // first index with !(markers[i] < p); the reference's scan never passes the last marker (it is >= max >= p); NaN -> 0
-  uint32_t lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (markers[mid] < p) lo = mid + 1; else hi = mid;
-  }
-  uint32_t index = lo;
-  if (index > 0 && p - markers[index - 1] < markers[index] - p) index -= 1;
+  while (index + 1 < n && markers[index] < p) index += 1;
+  while (index > 0 && !(markers[index - 1] < p)) index -= 1;
+  if (index > 0 && p - markers[index - 1] < markers[index] - p) index -= 1;  // "clamp values to the better fitting marker"
   return index;
 }
 
-__global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n,
-                                                            const double* __restrict__ mx, uint32_t nx, const double* __restrict__ my, uint32_t ny,
-                                                            const double* __restrict__ mz, uint32_t nz, uint64_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ idx) {
+struct AxisGrid { const double* markers; uint32_t n; uint32_t shift; double origin, inv_leaf; };
+
+__global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy,
+                                                            AxisGrid gz, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
     const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
-    const uint64_t kx = find_leaf_axis(x, mx, nx), ky = find_leaf_axis(y, my, ny), kz = find_leaf_axis(z, mz, nz);
-    keys[i] = (kx << 42) | (ky << 21) | kz;
+    const uint64_t kx = find_leaf_axis(x, gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(y, gy.markers, gy.n, gy.origin, gy.inv_leaf),
+                   kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
+    keys[i] = (kx << gx.shift) | (ky << gy.shift) | kz;  // x-major: integer order == the reference's (x, y, z) tuple order
     idx[i] = (uint32_t)i;
   }
 }
@@ -289,7 +289,8 @@ struct VoxelGridState {
 
 // Phase 1: keys, sort, voxel segmentation.  Returns the number of voxels (>= 1), or -1 on a HIP failure.
 long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
-                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, hipStream_t stream) {
+                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, const double origin[3], const double leaf[3],
+                           hipStream_t stream) {
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
   st = new VoxelGridState();
   st->n = n;
@@ -300,11 +301,15 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   if (ny) VCK(hipMemcpyAsync(dm + nx, markers_y, (size_t)ny * 8, hipMemcpyHostToDevice, stream));
   if (nz) VCK(hipMemcpyAsync(dm + nx + ny, markers_z, (size_t)nz * 8, hipMemcpyHostToDevice, stream));
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)device_cus() * 16));
-  hipLaunchKernelGGL(voxel_keys_kernel, dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, (const double*)dm, nx, (const double*)(dm + nx), ny,
-                     (const double*)(dm + nx + ny), nz, st->keys.as<uint64_t>(), st->idx.as<uint32_t>());
+  auto bits_for = [](uint32_t count) { uint32_t b = 1; while (b < 21 && (1u << b) < count) ++b; return b; };  // indices 0 .. count-1
+  const uint32_t bz = bits_for(nz), by = bits_for(ny), bx = bits_for(nx);
+  const int end_bit = (int)(bx + by + bz);
+  AxisGrid gx{dm, nx, by + bz, origin[0], 1.0 / leaf[0]}, gy{dm + nx, ny, bz, origin[1], 1.0 / leaf[1]}, gz{dm + nx + ny, nz, 0, origin[2], 1.0 / leaf[2]};
+  hipLaunchKernelGGL(voxel_keys_kernel, dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<uint64_t>(),
+                     st->idx.as<uint32_t>());
   size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
   VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                         st->idx2.as<uint32_t>(), (int)n, 0, 63, stream));
+                                         st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
   // unique/counts reuse the unsorted key / index arrays after the sort (n entries each)
   VCK(st->nruns.alloc(16));
   VCK(st->starts.alloc((n + 1) * 8));
@@ -313,7 +318,7 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n, stream));
   VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan))));
   VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                         st->idx2.as<uint32_t>(), (int)n, 0, 63, stream));
+                                         st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
   VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
                                             st->nruns.as<uint32_t>(), (int)n, stream));
   uint32_t runs = 0;

@@ -105,8 +105,9 @@ extern "C" int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x,
   const size_t pslot = (size_t)(pos - buffer->layout.members.data());
   const uint8_t* pos_base = buffer->columnar ? buffer->columns[pslot] : buffer->data + pos->offset;
   const uint64_t pos_stride = buffer->columnar ? pos->size : buffer->layout.size;
+  const double leafs[3] = {leafsize_x, leafsize_y, leafsize_z};
   const long long nv = pstk::voxel_grid_build(g.st, pos_base, pos_stride, n, mkx.data(), (uint32_t)mkx.size(), mky.data(), (uint32_t)mky.size(), mkz.data(),
-                                              (uint32_t)mkz.size(), s);
+                                              (uint32_t)mkz.size(), mn, leafs, s);
   if (nv < 0) throw Error(PST_ERR_HIP, std::string("voxel grid build failed: ") + hipGetErrorString(hipGetLastError()));
 
   // filtered_buffer.push_points(centroid) per voxel :161-164 == append nv zero-initialised points and fill the attributes
