@@ -271,10 +271,13 @@ __global__ __launch_bounds__(kBlock) void voxel_mode_big_kernel(const VoxelArgs 
   }
 }
 
+// stream-ordered allocations from the device's default pool (release threshold raised by buffer.cpp): no device-wide
+// synchronisation per call, unlike hipMalloc / hipFree of gigabytes
 struct DevBuf {
   void* p = nullptr;
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipStream_t s = nullptr;
+  hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return hipMallocAsync(&p, bytes ? bytes : 16, stream); }
+  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -294,8 +297,8 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
   st = new VoxelGridState();
   st->n = n;
-  VCK(st->keys.alloc(n * 8)); VCK(st->keys2.alloc(n * 8)); VCK(st->idx.alloc(n * 4)); VCK(st->idx2.alloc(n * 4));
-  VCK(st->markers.alloc(((size_t)nx + ny + nz + 1) * 8));
+  VCK(st->keys.alloc(n * 8, stream)); VCK(st->keys2.alloc(n * 8, stream)); VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
+  VCK(st->markers.alloc(((size_t)nx + ny + nz + 1) * 8, stream));
   double* dm = st->markers.as<double>();
   if (nx) VCK(hipMemcpyAsync(dm, markers_x, (size_t)nx * 8, hipMemcpyHostToDevice, stream));
   if (ny) VCK(hipMemcpyAsync(dm + nx, markers_y, (size_t)ny * 8, hipMemcpyHostToDevice, stream));
@@ -311,12 +314,12 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
                                          st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
   // unique/counts reuse the unsorted key / index arrays after the sort (n entries each)
-  VCK(st->nruns.alloc(16));
-  VCK(st->starts.alloc((n + 1) * 8));
+  VCK(st->nruns.alloc(16, stream));
+  VCK(st->starts.alloc((n + 1) * 8, stream));
   VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
                                             st->nruns.as<uint32_t>(), (int)n, stream));
   VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n, stream));
-  VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan))));
+  VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan)), stream));
   VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
                                          st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
   VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
@@ -344,7 +347,7 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
   a.n_voxels = st->n_voxels;
   a.dst_first = dst_first;
   const size_t max_big = (size_t)(st->n / kMidVoxel) + 1;
-  if (st->big_list.alloc(max_big * 4) != hipSuccess || st->big_count.alloc(16) != hipSuccess) return false;
+  if (st->big_list.alloc(max_big * 4, stream) != hipSuccess || st->big_count.alloc(16, stream) != hipSuccess) return false;
   if (hipMemsetAsync(st->big_count.p, 0, 16, stream) != hipSuccess) return false;
   a.big_list = st->big_list.as<uint32_t>();
   a.big_count = st->big_count.as<unsigned int>();
@@ -363,7 +366,7 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
     if (hipStreamSynchronize(stream) != hipSuccess) return false;
     if (n_big) {
       const unsigned bgrid = std::min<unsigned>(n_big, kBigBlocks);
-      if (st->hist.alloc((size_t)bgrid * 65536u * 4u) != hipSuccess) return false;
+      if (st->hist.alloc((size_t)bgrid * 65536u * 4u, stream) != hipSuccess) return false;
       hipLaunchKernelGGL(voxel_mode_big_kernel, dim3(bgrid), dim3(kBlock), 0, stream, a, st->hist.as<uint32_t>());
     }
   }
