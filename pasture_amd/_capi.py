@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libpasture_amd.so")
+LIB_PATH = os.environ.get("PASTURE_AMD_LIB") or os.path.join(PKG_DIR, "libpasture_amd.so")  # override: A/B runs of two builds
 
 # status codes (include/pasture_amd.h)
 OK = 0

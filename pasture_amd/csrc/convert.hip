@@ -165,74 +165,104 @@ __global__ __launch_bounds__(kBlock) void convert_direct_kernel(const ConvertHea
 // Which lanes work on an entry: all BLK lanes of the block, or (small entries) the 64 lanes of the one wave that owns it.
 struct LaneSpan { uint32_t first, step; };
 
-// interleaved (LDS) -> columnar (global): each lane produces one >= 4-byte chunk of the column
+// NE values of D as ONE vector store of 4 / 8 / 16 bytes (unaligned column starts are fine: range offsets are arbitrary)
+template <typename D, uint32_t NE>
+__device__ __forceinline__ void store_vec(gptr_t dst, const D (&v)[NE]) {
+  constexpr uint32_t B = (uint32_t)sizeof(D) * NE;
+  static_assert(B == 4 || B == 8 || B == 16, "one dword / dwordx2 / dwordx4 store");
+  if constexpr (B == 16) { u32x4 w; __builtin_memcpy(&w, v, 16); store_un<u32x4>(dst, w); }
+  else if constexpr (B == 8) { uint64_t w; __builtin_memcpy(&w, v, 8); store_un<uint64_t>(dst, w); }
+  else { uint32_t w; __builtin_memcpy(&w, v, 4); store_un<uint32_t>(dst, w); }
+}
+
+// interleaved (LDS) -> columnar (global): each lane produces 16 bytes of the column per iteration (one dwordx4 store =
+// 1 KiB per wave instruction) from NE = 16 / sizeof(D) strided LDS reads
 template <typename S, typename D>
 __device__ __forceinline__ void run_tile_to_column(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, uint64_t first, uint32_t cnt,
                                                    LaneSpan span, BoundsAcc& acc) {
   constexpr uint32_t E = ChunkOf<D>::value;
+  constexpr uint32_t NS = 16u / (uint32_t)sizeof(D);  // scalar attributes: values per lane and iteration (16 bytes)
+  constexpr uint32_t NE = NS < 4u ? NS : 4u;          // Vec3 attributes: at most four values (bounded register arrays)
   const uint32_t total = cnt * e.ncomp;
   const XfRegs x = load_xf(e);
   gptr_t col = as_global(e.dst_col) + first * e.ncomp * sizeof(D);
-  if constexpr (E == 1) {
-    if (e.ncomp == 3) {
-      // Vec3 values with >= 4-byte components: use step - step%3 lanes so that a lane's component index c = lane % 3 NEVER
-      // changes: no division, no per-value selects; scale / offset / AABB slot are per-lane constants; the LDS and column
-      // addresses advance by constants.  (255 of 256 lanes work on a shared entry.)
-      const uint32_t lanes = span.step - span.step % 3u;
-      if (span.first < lanes) {
-        const uint32_t c = span.first % 3u, p0 = span.first / 3u, ppi = lanes / 3u;
-        const double sc = pick3(c, x.s0, x.s1, x.s2), of = pick3(c, x.o0, x.o1, x.o2);
-        uint32_t la = p0 * h.src_stride + e.src_off + c * (uint32_t)sizeof(S);
-        uint32_t ga = span.first * (uint32_t)sizeof(D);
-        const uint32_t la_step = ppi * h.src_stride, ga_step = lanes * (uint32_t)sizeof(D);
-        double lo = kF64Max, hi = -kF64Max;
-        constexpr uint32_t kBatch = 4;  // LDS reads in flight per lane
-        for (uint32_t pp = p0; pp < cnt; pp += kBatch * ppi, la += kBatch * la_step, ga += kBatch * ga_step) {
-          S v[kBatch];
+  if (e.ncomp == 3) {
+    // Vec3 values: lanes - lanes%3 lanes work, so lane*NE and the per-iteration advance are multiples of... the advance
+    // (lanes*NE values) is a multiple of 3: the component of a lane's j-th value, (c0 + j) % 3 with c0 = (lane*NE) % 3, NEVER
+    // changes — no division in the loop, scale / offset / AABB slot per (lane, j) are loop constants, the LDS and column
+    // addresses advance by constants.  (255 of 256 lanes work on a shared entry, 63 of 64 on a wave-owned one.)
+    const uint32_t lanes = span.step - span.step % 3u;
+    if (span.first < lanes) {
+      const uint32_t k_lane = span.first * NE, p_lane = k_lane / 3u, c0 = k_lane - 3u * p_lane;
+      const uint32_t k_step = lanes * NE, p_step = k_step / 3u;
+      uint32_t la[NE];   // LDS byte offset of value j of this lane in iteration 0
+      double sc[NE], of[NE];
 #pragma unroll
-          for (uint32_t u = 0; u < kBatch; ++u) v[u] = pp + u * ppi < cnt ? lds_load<S>(lds_src + (la + u * la_step)) : S{};
+      for (uint32_t j = 0; j < NE; ++j) {
+        const uint32_t cj = (c0 + j) % 3u, pj = p_lane + (c0 + j) / 3u;
+        la[j] = pj * h.src_stride + e.src_off + cj * (uint32_t)sizeof(S);
+        sc[j] = pick3(cj, x.s0, x.s1, x.s2);
+        of[j] = pick3(cj, x.o0, x.o1, x.o2);
+      }
+      const uint32_t la_step = p_step * h.src_stride;
+      double lo[NE], hi[NE];
 #pragma unroll
-          for (uint32_t u = 0; u < kBatch; ++u) {
-            if (pp + u * ppi < cnt) {
-              const D w = convert_value_sc<S, D>(v[u], x, sc, of);
-              store_un<D>(col + (ga + u * ga_step), w);
-              if constexpr (std::is_same<D, double>::value) {
-                lo = __builtin_fmin(lo, w);
-                hi = __builtin_fmax(hi, w);
-              }
+      for (uint32_t j = 0; j < NE; ++j) { lo[j] = kF64Max; hi[j] = -kF64Max; }
+      uint32_t k = k_lane, lofs = 0;
+      for (; k + NE <= total; k += k_step, lofs += la_step) {
+        S v[NE];
+#pragma unroll
+        for (uint32_t j = 0; j < NE; ++j) v[j] = lds_load<S>(lds_src + (la[j] + lofs));
+        D w[NE];
+#pragma unroll
+        for (uint32_t j = 0; j < NE; ++j) {
+          w[j] = convert_value_sc<S, D>(v[j], x, sc[j], of[j]);
+          if constexpr (std::is_same<D, double>::value) {
+            lo[j] = __builtin_fmin(lo[j], w[j]);
+            hi[j] = __builtin_fmax(hi[j], w[j]);
+          }
+        }
+        store_vec<D, NE>(col + (uint64_t)k * sizeof(D), w);
+      }
+      if (k < total) {  // ragged end of the tile: fewer than NE values left for this lane
+#pragma unroll
+        for (uint32_t j = 0; j < NE; ++j) {
+          if (k + j < total) {
+            const D w = convert_value_sc<S, D>(lds_load<S>(lds_src + (la[j] + lofs)), x, sc[j], of[j]);
+            store_un<D>(col + (uint64_t)(k + j) * sizeof(D), w);
+            if constexpr (std::is_same<D, double>::value) {
+              lo[j] = __builtin_fmin(lo[j], w);
+              hi[j] = __builtin_fmax(hi[j], w);
             }
           }
         }
-        if constexpr (std::is_same<D, double>::value) {
-          if (e.bounds) acc.fold2(c, lo, hi);
+      }
+      if constexpr (std::is_same<D, double>::value) {
+        if (e.bounds) {
+#pragma unroll
+          for (uint32_t j = 0; j < NE; ++j) acc.fold2((c0 + j) % 3u, lo[j], hi[j]);
         }
       }
-      return;
     }
+    return;
   }
   if (e.ncomp == 1) {
-    // scalar attributes: a lane produces E consecutive points (one >= 4-byte chunk); addresses advance by constants
-    const uint32_t la_step = span.step * E * h.src_stride;
-    uint32_t la = span.first * E * h.src_stride + e.src_off;
-    for (uint32_t k0 = span.first * E; k0 < cnt; k0 += span.step * E, la += la_step) {
-      if (k0 + E <= cnt) {
-        if constexpr (E == 1) {
-          store_un<D>(col + (uint64_t)k0 * sizeof(D), convert_value_sc<S, D>(lds_load<S>(lds_src + la), x, x.s0, x.o0));
-        } else {
-          uint32_t packed = 0;
+    // scalar attributes: a lane produces NS consecutive points (16 bytes of the column)
+    const uint32_t la_step = span.step * NS * h.src_stride;
+    uint32_t la = span.first * NS * h.src_stride + e.src_off;
+    uint32_t k0 = span.first * NS;
+    for (; k0 + NS <= cnt; k0 += span.step * NS, la += la_step) {
+      S v[NS];
 #pragma unroll
-          for (uint32_t i = 0; i < E; ++i) {
-            const D w = convert_value_sc<S, D>(lds_load<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0);
-            typename std::make_unsigned<D>::type u;
-            __builtin_memcpy(&u, &w, sizeof(D));
-            packed |= (uint32_t)u << (8u * (uint32_t)sizeof(D) * i);
-          }
-          store_un<uint32_t>(col + (uint64_t)k0 * sizeof(D), packed);
-        }
-      } else {
-        for (uint32_t i = 0; k0 + i < cnt; ++i)
-          store_un<D>(col + (uint64_t)(k0 + i) * sizeof(D), convert_value_sc<S, D>(lds_load<S>(lds_src + (la + i * h.src_stride)), x, x.s0, x.o0));
-      }
+      for (uint32_t j = 0; j < NS; ++j) v[j] = lds_load<S>(lds_src + (la + j * h.src_stride));
+      D w[NS];
+#pragma unroll
+      for (uint32_t j = 0; j < NS; ++j) w[j] = convert_value_sc<S, D>(v[j], x, x.s0, x.o0);
+      store_vec<D, NS>(col + (uint64_t)k0 * sizeof(D), w);
+    }
+    if (k0 < cnt) {
+      for (uint32_t j = 0; k0 + j < cnt; ++j)
+        store_un<D>(col + (uint64_t)(k0 + j) * sizeof(D), convert_value_sc<S, D>(lds_load<S>(lds_src + (la + j * h.src_stride)), x, x.s0, x.o0));
     }
     return;
   }
