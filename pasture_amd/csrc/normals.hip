@@ -37,6 +37,7 @@ struct GridParams {
   double inv_h;    // 1 / cell edge
   double h;        // cell edge
   uint32_t dim[3]; // cells per axis (<= 2^21)
+  uint32_t dense;  // 1: keys are row-major cell numbers (x fastest) with a dense cell_start directory; 0: Morton keys + hash table
 };
 
 __device__ __forceinline__ uint64_t spread21(uint64_t v) {  // insert two zero bits between each of the low 21 bits
@@ -92,8 +93,12 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     uint64_t key = kInvalidKey;
     if (finite3(x, y, z)) {
-      key = morton3(cell_coord(x, g.org[0], g.inv_h, g.dim[0]), cell_coord(y, g.org[1], g.inv_h, g.dim[1]), cell_coord(z, g.org[2], g.inv_h, g.dim[2]));
+      const uint32_t cx = cell_coord(x, g.org[0], g.inv_h, g.dim[0]), cy = cell_coord(y, g.org[1], g.inv_h, g.dim[1]),
+                     cz = cell_coord(z, g.org[2], g.inv_h, g.dim[2]);
+      key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
       local += 1;
+    } else if (g.dense) {
+      key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
     }
     keys[i] = key;
     idx[i] = (uint32_t)i;
@@ -147,6 +152,25 @@ __device__ __forceinline__ uint32_t lookup_cell(const CellTable& t, uint64_t k) 
     if (kk == k) return t.starts[slot];
     if (kk == kInvalidKey) return kNoIndex;
     slot = (slot + 1) & t.mask;
+  }
+}
+
+// Dense directory (volume-like clouds: cells <= a few n): cell_start[c] = first sorted point with key >= c, c in [0, cells].
+// Sorted keys are row-major cell numbers, so the cells x0..x1 of one grid row are ONE contiguous range of sorted points.
+__global__ __launch_bounds__(kBlock) void build_directory_kernel(const uint64_t* __restrict__ keys, uint64_t nf, uint64_t cells,
+                                                                 uint32_t* __restrict__ cell_start) {
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j <= nf; j += step) {
+    // run head j (or the end sentinel j == nf): every cell number in (previous key, this key] starts here
+    const uint64_t k = j < nf ? keys[j] : cells;
+    uint64_t lo;
+    if (j == 0) lo = 0;
+    else {
+      const uint64_t prev = keys[j - 1];
+      if (prev == k) continue;
+      lo = prev + 1;
+    }
+    for (uint64_t c = lo; c <= k; ++c) cell_start[c] = (uint32_t)j;
   }
 }
 
@@ -356,10 +380,27 @@ __global__ __launch_bounds__(kBlock) void knn_bruteforce_kernel(const double* __
 }
 
 // ---- grid search ----------------------------------------------------------------------------------------------------
-template <int K>
+// Termination test shared by both directory kinds: searched cube = cells [c - r, c + r]^3.  Anything outside is at least
+// `margin` away; a side that already reaches the grid boundary has nothing beyond it.  The slack absorbs the rounding of the
+// cell assignment.  Returns true when the k-th best distance is inside the searched cube (or the cube covers the grid).
+__device__ __forceinline__ bool shell_done(const GridParams& g, double qx, double qy, double qz, int cx, int cy, int cz, int r, double kth) {
+  double margin = __builtin_inf();
+  const double qa[3] = {qx, qy, qz};
+  const int ca[3] = {cx, cy, cz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (ca[a] - r > 0) margin = __builtin_fmin(margin, qa[a] - (g.org[a] + (double)(ca[a] - r) * g.h));
+    if (ca[a] + r < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + r + 1) * g.h) - qa[a]);
+  }
+  if (margin == __builtin_inf()) return true;  // the cube covers the whole grid
+  margin = margin * (1.0 - 1e-12) - 1e-300;
+  return margin > 0.0 && kth <= margin * margin;
+}
+
+template <int K, bool DENSE>
 __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys,
                                                           const uint32_t* __restrict__ sidx, uint32_t nf, uint32_t k, GridParams g, CellTable table,
-                                                          NormalsOut out) {
+                                                          const uint32_t* __restrict__ cell_start, NormalsOut out) {
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= nf) return;
   const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
@@ -367,6 +408,12 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
   KBest<K> best;
   best.init();
+  auto scan = [&](uint32_t p, uint32_t p_end) __attribute__((always_inline)) {
+    for (; p < p_end; ++p) {
+      const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
+      best.insert(ddx * ddx + ddy * ddy + ddz * ddz, p);
+    }
+  };
   const int max_r = (int)max(g.dim[0], max(g.dim[1], g.dim[2]));
   for (int r = 0; r <= max_r; ++r) {
     for (int dz = -r; dz <= r; ++dz) {
@@ -376,35 +423,32 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
         const int y = cy + dy;
         if (y < 0 || y >= (int)g.dim[1]) continue;
         const bool face = (dz == -r || dz == r || dy == -r || dy == r);
-        const int xstep = face ? 1 : (2 * r > 0 ? 2 * r : 1);  // interior rows of the shell: only the two end cells
-        for (int dx = -r; dx <= r; dx += xstep) {
-          const int x = cx + dx;
-          if (x < 0 || x >= (int)g.dim[0]) continue;
-          const uint64_t key = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
-          uint32_t p = lookup_cell(table, key);
-          if (p == kNoIndex) continue;
-          for (; p < nf && skeys[p] == key; ++p) {
-            const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
-            const double d = ddx * ddx + ddy * ddy + ddz * ddz;
-            best.insert(d, p);
+        if constexpr (DENSE) {
+          const uint64_t row = ((uint64_t)z * g.dim[1] + (uint64_t)y) * g.dim[0];
+          if (face) {  // the whole row segment [cx - r, cx + r] is one contiguous range of sorted points
+            const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r >= (int)g.dim[0] ? (int)g.dim[0] - 1 : cx + r;
+            scan(cell_start[row + (uint32_t)x0], cell_start[row + (uint32_t)x1 + 1]);
+          } else {     // interior rows of the shell: only the two end cells
+            if (cx - r >= 0) scan(cell_start[row + (uint32_t)(cx - r)], cell_start[row + (uint32_t)(cx - r) + 1]);
+            if (cx + r < (int)g.dim[0]) scan(cell_start[row + (uint32_t)(cx + r)], cell_start[row + (uint32_t)(cx + r) + 1]);
+          }
+        } else {
+          const int xstep = face ? 1 : (2 * r > 0 ? 2 * r : 1);  // interior rows of the shell: only the two end cells
+          for (int dx = -r; dx <= r; dx += xstep) {
+            const int x = cx + dx;
+            if (x < 0 || x >= (int)g.dim[0]) continue;
+            const uint64_t key = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
+            uint32_t p = lookup_cell(table, key);
+            if (p == kNoIndex) continue;
+            for (; p < nf && skeys[p] == key; ++p) {
+              const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
+              best.insert(ddx * ddx + ddy * ddy + ddz * ddz, p);
+            }
           }
         }
       }
     }
-    // searched cube = cells [c - r, c + r]^3.  Anything outside is at least `margin` away; a side that already reaches
-    // the grid boundary has nothing beyond it.  The slack absorbs the rounding of the cell assignment.
-    double margin = __builtin_inf();
-    const double qa[3] = {qx, qy, qz};
-    const int ca[3] = {cx, cy, cz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (ca[a] - r > 0) margin = __builtin_fmin(margin, qa[a] - (g.org[a] + (double)(ca[a] - r) * g.h));
-      if (ca[a] + r < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + r + 1) * g.h) - qa[a]);
-    }
-    if (margin == __builtin_inf()) break;  // the cube covers the whole grid
-    margin = margin * (1.0 - 1e-12) - 1e-300;
-    const double kth = best.kth(k);
-    if (margin > 0.0 && kth <= margin * margin) break;
+    if (shell_done(g, qx, qy, qz, cx, cy, cz, r, best.kth(k))) break;
   }
   const uint32_t m = nf < k ? nf : k;
   const uint64_t orig = sidx[j];
@@ -478,13 +522,16 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
 
   const bool any_finite = mn[0] <= mx[0];
   const bool brute = n <= 2048 || !any_finite;
-#define KNN_DISPATCH(KERNEL, GRID, ...)                                                                        \
-  do {                                                                                                        \
-    if (k <= 8) hipLaunchKernelGGL((KERNEL<8>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);           \
-    else if (k <= 16) hipLaunchKernelGGL((KERNEL<16>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);    \
-    else if (k <= 32) hipLaunchKernelGGL((KERNEL<32>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);    \
-    else hipLaunchKernelGGL((KERNEL<64>), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);                 \
+#define KNN_DISPATCH_T(GRID, K1, K2, K3, K4, ...)                                                       \
+  do {                                                                                                  \
+    if (k <= 8) hipLaunchKernelGGL((K1), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);            \
+    else if (k <= 16) hipLaunchKernelGGL((K2), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);      \
+    else if (k <= 32) hipLaunchKernelGGL((K3), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);      \
+    else hipLaunchKernelGGL((K4), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);                   \
   } while (0)
+#define KNN_DISPATCH(KERNEL, GRID, ...) KNN_DISPATCH_T(GRID, KERNEL<8>, KERNEL<16>, KERNEL<32>, KERNEL<64>, __VA_ARGS__)
+#define KNN_DISPATCH_GRID(DENSE, GRID, ...) \
+  KNN_DISPATCH_T(GRID, (knn_grid_kernel<8, DENSE>), (knn_grid_kernel<16, DENSE>), (knn_grid_kernel<32, DENSE>), (knn_grid_kernel<64, DENSE>), __VA_ARGS__)
   if (brute) {
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     KNN_DISPATCH(knn_bruteforce_kernel, grid, xyz.as<double>(), (uint32_t)n, k, out);
@@ -511,6 +558,13 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     }
     g.h = h;
     g.inv_h = 1.0 / h;
+    // dense directory when the grid is not much larger than the cloud (volume-like data); else Morton keys + hash table
+    const uint64_t cells = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    bool dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
+    if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
+    g.dense = dense ? 1u : 0u;
+    int key_bits = 64;
+    if (dense) { key_bits = 1; while (key_bits < 63 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells
     DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp;
     NCK(keys.alloc(n * 8)); NCK(keys2.alloc(n * 8)); NCK(idx.alloc(n * 4)); NCK(idx2.alloc(n * 4)); NCK(sorted_xyz.alloc(n * 24));
     unsigned long long* n_finite = (unsigned long long*)counters.p;
@@ -518,28 +572,39 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     hipLaunchKernelGGL(keys_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
     size_t tmp_bytes = 0;
     NCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                           (int)n, 0, 64, stream));
+                                           (int)n, 0, key_bits, stream));
     NCK(tmp.alloc(tmp_bytes));
     NCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                           (int)n, 0, 64, stream));
+                                           (int)n, 0, key_bits, stream));
     hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
     unsigned long long h_counts[2] = {0, 0};
     NCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
     NCK(hipStreamSynchronize(stream));
     const uint64_t nf = h_counts[0];
-    hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
-    NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
-    NCK(hipStreamSynchronize(stream));
-    uint64_t cap = 64;
-    while (cap < 2 * h_counts[1]) cap <<= 1;
-    DevBuf tkeys, tstarts;
-    NCK(tkeys.alloc(cap * 8)); NCK(tstarts.alloc(cap * 4));
-    NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
-    CellTable table{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
-    hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
+    DevBuf tkeys, tstarts, directory;
+    CellTable table{nullptr, nullptr, 0};
+    if (dense) {
+      NCK(directory.alloc((cells + 2) * 4));
+      hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, cells, directory.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
+      NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
+      NCK(hipStreamSynchronize(stream));
+      uint64_t cap = 64;
+      while (cap < 2 * h_counts[1]) cap <<= 1;
+      NCK(tkeys.alloc(cap * 8)); NCK(tstarts.alloc(cap * 4));
+      NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
+      table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
+      hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
+    }
     if (nf) {
       const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
-      KNN_DISPATCH(knn_grid_kernel, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table, out);
+      if (dense)
+        KNN_DISPATCH_GRID(true, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table,
+                          (const uint32_t*)directory.as<uint32_t>(), out);
+      else
+        KNN_DISPATCH_GRID(false, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table,
+                          (const uint32_t*)nullptr, out);
     }
     if (nf < n) {
       // non-finite query points: every distance is NaN (-> +inf), so "the k nearest" is the reference's kd-tree tie order
@@ -555,7 +620,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   int errors = 0;
   NCK(hipMemcpyAsync(&errors, out.error_count, 4, hipMemcpyDeviceToHost, stream));
   NCK(hipStreamSynchronize(stream));
+#undef KNN_DISPATCH_GRID
 #undef KNN_DISPATCH
+#undef KNN_DISPATCH_T
 #undef NCK
   return errors;
 }
