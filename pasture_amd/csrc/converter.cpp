@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <optional>
 
+#include "las_layouts.hpp"
 #include "runtime.hpp"
 
 namespace pst {
@@ -65,6 +66,9 @@ static void validate_transform(const XfDesc& x) {
 struct pst_converter {
   pst::Layout from, to;
   std::vector<pst::Mapping> mappings;
+  // plan recognition cache for the specialised LAS record decoder (las_decode.hip): -2 = not examined yet, -1 = generic plan,
+  // 0..10 = "raw LAS records of this format -> its typed default layout with the mappings of get_default_las_converter"
+  mutable int las_decode_format = -2;
 };
 
 namespace pst {
@@ -159,6 +163,46 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
   }
 }
 
+// Is this converter exactly the plan get_default_las_converter (raw_readers.rs:31-167) builds for (raw records of format N ->
+// LasPointFormatN::layout())?  Then las_decode.hip runs it with the format as a compile-time parameter.
+static int match_las_decode_plan(const pst_converter& c) {
+  using namespace laslayout;
+  int format = -1;
+  for (uint32_t f = 0; f <= 10; ++f)
+    if (c.from == raw_layout(f) && c.to == typed_layout(f)) { format = (int)f; break; }
+  if (format < 0 || c.mappings.size() != c.to.members.size()) return -1;
+  const bool ext = format >= 6;
+  const char* flags = ext ? "LASExtendedFlags" : "LASBasicFlags";
+  struct Bits { const char* target; uint32_t shift; uint64_t mask; };
+  static const Bits basic[] = {{"ReturnNumber", 0, 7}, {"NumberOfReturns", 3, 7}, {"ScanDirectionFlag", 6, 1}, {"EdgeOfFlightLine", 7, 1}};
+  static const Bits extended[] = {{"ReturnNumber", 0, 15},    {"NumberOfReturns", 4, 15},   {"ClassificationFlags", 8, 15},
+                                  {"ScannerChannel", 12, 3},  {"ScanDirectionFlag", 14, 1}, {"EdgeOfFlightLine", 15, 1}};
+  std::vector<uint8_t> seen(c.to.members.size(), 0);
+  for (const Mapping& m : c.mappings) {
+    const int tslot = c.to.index_of(m.target.def);
+    if (tslot < 0 || seen[(size_t)tslot]) return -1;
+    seen[(size_t)tslot] = 1;
+    const std::string& tn = m.target.def.name;
+    if (tn == "Position3D") {
+      if (m.source.def.name != "LASLocalPosition" || !m.xf || m.xf->kind != PST_XF_AFFINE || m.xf->datatype.kind != PST_VEC3F64 || m.apply_to_source)
+        return -1;
+      continue;
+    }
+    const Bits* b = nullptr;
+    const Bits* table = ext ? extended : basic;
+    for (size_t i = 0; i < (ext ? 6u : 4u); ++i)
+      if (tn == table[i].target) b = &table[i];
+    if (b) {  // bit fields of the flags attribute, applied to the SOURCE value (raw_readers.rs:61-164)
+      if (m.source.def.name != flags || !m.xf || m.xf->kind != PST_XF_BITFIELD || !m.apply_to_source || m.xf->shift != b->shift ||
+          (m.xf->mask & 0xFFFFull) != b->mask)
+        return -1;
+      continue;
+    }
+    if (m.source.def.name != tn || m.xf || m.has_converter) return -1;  // plain copy of the same-named attribute
+  }
+  return format;
+}
+
 // ---- convert_into_range, buffer_conversion.rs:292-359 -----------------------------------------------------
 // bounds_out6: when non-null, {min xyz, max xyz} of the TARGET's POSITION_3D over the target range is written there
 // (device-accessible memory), fused into the conversion pass when possible.
@@ -182,6 +226,23 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   bool bounds_done = false;
 
   std::vector<PlanEntry> generic;
+  static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
+  if (las_fast && n > 0 && !src.columnar && dst.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
+  if (las_fast && n > 0 && !src.columnar && dst.columnar && c.las_decode_format >= 0) {
+    // the production plan of the LAS readers: format-specialised kernel (las_decode.hip)
+    const Mapping* pos = nullptr;
+    for (const Mapping& m : c.mappings)
+      if (m.target.def.name == "Position3D") pos = &m;
+    std::vector<uint64_t> cols(c.to.members.size());
+    for (size_t a = 0; a < cols.size(); ++a) cols[a] = col_addr(dst, a, t0);
+    double* partials = nullptr;
+    if (bounds_out6) partials = (double*)workspace().partials(pstk::bounds_partials_bytes(pstk::las_decode_grid(n)));
+    if (!pstk::launch_las_decode(c.las_decode_format, aos_addr(src, s0), n, cols.data(), (int)cols.size(), pos->xf->scale, pos->xf->offset, partials,
+                                 stream))
+      throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
+    if (bounds_out6) pstk::launch_finalize_bounds(partials, pstk::las_decode_grid(n), bounds_out6, stream);
+    return;
+  }
   if (!c.mappings.empty() && n > 0) {  // no mappings => silent no-op (:308-313)
     for (const Mapping& m : c.mappings) {
       PlanEntry e = entry_from_mapping(m);
@@ -243,6 +304,7 @@ using namespace pst;
 static AttributeDef def_from(const char* name, const pst_datatype* dt) { return AttributeDef{not_null(name, "name"), DataType::from_c(dt)}; }
 
 static void install_mapping(pst_converter& c, Mapping&& m, const AttributeDef& to_attribute) {
+  c.las_decode_format = -2;
   for (auto& prev : c.mappings)
     if (prev.target.def == to_attribute) { prev = std::move(m); return; }  // replace the mapping for this target (:168-176)
   c.mappings.push_back(std::move(m));

@@ -65,6 +65,11 @@ bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* at
                        double* out_bounds, unsigned long long* out_counts, hipStream_t stream);
 
 
+// LAS record decoder (las_decode.hip)
+unsigned las_decode_grid(uint64_t n);
+bool launch_las_decode(int format, uint64_t src, uint64_t n, const uint64_t* dst_cols, int n_cols, const double scale[3], const double offset[3],
+                       double* partials, hipStream_t stream);
+
 // predicate compaction (filter.hip)
 size_t filter_workspace_bytes(uint64_t n);
 uint32_t filter_tile(bool dst_aos, uint32_t dst_stride);

@@ -1,61 +1,11 @@
 // pst_las_encode_points: argument checks + plumbing for the LAS record encoder (las_encode.hip).
 // Reference: pasture-io/src/las/raw_writers.rs:203-363, 606-613; las_layout.rs:64-125; las_types.rs.
+#include "las_layouts.hpp"
 #include "runtime.hpp"
 
 using namespace pst;
 
-namespace {
-
-struct Fmt { bool ext, gps, color, nir, wave; };
-Fmt fmt_of(uint32_t n) {
-  return Fmt{n >= 6, n == 1 || n == 3 || n == 4 || n == 5 || n >= 6, n == 2 || n == 3 || n == 5 || n == 7 || n == 8 || n == 10, n == 8 || n == 10,
-             n == 4 || n == 5 || n == 9 || n == 10};
-}
-AttributeDef def(const char* name, uint32_t kind) {
-  AttributeDef d{name, DataType{}};
-  d.datatype.kind = kind;
-  return d;
-}
-// LasPointFormatN::layout(): #[repr(C, packed)] structs of las_types.rs, field order = attribute order
-Layout typed_layout(uint32_t format) {
-  const Fmt f = fmt_of(format);
-  Layout l;
-  auto add = [&](const char* n, uint32_t k) { l.add_attribute(def(n, k), true, 1); };
-  add("Position3D", PST_VEC3F64); add("Intensity", PST_U16); add("ReturnNumber", PST_U8); add("NumberOfReturns", PST_U8);
-  if (f.ext) { add("ClassificationFlags", PST_U8); add("ScannerChannel", PST_U8); }
-  add("ScanDirectionFlag", PST_U8); add("EdgeOfFlightLine", PST_U8); add("Classification", PST_U8);
-  if (f.ext) { add("UserData", PST_U8); add("ScanAngle", PST_I16); } else { add("ScanAngleRank", PST_I8); add("UserData", PST_U8); }
-  add("PointSourceID", PST_U16);
-  if (f.gps) add("GpsTime", PST_F64);
-  if (f.color) add("ColorRGB", PST_VEC3U16);
-  if (f.nir) add("NIR", PST_U16);
-  if (f.wave) {
-    add("WavePacketDescriptorIndex", PST_U8); add("WaveformDataOffset", PST_U64); add("WaveformPacketSize", PST_U32);
-    add("ReturnPointWaveformLocation", PST_F32); add("WaveformParameters", PST_VEC3F32);
-  }
-  return l;
-}
-// point_layout_from_las_point_format(format, exact_binary_representation = true), las_layout.rs:70-107
-Layout raw_layout(uint32_t format) {
-  const Fmt f = fmt_of(format);
-  Layout l;
-  auto add = [&](const char* n, uint32_t k) { l.add_attribute(def(n, k), true, 1); };
-  add("LASLocalPosition", PST_VEC3I32); add("Intensity", PST_U16);
-  if (f.ext) add("LASExtendedFlags", PST_U16); else add("LASBasicFlags", PST_U8);
-  add("Classification", PST_U8);
-  if (f.ext) { add("UserData", PST_U8); add("ScanAngle", PST_I16); } else { add("ScanAngleRank", PST_I8); add("UserData", PST_U8); }
-  add("PointSourceID", PST_U16);
-  if (f.gps) add("GpsTime", PST_F64);
-  if (f.color) add("ColorRGB", PST_VEC3U16);
-  if (f.nir) add("NIR", PST_U16);
-  if (f.wave) {
-    add("WavePacketDescriptorIndex", PST_U8); add("WaveformDataOffset", PST_U64); add("WaveformPacketSize", PST_U32);
-    add("ReturnPointWaveformLocation", PST_F32); add("WaveformParameters", PST_VEC3F32);
-  }
-  return l;
-}
-
-}  // namespace
+using namespace pst::laslayout;
 
 extern "C" int pst_las_encode_points(const pst_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], pst_buffer* dst,
                                      size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return) {

@@ -40,7 +40,7 @@ def test_synth_matches_oracle(hip, oracle, kind, packed):
 
 
 @pytest.mark.parametrize("target_kind", ["V", "H"])
-@pytest.mark.parametrize("fmt", [0, 1, 3, 6, 7, 10])
+@pytest.mark.parametrize("fmt", range(11))
 def test_raw_las_to_typed_layout_vs_oracle(hip, oracle, fmt, target_kind):
     """The production caller (raw_readers.rs:299-352) on 200k synthetic raw records per format, written in two ranges."""
     n = 200_003
