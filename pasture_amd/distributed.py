@@ -30,6 +30,49 @@ def allreduce_bounds_record(rec, group=None):
     return rec
 
 
+class PipelinedBoundsReduce:
+    """The same all-reduce for a stream of steps, overlapped with compute: step i writes its local {min xyz, max xyz} into
+    `current()`, `submit()` starts the reduction (MIN of the minima, MAX of the maxima) ASYNCHRONOUSLY (the collective runs on the backend's own stream
+    behind an event of the compute stream), and the next step's kernels are launched without waiting for it.  A ring of
+    `depth` record buffers keeps a record alive until its all-reduce has finished; `finish()` returns the last global record."""
+
+    def __init__(self, make_record, depth: int = 4, group=None):
+        self.recs = [make_record() for _ in range(depth)]
+        self.work = [None] * depth
+        self.group = group
+        self.i = 0
+
+    def current(self):
+        b = self.i % len(self.recs)
+        if self.work[b] is not None:  # the buffer's previous all-reduce (depth steps ago) must be complete before reuse
+            for w in self.work[b]:
+                w.wait()
+            self.work[b] = None
+        return self.recs[b]
+
+    def submit(self) -> None:
+        import torch.distributed as dist
+        b = self.i % len(self.recs)
+        rec = self.recs[b]
+        # MIN over the three minima + MAX over the three maxima: two 24-byte collectives on the backend's stream and NOTHING
+        # on the compute stream (the [min, -max] encoding of allreduce_bounds_record costs two extra kernels there)
+        self.work[b] = (dist.all_reduce(rec[:3], op=dist.ReduceOp.MIN, group=self.group, async_op=True),
+                        dist.all_reduce(rec[3:], op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+        self.i += 1
+
+    def finish(self):
+        """Waits for every pending all-reduce; returns the global record of the last submitted step (decoded), or None."""
+        last = None
+        for k in range(len(self.recs)):
+            if self.work[k] is not None:
+                for w in self.work[k]:
+                    w.wait()
+                self.work[k] = None
+        if self.i:
+            last = self.recs[(self.i - 1) % len(self.recs)]
+        return last
+
+
 def bounds_from_record(rec) -> Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]]:
     """AABB::from_min_max on the reduced record: None if every shard was empty, panics like math/bounds.rs:21-26 if min > max."""
     from ._capi import ERR_BOUNDS_INVALID, PasturePanic

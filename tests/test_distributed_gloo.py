@@ -78,3 +78,44 @@ def test_sharded_bounds_allreduce_gloo(oracle, n, empty_rank):
     buf.synth_fill(42, first)
     want = calculate_bounds(buf)
     assert got[0] == got[1] == (want.min(), want.max())
+
+
+def _pipeline_worker(rank, world, port, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pasture_amd.distributed import PipelinedBoundsReduce
+    ring = PipelinedBoundsReduce(lambda: torch.empty(6, dtype=torch.float64), depth=3)
+    seen = []
+    for i in range(steps):
+        rec = ring.current()  # step i of this rank "computes" a local record
+        lo = float(rank * 10 + i)
+        rec.copy_(torch.tensor([lo, lo + 1, lo + 2, lo + 100, lo + 101, lo + 102], dtype=torch.float64))
+        ring.submit()
+        if i >= 2:  # a record that left the ring window is complete and decoded on demand by its next user
+            pass
+    last = ring.finish()
+    q.put((rank, None if last is None else last.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 2, 7])
+def test_pipelined_bounds_allreduce_gloo(steps):
+    """The bench's overlapped variant: asynchronous all-reduces over a ring of record buffers; the last step's global record
+    is min over ranks of the mins and max over ranks of the maxes."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    i = steps - 1
+    lo0, lo1 = float(i), float(10 + i)
+    want = [lo0, lo0 + 1, lo0 + 2, lo1 + 100, lo1 + 101, lo1 + 102]
+    assert got[0] == got[1] == want
