@@ -18,6 +18,7 @@
 #include "tile_io.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace pstd;
 
@@ -252,8 +253,9 @@ size_t filter_workspace_bytes(uint64_t n) {
 // Points per tile: columnar targets 2048; interleaved targets as many records as fit ~40 KiB of LDS (a power of two >= 256).
 uint32_t filter_tile(bool dst_aos, uint32_t dst_stride) {
   if (!dst_aos) return 2048;
+  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 40L * 1024L; }();
   uint32_t t = 2048;
-  while (t > 256 && (uint64_t)t * dst_stride > 40u * 1024u) t >>= 1;
+  while (t > 256 && (uint64_t)t * dst_stride > (uint64_t)budget) t >>= 1;
   return t;
 }
 
