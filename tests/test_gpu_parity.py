@@ -511,3 +511,139 @@ def test_full_size_1e8_voxelgrid_properties(hip):
     occupied = torch.unique(keys_of(src.column_ptr(A.POSITION_3D), n))  # sorted
     assert out.len() == occupied.numel()
     assert torch.equal(keys_of(out.column_ptr(A.POSITION_3D), out.len()), occupied)
+
+
+def _fuzz_case(api, seed):
+    """One random conversion: random layouts (every datatype, packed or repr(C)), name-matched defaults with type changes,
+    custom mappings with affine / bit-field transformations on either side, random storage pairing and ranges."""
+    rng = np.random.default_rng(seed)
+    SC = [T.U8, T.I8, T.U16, T.I16, T.U32, T.I32, T.U64, T.I64, T.F32, T.F64]
+    V3 = [T.Vec3u8, T.Vec3u16, T.Vec3f32, T.Vec3i32, T.Vec3f64]
+    OPAQUE = [T.Vec4u8, T.ByteArray(5), T.ByteArray(16)]
+    n_src = int(rng.integers(1, 13))
+    src_attrs = []
+    for i in range(n_src):
+        fam = rng.integers(0, 10)
+        dt = SC[rng.integers(0, 10)] if fam < 6 else (V3[rng.integers(0, 5)] if fam < 9 else OPAQUE[rng.integers(0, 3)])
+        src_attrs.append(PointAttributeDefinition(f"a{i}", dt))
+
+    def convertible_to(dt):
+        if dt in SC:
+            return SC[rng.integers(0, 10)]
+        if dt in V3:
+            return V3[rng.integers(0, 5)]
+        return dt
+    # target: a random subset / permutation of the source names (+ sometimes a name the source lacks), datatypes often changed
+    order = rng.permutation(n_src)[: int(rng.integers(1, n_src + 1))]
+    tgt_attrs = [PointAttributeDefinition(src_attrs[i].name(), convertible_to(src_attrs[i].datatype()) if rng.random() < 0.5 else src_attrs[i].datatype())
+                 for i in order]
+    with_default = rng.random() < 0.4
+    if with_default and rng.random() < 0.7:
+        tgt_attrs.append(PointAttributeDefinition("only_in_target", SC[rng.integers(0, 10)]))
+
+    def make_layout(attrs):
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            return PointLayout.from_attributes(attrs, api=api)
+        return PointLayout.from_attributes_packed(attrs, int([1, 2, 4][rng.integers(0, 3)]), api=api)
+    sl, tl = make_layout(src_attrs), make_layout(tgt_attrs)
+    conv = (BufferLayoutConverter.for_layouts_with_default if with_default else BufferLayoutConverter.for_layouts)(sl, tl)
+    # custom mappings: one source attribute into a (possibly differently named) target attribute, optionally transformed
+    for _ in range(int(rng.integers(0, 4))):
+        t = tgt_attrs[rng.integers(0, len(tgt_attrs))]
+        cands = [a for a in src_attrs if (a.datatype() in SC and t.datatype() in SC) or (a.datatype() in V3 and t.datatype() in V3)
+                 or a.datatype() == t.datatype()]
+        if not cands:
+            continue
+        a = cands[rng.integers(0, len(cands))]
+        r = rng.random()
+        if r < 0.35:
+            conv.set_custom_mapping(a, t)
+            continue
+        on_source = bool(rng.random() < 0.5)
+        xt = a.datatype() if on_source else t.datatype()
+        if xt in (T.F64, T.F32):
+            conv.set_custom_mapping_with_transformation(a, t, Transform.affine(xt, (float(rng.uniform(-3, 3)),) * 3, (float(rng.uniform(-50, 50)),) * 3), on_source)
+        elif xt in (T.Vec3f64, T.Vec3f32):
+            conv.set_custom_mapping_with_transformation(a, t, Transform.affine(xt, tuple(rng.uniform(-3, 3, 3)), tuple(rng.uniform(-50, 50, 3))), on_source)
+        elif xt in (T.U8, T.U16, T.U32, T.U64):
+            bits = 8 * xt.size()
+            conv.set_custom_mapping_with_transformation(a, t, Transform.bitfield(xt, int(rng.integers(0, bits)), int(rng.integers(1, 1 << min(bits, 16)))), on_source)
+        else:
+            conv.set_custom_mapping(a, t)
+    n = int(rng.choice([0, 1, 63, 64, 65, 300, 1025, 4097, 20_011]))
+    rec = np.zeros(n, dtype=sl.numpy_record_dtype())
+    for a in sl.attributes():
+        npdt = a.datatype().numpy_dtype()
+        nc = a.datatype().num_components()
+        shape = (n, nc) if nc > 1 else (n,)
+        if npdt.kind == "f":
+            v = rng.uniform(-1e4, 1e4, shape)
+            if n:
+                special = rng.random(shape) < 0.02
+                v = np.where(special, rng.choice([np.nan, np.inf, -np.inf, 0.0, -0.0, 3e38, -1e300 if npdt.itemsize == 8 else -3e38, 0.5]), v)
+            rec[a.name()] = v.astype(npdt)
+        elif npdt.kind in "iu":
+            info = np.iinfo(npdt)
+            rec[a.name()] = rng.integers(info.min, info.max, size=shape, dtype=npdt, endpoint=True)
+        else:
+            rec[a.name()] = rng.integers(0, 256, size=(n, a.size()), dtype=np.uint8).view(npdt).reshape(shape if nc > 1 else (n,))
+    kinds = ("VH"[rng.integers(0, 2)], "VH"[rng.integers(0, 2)])
+    src = BUFFER_KINDS[kinds[0]].from_numpy(rec, sl)
+    pad = int(rng.integers(0, 3))
+    dst = BUFFER_KINDS[kinds[1]].new_from_layout(tl)
+    dst.resize(n + 2 * pad)
+    if n:
+        a0 = int(rng.integers(0, n))
+        a1 = int(rng.integers(a0, n + 1))
+    else:
+        a0 = a1 = 0
+    conv.convert_into_range(src, range(a0, a1), dst, range(pad + a0, pad + a1))
+    out = {a.name(): dst.view_attribute(a.attribute_definition()) for a in tl.attributes()}
+    return out, [(m.source.name(), m.target.name(), m.has_converter, m.transform_kind != 0, m.apply_to_source) for m in conv.mappings()]
+
+
+@pytest.mark.parametrize("seed", range(400))
+def test_random_conversions_vs_oracle(hip, oracle, seed):
+    """Differential fuzzing of the generic converter: identical mapping tables, and identical target bytes (NaN payload bits of
+    f64 -> f32 narrowing excepted: compared as NaN == NaN)."""
+    (h, hm), (o, om) = both(lambda api: _fuzz_case(api, seed), hip, oracle)
+    assert hm == om
+    for k in o:
+        a, b = h[k], o[k]
+        if a.dtype.kind == "f":
+            assert np.array_equal(np.isnan(a), np.isnan(b)), k
+            fin = ~np.isnan(b)
+            assert np.array_equal(a[fin].view(f"u{a.dtype.itemsize}"), b[fin].view(f"u{b.dtype.itemsize}")), k
+        else:
+            assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_filter_append_vs_oracle(hip, oracle, seed):
+    """Differential fuzzing of filter / append: random layouts (all attribute sizes incl. 3, 5, 6, 12, 16, 24 bytes; packed or
+    repr(C) with padding), random mask densities, both target kinds; then the result is appended to a second buffer."""
+    def run(api):
+        rng = np.random.default_rng(1000 + seed)
+        ALL = [T.U8, T.I8, T.U16, T.I16, T.U32, T.I32, T.U64, T.I64, T.F32, T.F64, T.Vec3u8, T.Vec3u16, T.Vec3f32, T.Vec3i32, T.Vec3f64, T.Vec4u8,
+               T.ByteArray(5), T.ByteArray(16), T.ByteArray(7)]
+        attrs = [PointAttributeDefinition(f"a{i}", ALL[rng.integers(0, len(ALL))]) for i in range(int(rng.integers(1, 36)))]
+        layout = PointLayout.from_attributes(attrs, api=api) if rng.random() < 0.4 else \
+            PointLayout.from_attributes_packed(attrs, int([1, 2, 4, 8][rng.integers(0, 4)]), api=api)
+        n = int(rng.choice([0, 1, 255, 256, 2047, 2048, 2049, 10_000, 33_333]))
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(seed, 17)
+        mask = rng.random(n) < float(rng.choice([0.0, 0.03, 0.5, 0.97, 1.0]))
+        kind = "VH"[rng.integers(0, 2)]
+        out = src.filter(BUFFER_KINDS[kind], mask)
+        other = BUFFER_KINDS["VH"[rng.integers(0, 2)]].new_from_layout(layout)
+        other.resize(int(rng.integers(0, 5)))
+        other.append(out)
+        other.append(src)
+        cols = {a.name(): other.view_attribute(a.attribute_definition()) for a in layout.attributes()}
+        return out.len(), cols
+    (hn, hc), (on, oc) = both(run, hip, oracle)
+    assert hn == on
+    for k in oc:
+        assert hc[k].tobytes() == oc[k].tobytes(), k
