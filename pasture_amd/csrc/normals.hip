@@ -184,16 +184,24 @@ struct KBest {
     for (int t = 0; t < K; ++t) { d[t] = __builtin_inf(); i[t] = kNoIndex; }
   }
   // Insert (dist, index) keeping ascending order; an equal distance goes AFTER the existing ones (first found wins).
+  // Distances: new[t] = min(d[t], max(d[t-1], dist)) — two f64 ops per slot instead of compare + 64-bit selects (the search is
+  // VALU-bound: ~145 candidates per query, every accepted one walks all K slots).  Indices follow the same three cases through
+  // keep[t] = d[t] <= dist (monotone in t because the list is sorted).  Distances are never NaN here.
   __device__ __forceinline__ void insert(double dist, uint32_t index) {
     if (!(dist < d[K - 1])) return;
+    bool keep_prev = true;  // "d[-1] <= dist"
+    double d_prev = -__builtin_inf();
+    uint32_t i_prev = index;
 #pragma unroll
-    for (int t = K - 1; t >= 0; --t) {
-      const bool keep = d[t] <= dist;                       // element t is not displaced
-      const bool here = t == 0 ? true : (d[t - 1] <= dist); // the new element lands exactly at t (if t is displaced)
-      const double nd = keep ? d[t] : (here ? dist : d[t > 0 ? t - 1 : 0]);
-      const uint32_t ni = keep ? i[t] : (here ? index : i[t > 0 ? t - 1 : 0]);
-      d[t] = nd;
-      i[t] = ni;
+    for (int t = 0; t < K; ++t) {
+      const double dt = d[t];
+      const uint32_t it = i[t];
+      const bool keep = dt <= dist;
+      d[t] = __builtin_fmin(dt, __builtin_fmax(d_prev, dist));
+      i[t] = keep ? it : (keep_prev ? index : i_prev);
+      keep_prev = keep;
+      d_prev = dt;
+      i_prev = it;
     }
   }
   __device__ __forceinline__ double kth(uint32_t k) const {  // d[k-1] without dynamic register indexing
