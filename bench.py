@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
     p.add_argument("--workload", default="convert_affine_bounds", choices=sorted(WORKLOADS))
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-points", type=int, default=10_000_000)
+    p.add_argument("--cpu-sample-points", type=int, default=100_000_000, help="CPU baseline sample (default: the whole 10^8-point workload, ~10 s of CPU work)")
     return p.parse_args()
 
 
