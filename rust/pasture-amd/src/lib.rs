@@ -173,3 +173,30 @@ pub fn compute_normals(buffer: &impl DeviceBuffer, n_points: usize, k_nn: usize)
     check(unsafe { pst_compute_normals(buffer.handle(), k_nn, normals.as_mut_ptr(), curvature.as_mut_ptr(), std::ptr::null_mut()) });
     (0..n_points).map(|i| (Vector3::new(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]), curvature[i])).collect()
 }
+
+/// pasture-algorithms/src/voxel_grid.rs:109
+pub fn voxelgrid_filter(buffer: &impl DeviceBuffer, leafsize_x: f64, leafsize_y: f64, leafsize_z: f64, filtered_buffer: &mut impl DeviceBuffer) {
+    check(unsafe { pst_voxelgrid_filter(buffer.handle(), leafsize_x, leafsize_y, leafsize_z, filtered_buffer.handle()) })
+}
+
+impl DeviceHashMapBuffer {
+    /// HashMapBuffer::filter_into (point_buffer.rs:1082-1136); the closure is evaluated into a byte mask once.
+    pub fn filter_into<F: Fn(usize) -> bool>(&self, buffer: &mut impl DeviceBuffer, predicate: F, num_matches_hint: Option<usize>, len: usize) -> usize {
+        let mask: Vec<u8> = (0..len).map(|i| predicate(i) as u8).collect();
+        let mut matches = 0usize;
+        check(unsafe { pst_buffer_filter_into(self.raw(), buffer.handle(), mask.as_ptr(), /* host memory */ 1,
+                                              num_matches_hint.map(|n| n as i64).unwrap_or(-1), &mut matches) });
+        matches
+    }
+}
+
+/// OwningBufferExt::append (point_buffer.rs:419-489)
+pub fn append(this: &mut impl DeviceBuffer, other: &impl DeviceBuffer) { check(unsafe { pst_buffer_append(this.handle(), other.handle()) }) }
+
+/// RawLASWriter::write_points_default_layout (pasture-io/src/las/raw_writers.rs:203-363): typed points -> raw records + header
+/// side effects.  `bounds` = [min xyz, max xyz] of the header, `points_by_return[r - 1]` the count of return number r.
+pub fn las_encode_points(points: &impl DeviceBuffer, point_format: u8, scale: [f64; 3], offset: [f64; 3], records: &mut DeviceVectorBuffer,
+                         first_record: usize, bounds: &mut [f64; 6], points_by_return: &mut [u64; 15], large_file: bool) {
+    check(unsafe { pst_las_encode_points(points.handle(), point_format as u32, scale.as_ptr(), offset.as_ptr(), records.raw(), first_record,
+                                         bounds.as_mut_ptr(), points_by_return.as_mut_ptr(), if large_file { 15 } else { 5 }) })
+}
