@@ -7,7 +7,8 @@
 //                        key = x | y | z packed x-major in as few bits as the marker counts need (fewer radix passes)
 //   hipCUB radix sort    (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library)
 //   hipCUB run-length    unique keys -> points per voxel; exclusive sum -> voxel starts                         (library)
-//   voxel_reduce_kernel  one wave per voxel, attribute by attribute (set_all_attributes :459-689):
+//   voxel_reduce_kernel  a wave per 64 voxels: averages / max-pools of small voxels one voxel per LANE (sequential loop = the
+//                        reference's loop); most-common attributes and large voxels one voxel per WAVE (set_all_attributes :459-689):
 //                          average:     64 values fetched in parallel, then ONE sequential f64 addition chain in point order
 //                                       (v_readlane + v_add_f64) so the sums round exactly like the reference's loop
 //                          max-pool:    per-lane strict '>' from 0.0, wave max (order-independent, NaN never wins)
@@ -137,100 +138,163 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
   return v;
 }
 
+constexpr uint32_t kSmallVoxel = 48;  // averages / max-pools of voxels up to this size run one voxel per LANE
+
+// averages and max-pools of ONE voxel computed by ONE lane: a sequential loop over the voxel's points — exactly the reference's
+// loop (same f64 addition order) — with 64 independent voxels per wave hiding the gather latency.
+__device__ __forceinline__ void reduce_voxel_by_lane(const VoxelAttr& at, const uint32_t* __restrict__ idx, uint32_t m, uint64_t out) {
+  gptr_t d = as_global(at.dst) + out * at.dst_stride;
+  const uint32_t sk = scalar_of(at.kind);
+  if (at.reduce == pstk::VX_MAX_POOL) {
+    double cur = 0.0;
+    for (uint32_t j = 0; j < m; ++j) {
+      const double x = load_as_f64(at, sk, idx[j], 0);
+      if (x > cur) cur = x;
+    }
+    if (at.kind == 9) store_un<double>(d, cur);
+    else if (at.kind == 6) store_un<uint64_t>(d, rust_as<uint64_t, double>(cur));
+    else store_un<uint8_t>(d, rust_as<uint8_t, double>(cur));
+    return;
+  }
+  const double np = (double)m;
+  if (at.reduce == pstk::VX_AVG_NUM) {
+    double sum = 0.0;
+    for (uint32_t j = 0; j < m; ++j) sum += load_as_f64(at, sk, idx[j], 0);
+    store_un<uint16_t>(d, rust_as<uint16_t, double>(sum / np));
+    return;
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint64_t i = idx[j];
+    s0 += load_as_f64(at, sk, i, 0); s1 += load_as_f64(at, sk, i, 1); s2 += load_as_f64(at, sk, i, 2);
+  }
+  const double a0 = s0 / np, a1 = s1 / np, a2 = s2 / np;
+  if (at.kind == 14) { store_un<double>(d, a0); store_un<double>(d + 8, a1); store_un<double>(d + 16, a2); }
+  else if (at.kind == 11) {
+    store_un<uint16_t>(d, rust_as<uint16_t, double>(a0)); store_un<uint16_t>(d + 2, rust_as<uint16_t, double>(a1));
+    store_un<uint16_t>(d + 4, rust_as<uint16_t, double>(a2));
+  } else { store_un<float>(d, (float)a0); store_un<float>(d + 4, (float)a1); store_un<float>(d + 8, (float)a2); }
+}
+
 __global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t wave0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-  for (uint64_t v = wave0; v < a.n_voxels; v += n_waves) {
-    const uint64_t s = a.starts[v];
-    const uint64_t m64 = a.starts[v + 1] - s;
-    const uint32_t m = (uint32_t)m64;  // n < 2^32
-    const uint32_t* idx = a.sorted_idx + s;
-    const uint64_t out = a.dst_first + v;
-    if (m > kMidVoxel && lane == 0) a.big_list[atomicAdd(a.big_count, 1u)] = (uint32_t)v;
-    for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
-      const VoxelAttr& at = a.attrs[ai];
-      if (at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM) {
-        const uint32_t nc = at.reduce == pstk::VX_AVG_VEC ? 3u : 1u, sk = scalar_of(at.kind);
-        double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0;
-        for (uint32_t b = 0; b < m; b += 64) {
-          const uint32_t cnt = m - b < 64u ? m - b : 64u;
-          double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-          if (lane < cnt) {
-            const uint64_t i = idx[b + lane];
-            x0 = load_as_f64(at, sk, i, 0);
-            if (nc == 3) { x1 = load_as_f64(at, sk, i, 1); x2 = load_as_f64(at, sk, i, 2); }
-          }
-          // the reference's loop: x_sum += v.x; ... one point after the other (:343-376, :400-431)
-          if (nc == 3) {
-            for (uint32_t j = 0; j < cnt; ++j) { sum0 += wave_bcast_f64(x0, j); sum1 += wave_bcast_f64(x1, j); sum2 += wave_bcast_f64(x2, j); }
-          } else {
-            for (uint32_t j = 0; j < cnt; ++j) sum0 += wave_bcast_f64(x0, j);
-          }
-        }
-        if (lane == 0) {
-          const double np = (double)m;
-          gptr_t d = as_global(at.dst) + out * at.dst_stride;
-          const double a0 = sum0 / np, a1 = sum1 / np, a2 = sum2 / np;
-          if (at.reduce == pstk::VX_AVG_NUM) {
-            store_un<uint16_t>(d, rust_as<uint16_t, double>(a0));  // `as u16` :489, :638
-          } else if (at.kind == 14) {
-            store_un<double>(d, a0); store_un<double>(d + 8, a1); store_un<double>(d + 16, a2);
-          } else if (at.kind == 11) {  // ColorRGB :626
-            store_un<uint16_t>(d, rust_as<uint16_t, double>(a0)); store_un<uint16_t>(d + 2, rust_as<uint16_t, double>(a1));
-            store_un<uint16_t>(d + 4, rust_as<uint16_t, double>(a2));
-          } else {  // Normal :676
-            store_un<float>(d, (float)a0); store_un<float>(d + 4, (float)a1); store_un<float>(d + 8, (float)a2);
-          }
-        }
-      } else if (at.reduce == pstk::VX_MAX_POOL) {
-        const uint32_t sk = scalar_of(at.kind);
-        double cur = 0.0;  // :175
-        for (uint32_t j = lane; j < m; j += 64) {
-          const double x = load_as_f64(at, sk, idx[j], 0);
-          if (x > cur) cur = x;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const double o = shfl_xor_any(cur, off);
-          if (o > cur) cur = o;
-        }
-        if (lane == 0) {
-          gptr_t d = as_global(at.dst) + out * at.dst_stride;
-          if (at.kind == 9) store_un<double>(d, cur);
-          else if (at.kind == 6) store_un<uint64_t>(d, rust_as<uint64_t, double>(cur));
-          else store_un<uint8_t>(d, rust_as<uint8_t, double>(cur));
-        }
-      } else {  // most common
-        if (m > kMidVoxel) continue;  // voxel_mode_big_kernel
-        uint64_t best = 0;
-        if (m <= 64) {
-          const bool valid = lane < m;
-          const int32_t x = valid ? load_as_int(at, idx[lane]) : 0;
-          const uint64_t vmask = __ballot(valid);
-          uint64_t same = vmask;
-          const uint32_t ux = (uint32_t)(x + 32768);
-#pragma unroll
-          for (int bit = 0; bit < 17; ++bit) {
-            const bool b1 = (ux >> bit) & 1u;
-            const uint64_t bal = __ballot(b1);
-            same &= b1 ? bal : ~bal;
-          }
-          if (valid) best = mode_key((uint32_t)__builtin_popcountll(same & vmask), x);
-        } else {
-          for (uint32_t ca = 0; ca < m; ca += 64) {  // candidates
-            const bool valid = ca + lane < m;
-            const int32_t x = valid ? load_as_int(at, idx[ca + lane]) : 0;
-            uint32_t count = 0;
-            for (uint32_t cb = 0; cb < m; cb += 64) {
-              const uint32_t cnt = m - cb < 64u ? m - cb : 64u;
-              const int32_t w = cb + lane < m ? load_as_int(at, idx[cb + lane]) : 0;
-              for (uint32_t j = 0; j < cnt; ++j) count += (x == __builtin_amdgcn_readlane(w, (int)j)) ? 1u : 0u;
+  const uint64_t n_groups = (a.n_voxels + 63) / 64;
+  bool any_mode = false;
+  for (uint32_t ai = 0; ai < a.n_attrs; ++ai) any_mode = any_mode || a.attrs[ai].reduce == pstk::VX_MOST_COMMON || a.attrs[ai].reduce == pstk::VX_MOST_COMMON_BOOL;
+  for (uint64_t grp = wave0; grp < n_groups; grp += n_waves) {
+    // ---- phase 1: lane l owns voxel 64*grp + l; averages and max-pools of small voxels ----
+    const uint64_t lv = grp * 64 + lane;
+    uint32_t lm = 0;
+    uint64_t ls = 0;
+    if (lv < a.n_voxels) { ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); }
+    const bool small = lm != 0 && lm <= kSmallVoxel;
+    if (small) {
+      for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+        const VoxelAttr& at = a.attrs[ai];
+        if (at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM || at.reduce == pstk::VX_MAX_POOL)
+          reduce_voxel_by_lane(at, a.sorted_idx + ls, lm, a.dst_first + lv);
+      }
+    }
+    // ---- phase 2: the wave walks the voxels that still need it: most-common attributes, and everything of large voxels ----
+    uint64_t todo = __ballot(lm != 0 && (any_mode || !small));
+    while (todo) {
+      const uint32_t vl = (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      const uint64_t v = grp * 64 + vl;
+      const uint64_t s = a.starts[v];
+      const uint32_t m = (uint32_t)(a.starts[v + 1] - s);  // n < 2^32
+      const bool by_lane_done = m <= kSmallVoxel;
+      const uint32_t* idx = a.sorted_idx + s;
+      const uint64_t out = a.dst_first + v;
+      if (m > kMidVoxel && lane == 0) a.big_list[atomicAdd(a.big_count, 1u)] = (uint32_t)v;
+      for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+        const VoxelAttr& at = a.attrs[ai];
+        if (at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM) {
+          if (by_lane_done) continue;
+          const uint32_t nc = at.reduce == pstk::VX_AVG_VEC ? 3u : 1u, sk = scalar_of(at.kind);
+          double sum0 = 0.0, sum1 = 0.0, sum2 = 0.0;
+          for (uint32_t b = 0; b < m; b += 64) {
+            const uint32_t cnt = m - b < 64u ? m - b : 64u;
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            if (lane < cnt) {
+              const uint64_t i = idx[b + lane];
+              x0 = load_as_f64(at, sk, i, 0);
+              if (nc == 3) { x1 = load_as_f64(at, sk, i, 1); x2 = load_as_f64(at, sk, i, 2); }
             }
-            if (valid) { const uint64_t k = mode_key(count, x); best = k > best ? k : best; }
+            // the reference's loop: x_sum += v.x; ... one point after the other (:343-376, :400-431)
+            if (nc == 3) {
+              for (uint32_t j = 0; j < cnt; ++j) { sum0 += wave_bcast_f64(x0, j); sum1 += wave_bcast_f64(x1, j); sum2 += wave_bcast_f64(x2, j); }
+            } else {
+              for (uint32_t j = 0; j < cnt; ++j) sum0 += wave_bcast_f64(x0, j);
+            }
           }
+          if (lane == 0) {
+            const double np = (double)m;
+            gptr_t d = as_global(at.dst) + out * at.dst_stride;
+            const double a0 = sum0 / np, a1 = sum1 / np, a2 = sum2 / np;
+            if (at.reduce == pstk::VX_AVG_NUM) {
+              store_un<uint16_t>(d, rust_as<uint16_t, double>(a0));  // `as u16` :489, :638
+            } else if (at.kind == 14) {
+              store_un<double>(d, a0); store_un<double>(d + 8, a1); store_un<double>(d + 16, a2);
+            } else if (at.kind == 11) {  // ColorRGB :626
+              store_un<uint16_t>(d, rust_as<uint16_t, double>(a0)); store_un<uint16_t>(d + 2, rust_as<uint16_t, double>(a1));
+              store_un<uint16_t>(d + 4, rust_as<uint16_t, double>(a2));
+            } else {  // Normal :676
+              store_un<float>(d, (float)a0); store_un<float>(d + 4, (float)a1); store_un<float>(d + 8, (float)a2);
+            }
+          }
+        } else if (at.reduce == pstk::VX_MAX_POOL) {
+          if (by_lane_done) continue;
+          const uint32_t sk = scalar_of(at.kind);
+          double cur = 0.0;  // :175
+          for (uint32_t j = lane; j < m; j += 64) {
+            const double x = load_as_f64(at, sk, idx[j], 0);
+            if (x > cur) cur = x;
+          }
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const double o = shfl_xor_any(cur, off);
+            if (o > cur) cur = o;
+          }
+          if (lane == 0) {
+            gptr_t d = as_global(at.dst) + out * at.dst_stride;
+            if (at.kind == 9) store_un<double>(d, cur);
+            else if (at.kind == 6) store_un<uint64_t>(d, rust_as<uint64_t, double>(cur));
+            else store_un<uint8_t>(d, rust_as<uint8_t, double>(cur));
+          }
+        } else {  // most common
+          if (m > kMidVoxel) continue;  // voxel_mode_big_kernel
+          uint64_t best = 0;
+          if (m <= 64) {
+            const bool valid = lane < m;
+            const int32_t x = valid ? load_as_int(at, idx[lane]) : 0;
+            const uint64_t vmask = __ballot(valid);
+            uint64_t same = vmask;
+            const uint32_t ux = (uint32_t)(x + 32768);
+#pragma unroll
+            for (int bit = 0; bit < 17; ++bit) {
+              const bool b1 = (ux >> bit) & 1u;
+              const uint64_t bal = __ballot(b1);
+              same &= b1 ? bal : ~bal;
+            }
+            if (valid) best = mode_key((uint32_t)__builtin_popcountll(same & vmask), x);
+          } else {
+            for (uint32_t ca = 0; ca < m; ca += 64) {  // candidates
+              const bool valid = ca + lane < m;
+              const int32_t x = valid ? load_as_int(at, idx[ca + lane]) : 0;
+              uint32_t count = 0;
+              for (uint32_t cb = 0; cb < m; cb += 64) {
+                const uint32_t cnt = m - cb < 64u ? m - cb : 64u;
+                const int32_t w = cb + lane < m ? load_as_int(at, idx[cb + lane]) : 0;
+                for (uint32_t j = 0; j < cnt; ++j) count += (x == __builtin_amdgcn_readlane(w, (int)j)) ? 1u : 0u;
+              }
+              if (valid) { const uint64_t k = mode_key(count, x); best = k > best ? k : best; }
+            }
+          }
+          best = wave_max_u64(best);
+          if (lane == 0) store_mode(at, out, mode_value(best));
         }
-        best = wave_max_u64(best);
-        if (lane == 0) store_mode(at, out, mode_value(best));
       }
     }
   }
@@ -357,7 +421,7 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
     a.attrs[i] = VoxelAttr{src_addr[i], dst_addr[i], src_stride[i], dst_stride[i], reduce[i], kind[i]};
     any_mode = any_mode || reduce[i] == VX_MOST_COMMON || reduce[i] == VX_MOST_COMMON_BOOL;
   }
-  const uint64_t waves_needed = st->n_voxels;
+  const uint64_t waves_needed = (st->n_voxels + 63) / 64;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, (uint64_t)device_cus() * 32));
   hipLaunchKernelGGL(voxel_reduce_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
   if (any_mode && st->n > kMidVoxel) {
