@@ -44,6 +44,13 @@ typedef const PST_AS_LDS uint8_t* clptr_t;
 
 __device__ __forceinline__ gptr_t as_global(uint64_t addr) { return (gptr_t)addr; }
 
+// XCD-aware logical workgroup id.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+// L2), so with tile = blockIdx every XCD touches every eighth tile of a stream.  Numbering the tiles (b % 8) * (G / 8) + b / 8
+// instead gives each XCD one contiguous eighth of the range: +2-5 % on the Vec3f64 stream kernel and +4 % on interleaved ->
+// columnar tiles, but -1..-4 % on the column, encoder, decoder and columnar -> interleaved kernels (same-box A/B) — applied selectively.  The host rounds the
+// grid G up to a multiple of 8; callers skip logical ids beyond their tile count.
+__device__ __forceinline__ uint32_t xcd_block_id() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
 // Unaligned typed access (packed(1) layouts have no natural alignment: Vec3f64 at offset 14, u16 at odd offsets).
 // gfx950 executes unaligned global and LDS accesses natively, so align-1 accesses stay single instructions.
 template <typename T>

@@ -57,6 +57,7 @@ struct StreamParams {
   double scale[3];
   double offset[3];
   double* partials;    // [gridDim.x][6] = {min xyz, max xyz}
+  uint32_t xcd_chunk;  // 0 = tile = blockIdx; else tiles per XCD: workgroups are dealt round-robin to the 8 XCDs, tile = (b % 8) * xcd_chunk + b / 8
 };
 
 // generic strided min/max

@@ -21,6 +21,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 using namespace pstd;
 
@@ -82,7 +83,15 @@ __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamPara
   };
 
   const uint64_t n_tiles = (p.n_vec + kTileVec - 1) / kTileVec;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // XCD-aware tile numbering (one tile per block): consecutive workgroup ids land on different XCDs, so without it every XCD
+  // touches every eighth tile of the stream; with it each XCD streams one contiguous eighth of the range.
+  uint64_t tile0 = blockIdx.x;
+  if (p.xcd_chunk) {
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    tile0 = (uint64_t)xcd * p.xcd_chunk + k;
+    if (tile0 >= n_tiles) tile0 = n_tiles;  // the up to seven surplus blocks still write their (identity) partial record
+  }
+  for (uint64_t tile = tile0; tile < n_tiles; tile += gridDim.x) {
     const uint64_t base = tile * kTileVec + t;
     if ((tile + 1) * (uint64_t)kTileVec <= p.n_vec) {
       f64x2 v[kLoads];
@@ -273,10 +282,15 @@ int stream_grid() { return device_cus() * 4; }
 int reduce_grid() { return device_cus() * 8; }
 size_t minmax_partials_bytes() { return (size_t)(reduce_grid() + kFoldBlocks) * 6 * sizeof(double); }
 
+static bool stream_xcd_aware() {
+  static const bool on = [] { const char* v = std::getenv("PST_STREAM_XCD"); return !(v && *v == '0'); }();  // on by default: +2-5 % on the fused convert + AABB (same-box A/B)
+  return on;
+}
 static uint64_t stream_launch_grid(uint64_t n_points, unsigned mode) {
   const uint64_t n_vec = (3 * n_points) / 2;
   const uint64_t n_tiles = std::max<uint64_t>(1, (n_vec + kStreamTileVec - 1) / kStreamTileVec);
-  return (mode & 2u) ? n_tiles : std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
+  if (mode & 2u) return stream_xcd_aware() ? 8 * ((n_tiles + 7) / 8) : n_tiles;
+  return std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
 }
 size_t stream_partials_bytes(uint64_t n_points, unsigned mode) {
   return (size_t)(stream_launch_grid(n_points, mode) + kFoldBlocks) * 6 * sizeof(double);
@@ -296,6 +310,7 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
   for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
   p.partials = partials;
   const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
+  p.xcd_chunk = (write && stream_xcd_aware()) ? grid / 8u : 0u;
 #define PST_STREAM(A, W, B) \
   hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p)
   switch (mode & 7u) {
