@@ -276,7 +276,7 @@ namespace pstk {
 //  * read-only AABB: persistent grid of 4 blocks per CU, 6 loads in flight per lane  -> ~7.1 TB/s (8 blocks/CU: 6.0 TB/s)
 //  * any mode that writes: ONE tile per block (non-persistent)                       -> ~5.9 TB/s (persistent: 5.45 TB/s);
 //    staggered block start times keep reads and writes interleaved at the memory controllers.
-constexpr int kStreamLoads = 6;
+constexpr int kStreamLoads = 6;  // re-checked under XCD-aware numbering: 3 loads 4.9 TB/s, 6 and 12 equal (6.1-6.2), 9 slightly lower
 constexpr int kStreamTileVec = kStreamLoads * kBlock;
 int stream_grid() { return device_cus() * 4; }
 int reduce_grid() { return device_cus() * 8; }
@@ -310,7 +310,7 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
   for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
   p.partials = partials;
   const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
-  p.xcd_chunk = (write && stream_xcd_aware()) ? grid / 8u : 0u;
+  p.xcd_chunk = (write && stream_xcd_aware()) ? grid / 8u : 0u;  // the read-only persistent grid loses 1.5 % with it
 #define PST_STREAM(A, W, B) \
   hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p)
   switch (mode & 7u) {
