@@ -492,10 +492,13 @@ __global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __r
   write_result(out, orig, f);
 }
 
+// stream-ordered allocations from the device's default pool (release threshold raised by buffer.cpp): hipMalloc / hipFree of
+// gigabytes synchronise the device and cost milliseconds per call
 struct DevBuf {
   void* p = nullptr;
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipStream_t s = nullptr;
+  hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return hipMallocAsync(&p, bytes ? bytes : 16, stream); }
+  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
   template <typename T> T* as() { return (T*)p; }
 };
 
@@ -511,9 +514,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   const unsigned cus = (unsigned)device_cus();
   const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
   DevBuf xyz, partials, counters;
-  NCK(xyz.alloc(n * 24));
-  NCK(partials.alloc((size_t)sgrid * 48));
-  NCK(counters.alloc(64));
+  NCK(xyz.alloc(n * 24, stream));
+  NCK(partials.alloc((size_t)sgrid * 48, stream));
+  NCK(counters.alloc(64, stream));
   NCK(hipMemsetAsync(counters.p, 0, 64, stream));
   hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, xyz.as<double>(), partials.as<double>());
   std::vector<double> hp((size_t)sgrid * 6);
@@ -574,14 +577,14 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     int key_bits = 64;
     if (dense) { key_bits = 1; while (key_bits < 63 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells
     DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp;
-    NCK(keys.alloc(n * 8)); NCK(keys2.alloc(n * 8)); NCK(idx.alloc(n * 4)); NCK(idx2.alloc(n * 4)); NCK(sorted_xyz.alloc(n * 24));
+    NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream)); NCK(sorted_xyz.alloc(n * 24, stream));
     unsigned long long* n_finite = (unsigned long long*)counters.p;
     unsigned long long* n_cells = n_finite + 1;
     hipLaunchKernelGGL(keys_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
     size_t tmp_bytes = 0;
     NCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
                                            (int)n, 0, key_bits, stream));
-    NCK(tmp.alloc(tmp_bytes));
+    NCK(tmp.alloc(tmp_bytes, stream));
     NCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
                                            (int)n, 0, key_bits, stream));
     hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
@@ -592,7 +595,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     DevBuf tkeys, tstarts, directory;
     CellTable table{nullptr, nullptr, 0};
     if (dense) {
-      NCK(directory.alloc((cells + 2) * 4));
+      NCK(directory.alloc((cells + 2) * 4, stream));
       hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, cells, directory.as<uint32_t>());
     } else {
       hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
@@ -600,7 +603,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       NCK(hipStreamSynchronize(stream));
       uint64_t cap = 64;
       while (cap < 2 * h_counts[1]) cap <<= 1;
-      NCK(tkeys.alloc(cap * 8)); NCK(tstarts.alloc(cap * 4));
+      NCK(tkeys.alloc(cap * 8, stream)); NCK(tstarts.alloc(cap * 4, stream));
       NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
       table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
       hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
