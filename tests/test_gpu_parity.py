@@ -6,6 +6,7 @@ import pytest
 
 from harness import BUFFER_KINDS, PAIRINGS
 from pasture_amd import las
+from pasture_amd._capi import PasturePanic
 from pasture_amd.algorithms import calculate_bounds, transform_attribute
 from pasture_amd.buffers import HashMapBuffer, VectorBuffer
 from pasture_amd.conversion import BufferLayoutConverter, Transform
@@ -647,3 +648,70 @@ def test_random_filter_append_vs_oracle(hip, oracle, seed):
     assert hn == on
     for k in oc:
         assert hc[k].tobytes() == oc[k].tobytes(), k
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_las_round_trips_vs_oracle(hip, oracle, seed):
+    """Differential fuzzing of the LAS pipeline: random point format, sizes around the tile boundaries, random scale / offset and
+    range offsets, both storage kinds: decode (raw -> typed) and encode (typed -> raw) byte-identical to the oracle."""
+    def run(api):
+        rng = np.random.default_rng(5000 + seed)
+        fmt = int(rng.integers(0, 11))
+        n = int(rng.choice([1, 5, 1023, 1024, 1025, 2048, 4099, 30_001]))
+        pad = int(rng.integers(0, 4))
+        scale = tuple(float(x) for x in rng.choice([0.001, 0.01, 0.25, 1.0], 3))
+        offset = tuple(float(x) for x in rng.uniform(-1e6, 1e6, 3))
+        raw = las.point_layout_from_las_point_format(las.Format(fmt), True, api=api)
+        typed = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+        src = VectorBuffer.new_from_layout(raw)
+        src.resize(n + pad)
+        src.synth_fill(seed, 3)
+        kind = "VH"[rng.integers(0, 2)]
+        dec = BUFFER_KINDS[kind].new_from_layout(typed)
+        dec.resize(n + 2 * pad)
+        conv = las.get_default_las_converter(raw, typed, scale, offset)
+        conv.convert_into_range(src, range(pad, pad + n), dec, range(2 * pad, 2 * pad + n))
+        decoded = dec.get_point_range(range(0, n + 2 * pad)).tobytes()
+        # encode the decoded points again (whole buffer, incl. the untouched zero points at the front)
+        enc = VectorBuffer.new_from_layout(raw)
+        enc.resize(n + 2 * pad + 1)
+        hb = [float(x) for x in rng.uniform(-10, 10, 6)]
+        ok = True
+        try:
+            bounds, counts = las.encode_points(dec, fmt, scale, offset, enc, target_first=1, header_bounds=hb, max_return=int(rng.choice([5, 15])))
+        except PasturePanic as e:  # zero points far from `offset` may not fit an i32 at a small scale: both sides must panic
+            ok, bounds, counts = False, str(e)[:40], None
+        encoded = enc.get_point_range(range(0, n + 2 * pad + 1)).tobytes() if ok else b""
+        return decoded, ok, bounds, counts, encoded
+    h, o = both(run, hip, oracle)
+    assert h[0] == o[0]
+    assert h[1:4] == o[1:4]
+    assert h[4] == o[4]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_voxelgrid_vs_oracle(hip, oracle, seed):
+    """Differential fuzzing of voxelgrid_filter: random subsets of the supported attributes in random order, packed or repr(C)
+    layouts, both storage kinds for source and target, anisotropic leaf sizes from 'every point its own voxel' to 'one voxel'."""
+    from pasture_amd.algorithms import voxelgrid_filter
+    supported = [A.INTENSITY, A.RETURN_NUMBER, A.NUMBER_OF_RETURNS, A.CLASSIFICATION_FLAGS, A.SCANNER_CHANNEL, A.SCAN_DIRECTION_FLAG,
+                 A.EDGE_OF_FLIGHT_LINE, A.CLASSIFICATION, A.SCAN_ANGLE_RANK, A.SCAN_ANGLE, A.USER_DATA, A.POINT_SOURCE_ID, A.COLOR_RGB, A.GPS_TIME,
+                 A.NIR, A.POINT_ID, A.NORMAL]
+
+    def run(api):
+        rng = np.random.default_rng(9000 + seed)
+        pick = [supported[i] for i in rng.permutation(len(supported))[: int(rng.integers(0, len(supported) + 1))]]
+        attrs = pick[: len(pick) // 2] + [A.POSITION_3D] + pick[len(pick) // 2:]
+        layout = PointLayout.from_attributes(attrs, api=api) if rng.random() < 0.5 else PointLayout.from_attributes_packed(attrs, 1, api=api)
+        n = int(rng.choice([1, 2, 65, 1000, 4097, 30_000]))
+        src = BUFFER_KINDS["VH"[rng.integers(0, 2)]].new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(seed, 0)  # x, y in [0, 1000), z in [0, 100)
+        leaf = tuple(float(x) for x in rng.choice([3.0, 40.0, 250.0, 2000.0], 3))
+        out = BUFFER_KINDS["VH"[rng.integers(0, 2)]].new_from_layout(layout)
+        out.resize(int(rng.integers(0, 3)))
+        voxelgrid_filter(src, *leaf, out)
+        return out.len(), out.get_point_range(range(0, out.len())).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h[0] == o[0]
+    assert h[1] == o[1]
