@@ -39,6 +39,7 @@ WORKLOADS = {
     "las0_to_columns_bounds": (70, "AoS LAS format-0 -> 10 SoA columns + AABB of the result, fused (35 R + 35 W)"),
     "rawlas_to_columns": (55, "raw LAS-0 records (20 B) -> 10 SoA columns, i32->f64 affine + bit fields (20 R + 35 W)"),
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
+    "rawlas_to_records": (55, "raw LAS-0 records (20 B) -> interleaved typed LAS-0 records (VectorBuffer of LasPointFormat0, 35 B): 20 R + 35 W"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
     "las0_encode": (55, "LAS writer: 10 SoA columns (typed LAS-0) -> raw LAS-0 records + header AABB + per-return counts, fused (35 R + 20 W)"),
     "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
@@ -235,6 +236,20 @@ def main():
         def step():
             out = pa.HashMapBuffer.new_from_layout(layout)
             pa.voxelgrid_filter(src, 2.5, 2.5, 2.5, out)
+    elif args.workload == "rawlas_to_records":
+        src_layout = las.point_layout_from_las_point_format(las.Format(0), True)
+        dst_layout = las.point_layout_from_las_point_format(las.Format(0), False)
+        src = pa.VectorBuffer.new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.VectorBuffer.new_from_layout(dst_layout)
+        dst.resize(n)
+        conv = las.get_default_las_converter(src_layout, dst_layout, SCALE, OFFSET)
+        conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+        pa.calculate_bounds_async(dst, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)

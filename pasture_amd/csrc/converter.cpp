@@ -227,12 +227,20 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
 
   std::vector<PlanEntry> generic;
   static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
-  if (las_fast && n > 0 && !src.columnar && dst.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
-  if (las_fast && n > 0 && !src.columnar && dst.columnar && c.las_decode_format >= 0) {
+  if (las_fast && n > 0 && !src.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
+  if (las_fast && n > 0 && !src.columnar && c.las_decode_format >= 0) {
     // the production plan of the LAS readers: format-specialised kernel (las_decode.hip)
     const Mapping* pos = nullptr;
     for (const Mapping& m : c.mappings)
       if (m.target.def.name == "Position3D") pos = &m;
+    if (!dst.columnar) {  // VectorBuffer of LasPointFormatN: one lane per point, records assembled in LDS
+      const unsigned grid = pstk::las_decode_aos_grid(c.las_decode_format, n);
+      double* partials = bounds_out6 ? (double*)workspace().partials(pstk::bounds_partials_bytes(grid)) : nullptr;
+      if (!pstk::launch_las_decode_aos(c.las_decode_format, aos_addr(src, s0), aos_addr(dst, t0), n, pos->xf->scale, pos->xf->offset, partials, stream))
+        throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
+      if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
+      return;
+    }
     std::vector<uint64_t> cols(c.to.members.size());
     for (size_t a = 0; a < cols.size(); ++a) cols[a] = col_addr(dst, a, t0);
     double* partials = nullptr;

@@ -69,6 +69,9 @@ bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* at
 unsigned las_decode_grid(uint64_t n);
 bool launch_las_decode(int format, uint64_t src, uint64_t n, const uint64_t* dst_cols, int n_cols, const double scale[3], const double offset[3],
                        double* partials, hipStream_t stream);
+unsigned las_decode_aos_grid(int format, uint64_t n);
+bool launch_las_decode_aos(int format, uint64_t src, uint64_t dst, uint64_t n, const double scale[3], const double offset[3], double* partials,
+                           hipStream_t stream);
 
 // predicate compaction (filter.hip)
 size_t filter_workspace_bytes(uint64_t n);

@@ -251,6 +251,106 @@ __device__ __forceinline__ void decode_point(const DecodeArgs& a, uint64_t i, cl
   }
 }
 
+// ---- interleaved typed target (VectorBuffer of LasPointFormatN): one lane per point -------------------------------------
+// The typed record (packed, las_types.rs) is assembled in registers at compile-time offsets and written to an LDS record tile
+// with dword stores; the tile leaves with 16-byte stores.  Source records come from the LDS-DMA staged tile as aligned dwords.
+template <int NB>
+struct RecordImage {
+  uint32_t w[(NB + 3) / 4 + 1] = {};
+  __device__ __forceinline__ void put(int off, int nbytes, uint64_t v) {  // v zero-extended to 8 bytes
+    const int wi = off >> 2, sh = (off & 3) * 8;
+    w[wi] |= (uint32_t)(v << sh);
+    if (sh + 8 * nbytes > 32) w[wi + 1] |= (uint32_t)(sh == 0 ? (v >> 32) : (v >> (32 - sh)));
+    if (sh + 8 * nbytes > 64) w[wi + 2] |= (uint32_t)(v >> (64 - sh));
+  }
+  __device__ __forceinline__ void store(lptr_t p) const {
+    int k = 0;
+#pragma unroll
+    for (; 4 * k + 4 <= NB; ++k) store_un<uint32_t>(p + 4 * k, w[k]);
+    if (NB - 4 * k >= 2) { store_un<uint16_t>(p + 4 * k, (uint16_t)w[k]); if (NB - 4 * k == 3) store_un<uint8_t>(p + 4 * k + 2, (uint8_t)(w[k] >> 16)); }
+    else if (NB - 4 * k == 1) store_un<uint8_t>(p + 4 * k, (uint8_t)w[k]);
+  }
+};
+
+struct DecodeAosArgs {
+  uint64_t src, dst;  // raw record 0 of the source range / typed record 0 of the target range
+  uint64_t n;
+  double scale[3], offset[3];
+  double* partial_bounds;
+  uint32_t tile;
+};
+
+template <int FORMAT>
+__global__ __launch_bounds__(kBlock) void las_decode_aos_kernel(const DecodeAosArgs a) {
+  constexpr Fmt F = fmt_of(FORMAT);
+  constexpr uint32_t RS = raw_size(F), TS = typed_size(F);
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  lptr_t lds_src = (lptr_t)lds_raw;
+  lptr_t lds_dst = lds_src + round_up16(a.tile * RS + 32u);
+  double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  const uint64_t n_tiles = (a.n + a.tile - 1) / a.tile;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t first = tile * a.tile;
+    const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
+    const uint64_t sa = a.src + first * RS, da = a.dst + first * TS;
+    const uint32_t smis = (uint32_t)(sa & 15u), dmis = (uint32_t)(da & 15u);
+    tile_load<kBlock>(lds_src, as_global(sa - smis), round_up16(smis + cnt * RS));
+    wait_tile_loads();
+    __syncthreads();
+    for (uint32_t lp = threadIdx.x; lp < cnt; lp += kBlock) {
+      const LdsBytes<RS> rec(lds_src + (smis + lp * RS));
+      RecordImage<TS> out;
+      int o = 0, t = 0;  // raw cursor, typed cursor
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int32_t raw = (int32_t)(uint32_t)rec.at(4 * c);
+        const double m = (double)raw * a.scale[c];  // (pos as f64 * scale) + offset, raw_readers.rs:42-48
+        const double w = m + a.offset[c];
+        out.put(8 * c, 8, __builtin_bit_cast(uint64_t, w));
+        mn[c] = __builtin_fmin(mn[c], w);
+        mx[c] = __builtin_fmax(mx[c], w);
+      }
+      o = 12; t = 24;
+      out.put(t, 2, rec.at(o) & 0xFFFFull); o += 2; t += 2;  // intensity
+      if constexpr (F.ext) {
+        const uint32_t g0 = (uint32_t)rec.at(o) & 255u, g1 = (uint32_t)rec.at(o + 1) & 255u;
+        o += 2;
+        out.put(t, 1, g0 & 15u); out.put(t + 1, 1, g0 >> 4); out.put(t + 2, 1, g1 & 15u); out.put(t + 3, 1, (g1 >> 4) & 3u);
+        out.put(t + 4, 1, (g1 >> 6) & 1u); out.put(t + 5, 1, g1 >> 7);
+        t += 6;
+      } else {
+        const uint32_t g = (uint32_t)rec.at(o) & 255u;
+        o += 1;
+        out.put(t, 1, g & 7u); out.put(t + 1, 1, (g >> 3) & 7u); out.put(t + 2, 1, (g >> 6) & 1u); out.put(t + 3, 1, g >> 7);
+        t += 4;
+      }
+      // classification, (user data, scan angle) / (scan angle rank, user data), point source id: same order and sizes on both sides
+      constexpr int kMid = F.ext ? 6 : 5;
+      out.put(t, kMid, rec.at(o) & ((1ull << (8 * kMid)) - 1ull)); o += kMid; t += kMid;
+      // GPS time, colour, NIR, waveform: identical bytes
+      constexpr int kTail = (F.gps ? 8 : 0) + (F.color ? 6 : 0) + (F.nir ? 2 : 0) + (F.wave ? 29 : 0);
+#pragma unroll
+      for (int b = 0; b < kTail; b += 8) {
+        const int nb = kTail - b < 8 ? kTail - b : 8;
+        const uint64_t v = rec.at(o + b);
+        out.put(t + b, nb, nb == 8 ? v : (v & ((1ull << (8 * nb)) - 1ull)));
+      }
+      out.store(lds_dst + (dmis + lp * TS));
+    }
+    __syncthreads();
+    tile_store<kBlock>(lds_dst, as_global(da - dmis), dmis, cnt * TS);
+    __syncthreads();
+  }
+  if (a.partial_bounds) {
+    __shared__ double scratch[(kBlock / 64) * 6];
+    block_reduce_minmax<double, 3>(mn, mx, scratch);
+    if (threadIdx.x == 0) {
+      double* o6 = a.partial_bounds + (uint64_t)blockIdx.x * 6;
+      o6[0] = mn[0]; o6[1] = mn[1]; o6[2] = mn[2]; o6[3] = mx[0]; o6[4] = mx[1]; o6[5] = mx[2];
+    }
+  }
+}
+
 template <int FORMAT>
 __global__ __launch_bounds__(kBlock) void las_decode_kernel(const DecodeArgs a) {
   constexpr uint32_t RS = raw_size(fmt_of(FORMAT));
@@ -308,6 +408,43 @@ bool launch_las_decode(int format, uint64_t src, uint64_t n, const uint64_t* dst
     (void)attr;                                                                                                                             \
     hipLaunchKernelGGL((las_decode_kernel<N>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                                            \
     break;                                                                                                                                  \
+  }
+  switch (format) {
+    PST_DEC(0) PST_DEC(1) PST_DEC(2) PST_DEC(3) PST_DEC(4) PST_DEC(5) PST_DEC(6) PST_DEC(7) PST_DEC(8) PST_DEC(9) PST_DEC(10)
+    default: return false;
+  }
+#undef PST_DEC
+  return hipGetLastError() == hipSuccess;
+}
+
+
+static uint32_t las_decode_aos_tile(int format) {
+  const uint32_t per_point = raw_size(fmt_of(format)) + typed_size(fmt_of(format));
+  return std::max<uint32_t>(kBlock, ((48u * 1024u) / per_point) / kBlock * kBlock);
+}
+unsigned las_decode_aos_grid(int format, uint64_t n) {
+  const uint32_t tile = las_decode_aos_tile(format);
+  return (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, (n + tile - 1) / tile), 16384);
+}
+// raw records -> interleaved typed records (VectorBuffer of LasPointFormatN)
+bool launch_las_decode_aos(int format, uint64_t src, uint64_t dst, uint64_t n, const double scale[3], const double offset[3], double* partials,
+                           hipStream_t stream) {
+  DecodeAosArgs a{};
+  a.src = src;
+  a.dst = dst;
+  a.n = n;
+  for (int c = 0; c < 3; ++c) { a.scale[c] = scale[c]; a.offset[c] = offset[c]; }
+  a.partial_bounds = partials;
+  a.tile = las_decode_aos_tile(format);
+  const unsigned grid = las_decode_aos_grid(format, n);
+  const Fmt f = fmt_of(format);
+  const size_t lds_bytes = (((size_t)a.tile * raw_size(f) + 32 + 15) & ~(size_t)15) + (size_t)a.tile * typed_size(f) + 64;
+#define PST_DEC(N)                                                                                                                              \
+  case N: {                                                                                                                                     \
+    static const hipError_t attr = hipFuncSetAttribute((const void*)las_decode_aos_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    (void)attr;                                                                                                                                 \
+    hipLaunchKernelGGL((las_decode_aos_kernel<N>), dim3(grid), dim3(kBlock), lds_bytes, stream, a);                                            \
+    break;                                                                                                                                      \
   }
   switch (format) {
     PST_DEC(0) PST_DEC(1) PST_DEC(2) PST_DEC(3) PST_DEC(4) PST_DEC(5) PST_DEC(6) PST_DEC(7) PST_DEC(8) PST_DEC(9) PST_DEC(10)
