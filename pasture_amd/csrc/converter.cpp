@@ -69,6 +69,7 @@ struct pst_converter {
   // plan recognition cache for the specialised LAS record decoder (las_decode.hip): -2 = not examined yet, -1 = generic plan,
   // 0..10 = "raw LAS records of this format -> its typed default layout with the mappings of get_default_las_converter"
   mutable int las_decode_format = -2;
+  mutable int identity_records = -2;  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
 };
 
 namespace pst {
@@ -163,6 +164,22 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
   }
 }
 
+// Identity between two buffers of the same layout in which the mappings cover every byte of the record (no padding, no
+// unmapped attribute): interleaved -> interleaved is then a plain byte copy of the records (what the reference's per-attribute
+// loops add up to, buffer_conversion.rs:606-662).
+static bool match_identity_records(const pst_converter& c) {
+  if (!(c.from == c.to) || c.mappings.size() != c.to.members.size()) return false;
+  uint64_t covered = 0;
+  std::vector<uint8_t> seen(c.to.members.size(), 0);
+  for (const Mapping& m : c.mappings) {
+    const int tslot = c.to.index_of(m.target.def), sslot = c.from.index_of(m.source.def);
+    if (tslot < 0 || tslot != sslot || seen[(size_t)tslot] || m.xf || m.has_converter) return false;
+    seen[(size_t)tslot] = 1;
+    covered += m.target.size;
+  }
+  return covered == c.to.size;
+}
+
 // Is this converter exactly the plan get_default_las_converter (raw_readers.rs:31-167) builds for (raw records of format N ->
 // LasPointFormatN::layout())?  Then las_decode.hip runs it with the format as a compile-time parameter.
 static int match_las_decode_plan(const pst_converter& c) {
@@ -225,6 +242,19 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   }
   bool bounds_done = false;
 
+  if (n > 0 && !src.columnar && !dst.columnar && !bounds_out6) {
+    if (c.identity_records == -2) c.identity_records = match_identity_records(c) ? 1 : 0;
+    if (c.identity_records == 1) {  // one wide-vector byte copy of the record range (columns.hip)
+      PlanEntry e{};
+      e.src_col = aos_addr(src, s0);
+      e.dst_col = aos_addr(dst, t0);
+      e.src_size = e.dst_size = (uint32_t)c.to.size;
+      e.ncomp = 1;
+      if (!pstk::launch_column(e, n, nullptr, stream))
+        throw Error(PST_ERR_HIP, std::string("record copy launch failed: ") + hipGetErrorString(hipGetLastError()));
+      return;
+    }
+  }
   std::vector<PlanEntry> generic;
   static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
@@ -313,6 +343,7 @@ static AttributeDef def_from(const char* name, const pst_datatype* dt) { return 
 
 static void install_mapping(pst_converter& c, Mapping&& m, const AttributeDef& to_attribute) {
   c.las_decode_format = -2;
+  c.identity_records = -2;
   for (auto& prev : c.mappings)
     if (prev.target.def == to_attribute) { prev = std::move(m); return; }  // replace the mapping for this target (:168-176)
   c.mappings.push_back(std::move(m));
