@@ -69,7 +69,8 @@ struct pst_converter {
   // plan recognition cache for the specialised LAS record decoder (las_decode.hip): -2 = not examined yet, -1 = generic plan,
   // 0..10 = "raw LAS records of this format -> its typed default layout with the mappings of get_default_las_converter"
   mutable int las_decode_format = -2;
-  mutable int identity_records = -2;  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
+  mutable int identity_records = -2;
+  mutable int las_typed_format = -2;  // -2 not examined, -1 no, 0..10: identity plan over LasPointFormatN::layout() (las_transpose.hip)  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
 };
 
 namespace pst {
@@ -255,8 +256,27 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       return;
     }
   }
-  std::vector<PlanEntry> generic;
   static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
+  if (las_fast && n > 0 && src.columnar != dst.columnar) {
+    if (c.las_typed_format == -2) {
+      c.las_typed_format = -1;
+      if (match_identity_records(c))
+        for (uint32_t f = 0; f <= 10; ++f)
+          if (c.to == laslayout::typed_layout(f)) { c.las_typed_format = (int)f; break; }
+    }
+    if (c.las_typed_format >= 0) {  // typed LAS points, columns <-> packed records: format-specialised transposition
+      const pst_buffer& soa = src.columnar ? src : dst;
+      const size_t p0 = src.columnar ? s0 : t0;
+      std::vector<uint64_t> cols(c.to.members.size());
+      for (size_t a = 0; a < cols.size(); ++a) cols[a] = col_addr(soa, a, p0);
+      const uint64_t aos = src.columnar ? aos_addr(dst, t0) : aos_addr(src, s0);
+      if (!pstk::launch_las_transpose(c.las_typed_format, src.columnar, aos, cols.data(), (int)cols.size(), n, stream))
+        throw Error(PST_ERR_HIP, std::string("LAS transposition launch failed: ") + hipGetErrorString(hipGetLastError()));
+      if (bounds_out6) bounds_of_range(dst, t0, n, bounds_out6, stream);
+      return;
+    }
+  }
+  std::vector<PlanEntry> generic;
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format >= 0) {
     // the production plan of the LAS readers: format-specialised kernel (las_decode.hip)
@@ -344,6 +364,7 @@ static AttributeDef def_from(const char* name, const pst_datatype* dt) { return 
 static void install_mapping(pst_converter& c, Mapping&& m, const AttributeDef& to_attribute) {
   c.las_decode_format = -2;
   c.identity_records = -2;
+  c.las_typed_format = -2;
   for (auto& prev : c.mappings)
     if (prev.target.def == to_attribute) { prev = std::move(m); return; }  // replace the mapping for this target (:168-176)
   c.mappings.push_back(std::move(m));

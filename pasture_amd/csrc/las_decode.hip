@@ -33,56 +33,6 @@ struct DecodeArgs {
   double* partial_bounds;        // [grid][6] or null
 };
 
-// N bytes at an arbitrarily aligned LDS address as aligned dwords re-aligned in registers (r[0] = bytes 0..3, ...)
-template <int N>
-struct LdsBytes {
-  static constexpr int NW = (N + 3) / 4;
-  uint32_t r[NW + 2];
-  __device__ __forceinline__ explicit LdsBytes(clptr_t p) {
-    const uint32_t m = (uint32_t)(uintptr_t)p & 3u;
-    const PST_AS_LDS uint32_t* q = (const PST_AS_LDS uint32_t*)(p - m);
-    uint32_t d[NW + 1];
-#pragma unroll
-    for (int k = 0; k <= NW; ++k) d[k] = q[k];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) r[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], m);
-    r[NW] = 0; r[NW + 1] = 0;
-  }
-  __device__ __forceinline__ uint64_t at(int off) const {  // 8 bytes starting at byte `off` (compile-time after unrolling)
-    const int wi = off >> 2, sh = (off & 3) * 8;
-    const uint64_t lo = r[wi], mid = r[wi + 1], hi = r[wi + 2];
-    const uint64_t v = lo | (mid << 32);
-    return sh == 0 ? v : ((v >> sh) | (hi << (64 - sh)));
-  }
-};
-
-// The values of four consecutive points of a B-byte attribute, stored with as few vector stores as possible.
-template <int B>
-struct Pack4 {
-  uint32_t w[B] = {};
-  __device__ __forceinline__ void put_at(int off, int nbytes, uint64_t v) {  // v zero-extended
-    const int wi = off >> 2, sh = (off & 3) * 8;
-    w[wi] |= (uint32_t)(v << sh);
-    if (sh + 8 * nbytes > 32) w[wi + 1] |= (uint32_t)(sh == 0 ? (v >> 32) : (v >> (32 - sh)));
-    if (sh + 8 * nbytes > 64) w[wi + 2] |= (uint32_t)(v >> (64 - sh));
-  }
-  __device__ __forceinline__ void put(int t, uint64_t v) { put_at(t * B, B < 8 ? B : 8, B >= 8 ? v : (v & ((1ull << (8 * (B & 7))) - 1ull))); }
-  __device__ __forceinline__ void store(gptr_t dst) const {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    constexpr int K4 = B / 4 * 4, K2 = K4 + ((B - K4) >= 2 ? 2 : 0);
-#pragma unroll
-    for (int k = 0; k < K4; k += 4) {
-      u32x4 v; v.x = w[k]; v.y = w[k + 1]; v.z = w[k + 2]; v.w = w[k + 3];
-      __builtin_nontemporal_store(v, reinterpret_cast<PST_AS_GLOBAL Unaligned<u32x4>::type*>(dst + 4 * k));
-    }
-    if constexpr (K2 > K4) {
-      u32x2 v; v.x = w[K4]; v.y = w[K4 + 1];
-      __builtin_nontemporal_store(v, reinterpret_cast<PST_AS_GLOBAL Unaligned<u32x2>::type*>(dst + 4 * K4));
-    }
-    if constexpr (B > K2) __builtin_nontemporal_store(w[K2], reinterpret_cast<PST_AS_GLOBAL Unaligned<uint32_t>::type*>(dst + 4 * K2));
-  }
-};
-
 __device__ __forceinline__ uint32_t round_up16(uint32_t v) { return (v + 15u) & ~15u; }
 
 // one full tile: records staged at lds + smis, typed point index of the tile's first point = first
@@ -254,24 +204,6 @@ __device__ __forceinline__ void decode_point(const DecodeArgs& a, uint64_t i, cl
 // ---- interleaved typed target (VectorBuffer of LasPointFormatN): one lane per point -------------------------------------
 // The typed record (packed, las_types.rs) is assembled in registers at compile-time offsets and written to an LDS record tile
 // with dword stores; the tile leaves with 16-byte stores.  Source records come from the LDS-DMA staged tile as aligned dwords.
-template <int NB>
-struct RecordImage {
-  uint32_t w[(NB + 3) / 4 + 1] = {};
-  __device__ __forceinline__ void put(int off, int nbytes, uint64_t v) {  // v zero-extended to 8 bytes
-    const int wi = off >> 2, sh = (off & 3) * 8;
-    w[wi] |= (uint32_t)(v << sh);
-    if (sh + 8 * nbytes > 32) w[wi + 1] |= (uint32_t)(sh == 0 ? (v >> 32) : (v >> (32 - sh)));
-    if (sh + 8 * nbytes > 64) w[wi + 2] |= (uint32_t)(v >> (64 - sh));
-  }
-  __device__ __forceinline__ void store(lptr_t p) const {
-    int k = 0;
-#pragma unroll
-    for (; 4 * k + 4 <= NB; ++k) store_un<uint32_t>(p + 4 * k, w[k]);
-    if (NB - 4 * k >= 2) { store_un<uint16_t>(p + 4 * k, (uint16_t)w[k]); if (NB - 4 * k == 3) store_un<uint8_t>(p + 4 * k + 2, (uint8_t)(w[k] >> 16)); }
-    else if (NB - 4 * k == 1) store_un<uint8_t>(p + 4 * k, (uint8_t)w[k]);
-  }
-};
-
 struct DecodeAosArgs {
   uint64_t src, dst;  // raw record 0 of the source range / typed record 0 of the target range
   uint64_t n;

@@ -150,59 +150,6 @@ __device__ __forceinline__ void encode_point(const EncodeArgs& a, const Src& src
   }
 }
 
-// ---- columnar fast path: four consecutive points per lane ------------------------------------------------------------
-// A column of B-byte values is read as one 4*B-byte vector per lane (wave = 256 consecutive points, fully coalesced);
-// the words are then cut apart with compile-time shifts.  QuadCol<B>::w holds the 4 values of this lane's points.
-template <int B>
-struct QuadCol {
-  uint32_t w[B + 2];  // 4 * B bytes + two zero words so that bytes_at() needs no guards
-  __device__ __forceinline__ void load(cgptr_t p) {
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    w[B] = 0; w[B + 1] = 0;
-    constexpr int K4 = B / 4 * 4, K2 = K4 + ((B - K4) >= 2 ? 2 : 0);
-#pragma unroll
-    for (int k = 0; k < K4; k += 4) {
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<u32x4>::type*>(p + 4 * k));
-      w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
-    }
-    if constexpr (K2 > K4) {
-      const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<u32x2>::type*>(p + 4 * K4));
-      w[K4] = v.x; w[K4 + 1] = v.y;
-    }
-    if constexpr (B > K2) w[K2] = __builtin_nontemporal_load(reinterpret_cast<const PST_AS_GLOBAL Unaligned<uint32_t>::type*>(p + 4 * K2));
-  }
-  // up to 8 bytes starting at byte `off` of the 4*B-byte vector (compile-time `off` after unrolling)
-  __device__ __forceinline__ uint64_t bytes_at(int off) const {
-    const int wi = off >> 2, sh = (off & 3) * 8;
-    const uint64_t lo = w[wi], mid = w[wi + 1], hi = w[wi + 2];
-    const uint64_t v = lo | (mid << 32);
-    return sh == 0 ? v : ((v >> sh) | (hi << (64 - sh)));
-  }
-  __device__ __forceinline__ uint64_t value(int t) const {  // point t's B bytes (B <= 8), zero-extended
-    const uint64_t v = bytes_at(t * B);
-    return B >= 8 ? v : (v & ((1ull << (8 * (B & 7))) - 1ull));
-  }
-};
-
-// The non-position bytes of one record, assembled in registers at compile-time offsets and written with word stores.
-template <int NB>
-struct RecTail {
-  uint32_t w[(NB + 3) / 4] = {};
-  __device__ __forceinline__ void put(int off, int nbytes, uint64_t v) {  // v zero-extended to 8 bytes
-    const int wi = off >> 2, sh = (off & 3) * 8;
-    w[wi] |= (uint32_t)(v << sh);
-    if (sh + 8 * nbytes > 32) w[wi + 1] |= (uint32_t)(sh == 0 ? (v >> 32) : (v >> (32 - sh)));
-    if (sh + 8 * nbytes > 64) w[wi + 2] |= (uint32_t)(v >> (64 - sh));
-  }
-  __device__ __forceinline__ void store(lptr_t p) const {
-    int k = 0;
-#pragma unroll
-    for (; 4 * k + 4 <= NB; ++k) store_un<uint32_t>(p + 4 * k, w[k]);
-    if (NB - 4 * k >= 2) { store_un<uint16_t>(p + 4 * k, (uint16_t)w[k]); if (NB - 4 * k == 3) store_un<uint8_t>(p + 4 * k + 2, (uint8_t)(w[k] >> 16)); }
-    else if (NB - 4 * k == 1) store_un<uint8_t>(p + 4 * k, (uint8_t)w[k]);
-  }
-};
-
 constexpr uint32_t kQuadTile = 4 * kBlock;  // points per tile of the columnar path
 
 // One full tile of kQuadTile points starting at `first`; records staged at lds + mis.

@@ -715,3 +715,25 @@ def test_random_voxelgrid_vs_oracle(hip, oracle, seed):
     h, o = both(run, hip, oracle)
     assert h[0] == o[0]
     assert h[1] == o[1]
+
+
+@pytest.mark.parametrize("fmt", range(11))
+@pytest.mark.parametrize("pair", [("V", "H"), ("H", "V")])
+def test_typed_las_storage_transposition_vs_oracle(hip, oracle, fmt, pair):
+    """BufferLayoutConverter::for_layouts(L, L) between a VectorBuffer and a HashMapBuffer of LasPointFormatN::layout()
+    (configs[2] is V -> H for format 0): the format-specialised transposition, in two ragged ranges with offsets."""
+    n, cut, pad = 150_003, 40_001, 3
+
+    def run(api):
+        layout = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+        src = BUFFER_KINDS[pair[0]].new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(77 + fmt, 9)
+        dst = BUFFER_KINDS[pair[1]].new_from_layout(layout)
+        dst.resize(n + pad)
+        conv = BufferLayoutConverter.for_layouts(layout, layout)
+        conv.convert_into_range(src, range(0, cut), dst, range(pad, pad + cut))
+        conv.convert_into_range(src, range(cut, n), dst, range(pad + cut, pad + n))
+        return dst.get_point_range(range(0, n + pad)).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h == o
