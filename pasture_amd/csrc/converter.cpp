@@ -270,9 +270,11 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       std::vector<uint64_t> cols(c.to.members.size());
       for (size_t a = 0; a < cols.size(); ++a) cols[a] = col_addr(soa, a, p0);
       const uint64_t aos = src.columnar ? aos_addr(dst, t0) : aos_addr(src, s0);
-      if (!pstk::launch_las_transpose(c.las_typed_format, src.columnar, aos, cols.data(), (int)cols.size(), n, stream))
+      const unsigned grid = pstk::las_transpose_grid(n);
+      double* partials = bounds_out6 ? (double*)workspace().partials(pstk::bounds_partials_bytes(grid)) : nullptr;
+      if (!pstk::launch_las_transpose(c.las_typed_format, src.columnar, aos, cols.data(), (int)cols.size(), n, partials, stream))
         throw Error(PST_ERR_HIP, std::string("LAS transposition launch failed: ") + hipGetErrorString(hipGetLastError()));
-      if (bounds_out6) bounds_of_range(dst, t0, n, bounds_out6, stream);
+      if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
       return;
     }
   }

@@ -74,7 +74,9 @@ bool launch_las_decode_aos(int format, uint64_t src, uint64_t dst, uint64_t n, c
                            hipStream_t stream);
 
 // typed LAS points, columns <-> packed records (las_transpose.hip)
-bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint64_t* cols, int n_cols, uint64_t n, hipStream_t stream);
+unsigned las_transpose_grid(uint64_t n);
+bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint64_t* cols, int n_cols, uint64_t n, double* partials,
+                          hipStream_t stream);
 
 // predicate compaction (filter.hip)
 size_t filter_workspace_bytes(uint64_t n);

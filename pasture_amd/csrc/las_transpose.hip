@@ -22,6 +22,7 @@ struct TransposeArgs {
   uint64_t aos;                // address of typed record 0 of the range
   uint64_t n;
   uint64_t col[kMaxAttrs];     // typed attribute columns (slot order): address of point 0 of the range
+  double* partial_bounds;      // null, or [gridDim.x][6] records {min xyz, max xyz} of the positions moved (fused AABB)
 };
 
 __device__ __forceinline__ uint32_t round_up16(uint32_t v) { return (v + 15u) & ~15u; }
@@ -47,6 +48,33 @@ __device__ __forceinline__ void for_each_tail_slot(F&& f) {
   if constexpr (M.wave) { emit(1); emit(8); emit(4); emit(4); emit(12); }
 }
 
+// AABB of the positions a lane moves in the chunk layout: element (j, e) of a lane has component (c0 + (512 j + e) % 3) % 3, so
+// three accumulator pairs indexed by the compile-time r = (512 j + e) % 3 are kept "rotated by c0" and un-rotated once.
+struct RotBounds {
+  double rmn[3] = {kF64Max, kF64Max, kF64Max}, rmx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  __device__ __forceinline__ void fold(uint32_t r, uint64_t bits) {
+    const double w = __builtin_bit_cast(double, bits);
+    rmn[r] = __builtin_fmin(rmn[r], w);
+    rmx[r] = __builtin_fmax(rmx[r], w);
+  }
+  __device__ __forceinline__ void unrotate(uint32_t c0, double (&mn)[3], double (&mx)[3]) const {
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+      const uint32_t r = c >= c0 ? c - c0 : c + 3u - c0;
+      mn[c] = __builtin_fmin(mn[c], pick3(r, rmn[0], rmn[1], rmn[2]));
+      mx[c] = __builtin_fmax(mx[c], pick3(r, rmx[0], rmx[1], rmx[2]));
+    }
+  }
+};
+__device__ __forceinline__ void write_partial_bounds(double* partials, double (&mn)[3], double (&mx)[3]) {
+  __shared__ double scratch[(kBlock / 64) * 6];
+  block_reduce_minmax<double, 3>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+    double* o = partials + (uint64_t)blockIdx.x * 6;
+    o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
+  }
+}
+
 // ---- columns -> records -------------------------------------------------------------------------------------------------
 template <int FORMAT>
 __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const TransposeArgs a) {
@@ -55,6 +83,7 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   lptr_t lds = (lptr_t)lds_raw;
   const uint32_t tid = threadIdx.x;
+  double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
   const uint64_t n_tiles = (a.n + kQuadTile - 1) / kQuadTile;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * kQuadTile;
@@ -87,6 +116,7 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
         else c12.load(p);
       });
       const uint32_t d0 = 2u * tid, q0 = d0 / 3u, c0 = d0 - 3u * q0;
+      RotBounds rb;
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
 #pragma unroll
@@ -96,8 +126,10 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
           const uint32_t c = wrap ? c0 + r - 3u : c0 + r, q = q0 + A + (wrap ? 1u : 0u);
           const uint64_t bits = (uint64_t)(e ? pc[j].z : pc[j].x) | ((uint64_t)(e ? pc[j].w : pc[j].y) << 32);
           store_un<uint64_t>(lds + (mis + q * TS + 8u * c), bits);
+          if (a.partial_bounds) rb.fold(r, bits);
         }
       }
+      if (a.partial_bounds) rb.unrotate(c0, mn, mx);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         RecTail<TS - 24> rec;
@@ -118,7 +150,13 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
         const uint64_t i = first + lp;
         lptr_t rec = lds + (mis + lp * TS);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) store_un<uint64_t>(rec + 8 * c, load_un<uint64_t>((cgptr_t)as_global(a.col[0]) + i * 24u + 8u * c));
+        for (int c = 0; c < 3; ++c) {
+          const uint64_t bits = load_un<uint64_t>((cgptr_t)as_global(a.col[0]) + i * 24u + 8u * c);
+          store_un<uint64_t>(rec + 8 * c, bits);
+          const double w = __builtin_bit_cast(double, bits);
+          mn[c] = __builtin_fmin(mn[c], w);
+          mx[c] = __builtin_fmax(mx[c], w);
+        }
         for_each_tail_slot<FORMAT>([&](int slot, uint32_t off, uint32_t size) __attribute__((always_inline)) {
           cgptr_t p = (cgptr_t)as_global(a.col[slot]) + i * size;
           for (uint32_t b = 0; b < size; ++b) rec[off + b] = p[b];
@@ -129,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
     tile_store<kBlock>(lds, as_global(ga - mis), mis, cnt * TS);
     __syncthreads();
   }
+  if (a.partial_bounds) write_partial_bounds(a.partial_bounds, mn, mx);
 }
 
 // ---- records -> columns -------------------------------------------------------------------------------------------------
@@ -139,6 +178,7 @@ __global__ __launch_bounds__(kBlock) void las_records_to_columns_kernel(const Tr
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   lptr_t lds = (lptr_t)lds_raw;
   const uint32_t tid = threadIdx.x;
+  double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
   const uint64_t n_tiles = (a.n + kQuadTile - 1) / kQuadTile;
   for (uint64_t tile = xcd_block_id(); tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * kQuadTile;
@@ -161,6 +201,12 @@ __global__ __launch_bounds__(kBlock) void las_records_to_columns_kernel(const Tr
           const uint32_t c = wrap ? c0 + r - 3u : c0 + r, q = q0 + A + (wrap ? 1u : 0u);
           pv[2 * j + e] = lds_load<uint64_t>(lds + (smis + q * TS + 8u * c));
         }
+      }
+      if (a.partial_bounds) {
+        RotBounds rb;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { rb.fold((512u * j) % 3u, pv[2 * j]); rb.fold((512u * j + 1u) % 3u, pv[2 * j + 1]); }
+        rb.unrotate(c0, mn, mx);
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -204,7 +250,13 @@ __global__ __launch_bounds__(kBlock) void las_records_to_columns_kernel(const Tr
         const uint64_t i = first + lp;
         clptr_t rec = lds + (smis + lp * TS);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) store_un<uint64_t>(as_global(a.col[0]) + i * 24u + 8u * c, lds_load<uint64_t>(rec + 8 * c));
+        for (int c = 0; c < 3; ++c) {
+          const uint64_t bits = lds_load<uint64_t>(rec + 8 * c);
+          store_un<uint64_t>(as_global(a.col[0]) + i * 24u + 8u * c, bits);
+          const double w = __builtin_bit_cast(double, bits);
+          mn[c] = __builtin_fmin(mn[c], w);
+          mx[c] = __builtin_fmax(mx[c], w);
+        }
         for_each_tail_slot<FORMAT>([&](int slot, uint32_t off, uint32_t size) __attribute__((always_inline)) {
           gptr_t p = as_global(a.col[slot]) + i * size;
           for (uint32_t b = 0; b < size; ++b) p[b] = rec[off + b];
@@ -213,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void las_records_to_columns_kernel(const Tr
     }
     __syncthreads();  // the next tile's DMA overwrites the records
   }
+  if (a.partial_bounds) write_partial_bounds(a.partial_bounds, mn, mx);
 }
 
 }  // namespace
@@ -220,13 +273,20 @@ __global__ __launch_bounds__(kBlock) void las_records_to_columns_kernel(const Tr
 namespace pstk {
 
 // to_records = true: columns -> packed typed records; false: records -> columns.  cols in LasPointFormatN slot order.
-bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint64_t* cols, int n_cols, uint64_t n, hipStream_t stream) {
+unsigned las_transpose_grid(uint64_t n) {
+  const uint64_t n_tiles = std::max<uint64_t>(1, (n + kQuadTile - 1) / kQuadTile);
+  return (unsigned)((std::min<uint64_t>(n_tiles, 1u << 22) + 7) / 8 * 8);  // one tile per block; multiple of 8 for xcd_block_id()
+}
+
+// partials: null, or las_transpose_grid(n) records of 6 doubles (fused AABB of the positions; finish with launch_finalize_bounds)
+bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint64_t* cols, int n_cols, uint64_t n, double* partials,
+                          hipStream_t stream) {
   TransposeArgs a{};
+  a.partial_bounds = partials;
   a.aos = aos;
   a.n = n;
   for (int i = 0; i < n_cols && i < kMaxAttrs; ++i) a.col[i] = cols[i];
-  const uint64_t n_tiles = std::max<uint64_t>(1, (n + kQuadTile - 1) / kQuadTile);
-  const unsigned grid = (unsigned)((std::min<uint64_t>(n_tiles, 1u << 22) + 7) / 8 * 8);  // one tile per block; multiple of 8 for xcd_block_id()
+  const unsigned grid = las_transpose_grid(n);
   const size_t lds_bytes = (size_t)kQuadTile * typed_size(fmt_of(format)) + 64;
 #define PST_TR(N)                                                                                                                                   \
   case N: {                                                                                                                                         \

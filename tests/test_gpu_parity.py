@@ -737,3 +737,40 @@ def test_typed_las_storage_transposition_vs_oracle(hip, oracle, fmt, pair):
         return dst.get_point_range(range(0, n + pad)).tobytes()
     h, o = both(run, hip, oracle)
     assert h == o
+
+
+@pytest.mark.parametrize("case", ["typed_V_H", "typed_H_V", "raw_H", "raw_V"])
+@pytest.mark.parametrize("fmt", [0, 3, 6, 10])
+def test_fused_bounds_of_specialised_las_paths(hip, oracle, fmt, case):
+    """convert_into_with_bounds on the format-specialised LAS kernels (decoder, interleaved decoder, transposer): the fused AABB
+    equals calculate_bounds of the oracle's result over the same target range, and the converted bytes are identical."""
+    n, a0, a1 = 70_001, 1_234, 66_000
+
+    def run(api, with_bounds):
+        raw = las.point_layout_from_las_point_format(las.Format(fmt), True, api=api)
+        typed = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+        if case.startswith("typed"):
+            src = BUFFER_KINDS[case[6]].new_from_layout(typed)
+            conv = BufferLayoutConverter.for_layouts(typed, typed)
+            kind = case[8]
+        else:
+            src = VectorBuffer.new_from_layout(raw)
+            conv = las.get_default_las_converter(raw, typed, SCALE, OFFSET)
+            kind = case[4]
+        src.resize(n)
+        src.synth_fill(3, 0)
+        dst = BUFFER_KINDS[kind].new_from_layout(typed)
+        dst.resize(n)
+        if with_bounds:
+            b = conv.convert_into_with_bounds(src, dst, range(a0, a1), range(a0, a1))
+        else:
+            conv.convert_into_range(src, range(a0, a1), dst, range(a0, a1))
+            sub = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+            sub.resize(a1 - a0)
+            sub.set_attribute_range(A.POSITION_3D, range(0, a1 - a0), dst.view_attribute(A.POSITION_3D)[a0:a1])
+            b = calculate_bounds(sub)
+        return dst.get_point_range(range(0, n)).tobytes(), (b.min(), b.max())
+    hb, hbounds = run(hip, True)
+    ob, obounds = run(oracle, False)
+    assert hb == ob
+    assert hbounds == obounds
