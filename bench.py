@@ -136,6 +136,9 @@ def main():
     distributed = world > 1 or (os.environ.get("PASTURE_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the 48-byte AABB collectives must not queue behind the 97k-workgroup conversion kernels: high-priority RCCL stream
+        # (measured with one rank: step 0.806 -> 0.774 ms, kernel-only 0.767 ms; tools/exp_dist_overhead.py)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import pasture_amd as pa
