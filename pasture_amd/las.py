@@ -164,6 +164,52 @@ def write_points(points, point_format: int, scale, offset, target, target_first:
     return bounds, [0] * len(counts)
 
 
+def read_records_into(records, point_format: int, scale, offset, target, chunk_points: int = 4 << 20):
+    """Host side of a device LAS reader (RawLASReader::read_into_custom_layout, raw_readers.rs:299-352, with the chunk loop of
+    :266-289): raw point records in HOST memory -> `target` (typed layout, device buffer), in chunks that are copied over PCIe on
+    a second stream while the previous chunk is being decoded.  `records`: a 1-D uint8 torch tensor on the CPU (pinned memory
+    gives the full link rate; pageable tensors are staged through pinned buffers first) whose length is a multiple of the
+    record size.  Returns the number of points read.  torch is used for streams / events / pinned memory only."""
+    import ctypes as C
+
+    import torch
+    from .buffers import ExternalMemoryBuffer
+    api = target.api
+    raw_layout = point_layout_from_las_point_format(Format(point_format), True, api=api)
+    rs = raw_layout.size_of_point_entry()
+    assert records.dtype == torch.uint8 and records.dim() == 1 and records.numel() % rs == 0
+    n = records.numel() // rs
+    if target.len() < n:
+        raise ValueError("point_buffer.len() must be >= count")  # raw_readers.rs:375-377
+    converter = get_default_las_converter(raw_layout, target.point_layout(), scale, offset)
+    compute = torch.cuda.current_stream()
+    copier = torch.cuda.Stream()
+    chunk = max(1, min(chunk_points, n))
+    staging = [torch.empty(chunk * rs, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    views = [ExternalMemoryBuffer(t, raw_layout) for t in staging]
+    bounce = None if records.is_pinned() else [torch.empty(chunk * rs, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    decoded = [torch.cuda.Event() for _ in range(2)]
+    api.set_stream(C.c_void_p(compute.cuda_stream))
+    for c, first in enumerate(range(0, n, chunk)):
+        b = c & 1
+        cnt = min(chunk, n - first)
+        src = records[first * rs:(first + cnt) * rs]
+        if c >= 2:
+            decoded[b].synchronize() if bounce is not None else copier.wait_event(decoded[b])  # staging[b] is free again
+        if bounce is not None:
+            bounce[b][:cnt * rs].copy_(src)
+            src = bounce[b][:cnt * rs]
+        with torch.cuda.stream(copier):
+            staging[b][:cnt * rs].copy_(src, non_blocking=True)
+            copied[b].record(copier)
+        compute.wait_event(copied[b])
+        converter.convert_into_range_async(views[b], range(0, cnt), target, range(first, first + cnt))
+        decoded[b].record(compute)
+    compute.synchronize()
+    return n
+
+
 @dataclass
 class LasFile:
     """Just enough of an uncompressed .las file to use the reference's fixtures as golden vectors."""

@@ -774,3 +774,27 @@ def test_fused_bounds_of_specialised_las_paths(hip, oracle, fmt, case):
     ob, obounds = run(oracle, False)
     assert hb == ob
     assert hbounds == obounds
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("fmt,kind", [(0, "H"), (3, "V"), (7, "H")])
+def test_read_records_into_pipelined_matches_one_shot(hip, fmt, kind, pinned):
+    """las.read_records_into: host records -> device typed buffer through double-buffered PCIe copies on a second stream; the
+    result equals the one-shot conversion of the same records (ragged last chunk, chunk not a multiple of the tile)."""
+    import torch
+    n = 250_003
+    raw = las.point_layout_from_las_point_format(las.Format(fmt), True, api=hip)
+    typed = las.point_layout_from_las_point_format(las.Format(fmt), False, api=hip)
+    src = VectorBuffer.new_from_layout(raw)
+    src.resize(n)
+    src.synth_fill(21, 0)
+    host = torch.from_numpy(np.ascontiguousarray(src.get_point_range(range(0, n))).view(np.uint8).reshape(-1).copy())
+    if pinned:
+        host = host.pin_memory()
+    want = BUFFER_KINDS[kind].new_from_layout(typed)
+    want.resize(n)
+    las.get_default_las_converter(raw, typed, SCALE, OFFSET).convert_into(src, want)
+    got = BUFFER_KINDS[kind].new_from_layout(typed)
+    got.resize(n)
+    assert las.read_records_into(host, fmt, SCALE, OFFSET, got, chunk_points=60_001) == n
+    assert got.get_point_range(range(0, n)).tobytes() == want.get_point_range(range(0, n)).tobytes()
