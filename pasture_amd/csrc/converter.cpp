@@ -115,7 +115,9 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
                      uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6) {
   if (n == 0 || entries.empty()) return;
   ensure_device();
-  const uint32_t tile = pick_tile(src_aos, src_stride, dst_aos, dst_stride);
+  // interleaved in place (transform_attribute on a VectorBuffer): one record tile, transformed in LDS
+  const bool in_place = src_aos && dst_aos && src_base == dst_base && src_stride == dst_stride;
+  const uint32_t tile = pick_tile(src_aos && !in_place, src_stride, dst_aos, dst_stride);
   const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 1;
   for (size_t begin = 0; begin < entries.size(); begin += PST_PLAN_MAX_ENTRIES) {
     const size_t cnt = std::min<size_t>(PST_PLAN_MAX_ENTRIES, entries.size() - begin);
@@ -127,6 +129,7 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
     plan.h.dst_stride = dst_stride;
     plan.h.n_entries = (uint32_t)cnt;
     plan.h.tile = tile;
+    plan.h.in_place = in_place ? 1u : 0u;
     std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
     bool wants_bounds = false;
     for (size_t i = 0; i < cnt; ++i) {

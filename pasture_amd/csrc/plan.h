@@ -37,7 +37,7 @@ struct ConvertHeader {
   uint32_t n_entries;
   uint32_t tile;              // points per LDS tile (tile kernels)
   uint32_t dst_fully_covered; // interleaved target: every byte of the record is written by some mapping
-  uint32_t reserved;
+  uint32_t in_place;          // tile kernels, interleaved -> interleaved with src == dst: ONE record tile, transformed in LDS
   uint64_t bounds_partials;   // 0, or device address of gridDim.x records {min xyz, max xyz} (f64) for entries with .bounds
 };
 struct ConvertPlan {

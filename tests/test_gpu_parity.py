@@ -798,3 +798,30 @@ def test_read_records_into_pipelined_matches_one_shot(hip, fmt, kind, pinned):
     got.resize(n)
     assert las.read_records_into(host, fmt, SCALE, OFFSET, got, chunk_points=60_001) == n
     assert got.get_point_range(range(0, n)).tobytes() == want.get_point_range(range(0, n)).tobytes()
+
+
+@pytest.mark.parametrize("kind", ["V", "H"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_in_place_transforms_every_descriptor_vs_oracle(hip, oracle, kind, packed):
+    """transform_attribute in place (point_buffer.rs:391-404) for every supported descriptor / datatype, one after the other on
+    the same buffer; interleaved buffers go through one LDS record tile — untouched attributes and padding must survive."""
+    attrs = [A.CLASSIFICATION, A.POSITION_3D, A.INTENSITY, A.NORMAL, A.GPS_TIME, PointAttributeDefinition("f", T.F32), A.POINT_ID,
+             PointAttributeDefinition("w", T.U32), A.USER_DATA]
+
+    def run(api):
+        layout = PointLayout.from_attributes_packed(attrs, 1, api=api) if packed else PointLayout.from_attributes(attrs, api=api)
+        n = 70_003
+        buf = BUFFER_KINDS[kind].new_from_layout(layout)
+        buf.resize(n)
+        buf.synth_fill(5, 0)
+        transform_attribute(buf, A.POSITION_3D, Transform.affine(T.Vec3f64, (0.5, 2.0, -1.0), (10.0, -20.0, 0.25)))
+        transform_attribute(buf, A.NORMAL, Transform.affine(T.Vec3f32, (3.0, 0.1, 7.0), (1.0, 2.0, 3.0)))
+        transform_attribute(buf, A.GPS_TIME, Transform.affine(T.F64, (1.5,) * 3, (100.0,) * 3))
+        transform_attribute(buf, PointAttributeDefinition("f", T.F32), Transform.add_scalar(T.F32, 42.0))
+        transform_attribute(buf, A.INTENSITY, Transform.bitfield(T.U16, 3, 0x1FF))
+        transform_attribute(buf, A.POINT_ID, Transform.bitfield(T.U64, 40, 0xFFFFF))
+        transform_attribute(buf, PointAttributeDefinition("w", T.U32), Transform.bitfield(T.U32, 1, 0xFFFF))
+        transform_attribute(buf, A.USER_DATA, Transform.bitfield(T.U8, 4, 0xF))
+        return buf.get_point_range(range(0, n)).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h == o
