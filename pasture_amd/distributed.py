@@ -73,6 +73,36 @@ class PipelinedBoundsReduce:
         return last
 
 
+def shard_output_offsets(local_count: int, group=None):
+    """Compaction (`filter`) over index-range shards: rank r keeps its matches in order, so its slice of the global result
+    starts at the sum of the match counts of ranks < r.  One all-gather of one int64 per rank.  Returns (offset, total)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor([int(local_count)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts = [int(c.item()) for c in counts]
+    rank = dist.get_rank(group)
+    return sum(counts[:rank]), sum(counts)
+
+
+def allreduce_las_header(bounds6, points_by_return, group=None):
+    """The LAS writer's header side effects over shards (raw_writers.rs:28-83): header bounds = MIN / MAX of the per-shard
+    bounds, points-by-return = SUM of the per-shard histograms.  `bounds6` = [min xyz, max xyz] (6 floats), `points_by_return`
+    a list of ints.  Returns the global (bounds6, points_by_return)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    b = torch.tensor(list(bounds6), dtype=torch.float64, device=dev)
+    allreduce_bounds_record(b, group)
+    c = torch.tensor(list(points_by_return), dtype=torch.int64, device=dev)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    return [float(x) for x in b.tolist()], [int(x) for x in c.tolist()]
+
+
 def bounds_from_record(rec) -> Optional[Tuple[Tuple[float, float, float], Tuple[float, float, float]]]:
     """AABB::from_min_max on the reduced record: None if every shard was empty, panics like math/bounds.rs:21-26 if min > max."""
     from ._capi import ERR_BOUNDS_INVALID, PasturePanic

@@ -119,3 +119,65 @@ def test_pipelined_bounds_allreduce_gloo(steps):
     lo0, lo1 = float(i), float(10 + i)
     want = [lo0, lo0 + 1, lo0 + 2, lo1 + 100, lo1 + 101, lo1 + 102]
     assert got[0] == got[1] == want
+
+
+def _sharded_ops_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import _load_oracle
+    from pasture_amd import las
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    from pasture_amd.distributed import allreduce_las_header, shard_output_offsets, shard_range
+    orc = _load_oracle()
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=orc)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=orc)
+    r = shard_range(n, rank, world)
+    pts = HashMapBuffer.new_from_layout(typed)
+    pts.resize(len(r))
+    pts.synth_fill(9, r.start)
+    # compaction: every third global index survives; the shard's slice of the global output starts at `offset`
+    mask = (np.arange(r.start, r.stop) % 3) == 0
+    kept = pts.filter(HashMapBuffer, mask)
+    offset, total = shard_output_offsets(kept.len())
+    # LAS writer header: per-shard encode, then one MIN/MAX + one SUM
+    rec = VectorBuffer.new_from_layout(raw)
+    rec.resize(len(r))
+    bounds, counts = las.encode_points(pts, 0, (0.001,) * 3, (0.0,) * 3, rec)
+    gb, gc = allreduce_las_header(list(bounds[0]) + list(bounds[1]), counts)
+    q.put((rank, offset, total, kept.len(), gb, gc))
+    dist.destroy_process_group()
+
+
+def test_sharded_filter_offsets_and_las_header_gloo(oracle):
+    """N > 1 for the 8(f) additions: compaction output placement (all-gather of match counts) and the LAS header merge
+    (MIN/MAX of bounds, SUM of the return histogram) equal the single-process results."""
+    from pasture_amd import las
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    world, n = 2, 10_001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_ops_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=oracle)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=oracle)
+    pts = HashMapBuffer.new_from_layout(typed)
+    pts.resize(n)
+    pts.synth_fill(9, 0)
+    total = int(((np.arange(n) % 3) == 0).sum())
+    assert [g[2] for g in got] == [total, total]
+    assert got[0][1] == 0 and got[1][1] == got[0][3] and got[0][3] + got[1][3] == total
+    rec = VectorBuffer.new_from_layout(raw)
+    rec.resize(n)
+    bounds, counts = las.encode_points(pts, 0, (0.001,) * 3, (0.0,) * 3, rec)
+    want_b = list(bounds[0]) + list(bounds[1])
+    for g in got:
+        assert g[4] == want_b and g[5] == counts
