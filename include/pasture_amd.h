@@ -218,6 +218,14 @@ int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x, double lea
  * (5 for legacy headers, 15 with the large_file block, :220-229). */
 int pst_las_encode_points(const pst_buffer* src, uint32_t point_format, const double scale[3], const double offset[3], pst_buffer* dst,
                           size_t dst_first, double bounds_inout[6], uint64_t points_by_return[15], uint32_t max_return);
+/* Asynchronous, ranged variant for pipelined writers (device-side encode of chunk i overlapping the D2H copy of chunk i-1):
+ * encodes source points [src_first, src_first + count) into dst[dst_first ..) on the current stream.  THIS call's header
+ * contribution is left in device memory: device_bounds6 = {min xyz, max xyz} seeded with the identities; device_counts16[0] =
+ * number of positions outside the i32 range (> 0 is the panic of write_helpers.rs:15-17 — the caller checks it after
+ * synchronising), device_counts16[r] = points with return number r (1..max_return). */
+int pst_las_encode_range_async(const pst_buffer* src, size_t src_first, size_t count, uint32_t point_format, const double scale[3],
+                               const double offset[3], pst_buffer* dst, size_t dst_first, double* device_bounds6, uint64_t* device_counts16,
+                               uint32_t max_return);
 
 #ifdef __cplusplus
 }

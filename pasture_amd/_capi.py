@@ -131,6 +131,7 @@ _PRODUCT_SIGNATURES = {
     "converter_convert_into_range_with_bounds": [_P, _P, _SZ, _SZ, _P, _SZ, _SZ, _D3, _D3, C.POINTER(C.c_int)],
     "converter_convert_into_range_with_bounds_async": [_P, _P, _SZ, _SZ, _P, _SZ, _SZ, _P],
     "calculate_bounds_async": [_P, _P],
+    "las_encode_range_async": [_P, _SZ, _SZ, C.c_uint32, _D3, _D3, _P, _SZ, _P, _P, C.c_uint32],
     "compute_normals_into": [_P, _SZ, _P],
 }
 

@@ -210,6 +210,77 @@ def read_records_into(records, point_format: int, scale, offset, target, chunk_p
     return n
 
 
+def write_records_from(points, point_format: int, scale, offset, records_out, header_bounds=None, max_return: int = 15,
+                       chunk_points: int = 4 << 20):
+    """Host side of a device LAS writer (RawLASWriter::write_points_default_layout, raw_writers.rs:203-363, whose own loop works in
+    chunks of 50 000 points): typed points on the device (the format's default layout) -> raw records in HOST memory
+    (`records_out`: 1-D uint8 CPU tensor, pinned for the full link rate, n * record size bytes).  Chunk i is encoded on the
+    compute stream while chunk i-1 crosses PCIe on a second stream.  Returns (bounds, points_by_return) like `encode_points`;
+    raises the writer's panic if any position does not fit an i32."""
+    import ctypes as C
+
+    import torch
+    from ._capi import ERR_RANGE, PasturePanic
+    from .buffers import ExternalMemoryBuffer
+    api = points.api
+    raw_layout = point_layout_from_las_point_format(Format(point_format), True, api=api)
+    rs = raw_layout.size_of_point_entry()
+    n = points.len()
+    assert records_out.dtype == torch.uint8 and records_out.dim() == 1 and records_out.numel() >= n * rs
+    compute = torch.cuda.current_stream()
+    copier = torch.cuda.Stream()
+    chunk = max(1, min(chunk_points, max(n, 1)))
+    n_chunks = (n + chunk - 1) // chunk
+    staging = [torch.empty(chunk * rs, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    views = [ExternalMemoryBuffer(t, raw_layout) for t in staging]
+    bounce = None if records_out.is_pinned() else [torch.empty(chunk * rs, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    dev_bounds = torch.empty(max(n_chunks, 1), 6, dtype=torch.float64, device="cuda")
+    dev_counts = torch.zeros(max(n_chunks, 1), 16, dtype=torch.int64, device="cuda")
+    encoded = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    sc, of = (C.c_double * 3)(*scale), (C.c_double * 3)(*offset)
+    api.set_stream(C.c_void_p(compute.cuda_stream))
+    pending = [None, None]  # (bounce buffer, destination slice) whose D2H copy is in flight
+    for c in range(n_chunks):
+        b = c & 1
+        first = c * chunk
+        cnt = min(chunk, n - first)
+        if c >= 2:
+            compute.wait_event(copied[b])  # staging[b] has left the device
+        api.las_encode_range_async(points._h, first, cnt, point_format, sc, of, views[b]._h, 0, C.c_void_p(dev_bounds[c].data_ptr()),
+                                   C.c_void_p(dev_counts[c].data_ptr()), max_return)
+        encoded[b].record(compute)
+        if pending[b] is not None:  # pageable destination: finish the previous use of this bounce buffer on the host
+            copied[b].synchronize()
+            pending[b][1].copy_(pending[b][0][:pending[b][1].numel()])
+            pending[b] = None
+        with torch.cuda.stream(copier):
+            copier.wait_event(encoded[b])
+            dst = records_out[first * rs:(first + cnt) * rs]
+            if bounce is None:
+                dst.copy_(staging[b][:cnt * rs], non_blocking=True)
+            else:
+                bounce[b][:cnt * rs].copy_(staging[b][:cnt * rs], non_blocking=True)
+                pending[b] = (bounce[b], dst)
+            copied[b].record(copier)
+    copier.synchronize()
+    compute.synchronize()
+    for b in range(2):
+        if pending[b] is not None:
+            pending[b][1].copy_(pending[b][0][:pending[b][1].numel()])
+    hb = list(header_bounds) if header_bounds is not None else [1.7976931348623157e308] * 3 + [-1.7976931348623157e308] * 3
+    counts = [0] * max_return
+    if n_chunks:
+        cb, cc = dev_bounds[:n_chunks].cpu(), dev_counts[:n_chunks].cpu()
+        bad = int(cc[:, 0].sum())
+        if bad:
+            raise PasturePanic(ERR_RANGE, f"write_position_as_las_position: Position is out of bounds given the current LAS offset and scale! ({bad} positions)")
+        mn, mx = cb[:, :3].min(dim=0).values.tolist(), cb[:, 3:].max(dim=0).values.tolist()
+        hb = [min(hb[i], mn[i]) for i in range(3)] + [max(hb[3 + i], mx[i]) for i in range(3)]
+        counts = [int(x) for x in cc[:, 1:max_return + 1].sum(dim=0).tolist()]
+    return (tuple(hb[:3]), tuple(hb[3:])), counts
+
+
 @dataclass
 class LasFile:
     """Just enough of an uncompressed .las file to use the reference's fixtures as golden vectors."""

@@ -825,3 +825,28 @@ def test_in_place_transforms_every_descriptor_vs_oracle(hip, oracle, kind, packe
         return buf.get_point_range(range(0, n)).tobytes()
     h, o = both(run, hip, oracle)
     assert h == o
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("fmt,kind", [(0, "H"), (3, "V"), (6, "H")])
+def test_write_records_from_pipelined_matches_one_shot(hip, fmt, kind, pinned):
+    """las.write_records_from: device typed points -> host records through chunked asynchronous encodes and D2H copies on a
+    second stream; records, header bounds and return counts equal the one-shot encoder's."""
+    import torch
+    n = 250_003
+    typed = las.point_layout_from_las_point_format(las.Format(fmt), False, api=hip)
+    raw = las.point_layout_from_las_point_format(las.Format(fmt), True, api=hip)
+    src = BUFFER_KINDS[kind].new_from_layout(typed)
+    src.resize(n)
+    src.synth_fill(8, 0)
+    scale, offset = (0.01, 0.01, 0.01), (0.0, 0.0, 0.0)
+    want = VectorBuffer.new_from_layout(raw)
+    want.resize(n)
+    hb = [5.0, 5.0, 5.0, 6.0, 6.0, 6.0]
+    wb, wc = las.encode_points(src, fmt, scale, offset, want, header_bounds=hb)
+    host = torch.empty(n * raw.size_of_point_entry(), dtype=torch.uint8, pin_memory=pinned)
+    gb, gc = las.write_records_from(src, fmt, scale, offset, host, header_bounds=hb, chunk_points=60_001)
+    assert (gb, gc) == (wb, wc)
+    assert host.numpy().tobytes() == want.get_point_range(range(0, n)).tobytes()
+    with pytest.raises(PasturePanic, match="out of bounds given the current LAS offset and scale"):
+        las.write_records_from(src, fmt, (1e-9, 1e-9, 1e-9), offset, host, chunk_points=100_000)
