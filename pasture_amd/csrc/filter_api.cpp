@@ -17,6 +17,7 @@ struct TempDev {
 
 // Compaction of src's points with mask != 0 into dst[0, matches); returns the number of matches.
 size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, bool mask_on_device, int64_t num_matches_hint) {
+  if (!src.columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
   if (dst.layout != src.layout) throw Error(PST_ERR_LAYOUT_MISMATCH, "PointLayouts must match");  // :1088-1090
   const size_t n = src.len;
   if (n == 0) return 0;
@@ -82,6 +83,7 @@ int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_
   PST_API_BEGIN
   not_null(src, "src");
   not_null(out, "out");
+  if (!src->columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
   if (out_storage > PST_STORAGE_COLUMNAR) throw Error(PST_ERR_INVALID_ARGUMENT, "invalid storage kind");
   if (mask_memkind > PST_MEM_PINNED_HOST) throw Error(PST_ERR_INVALID_ARGUMENT, "invalid mask memory kind");
   auto b = std::make_unique<pst_buffer>();

@@ -119,6 +119,9 @@ def test_filter_into_hint_and_panics(api):
         src.filter_into(short, mask)
     with pytest.raises(PasturePanic):  # hint smaller than the real number of matches: slice index panic in the reference
         src.filter_into(dst, mask, k - 5)
+    from pasture_amd._capi import PastureError
+    with pytest.raises(PastureError, match="filter is defined on HashMapBuffer"):  # the reference has no VectorBuffer::filter
+        VectorBuffer.from_numpy(rec, layout).filter(HashMapBuffer, mask)
     other = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
     other.resize(n)
     with pytest.raises(PasturePanic, match="PointLayouts must match"):
