@@ -14,6 +14,9 @@ from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefini
 
 pytestmark = pytest.mark.gpu
 
+import os as _os
+FUZZ = int(_os.environ.get("PST_FUZZ_SCALE", "1"))  # multiplies the number of differential fuzz cases (one-off deep runs)
+
 SCALE, OFFSET = (0.001, 0.001, 0.001), (500000.0, 5400000.0, 100.0)
 
 
@@ -604,7 +607,7 @@ def _fuzz_case(api, seed):
     return out, [(m.source.name(), m.target.name(), m.has_converter, m.transform_kind != 0, m.apply_to_source) for m in conv.mappings()]
 
 
-@pytest.mark.parametrize("seed", range(400))
+@pytest.mark.parametrize("seed", range(400 * FUZZ))
 def test_random_conversions_vs_oracle(hip, oracle, seed):
     """Differential fuzzing of the generic converter: identical mapping tables, and identical target bytes (NaN payload bits of
     f64 -> f32 narrowing excepted: compared as NaN == NaN)."""
@@ -620,7 +623,7 @@ def test_random_conversions_vs_oracle(hip, oracle, seed):
             assert np.array_equal(a, b), k
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 * FUZZ))
 def test_random_filter_append_vs_oracle(hip, oracle, seed):
     """Differential fuzzing of filter / append: random layouts (all attribute sizes incl. 3, 5, 6, 12, 16, 24 bytes; packed or
     repr(C) with padding), random mask densities, both target kinds; then the result is appended to a second buffer."""
@@ -650,7 +653,7 @@ def test_random_filter_append_vs_oracle(hip, oracle, seed):
         assert hc[k].tobytes() == oc[k].tobytes(), k
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * FUZZ))
 def test_random_las_round_trips_vs_oracle(hip, oracle, seed):
     """Differential fuzzing of the LAS pipeline: random point format, sizes around the tile boundaries, random scale / offset and
     range offsets, both storage kinds: decode (raw -> typed) and encode (typed -> raw) byte-identical to the oracle."""
@@ -689,7 +692,7 @@ def test_random_las_round_trips_vs_oracle(hip, oracle, seed):
     assert h[4] == o[4]
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * FUZZ))
 def test_random_voxelgrid_vs_oracle(hip, oracle, seed):
     """Differential fuzzing of voxelgrid_filter: random subsets of the supported attributes in random order, packed or repr(C)
     layouts, both storage kinds for source and target, anisotropic leaf sizes from 'every point its own voxel' to 'one voxel'."""
