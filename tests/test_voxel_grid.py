@@ -228,3 +228,23 @@ def test_appends_and_panics(api):
     with pytest.raises(PasturePanic):  # target asks for an attribute the source does not have
         l5 = PointLayout.from_attributes([A.POSITION_3D], api=api)
         voxelgrid_filter(VectorBuffer.from_numpy(np.zeros(3, dtype=l5.numpy_record_dtype()), l5), 1, 1, 1, VectorBuffer.new_from_layout(layout))
+
+
+def test_nan_coordinates_fall_into_marker_zero(api):
+    """find_leaf (:21-52): `markers[i] < NaN` is false, so a NaN coordinate lands in cell 0 of that axis; calculate_bounds
+    ignores NaN (strict compares).  The NaN then poisons the centroid of that voxel, like in the reference."""
+    layout = PointLayout.from_attributes([A.POSITION_3D, A.INTENSITY], api=api)
+    rec = np.zeros(6, dtype=layout.numpy_record_dtype())
+    rec[A.POSITION_3D.name()] = [[0.2, 0.2, 0.2], [np.nan, 0.3, 0.3], [9.0, 9.0, 9.0], [9.1, np.nan, 9.0], [5.0, 5.0, 5.0], [0.1, 0.1, 0.1]]
+    rec[A.INTENSITY.name()] = [10, 20, 30, 40, 50, 60]
+    buf = HashMapBuffer.from_numpy(rec, layout)
+    out = HashMapBuffer.new_from_layout(layout)
+    voxelgrid_filter(buf, 2.0, 2.0, 2.0, out)
+    pos, inten = out.view_attribute(A.POSITION_3D), out.view_attribute(A.INTENSITY)
+    # markers 2.1, 4.1, .. 10.1 per axis; voxels in (x, y, z) order: (0,0,0) holds points 0, 1, 5 (x = NaN -> cell 0); (2,2,2);
+    # (3,3,3) = point 2 (9.0 is nearer to 8.1 than to 10.1); (4,0,3) = point 3 (9.1 ties -> upper marker; y = NaN -> 0)
+    assert out.len() == 4
+    assert np.isnan(pos[0][0]) and pos[0][1] == (0.2 + 0.3 + 0.1) / 3.0 and inten[0] == 30
+    assert np.array_equal(pos[1], [5.0, 5.0, 5.0]) and inten[1] == 50
+    assert np.array_equal(pos[2], [9.0, 9.0, 9.0]) and inten[2] == 30
+    assert pos[3][0] == 9.1 and np.isnan(pos[3][1]) and inten[3] == 40
