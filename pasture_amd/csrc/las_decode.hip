@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void las_decode_kernel(const DecodeArgs a) 
   lptr_t lds = (lptr_t)lds_raw;
   double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
   const uint64_t n_tiles = (a.n + kQuadTile - 1) / kQuadTile;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (uint64_t tile = xcd_block_id(); tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * kQuadTile;
     const uint32_t cnt = (uint32_t)((a.n - first) < kQuadTile ? (a.n - first) : kQuadTile);
     const uint64_t sa = a.src + first * RS;
@@ -319,7 +319,7 @@ namespace pstk {
 
 unsigned las_decode_grid(uint64_t n) {
   const uint64_t n_tiles = std::max<uint64_t>(1, (n + kQuadTile - 1) / kQuadTile);
-  return (unsigned)std::min<uint64_t>(n_tiles, 1u << 22);  // one tile per block: +5 % over a persistent grid of 16384 (same-box A/B)
+  return (unsigned)((std::min<uint64_t>(n_tiles, 1u << 22) + 7) / 8 * 8);  // one tile per block: +5 % over a persistent grid of 16384 (same-box A/B)
 }
 
 // dst_cols: typed attribute columns in LasPointFormatN slot order (address of the first target point).  partials: null, or
