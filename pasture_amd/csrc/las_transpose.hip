@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
   const uint32_t tid = threadIdx.x;
   double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
   const uint64_t n_tiles = (a.n + kQuadTile - 1) / kQuadTile;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (uint64_t tile = xcd_block_id(); tile < n_tiles; tile += gridDim.x) {
     const uint64_t first = tile * kQuadTile;
     const uint32_t cnt = (uint32_t)((a.n - first) < kQuadTile ? (a.n - first) : kQuadTile);
     const uint64_t ga = a.aos + first * TS;
