@@ -361,7 +361,7 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
   st = new VoxelGridState();
   st->n = n;
-  VCK(st->keys.alloc(n * 8, stream)); VCK(st->keys2.alloc(n * 8, stream)); VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
+  VCK(st->keys.alloc(n * 8, stream)); VCK(st->keys2.alloc(n * 8, stream)); VCK(st->idx.alloc((n + 1) * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
   VCK(st->markers.alloc(((size_t)nx + ny + nz + 1) * 8, stream));
   double* dm = st->markers.as<double>();
   if (nx) VCK(hipMemcpyAsync(dm, markers_x, (size_t)nx * 8, hipMemcpyHostToDevice, stream));
@@ -382,7 +382,7 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   VCK(st->starts.alloc((n + 1) * 8, stream));
   VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
                                             st->nruns.as<uint32_t>(), (int)n, stream));
-  VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n, stream));
+  VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n + 1, stream));
   VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan)), stream));
   VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
                                          st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
@@ -392,11 +392,9 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   VCK(hipMemcpyAsync(&runs, st->nruns.p, 4, hipMemcpyDeviceToHost, stream));
   VCK(hipStreamSynchronize(stream));
   st->n_voxels = runs;
-  // starts[v] = exclusive sum of counts; starts[n_voxels] = n
-  VCK(hipcub::DeviceScan::ExclusiveSum(st->tmp.p, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)runs, stream));
-  const unsigned long long total = n;
-  VCK(hipMemcpyAsync(st->starts.as<unsigned long long>() + runs, &total, 8, hipMemcpyHostToDevice, stream));
-  VCK(hipStreamSynchronize(stream));
+  // starts[v] = exclusive sum of counts over runs + 1 items: starts[n_voxels] = n comes out of the same scan (the extra input
+  // element is never added to an output), so no host round trip is needed here
+  VCK(hipcub::DeviceScan::ExclusiveSum(st->tmp.p, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)runs + 1, stream));
   return (long long)runs;
 #undef VCK
 }
