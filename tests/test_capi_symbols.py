@@ -49,3 +49,36 @@ def test_product_never_references_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in src and "pasture_oracle" not in src and "oracle_capi" not in src, os.path.join(dirpath, f)
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    lib_dir = os.path.join(ROOT, "pasture_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", lib_dir,
+           "-lpasture_amd", f"-Wl,-rpath,{lib_dir}", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_plain_c_program_links_against_the_boundary_and_fails_loudly_without_gpu(tmp_path):
+    """The boundary is usable from plain C (no C++ / torch types): examples/c_abi_demo.c compiles with -Wall -Werror against
+    include/pasture_amd.h and links to libpasture_amd.so.  Without a GPU its first compute call must fail with
+    PST_ERR_NO_DEVICE (exit code 77 of the demo) — never fall back to a CPU path."""
+    import subprocess
+    import torch
+    exe = _build_c_demo(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked run of the demo")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 77, r.stderr
+    assert "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_program_runs_on_the_gpu(tmp_path):
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("OK: 100000 points")
