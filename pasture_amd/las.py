@@ -290,13 +290,57 @@ class LasFile:
     scale: Tuple[float, float, float]
     offset: Tuple[float, float, float]
     records: np.ndarray  # (num_points, record_length) uint8
+    extra_bytes_attributes: tuple = ()  # attribute definitions of the Extra Bytes VLR
+
+
+# ExtraBytesDataType -> PointAttributeDataType, las_metadata.rs:289-315 (LAS 1.4 Extra Bytes VLR data_type codes 1..10)
+_EXTRA_BYTES_TYPES = {1: T.U8, 2: T.I8, 3: T.U16, 4: T.I16, 5: T.U32, 6: T.I32, 7: T.U64, 8: T.I64, 9: T.F32, 10: T.F64}
+
+
+def parse_extra_bytes_vlr(raw: bytes, header_size: int, n_vlrs: int):
+    """Attribute definitions of the Extra Bytes VLR (user id "LASF_Spec", record id 4; 192-byte entries: data_type at byte 2,
+    name at bytes 4..36) — ExtraBytesEntry::get_point_attribute, las_metadata.rs:508-515."""
+    pos = header_size
+    attrs = []
+    for _ in range(n_vlrs):
+        user_id = raw[pos + 2:pos + 18].split(b"\0")[0]
+        record_id, length = struct.unpack_from("<HH", raw, pos + 18)
+        body = raw[pos + 54:pos + 54 + length]
+        if user_id == b"LASF_Spec" and record_id == 4:
+            for off in range(0, len(body) - 191, 192):
+                code = body[off + 2]
+                if code not in _EXTRA_BYTES_TYPES:
+                    raise ValueError("Extra bytes of type 'undocumented' / 'deprecated' / 'reserved' are currently unsupported in pasture")
+                name = body[off + 4:off + 36].split(b"\0")[0].decode("utf-8")
+                attrs.append(PointAttributeDefinition.custom(name, _EXTRA_BYTES_TYPES[code]))
+        pos += 54 + length
+    return attrs
+
+
+def point_layout_from_las_metadata(fmt: Format, num_extra_bytes: int, extra_byte_attributes, exact_binary_representation: bool,
+                                   api=None) -> PointLayout:
+    """las_layout.rs:134-185: the format's layout plus the Extra Bytes VLR attributes (Packed(1)); bytes the VLR does not
+    describe become one `UndescribedExtraBytes` byte array whose length is — as in the reference (:171-181, sic) — the number
+    of DESCRIBED bytes."""
+    layout = point_layout_from_las_point_format(fmt, exact_binary_representation, api=api)
+    if num_extra_bytes == 0:
+        return layout
+    described = 0
+    for a in extra_byte_attributes:
+        layout.add_attribute(a, FieldAlignment.Packed(1))
+        described += a.datatype().size()
+    if num_extra_bytes - described > 0:
+        layout.add_attribute(PointAttributeDefinition.custom("UndescribedExtraBytes", T.ByteArray(described)), FieldAlignment.Packed(1))
+    return layout
 
 
 def read_las_records(path: str) -> LasFile:
-    """LAS 1.2-1.4 public header block (ASPRS LAS specification): offsets 94/96/104/105/107/131/155."""
+    """LAS 1.2-1.4 public header block (ASPRS LAS specification): offsets 94/96/100/104/105/107/131/155."""
     raw = open(path, "rb").read()
     assert raw[:4] == b"LASF"
     minor = raw[25]
+    header_size = struct.unpack_from("<H", raw, 94)[0]
+    n_vlrs = struct.unpack_from("<I", raw, 100)[0]
     offset_to_points = struct.unpack_from("<I", raw, 96)[0]
     fmt = raw[104] & 0x3F
     rec_len = struct.unpack_from("<H", raw, 105)[0]
@@ -306,4 +350,6 @@ def read_las_records(path: str) -> LasFile:
         n = struct.unpack_from("<Q", raw, 247)[0]
     sx, sy, sz, ox, oy, oz = struct.unpack_from("<6d", raw, 131)
     recs = np.frombuffer(raw, dtype=np.uint8, count=n * rec_len, offset=offset_to_points).reshape(n, rec_len).copy()
-    return LasFile(fmt, rec_len, n, (sx, sy, sz), (ox, oy, oz), recs)
+    f = LasFile(fmt, rec_len, n, (sx, sy, sz), (ox, oy, oz), recs)
+    f.extra_bytes_attributes = parse_extra_bytes_vlr(raw, header_size, n_vlrs)
+    return f

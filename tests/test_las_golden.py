@@ -134,3 +134,31 @@ def test_las_mapping_table(api):
                    ("PointSourceID", "PointSourceID", False, False, False), ("LASLocalPosition", "Position3D", True, True, False),
                    ("LASBasicFlags", "ReturnNumber", False, True, True), ("LASBasicFlags", "NumberOfReturns", False, True, True),
                    ("LASBasicFlags", "ScanDirectionFlag", False, True, True), ("LASBasicFlags", "EdgeOfFlightLine", False, True, True)]
+
+
+@pytest.mark.parametrize("fmt", range(11))
+@pytest.mark.parametrize("target_kind", ["V", "H"])
+def test_read_with_extra_bytes(api, fmt, target_kind):
+    """test_raw_las_reader_read_with_extra_bytes (raw_readers.rs:1054-1071): fixtures with 4 extra bytes per record, described
+    by the Extra Bytes VLR as the u32 attribute "TestExtraBytes"; layouts from point_layout_from_las_metadata
+    (las_layout.rs:134-185); expected extra values 0..9 (test_util.rs:186-188, :427-436)."""
+    f = las.read_las_records(os.path.join(GOLDEN, f"10_points_with_extra_bytes_format_{fmt}.las"))
+    F = las.Format(fmt)
+    assert f.point_format == fmt and f.num_points == 10
+    assert [(a.name(), a.datatype()) for a in f.extra_bytes_attributes] == [("TestExtraBytes", T.U32)]
+    raw_layout = las.point_layout_from_las_metadata(F, 4, f.extra_bytes_attributes, True, api=api)
+    typed_layout = las.point_layout_from_las_metadata(F, 4, f.extra_bytes_attributes, False, api=api)
+    assert f.record_length == raw_layout.size_of_point_entry()
+    base_typed = las.point_layout_from_las_point_format(F, False, api=api)
+    assert typed_layout.size_of_point_entry() == base_typed.size_of_point_entry() + 4
+    conv = las.get_default_las_converter(raw_layout, typed_layout, f.scale, f.offset)
+    scratch = VectorBuffer.from_numpy(f.records, raw_layout)
+    target = BUFFER_KINDS[target_kind].new_from_layout(typed_layout)
+    target.resize(10)
+    conv.convert_into_range(scratch, range(0, 10), target, range(0, 10))
+    check_against_reference_data(target, fmt)
+    extra = f.extra_bytes_attributes[0]
+    assert np.array_equal(target.view_attribute(extra), np.arange(10, dtype=np.uint32))
+    # undescribed extra bytes become one byte array (length = number of DESCRIBED bytes, as in the reference)
+    odd = las.point_layout_from_las_metadata(F, 7, f.extra_bytes_attributes, True, api=api)
+    assert odd.size_of_point_entry() == las.point_layout_from_las_point_format(F, True, api=api).size_of_point_entry() + 4 + 4
