@@ -64,14 +64,15 @@ __device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __res
 
 struct AxisGrid { const double* markers; uint32_t n; uint32_t shift; double origin, inv_leaf; };
 
+template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy,
-                                                            AxisGrid gz, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+                                                            AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
     const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
     const uint64_t kx = find_leaf_axis(x, gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(y, gy.markers, gy.n, gy.origin, gy.inv_leaf),
                    kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
-    keys[i] = (kx << gx.shift) | (ky << gy.shift) | kz;  // x-major: integer order == the reference's (x, y, z) tuple order
+    keys[i] = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
     idx[i] = (uint32_t)i;
   }
 }
@@ -355,39 +356,30 @@ struct VoxelGridState {
 };
 
 // Phase 1: keys, sort, voxel segmentation.  Returns the number of voxels (>= 1), or -1 on a HIP failure.
-long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
-                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, const double origin[3], const double leaf[3],
-                           hipStream_t stream) {
+// KeyT = uint32_t when the packed (x, y, z) key fits 32 bits (half the key traffic of the radix sort), else uint64_t.
+template <typename KeyT>
+static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy, AxisGrid gz,
+                                        int end_bit, hipStream_t stream) {
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
-  st = new VoxelGridState();
-  st->n = n;
-  VCK(st->keys.alloc(n * 8, stream)); VCK(st->keys2.alloc(n * 8, stream)); VCK(st->idx.alloc((n + 1) * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
-  VCK(st->markers.alloc(((size_t)nx + ny + nz + 1) * 8, stream));
-  double* dm = st->markers.as<double>();
-  if (nx) VCK(hipMemcpyAsync(dm, markers_x, (size_t)nx * 8, hipMemcpyHostToDevice, stream));
-  if (ny) VCK(hipMemcpyAsync(dm + nx, markers_y, (size_t)ny * 8, hipMemcpyHostToDevice, stream));
-  if (nz) VCK(hipMemcpyAsync(dm + nx + ny, markers_z, (size_t)nz * 8, hipMemcpyHostToDevice, stream));
+  VCK(st->keys.alloc(n * sizeof(KeyT), stream)); VCK(st->keys2.alloc(n * sizeof(KeyT), stream));
+  VCK(st->idx.alloc((n + 1) * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)device_cus() * 16));
-  auto bits_for = [](uint32_t count) { uint32_t b = 1; while (b < 21 && (1u << b) < count) ++b; return b; };  // indices 0 .. count-1
-  const uint32_t bz = bits_for(nz), by = bits_for(ny), bx = bits_for(nx);
-  const int end_bit = (int)(bx + by + bz);
-  AxisGrid gx{dm, nx, by + bz, origin[0], 1.0 / leaf[0]}, gy{dm + nx, ny, bz, origin[1], 1.0 / leaf[1]}, gz{dm + nx + ny, nz, 0, origin[2], 1.0 / leaf[2]};
-  hipLaunchKernelGGL(voxel_keys_kernel, dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<uint64_t>(),
+  hipLaunchKernelGGL((voxel_keys_kernel<KeyT>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
                      st->idx.as<uint32_t>());
   size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
-  VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                         st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
+  VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<KeyT>(), st->keys2.as<KeyT>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(),
+                                         (int)n, 0, end_bit, stream));
   // unique/counts reuse the unsorted key / index arrays after the sort (n entries each)
   VCK(st->nruns.alloc(16, stream));
   VCK(st->starts.alloc((n + 1) * 8, stream));
-  VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                            st->nruns.as<uint32_t>(), (int)n, stream));
+  VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<KeyT>(), st->keys.as<KeyT>(), st->idx.as<uint32_t>(), st->nruns.as<uint32_t>(),
+                                            (int)n, stream));
   VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n + 1, stream));
   VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan)), stream));
-  VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                         st->idx2.as<uint32_t>(), (int)n, 0, end_bit, stream));
-  VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<uint64_t>(), st->keys.as<uint64_t>(), st->idx.as<uint32_t>(),
-                                            st->nruns.as<uint32_t>(), (int)n, stream));
+  VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<KeyT>(), st->keys2.as<KeyT>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(),
+                                         (int)n, 0, end_bit, stream));
+  VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<KeyT>(), st->keys.as<KeyT>(), st->idx.as<uint32_t>(), st->nruns.as<uint32_t>(),
+                                            (int)n, stream));
   uint32_t runs = 0;
   VCK(hipMemcpyAsync(&runs, st->nruns.p, 4, hipMemcpyDeviceToHost, stream));
   VCK(hipStreamSynchronize(stream));
@@ -397,6 +389,24 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   VCK(hipcub::DeviceScan::ExclusiveSum(st->tmp.p, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)runs + 1, stream));
   return (long long)runs;
 #undef VCK
+}
+
+long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
+                           const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, const double origin[3], const double leaf[3],
+                           hipStream_t stream) {
+  st = new VoxelGridState();
+  st->n = n;
+  if (st->markers.alloc(((size_t)nx + ny + nz + 1) * 8, stream) != hipSuccess) return -1;
+  double* dm = st->markers.as<double>();
+  if (nx && hipMemcpyAsync(dm, markers_x, (size_t)nx * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+  if (ny && hipMemcpyAsync(dm + nx, markers_y, (size_t)ny * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+  if (nz && hipMemcpyAsync(dm + nx + ny, markers_z, (size_t)nz * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
+  auto bits_for = [](uint32_t count) { uint32_t b = 1; while (b < 21 && (1u << b) < count) ++b; return b; };  // indices 0 .. count-1
+  const uint32_t bz = bits_for(nz), by = bits_for(ny), bx = bits_for(nx);
+  const int end_bit = (int)(bx + by + bz);
+  AxisGrid gx{dm, nx, by + bz, origin[0], 1.0 / leaf[0]}, gy{dm + nx, ny, bz, origin[1], 1.0 / leaf[1]}, gz{dm + nx + ny, nz, 0, origin[2], 1.0 / leaf[2]};
+  return end_bit <= 32 ? voxel_grid_build_typed<uint32_t>(st, pos_base, pos_stride, n, gx, gy, gz, end_bit, stream)
+                       : voxel_grid_build_typed<uint64_t>(st, pos_base, pos_stride, n, gx, gy, gz, end_bit, stream);
 }
 
 // Phase 2: reductions into target points [dst_first, dst_first + n_voxels).

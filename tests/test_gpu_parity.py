@@ -907,3 +907,24 @@ def test_random_knn_normals_vs_oracle(hip, oracle, seed):
     assert np.array_equal(hk, ok)
     bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
     assert bad.sum() == 0 and cbad.sum() == 0
+
+
+def test_voxelgrid_fine_grid_needs_64_bit_keys(hip, oracle):
+    """Leaf size so small that the packed (x, y, z) key needs more than 32 bits (4 000 markers per axis = 36 bits): the 64-bit
+    key path of the sort; every point ends up in its own voxel, in (x, y, z) order."""
+    from pasture_amd.algorithms import voxelgrid_filter
+    n = 3_000
+    pts = np.random.default_rng(12).uniform(0.0, 20.0, (n, 3))
+
+    def run(api):
+        layout = PointLayout.from_attributes([A.POSITION_3D, A.INTENSITY], api=api)
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        src.set_attribute_range(A.INTENSITY, range(0, n), np.arange(n, dtype=np.uint16))
+        out = HashMapBuffer.new_from_layout(layout)
+        voxelgrid_filter(src, 0.005, 0.005, 0.005, out)
+        return out.len(), out.get_point_range(range(0, out.len())).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h[0] == o[0] == n
+    assert h[1] == o[1]
