@@ -928,3 +928,17 @@ def test_voxelgrid_fine_grid_needs_64_bit_keys(hip, oracle):
     h, o = both(run, hip, oracle)
     assert h[0] == o[0] == n
     assert h[1] == o[1]
+
+
+def test_example_pipeline_runs(hip):
+    """examples/las_pipeline.py on a fixture: read -> transform -> bounds -> voxel grid -> normals -> write."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("las_pipeline", os.path.join(root, "examples", "las_pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, header_bounds = mod.main(os.path.join(root, "tests", "golden", "las", "10_points_format_3.las"))
+    # ten points (i, i, i) shifted by (100, 200, 0): markers every 2.0 -> voxels {0}, {1,2}, {3,4}, {5,6}, {7,8}, {9}... by nearest marker
+    assert 4 <= n <= 6
+    assert header_bounds[0][0] >= 100.0 and header_bounds[1][0] <= 109.0
