@@ -942,3 +942,50 @@ def test_example_pipeline_runs(hip):
     # ten points (i, i, i) shifted by (100, 200, 0): markers every 2.0 -> voxels {0}, {1,2}, {3,4}, {5,6}, {7,8}, {9}... by nearest marker
     assert 4 <= n <= 6
     assert header_bounds[0][0] >= 100.0 and header_bounds[1][0] <= 109.0
+
+
+def test_two_threads_two_streams(hip):
+    """The C ABI keeps its stream, scratch and last-error state per thread: two Python threads, each with its own HIP stream,
+    run conversions + fused bounds + compaction concurrently and must both get the single-threaded answers."""
+    import ctypes
+    import threading
+    import torch
+    n = 400_000
+    raw = las.point_layout_from_las_point_format(las.Format(1), True, api=hip)
+    typed = las.point_layout_from_las_point_format(las.Format(1), False, api=hip)
+    xyz = PointLayout.from_attributes_packed([A.POSITION_3D, A.CLASSIFICATION.with_custom_datatype(T.U32)], 1, api=hip)
+
+    def work(seed):
+        src = VectorBuffer.new_from_layout(raw)
+        src.resize(n)
+        src.synth_fill(seed, 0)
+        dst = HashMapBuffer.new_from_layout(typed)
+        dst.resize(n)
+        b = las.get_default_las_converter(raw, typed, SCALE, OFFSET).convert_into_with_bounds(src, dst)
+        small = VectorBuffer.new_from_layout(xyz)
+        small.resize(n)
+        BufferLayoutConverter.for_layouts_with_default(typed, xyz).convert_into(dst, small)  # interpreted plan, type change u8 -> u32
+        mask = (np.arange(n) % (3 + seed)) == 0
+        kept = dst.filter(HashMapBuffer, mask)
+        return (b.min(), b.max()), small.get_point_range(range(0, n)).tobytes(), kept.get_point_range(range(0, kept.len())).tobytes()
+    hip.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    want = {s: work(s) for s in (1, 2)}
+    got, errors = {}, []
+
+    def runner(seed):
+        try:
+            stream = torch.cuda.Stream()
+            hip.set_stream(ctypes.c_void_p(stream.cuda_stream))  # thread-local
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    got[seed] = work(seed)
+            stream.synchronize()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+    threads = [threading.Thread(target=runner, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert got[1] == want[1] and got[2] == want[2]
