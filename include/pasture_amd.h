@@ -8,7 +8,7 @@
  *
  * Conventions
  *  - every function returns a pst_status; 0 = ok.  The reference signals precondition violations with
- *    panic!/assert!/expect; nothing unwinds across this ABI — the shim re-raises codes 2..13 as panic!.
+ *    panic!/assert!/expect; nothing unwinds across this ABI — the shim re-raises codes 2..14 as panic!.
  *    pst_last_error() returns the panic message of the last failing call on the calling thread.
  *  - plain pointers and sizes only; no torch / C++ types.  Device pointers are HIP device addresses.
  *  - all device work is enqueued on the calling thread's current stream (pst_set_stream; default = the null
