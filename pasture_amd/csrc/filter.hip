@@ -162,7 +162,16 @@ __device__ __forceinline__ void copy_granules(const FilterAttr& a, const uint16_
     for (uint32_t u = 0; u < kBatch; ++u) {
       const uint32_t k = k0 + u * kBlock;
       if (k < total) {
-        if (dst_aos) store_un<U>(lds + (mis + jj[u] * dst_stride + a.dst_off + cc[u] * (uint32_t)sizeof(U)), v[u]);
+        if (dst_aos) {
+          // unaligned LDS stores stall the LDS pipeline (SQ_LDS_UNALIGNED_STALL): split by the alignment class of the address
+          lptr_t q = lds + (mis + jj[u] * dst_stride + a.dst_off + cc[u] * (uint32_t)sizeof(U));
+          if constexpr (sizeof(U) == 16) {
+            lds_store<uint64_t>(q, (uint64_t)v[u].x | ((uint64_t)v[u].y << 32));
+            lds_store<uint64_t>(q + 8, (uint64_t)v[u].z | ((uint64_t)v[u].w << 32));
+          } else {
+            lds_store<U>(q, v[u]);
+          }
+        }
         else store_un<U>(dst + (uint64_t)k * sizeof(U), v[u]);
       }
     }
