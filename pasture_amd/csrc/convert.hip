@@ -410,6 +410,167 @@ __device__ __forceinline__ void run_tile_from_column(const ConvertHeader& h, con
   }
 }
 
+// ---- columnar (global) -> interleaved (LDS), four consecutive points per lane ------------------------------------
+// A lane that owns the points 4q .. 4q+3 reads 4*NC*sizeof(S) contiguous column bytes with vector loads, and the LDS address of
+// its i-th record is (tile base + 4q*stride) + i*stride + offset: the alignment class (address & 3) of every store depends only
+// on i, so it is wave-uniform and each value is written as head bytes + aligned dwords (re-cut with v_alignbyte) + tail bytes
+// behind a SCALAR branch -- no unaligned ds_write (SQ_LDS_UNALIGNED_STALL), no divergence.
+template <uint32_t ND>
+__device__ __forceinline__ void load_dwords(cgptr_t p, uint32_t (&r)[ND]) {
+#pragma unroll
+  for (uint32_t i = 0; i + 4 <= ND; i += 4) {
+    const u32x4 v = load_un<u32x4>(p + 4u * i);
+    r[i] = v.x; r[i + 1] = v.y; r[i + 2] = v.z; r[i + 3] = v.w;
+  }
+  if constexpr (ND % 4 >= 2) {
+    const uint64_t v = load_un<uint64_t>(p + 4u * (ND & ~3u));
+    r[ND & ~3u] = (uint32_t)v; r[(ND & ~3u) + 1] = (uint32_t)(v >> 32);
+  }
+  if constexpr (ND % 2 == 1) r[ND - 1] = load_un<uint32_t>(p + 4u * (ND - 1));
+}
+
+template <typename S, uint32_t ND>
+__device__ __forceinline__ S quad_elem(const uint32_t (&r)[ND], uint32_t el) {
+  if constexpr (sizeof(S) == 8) {
+    return __builtin_bit_cast(S, (uint64_t)r[2 * el] | ((uint64_t)r[2 * el + 1] << 32));
+  } else if constexpr (sizeof(S) == 4) {
+    return __builtin_bit_cast(S, r[el]);
+  } else if constexpr (sizeof(S) == 2) {
+    return __builtin_bit_cast(S, (uint16_t)(r[el >> 1] >> (16u * (el & 1u))));
+  } else {
+    return __builtin_bit_cast(S, (uint8_t)(r[el >> 2] >> (8u * (el & 3u))));
+  }
+}
+
+// L contiguous bytes (little-endian in w[], one spare dword behind them) stored at an LDS address of alignment class CLS
+template <uint32_t L, uint32_t CLS>
+__device__ __forceinline__ void lds_store_string(lptr_t p, const uint32_t (&w)[(L + 3) / 4 + 1]) {
+  typedef PST_AS_LDS uint8_t* p8;
+  typedef PST_AS_LDS uint16_t* p16;
+  typedef PST_AS_LDS uint32_t* p32;
+  constexpr uint32_t H = CLS == 0 ? 0u : ((4u - CLS) < L ? (4u - CLS) : L);  // bytes in front of the first dword boundary
+  if constexpr (H == 1) {
+    *(p8)p = (uint8_t)w[0];
+  } else if constexpr (H == 2) {
+    if constexpr (CLS == 2) *(p16)p = (uint16_t)w[0];
+    else { *(p8)p = (uint8_t)w[0]; *(p8)(p + 1) = (uint8_t)(w[0] >> 8); }
+  } else if constexpr (H == 3) {
+    *(p8)p = (uint8_t)w[0];
+    *(p16)(p + 1) = (uint16_t)(w[0] >> 8);
+  }
+  auto cut = [&](uint32_t o) -> uint32_t {  // the dword that starts at byte o of the string
+    const uint32_t j = o >> 2, sh = o & 3u;
+    return sh == 0 ? w[j] : __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+  };
+  constexpr uint32_t NB = (L - H) / 4u, R = (L - H) % 4u;
+#pragma unroll
+  for (uint32_t k = 0; k < NB; ++k) *(p32)(p + H + 4u * k) = cut(H + 4u * k);
+  if constexpr (R != 0) {
+    const uint32_t d = cut(H + 4u * NB);
+    lptr_t t = p + H + 4u * NB;
+    if constexpr (R == 1) *(p8)t = (uint8_t)d;
+    else if constexpr (R == 2) *(p16)t = (uint16_t)d;
+    else { *(p16)t = (uint16_t)d; *(p8)(t + 2) = (uint8_t)(d >> 16); }
+  }
+}
+
+template <typename S, typename D, uint32_t NC>
+__device__ __forceinline__ void run_tile_from_column_quad(const ConvertHeader& h, const PlanEntry& e, lptr_t lds_dst, uint64_t first, uint32_t cnt,
+                                                          LaneSpan span, BoundsAcc& acc) {
+  constexpr uint32_t ND = NC * (uint32_t)sizeof(S);  // dwords of the column per quad of points
+  constexpr uint32_t L = NC * (uint32_t)sizeof(D);   // bytes of the attribute in a record
+  constexpr uint32_t LW = (L + 3) / 4;
+  constexpr uint32_t KB = ND <= 2 ? 4u : ND <= 6 ? 2u : 1u;  // quads in flight per lane
+  constexpr bool kBounds = std::is_same<D, double>::value && NC == 3;
+  const XfRegs x = load_xf(e);
+  cgptr_t col = as_global(e.src_col) + first * (NC * sizeof(S));
+  const uint32_t quads = cnt >> 2, st = h.dst_stride;
+  const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)lds_dst + e.dst_off));
+  const uint32_t cls[4] = {a0 & 3u, (a0 + st) & 3u, (a0 + 2u * st) & 3u, (a0 + 3u * st) & 3u};
+  double lo[3] = {kF64Max, kF64Max, kF64Max}, hi[3] = {-kF64Max, -kF64Max, -kF64Max};
+  for (uint32_t q0 = span.first; q0 < quads; q0 += KB * span.step) {
+    uint32_t r[KB][ND];
+#pragma unroll
+    for (uint32_t u = 0; u < KB; ++u) {
+      const uint32_t q = q0 + u * span.step;
+      if (q < quads) load_dwords<ND>(col + (uint64_t)q * (ND * 4u), r[u]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < KB; ++u) {
+      const uint32_t q = q0 + u * span.step;
+      if (q < quads) {
+        lptr_t base = lds_dst + (q * 4u * st + e.dst_off);
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+          uint32_t w[LW + 1];
+#pragma unroll
+          for (uint32_t j = 0; j <= LW; ++j) w[j] = 0;
+#pragma unroll
+          for (uint32_t c = 0; c < NC; ++c) {
+            const S v = quad_elem<S, ND>(r[u], i * NC + c);
+            D d;
+            if constexpr (NC == 3) d = convert_value_sc<S, D>(v, x, c == 0 ? x.s0 : c == 1 ? x.s1 : x.s2, c == 0 ? x.o0 : c == 1 ? x.o1 : x.o2);
+            else if constexpr (NC == 1) d = convert_value_sc<S, D>(v, x, x.s0, x.o0);
+            else d = convert_value<S, D>(v, x, c);
+            if constexpr (kBounds) {
+              if (e.bounds) {  // wave-uniform
+                lo[c] = __builtin_fmin(lo[c], d);
+                hi[c] = __builtin_fmax(hi[c], d);
+              }
+            }
+            if constexpr (sizeof(D) == 8) {
+              const uint64_t b = __builtin_bit_cast(uint64_t, d);
+              w[2 * c] = (uint32_t)b; w[2 * c + 1] = (uint32_t)(b >> 32);
+            } else if constexpr (sizeof(D) == 4) {
+              w[c] = __builtin_bit_cast(uint32_t, d);
+            } else if constexpr (sizeof(D) == 2) {
+              w[c >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, d) << (16u * (c & 1u));
+            } else {
+              w[c >> 2] |= (uint32_t)__builtin_bit_cast(uint8_t, d) << (8u * (c & 3u));
+            }
+          }
+          lptr_t p = base + i * st;
+          if constexpr (L == 1) {
+            lds_store_string<1, 0>(p, w);  // a byte store is aligned wherever it lands
+          } else if constexpr (L == 2) {
+            if ((cls[i] & 1u) == 0) lds_store_string<2, 0>(p, w);
+            else lds_store_string<2, 1>(p, w);
+          } else {
+            switch (cls[i]) {  // wave-uniform
+              case 0: lds_store_string<L, 0>(p, w); break;
+              case 1: lds_store_string<L, 1>(p, w); break;
+              case 2: lds_store_string<L, 2>(p, w); break;
+              default: lds_store_string<L, 3>(p, w); break;
+            }
+          }
+        }
+      }
+    }
+  }
+  // the last tile of a range may end inside a quad
+  const uint32_t done = quads * 4u, rem = (cnt - done) * NC;
+  if (span.first < rem) {
+    const uint32_t k = done * NC + span.first, pt = k / NC, c = k - pt * NC;
+    const D d = convert_value<S, D>(load_un<S>(col + (uint64_t)k * sizeof(S)), x, c);
+    store_un<D>(lds_dst + (pt * st + e.dst_off + c * (uint32_t)sizeof(D)), d);
+    if constexpr (kBounds) {
+      if (e.bounds) acc.fold(c, d);
+    }
+  }
+  if constexpr (kBounds) {
+    if (e.bounds) {
+      acc.mn0 = __builtin_fmin(acc.mn0, lo[0]); acc.mx0 = __builtin_fmax(acc.mx0, hi[0]);
+      acc.mn1 = __builtin_fmin(acc.mn1, lo[1]); acc.mx1 = __builtin_fmax(acc.mx1, hi[1]);
+      acc.mn2 = __builtin_fmin(acc.mn2, lo[2]); acc.mx2 = __builtin_fmax(acc.mx2, hi[2]);
+    }
+  }
+}
+
+template <typename T> struct Vec3Able {
+  static constexpr bool value = std::is_same<T, uint8_t>::value || std::is_same<T, uint16_t>::value || std::is_same<T, int32_t>::value ||
+                                std::is_same<T, float>::value || std::is_same<T, double>::value;
+};
+
 // interleaved (LDS) -> interleaved (LDS)
 template <typename S, typename D>
 __device__ __forceinline__ void run_tile_lds_to_lds(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint32_t cnt,
@@ -432,7 +593,18 @@ __device__ __forceinline__ void run_tile(const ConvertHeader& h, const PlanEntry
                                          uint32_t cnt, LaneSpan span, BoundsAcc& acc) {
   if constexpr (SRC_AOS && DST_AOS) run_tile_lds_to_lds<S, D>(h, e, lds_src, lds_dst, cnt, span, acc);
   else if constexpr (SRC_AOS) run_tile_to_column<S, D>(h, e, lds_src, first, cnt, span, acc);
-  else run_tile_from_column<S, D>(h, e, lds_dst, first, cnt, span, acc);
+  else {
+    if (h.quad) {
+      if (e.ncomp == 1) { run_tile_from_column_quad<S, D, 1>(h, e, lds_dst, first, cnt, span, acc); return; }
+      if constexpr (Vec3Able<S>::value && Vec3Able<D>::value) {
+        if (e.ncomp == 3) { run_tile_from_column_quad<S, D, 3>(h, e, lds_dst, first, cnt, span, acc); return; }
+      }
+      if constexpr (std::is_same<S, uint8_t>::value && std::is_same<D, uint8_t>::value) {
+        if (e.ncomp == 4) { run_tile_from_column_quad<S, D, 4>(h, e, lds_dst, first, cnt, span, acc); return; }
+      }
+    }
+    run_tile_from_column<S, D>(h, e, lds_dst, first, cnt, span, acc);
+  }
 }
 
 // Entry scheduling inside a block.  Interpreting an entry (scalar fetch, type dispatch, loop set-up) costs every wave

@@ -39,6 +39,8 @@ struct ConvertHeader {
   uint32_t dst_fully_covered; // interleaved target: every byte of the record is written by some mapping
   uint32_t in_place;          // tile kernels, interleaved -> interleaved with src == dst: ONE record tile, transformed in LDS
   uint64_t bounds_partials;   // 0, or device address of gridDim.x records {min xyz, max xyz} (f64) for entries with .bounds
+  uint32_t quad;              // tile kernels, columnar -> interleaved: four consecutive points per lane (wave-uniform LDS alignment classes)
+  uint32_t reserved;
 };
 struct ConvertPlan {
   ConvertHeader h;

@@ -15,7 +15,7 @@ import sqlite3, glob
 db = glob.glob("$out/*_results.db")
 if db:
     cur = sqlite3.connect(db[0]).cursor()
-    for r in cur.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like '%$k%' group by counter_name"):
-        print(r[0], f"{r[1]:.4g}", r[2])
+    for r in cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%$k%' group by kernel_name, counter_name"):
+        print(r[0].split('(')[0][-60:], r[1], f"{r[2]:.4g}", r[3])
 PY
 done
