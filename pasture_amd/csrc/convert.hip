@@ -588,10 +588,141 @@ __device__ __forceinline__ void run_tile_lds_to_lds(const ConvertHeader& h, cons
   }
 }
 
+// L contiguous bytes read from an LDS address of (wave-uniform) alignment class CLS: aligned dwords, re-cut with v_alignbyte
+template <uint32_t L, uint32_t CLS>
+__device__ __forceinline__ void lds_load_string(clptr_t p, uint32_t (&w)[(L + 3) / 4 + 1]) {
+  typedef const PST_AS_LDS uint8_t* p8;
+  typedef const PST_AS_LDS uint16_t* p16;
+  typedef const PST_AS_LDS uint32_t* p32;
+  constexpr uint32_t LW = (L + 3) / 4;
+  w[LW] = 0;
+  if constexpr (L == 1) {
+    w[0] = *(p8)p;
+  } else if constexpr (L == 2 && (CLS & 1u) == 0) {
+    w[0] = *(p16)p;
+  } else {
+    constexpr uint32_t NR = (CLS + L + 3) / 4;  // aligned dwords that cover the string
+    uint32_t d[NR + 1];
+    clptr_t b = p - CLS;
+#pragma unroll
+    for (uint32_t k = 0; k < NR; ++k) d[k] = *(p32)(b + 4u * k);
+    d[NR] = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < LW; ++j) w[j] = CLS == 0 ? d[j] : __builtin_amdgcn_alignbyte(d[j + 1 < NR ? j + 1 : NR], d[j], CLS);
+  }
+}
+
+// interleaved (LDS) -> interleaved (LDS), four consecutive records per lane: both alignment classes are wave-uniform
+template <typename S, typename D, uint32_t NC>
+__device__ __forceinline__ void run_tile_lds_to_lds_quad(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint32_t cnt,
+                                                         LaneSpan span, BoundsAcc& acc) {
+  constexpr uint32_t LS = NC * (uint32_t)sizeof(S), LD = NC * (uint32_t)sizeof(D);
+  constexpr uint32_t LWS = (LS + 3) / 4, LWD = (LD + 3) / 4;
+  constexpr bool kBounds = std::is_same<D, double>::value && NC == 3;
+  const XfRegs x = load_xf(e);
+  const uint32_t quads = cnt >> 2, ss = h.src_stride, ds = h.dst_stride;
+  const uint32_t as0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)lds_src + e.src_off));
+  const uint32_t ad0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(uintptr_t)lds_dst + e.dst_off));
+  const uint32_t cs[4] = {as0 & 3u, (as0 + ss) & 3u, (as0 + 2u * ss) & 3u, (as0 + 3u * ss) & 3u};
+  const uint32_t cd[4] = {ad0 & 3u, (ad0 + ds) & 3u, (ad0 + 2u * ds) & 3u, (ad0 + 3u * ds) & 3u};
+  double lo[3] = {kF64Max, kF64Max, kF64Max}, hi[3] = {-kF64Max, -kF64Max, -kF64Max};
+  for (uint32_t q = span.first; q < quads; q += span.step) {
+    clptr_t sb = lds_src + (q * 4u * ss + e.src_off);
+    lptr_t db = lds_dst + (q * 4u * ds + e.dst_off);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      uint32_t ws[LWS + 1];
+      clptr_t sp = sb + i * ss;
+      if constexpr (LS == 1) {
+        lds_load_string<1, 0>(sp, ws);
+      } else if constexpr (LS == 2) {
+        if ((cs[i] & 1u) == 0) lds_load_string<2, 0>(sp, ws);
+        else if (cs[i] == 1u) lds_load_string<2, 1>(sp, ws);
+        else lds_load_string<2, 3>(sp, ws);
+      } else {
+        switch (cs[i]) {  // wave-uniform
+          case 0: lds_load_string<LS, 0>(sp, ws); break;
+          case 1: lds_load_string<LS, 1>(sp, ws); break;
+          case 2: lds_load_string<LS, 2>(sp, ws); break;
+          default: lds_load_string<LS, 3>(sp, ws); break;
+        }
+      }
+      uint32_t w[LWD + 1];
+#pragma unroll
+      for (uint32_t j = 0; j <= LWD; ++j) w[j] = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < NC; ++c) {
+        const S v = quad_elem<S, LWS + 1>(ws, c);
+        D d;
+        if constexpr (NC == 3) d = convert_value_sc<S, D>(v, x, c == 0 ? x.s0 : c == 1 ? x.s1 : x.s2, c == 0 ? x.o0 : c == 1 ? x.o1 : x.o2);
+        else if constexpr (NC == 1) d = convert_value_sc<S, D>(v, x, x.s0, x.o0);
+        else d = convert_value<S, D>(v, x, c);
+        if constexpr (kBounds) {
+          if (e.bounds) {
+            lo[c] = __builtin_fmin(lo[c], d);
+            hi[c] = __builtin_fmax(hi[c], d);
+          }
+        }
+        if constexpr (sizeof(D) == 8) {
+          const uint64_t b = __builtin_bit_cast(uint64_t, d);
+          w[2 * c] = (uint32_t)b; w[2 * c + 1] = (uint32_t)(b >> 32);
+        } else if constexpr (sizeof(D) == 4) {
+          w[c] = __builtin_bit_cast(uint32_t, d);
+        } else if constexpr (sizeof(D) == 2) {
+          w[c >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, d) << (16u * (c & 1u));
+        } else {
+          w[c >> 2] |= (uint32_t)__builtin_bit_cast(uint8_t, d) << (8u * (c & 3u));
+        }
+      }
+      lptr_t dp = db + i * ds;
+      if constexpr (LD == 1) {
+        lds_store_string<1, 0>(dp, w);
+      } else if constexpr (LD == 2) {
+        if ((cd[i] & 1u) == 0) lds_store_string<2, 0>(dp, w);
+        else lds_store_string<2, 1>(dp, w);
+      } else {
+        switch (cd[i]) {
+          case 0: lds_store_string<LD, 0>(dp, w); break;
+          case 1: lds_store_string<LD, 1>(dp, w); break;
+          case 2: lds_store_string<LD, 2>(dp, w); break;
+          default: lds_store_string<LD, 3>(dp, w); break;
+        }
+      }
+    }
+  }
+  const uint32_t done = quads * 4u, rem = (cnt - done) * NC;
+  if (span.first < rem) {
+    const uint32_t k = done * NC + span.first, pt = k / NC, c = k - pt * NC;
+    const D d = convert_value<S, D>(lds_load<S>(lds_src + (pt * ss + e.src_off + c * (uint32_t)sizeof(S))), x, c);
+    lds_store<D>(lds_dst + (pt * ds + e.dst_off + c * (uint32_t)sizeof(D)), d);
+    if constexpr (kBounds) {
+      if (e.bounds) acc.fold(c, d);
+    }
+  }
+  if constexpr (kBounds) {
+    if (e.bounds) {
+      acc.mn0 = __builtin_fmin(acc.mn0, lo[0]); acc.mx0 = __builtin_fmax(acc.mx0, hi[0]);
+      acc.mn1 = __builtin_fmin(acc.mn1, lo[1]); acc.mx1 = __builtin_fmax(acc.mx1, hi[1]);
+      acc.mn2 = __builtin_fmin(acc.mn2, lo[2]); acc.mx2 = __builtin_fmax(acc.mx2, hi[2]);
+    }
+  }
+}
+
 template <bool SRC_AOS, bool DST_AOS, typename S, typename D>
 __device__ __forceinline__ void run_tile(const ConvertHeader& h, const PlanEntry& e, clptr_t lds_src, lptr_t lds_dst, uint64_t first,
                                          uint32_t cnt, LaneSpan span, BoundsAcc& acc) {
-  if constexpr (SRC_AOS && DST_AOS) run_tile_lds_to_lds<S, D>(h, e, lds_src, lds_dst, cnt, span, acc);
+  if constexpr (SRC_AOS && DST_AOS) {
+    if (h.quad) {
+      if (e.ncomp == 1) { run_tile_lds_to_lds_quad<S, D, 1>(h, e, lds_src, lds_dst, cnt, span, acc); return; }
+      if constexpr (Vec3Able<S>::value && Vec3Able<D>::value) {
+        if (e.ncomp == 3) { run_tile_lds_to_lds_quad<S, D, 3>(h, e, lds_src, lds_dst, cnt, span, acc); return; }
+      }
+      if constexpr (std::is_same<S, uint8_t>::value && std::is_same<D, uint8_t>::value) {
+        if (e.ncomp == 4) { run_tile_lds_to_lds_quad<S, D, 4>(h, e, lds_src, lds_dst, cnt, span, acc); return; }
+      }
+    }
+    run_tile_lds_to_lds<S, D>(h, e, lds_src, lds_dst, cnt, span, acc);
+  }
   else if constexpr (SRC_AOS) run_tile_to_column<S, D>(h, e, lds_src, first, cnt, span, acc);
   else {
     if (h.quad) {

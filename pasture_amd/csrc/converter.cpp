@@ -134,7 +134,7 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
     // pile them onto the same LDS banks (measured 32 B: 5.96 -> 4.55 TB/s), every other stride gains (41 B: 4.20 -> 5.87).
     // PST_TILE_QUAD=0 / 1 forces the mapping (tuning).
     static const int quad_env = [] { const char* v = std::getenv("PST_TILE_QUAD"); return v && *v ? (*v == '0' ? 0 : 1) : -1; }();
-    plan.h.quad = quad_env >= 0 ? (uint32_t)quad_env : (dst_stride % 32u != 0 ? 1u : 0u);
+    plan.h.quad = quad_env >= 0 ? (uint32_t)quad_env : ((dst_stride % 32u != 0 && !(src_aos && src_stride % 32u == 0)) ? 1u : 0u);
     std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
     bool wants_bounds = false;
     for (size_t i = 0; i < cnt; ++i) {
