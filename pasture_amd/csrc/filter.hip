@@ -114,6 +114,8 @@ struct FilterArgs {
   uint32_t tile;
   uint32_t n_attrs;
   uint32_t dst_covered;  // interleaved target: attributes cover every byte of the record (no read-modify-write needed)
+  uint32_t chunk;        // interleaved target: records per LDS chunk (multiple of 16)
+  uint32_t reserved;
   FilterAttr attrs[kMaxFilterAttrs];
 };
 
@@ -222,31 +224,47 @@ __global__ __launch_bounds__(kBlock) void filter_scatter_kernel(const FilterArgs
   for (int i = 0; i < PPL; ++i) if (mb[i] != 0) sel[r++] = (uint16_t)(p0 + i);
 
   if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);  // more matches than num_matches: the host raises the panic
-  uint32_t mis = 0;
-  uint64_t ga = 0;
+  m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);  // block-uniform by construction: keep the chunk loop on the scalar unit
   if constexpr (DST_AOS) {
-    ga = a.dst_aos + out0 * a.dst_stride;
-    mis = (uint32_t)(ga & 15u);
-    if (!a.dst_covered) {  // padding bytes of the target records must survive
-      tile_load<kBlock>(lds, as_global(ga - mis), (mis + m * a.dst_stride + 15u) & ~15u);
-      wait_tile_loads();
+    // The tile's selected records go through the LDS record tile in balanced chunks of <= a.chunk records: ranks and `sel` are
+    // computed once per 2048 input points while the LDS footprint (and with it the number of resident blocks) stays small.
+    const uint32_t nch = (m + a.chunk - 1) / a.chunk;
+    const uint32_t mc = ((m + nch - 1) / nch + 15u) & ~15u;  // <= a.chunk (a multiple of 16)
+    for (uint32_t j0 = 0; j0 < m; j0 += mc) {
+      const uint32_t cm = (m - j0) < mc ? (m - j0) : mc;
+      const uint64_t ga = a.dst_aos + (out0 + j0) * a.dst_stride;
+      const uint32_t mis = (uint32_t)(ga & 15u);
+      if (!a.dst_covered) {  // padding bytes of the target records must survive
+        tile_load<kBlock>(lds, as_global(ga - mis), (mis + cm * a.dst_stride + 15u) & ~15u);
+        wait_tile_loads();
+      }
+      __syncthreads();
+      for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+        const FilterAttr& at = a.attrs[ai];
+        switch (at.unit) {
+          case 16: copy_granules<u32x4>(at, sel + j0, first, 0, cm, true, lds, mis, a.dst_stride); break;
+          case 8: copy_granules<uint64_t>(at, sel + j0, first, 0, cm, true, lds, mis, a.dst_stride); break;
+          case 4: copy_granules<uint32_t>(at, sel + j0, first, 0, cm, true, lds, mis, a.dst_stride); break;
+          case 2: copy_granules<uint16_t>(at, sel + j0, first, 0, cm, true, lds, mis, a.dst_stride); break;
+          default: copy_granules<uint8_t>(at, sel + j0, first, 0, cm, true, lds, mis, a.dst_stride); break;
+        }
+      }
+      __syncthreads();
+      tile_store<kBlock>(lds, as_global(ga - mis), mis, cm * a.dst_stride);
+      if (j0 + mc < m) __syncthreads();  // the next chunk overwrites the record tile
     }
-  }
-  __syncthreads();
-
-  for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
-    const FilterAttr& at = a.attrs[ai];
-    switch (at.unit) {
-      case 16: copy_granules<u32x4>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
-      case 8: copy_granules<uint64_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
-      case 4: copy_granules<uint32_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
-      case 2: copy_granules<uint16_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
-      default: copy_granules<uint8_t>(at, sel, first, out0, m, DST_AOS, lds, mis, a.dst_stride); break;
-    }
-  }
-  if constexpr (DST_AOS) {
+  } else {
     __syncthreads();
-    tile_store<kBlock>(lds, as_global(ga - mis), mis, m * a.dst_stride);
+    for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+      const FilterAttr& at = a.attrs[ai];
+      switch (at.unit) {
+        case 16: copy_granules<u32x4>(at, sel, first, out0, m, false, lds, 0, 0); break;
+        case 8: copy_granules<uint64_t>(at, sel, first, out0, m, false, lds, 0, 0); break;
+        case 4: copy_granules<uint32_t>(at, sel, first, out0, m, false, lds, 0, 0); break;
+        case 2: copy_granules<uint16_t>(at, sel, first, out0, m, false, lds, 0, 0); break;
+        default: copy_granules<uint8_t>(at, sel, first, out0, m, false, lds, 0, 0); break;
+      }
+    }
   }
 }
 
@@ -259,13 +277,18 @@ size_t filter_workspace_bytes(uint64_t n) {
   return (size_t)(max_tiles * (sizeof(uint32_t) + sizeof(unsigned long long)) + 64);
 }
 
-// Points per tile: columnar targets 2048; interleaved targets as many records as fit ~40 KiB of LDS (a power of two >= 256).
-uint32_t filter_tile(bool dst_aos, uint32_t dst_stride) {
-  if (!dst_aos) return 2048;
-  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 40L * 1024L; }();
-  uint32_t t = 2048;
-  while (t > 256 && (uint64_t)t * dst_stride > (uint64_t)budget) t >>= 1;
-  return t;
+// Input points per tile (ranks are computed once per tile).
+uint32_t filter_tile(bool, uint32_t) { return 2048; }
+
+// Interleaved targets: records per LDS chunk -- about 16 KiB of records (same-box sweep, 41-byte records: 8 KiB 3.99, 12 KiB 4.51,
+// 16 KiB 4.60, 21 KiB 4.43, 32 KiB 3.76 TB/s), a multiple of 16.  PST_FILTER_TILE_LDS overrides the byte budget (tuning).
+static uint32_t filter_chunk(uint32_t dst_stride) {
+  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 16L * 1024L; }();
+  uint64_t c = (uint64_t)budget / (dst_stride ? dst_stride : 1u);
+  c = c / 16 * 16;
+  if (c < 16) c = 16;
+  if (c > 2048) c = 2048;
+  return (uint32_t)c;
 }
 
 // Phase 1: counts + offsets (offsets[n_tiles] = number of matches), device memory inside `workspace`.
@@ -293,7 +316,9 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
   a.dst_aos = dst_aos_base;
   a.dst_stride = dst_stride;
   a.tile = tile;
-  const size_t lds_bytes = (((size_t)tile * 2 + 15) & ~(size_t)15) + (dst_aos ? (size_t)tile * dst_stride + 48 : 0);
+  a.chunk = dst_aos ? filter_chunk(dst_stride) : 0u;
+  const size_t lds_bytes = (((size_t)tile * 2 + 15) & ~(size_t)15) + (dst_aos ? (size_t)a.chunk * dst_stride + 48 : 0);
+  if (lds_bytes > 160 * 1024 - 256) return false;  // records too large for the LDS record tile
   for (int g = 0; g < n_attrs; g += kMaxFilterAttrs) {
     const int ng = std::min(kMaxFilterAttrs, n_attrs - g);
     a.n_attrs = (uint32_t)ng;
