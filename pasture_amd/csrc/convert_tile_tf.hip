@@ -1,0 +1,12 @@
+// convert_tile_kernel<256, true, false> (interleaved -> columnar) as its own translation unit; see convert.hip / convert_kernels.hpp.
+#include "convert_kernels.hpp"
+
+namespace pstk {
+
+void launch_convert_tile_tf(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries) {
+  auto kfn = convert_tile_kernel<256, true, false>;
+  if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds_bytes, stream, h, entries);
+}
+
+}  // namespace pstk
