@@ -41,6 +41,10 @@ WORKLOADS = {
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
     "rawlas_to_records": (55, "raw LAS-0 records (20 B) -> interleaved typed LAS-0 records (VectorBuffer of LasPointFormat0, 35 B): 20 R + 35 W"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
+    "columns_to_custom41": (82, "INTERPRETED plan: CustomPointTypeBig (41 B, 5 attrs, packed) columnar -> VectorBuffer (41 R + 41 W); "
+                                "generic tile kernel, four points per lane"),
+    "las1_records_to_custom27": (70, "INTERPRETED plan: typed LAS-1 records (43 B) -> packed records {Position3D, Intensity, Classification} "
+                                     "(27 B): 43 R + 27 W; generic interleaved -> interleaved tile kernel"),
     "las0_encode": (55, "LAS writer: 10 SoA columns (typed LAS-0) -> raw LAS-0 records + header AABB + per-return counts, fused (35 R + 20 W)"),
     "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
                                   "resident in HBM (2 mask reads + 41 R + 20.5 W per input point)"),
@@ -250,6 +254,31 @@ def main():
         conv = las.get_default_las_converter(src_layout, dst_layout, SCALE, OFFSET)
         conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
         pa.calculate_bounds_async(dst, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload == "columns_to_custom41":
+        big = pa.PointLayout.from_attributes_packed([A.GPS_TIME, A.COLOR_RGB, A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY.with_custom_datatype(T.I16)], 1)
+        src = pa.HashMapBuffer.new_from_layout(big)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.VectorBuffer.new_from_layout(big)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(big, big)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload == "las1_records_to_custom27":
+        src_layout = las.point_layout_from_las_point_format(las.Format(1), False)
+        dst_layout = pa.PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], 1)
+        src = pa.VectorBuffer.new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.VectorBuffer.new_from_layout(dst_layout)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(src_layout, dst_layout)
+        pa.calculate_bounds_async(src, rec.data_ptr())
 
         def step():
             conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
