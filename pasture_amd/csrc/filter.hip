@@ -181,7 +181,7 @@ __device__ __forceinline__ void copy_granules(const FilterAttr& a, const uint16_
 }
 
 template <int PPL, bool DST_AOS>
-__global__ __launch_bounds__(kBlock) void filter_scatter_kernel(const FilterArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DST_AOS ? 8 : 4, 8))) void filter_scatter_kernel(const FilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   uint16_t* sel = (uint16_t*)lds_raw;                         // [tile] local indices of the selected points, ascending
   lptr_t lds = (lptr_t)lds_raw + ((a.tile * 2u + 15u) & ~15u);  // interleaved target: record tile
@@ -280,10 +280,11 @@ size_t filter_workspace_bytes(uint64_t n) {
 // Input points per tile (ranks are computed once per tile).
 uint32_t filter_tile(bool, uint32_t) { return 2048; }
 
-// Interleaved targets: records per LDS chunk -- about 16 KiB of records (same-box sweep, 41-byte records: 8 KiB 3.99, 12 KiB 4.51,
-// 16 KiB 4.60, 21 KiB 4.43, 32 KiB 3.76 TB/s), a multiple of 16.  PST_FILTER_TILE_LDS overrides the byte budget (tuning).
+// Interleaved targets: records per LDS chunk -- about 15 KiB of records (same-box sweep, 41-byte records: 8 KiB 3.99, 12 KiB 4.51,
+// 16 KiB 4.60, 21 KiB 4.43, 32 KiB 3.76 TB/s; 15 KiB + the 4 KiB index list leave room for eight blocks per CU, which the kernel's
+// register budget -- amdgpu_waves_per_eu(8) -- matches: +3 %), a multiple of 16.  PST_FILTER_TILE_LDS overrides the byte budget (tuning).
 static uint32_t filter_chunk(uint32_t dst_stride) {
-  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 16L * 1024L; }();
+  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 15L * 1024L; }();
   uint64_t c = (uint64_t)budget / (dst_stride ? dst_stride : 1u);
   c = c / 16 * 16;
   if (c < 16) c = 16;
