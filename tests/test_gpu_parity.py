@@ -756,6 +756,47 @@ def test_typed_las_storage_transposition_vs_oracle(hip, oracle, fmt, pair):
     assert h == o
 
 
+_STRIDE_LAYOUTS = {
+    16: ["GPS_TIME", "POINT_ID"],
+    24: ["POSITION_3D"],
+    26: ["POSITION_3D", "INTENSITY"],
+    27: ["POSITION_3D", "INTENSITY", "CLASSIFICATION"],
+    28: ["POSITION_3D", "INTENSITY", "POINT_SOURCE_ID"],
+    32: ["POSITION_3D", "GPS_TIME"],
+    33: ["GPS_TIME", "CLASSIFICATION", "POSITION_3D"],
+    36: ["POSITION_3D", "NORMAL"],
+    41: ["GPS_TIME", "COLOR_RGB", "POSITION_3D", "CLASSIFICATION", "INTENSITY"],
+    48: ["POSITION_3D", "GPS_TIME", "POINT_ID", "WAVEFORM_DATA_OFFSET"],
+    64: ["POSITION_3D", "GPS_TIME", "COLOR_RGB", "INTENSITY", "NORMAL", "WAVEFORM_PARAMETERS"],
+}
+
+
+@pytest.mark.parametrize("pair", ["HV", "VV", "VH"])
+@pytest.mark.parametrize("stride", sorted(_STRIDE_LAYOUTS))
+def test_interpreted_plans_by_record_size_vs_oracle(hip, oracle, stride, pair):
+    """The interpreted tile kernels pick the lane -> point mapping by record size (four points per lane unless the size is a
+    multiple of 32 bytes): every size class, every storage pairing, ragged ranges (tile tails inside a quad), target offsets that
+    shift the alignment classes, and a source that is a superset in another order (typed LAS-1 records / columns)."""
+    n, cut, pad = 70_003, 33_331, 5
+
+    def run(api):
+        src_layout = las.point_layout_from_las_point_format(las.Format(1), False, api=api)
+        defs = [getattr(A, k) for k in _STRIDE_LAYOUTS[stride]]
+        tgt_layout = PointLayout.from_attributes_packed(defs, 1, api=api)
+        assert tgt_layout.size_of_point_entry() == stride
+        src = BUFFER_KINDS[pair[0]].new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(1000 + stride, 17)
+        dst = BUFFER_KINDS[pair[1]].new_from_layout(tgt_layout)
+        dst.resize(n + pad)
+        conv = BufferLayoutConverter.for_layouts_with_default(src_layout, tgt_layout)
+        conv.convert_into_range(src, range(0, cut), dst, range(pad, pad + cut))
+        conv.convert_into_range(src, range(cut, n), dst, range(pad + cut, pad + n))
+        return dst.get_point_range(range(0, n + pad)).tobytes()
+    h, o = both(run, hip, oracle)
+    assert h == o
+
+
 @pytest.mark.parametrize("case", ["typed_V_H", "typed_H_V", "raw_H", "raw_V"])
 @pytest.mark.parametrize("fmt", [0, 3, 6, 10])
 def test_fused_bounds_of_specialised_las_paths(hip, oracle, fmt, case):
