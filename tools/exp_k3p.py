@@ -7,7 +7,7 @@ from pasture_amd import las
 api = pa.product_api(); s = torch.cuda.current_stream(); api.set_stream(ctypes.c_void_p(s.cuda_stream))
 n = 100_000_000
 mode = sys.argv[1] if len(sys.argv) > 1 else "h2v"
-las0 = las.point_layout_from_las_point_format(las.Format(0), False)
+las0 = las.point_layout_from_las_point_format(las.Format(int(os.environ.get("FMT", "0"))), False)
 src = (pa.HashMapBuffer if mode[0] == "h" else pa.VectorBuffer).new_from_layout(las0); src.resize(n); src.synth_fill(42, 0)
 dst = (pa.HashMapBuffer if mode[2] == "h" else pa.VectorBuffer).new_from_layout(las0); dst.resize(n)
 conv = pa.BufferLayoutConverter.for_layouts(las0, las0)
@@ -18,4 +18,5 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(s)
 for _ in range(5): conv.convert_into_range_async(src, r, dst, r)
 e1.record(s); torch.cuda.synchronize()
-print(mode, e0.elapsed_time(e1) / 5, "ms")
+ms = e0.elapsed_time(e1) / 5
+print(mode, "fmt", os.environ.get("FMT", "0"), ms, "ms", 2 * las0.size_of_point_entry() * n / ms / 1e9, "TB/s")
