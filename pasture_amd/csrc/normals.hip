@@ -215,37 +215,48 @@ struct KBest {
 // ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
 struct Fit { double nx, ny, nz, curvature; int ok; };
 
-template <typename GetPoint>
+// KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
+// compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
+template <int KMAX = 0, typename GetPoint>
 __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   Fit f{0, 0, 0, 0, 1};
+  auto for_each = [&](auto&& body) __attribute__((always_inline)) {
+    if constexpr (KMAX > 0) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) if ((uint32_t)t < m) body((uint32_t)t);
+    } else {
+      for (uint32_t t = 0; t < m; ++t) body(t);
+    }
+  };
   // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points)
   bool dense = true;
-  for (uint32_t t = 0; t < m; ++t) {
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
     if (x != x || y != y || z != z) dense = false;
-  }
+  });
   // compute_centroid :198-237
   double sx = 0, sy = 0, sz = 0;
   long long cnt = 0;
-  for (uint32_t t = 0; t < m; ++t) {
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
     if (dense || finite3(x, y, z)) { sx += x; sy += y; sz += z; cnt += 1; }
-  }
+  });
   const double div = dense ? (double)m : (double)cnt;
   const double cx = sx / div, cy = sy / div, cz = sz / div;
   // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
   double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
   long long used = 0;
-  for (uint32_t t = 0; t < m; ++t) {
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
-    if (!dense && !finite3(x, y, z)) continue;
-    double d0 = x - cx, d1 = y - cy, d2 = z - cz;
-    c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
-    const double dx = d0;
-    d0 *= dx; d1 *= dx; d2 *= dx;
-    c00 += d0; c01 += d1; c02 += d2;
-    used += 1;
-  }
+    if (dense || finite3(x, y, z)) {
+      double d0 = x - cx, d1 = y - cy, d2 = z - cz;
+      c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+      const double dx = d0;
+      d0 *= dx; d1 *= dx; d2 *= dx;
+      c00 += d0; c01 += d1; c02 += d2;
+      used += 1;
+    }
+  });
   if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
   const double c10 = c01, c20 = c02, c21 = c12;
   // eigen_3x3 :429-453
@@ -473,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
       for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = (long long)sidx[best.i[u]];
       out.knn[orig * k + t] = v;
     }
-  const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
+  const Fit f = plane_fit<K>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
     uint32_t p = 0;
 #pragma unroll
     for (int u = 0; u < K; ++u) if ((uint32_t)u == t) p = best.i[u];
