@@ -114,12 +114,15 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
   }
   hipStream_t s = current_stream();
   if (count > b.capacity) {
+    // pool allocations are stream-ordered (hipMallocAsync / hipFreeAsync on the current stream): copy and free need no host round trip
+    // -- one per column made every growing call (append, filter, voxel grid output) pay several on a loaded host
+    const bool ordered = pool_ready() && b.memkind != PST_MEM_PINNED_HOST;
     if (b.columnar) {
       for (size_t a = 0; a < b.columns.size(); ++a) {
         const size_t sz = b.layout.members[a].size;
         uint8_t* fresh = dev_alloc(count * sz, b.memkind);
         if (b.len && fresh) PST_HIP_CHECK(hipMemcpyAsync(fresh, b.columns[a], b.len * sz, hipMemcpyDefault, s));
-        stream_sync(s);
+        if (!ordered) stream_sync(s);
         dev_free(b.columns[a], b.memkind);
         b.columns[a] = fresh;
       }
@@ -127,7 +130,7 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
       const size_t sz = b.layout.size;
       uint8_t* fresh = dev_alloc(count * sz, b.memkind);
       if (b.len && fresh) PST_HIP_CHECK(hipMemcpyAsync(fresh, b.data, b.len * sz, hipMemcpyDefault, s));
-      stream_sync(s);
+      if (!ordered) stream_sync(s);
       dev_free(b.data, b.memkind);
       b.data = fresh;
     }
