@@ -204,7 +204,8 @@ int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst);
  * sums in point order), most common (return fields, classification, scan angle, user data, point source id; ties: smallest
  * value — the reference's HashMap order is random), max-pool from 0.0 (ClassificationFlags, GpsTime, PointID).
  * Panics: no Position3D -> PST_ERR_MISSING_ATTRIBUTE; empty buffer -> PST_ERR_BOUNDS_INVALID (unwrap on None); waveform or
- * non-standard attribute in filtered's layout -> PST_ERR_UNSUPPORTED_ATTRIBUTE; attribute missing in `buffer` -> PST_ERR_MISSING_ATTRIBUTE. */
+ * non-standard attribute in filtered's layout -> PST_ERR_UNSUPPORTED_ATTRIBUTE; attribute missing in `buffer` -> PST_ERR_MISSING_ATTRIBUTE.
+ * filtered's length is final on return; the attribute reductions are enqueued on the current stream (no final synchronisation). */
 int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, pst_buffer* filtered);
 
 /* ---- LAS record encoder (the writer side of the hot path) ---------------------------- */
