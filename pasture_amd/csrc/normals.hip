@@ -650,8 +650,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       hipLaunchKernelGGL(knn_nonfinite_kernel, dim3(grid), dim3(kBlock), 0, stream, xyz.as<double>(), sorted_xyz.as<double>(), idx2.as<uint32_t>(),
                          (uint32_t)nf, (uint32_t)n, k, out);
     }
-    NCK(hipGetLastError());
-    NCK(hipStreamSynchronize(stream));  // temporaries die here
+    NCK(hipGetLastError());  // the temporaries are released stream-ordered (DevBuf): no host round trip here
   }
   NCK(hipGetLastError());
   int errors = 0;
