@@ -16,7 +16,9 @@ struct TempDev {
 };
 
 // Compaction of src's points with mask != 0 into dst[0, matches); returns the number of matches.
-size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, bool mask_on_device, int64_t num_matches_hint) {
+// counted: the caller has just run launch_filter_count for the same mask / length (the tile counts and offsets are still in the
+// workspace and `num_matches_hint` is the count it read): the count and scan launches are not repeated.
+size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, bool mask_on_device, int64_t num_matches_hint, bool counted = false) {
   if (!src.columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
   if (dst.layout != src.layout) throw Error(PST_ERR_LAYOUT_MISMATCH, "PointLayouts must match");  // :1088-1090
   const size_t n = src.len;
@@ -35,9 +37,11 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   const uint32_t tile = pstk::filter_tile(dst_aos, dst_stride);
   uint8_t* scratch = workspace().partials(pstk::filter_workspace_bytes(n));
   const unsigned long long* total_dev = nullptr;
-  pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s);
   Workspace& ws = workspace();
-  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (!counted) {
+    pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s);
+    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  }
   // With Some(num_matches) (the reference's bench passes it) nothing on the host depends on the count before the copies are
   // launched: count, scan and scatter run back to back and the count is read once, at the end.  Without it the target check
   // (:1093-1095) needs the count first.
@@ -125,7 +129,7 @@ int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_
       for (auto& m : b->layout.members) covered += m.size;
       if (covered != b->layout.size) PST_HIP_CHECK(hipMemsetAsync(b->data, 0, matches * b->layout.size, s));
     }
-    filter_into(*src, *b, mask_dev, true, (int64_t)matches);
+    filter_into(*src, *b, mask_dev, true, (int64_t)matches, true);
   }
   *out = b.release();
   PST_API_END
