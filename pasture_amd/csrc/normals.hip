@@ -228,19 +228,20 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
       for (uint32_t t = 0; t < m; ++t) body(t);
     }
   };
-  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points)
+  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points) and compute_centroid :198-237 in ONE
+  // pass over the neighbours (each pass re-gathers 16 points): both candidate sums are accumulated in point order -- over all points
+  // (the dense path) and over the finite ones (the other path) -- and the one `dense` selects is used, so every sum is the same sequence
+  // of additions as in the reference.
   bool dense = true;
-  for_each([&](uint32_t t) __attribute__((always_inline)) {
-    double x, y, z; get(t, x, y, z);
-    if (x != x || y != y || z != z) dense = false;
-  });
-  // compute_centroid :198-237
-  double sx = 0, sy = 0, sz = 0;
+  double ax = 0, ay = 0, az = 0, fx = 0, fy = 0, fz = 0;
   long long cnt = 0;
   for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
-    if (dense || finite3(x, y, z)) { sx += x; sy += y; sz += z; cnt += 1; }
+    if (x != x || y != y || z != z) dense = false;
+    ax += x; ay += y; az += z;
+    if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
   });
+  const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
   const double div = dense ? (double)m : (double)cnt;
   const double cx = sx / div, cy = sy / div, cz = sz / div;
   // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
