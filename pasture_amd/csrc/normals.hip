@@ -428,10 +428,19 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
   KBest<K> best;
   best.init();
+  // candidates in pairs: both coordinate triples are requested before the first insertion (the loop was waiting on one dependent load
+  // per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the pair)
   auto scan = [&](uint32_t p, uint32_t p_end) __attribute__((always_inline)) {
-    for (; p < p_end; ++p) {
-      const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
-      best.insert(ddx * ddx + ddy * ddy + ddz * ddz, p);
+    for (; p < p_end; p += 2) {
+      const bool two = p + 1 < p_end;
+      const uint32_t pb = two ? p + 1 : p;
+      const double ax = sxyz[3 * (uint64_t)p], ay = sxyz[3 * (uint64_t)p + 1], az = sxyz[3 * (uint64_t)p + 2];
+      const double bx = sxyz[3 * (uint64_t)pb], by = sxyz[3 * (uint64_t)pb + 1], bz = sxyz[3 * (uint64_t)pb + 2];
+      const double adx = ax - qx, ady = ay - qy, adz = az - qz, bdx = bx - qx, bdy = by - qy, bdz = bz - qz;
+      const double da = adx * adx + ady * ady + adz * adz;
+      const double db = two ? bdx * bdx + bdy * bdy + bdz * bdz : __builtin_inf();
+#pragma nounroll
+      for (int u = 0; u < 2; ++u) best.insert(u ? db : da, u ? pb : p);
     }
   };
   const int max_r = (int)max(g.dim[0], max(g.dim[1], g.dim[2]));
