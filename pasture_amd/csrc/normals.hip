@@ -429,18 +429,22 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   KBest<K> best;
   best.init();
   // candidates in pairs: both coordinate triples are requested before the first insertion (the loop was waiting on one dependent load
-  // per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the pair)
-  auto scan = [&](uint32_t p, uint32_t p_end) __attribute__((always_inline)) {
-    for (; p < p_end; p += 2) {
-      const bool two = p + 1 < p_end;
-      const uint32_t pb = two ? p + 1 : p;
-      const double ax = sxyz[3 * (uint64_t)p], ay = sxyz[3 * (uint64_t)p + 1], az = sxyz[3 * (uint64_t)p + 2];
+  // per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the pair).  The two ranges of a row are walked
+  // as one sequence, so the two single end cells of an interior row share a round trip.
+  auto scan2 = [&](uint32_t p0, uint32_t p1, uint32_t q0, uint32_t q1) __attribute__((always_inline)) {
+    const uint32_t lp = p1 - p0, total = lp + (q1 - q0);
+    for (uint32_t v = 0; v < total; v += 2) {
+      const bool two = v + 1 < total;
+      const uint32_t pa = v < lp ? p0 + v : q0 + (v - lp);
+      const uint32_t vb = two ? v + 1 : v;
+      const uint32_t pb = vb < lp ? p0 + vb : q0 + (vb - lp);
+      const double ax = sxyz[3 * (uint64_t)pa], ay = sxyz[3 * (uint64_t)pa + 1], az = sxyz[3 * (uint64_t)pa + 2];
       const double bx = sxyz[3 * (uint64_t)pb], by = sxyz[3 * (uint64_t)pb + 1], bz = sxyz[3 * (uint64_t)pb + 2];
       const double adx = ax - qx, ady = ay - qy, adz = az - qz, bdx = bx - qx, bdy = by - qy, bdz = bz - qz;
       const double da = adx * adx + ady * ady + adz * adz;
       const double db = two ? bdx * bdx + bdy * bdy + bdz * bdz : __builtin_inf();
 #pragma nounroll
-      for (int u = 0; u < 2; ++u) best.insert(u ? db : da, u ? pb : p);
+      for (int u = 0; u < 2; ++u) best.insert(u ? db : da, u ? pb : pa);
     }
   };
   const int max_r = (int)max(g.dim[0], max(g.dim[1], g.dim[2]));
@@ -464,9 +468,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             if (cx - r >= 0) { p0 = cell_start[row + (uint32_t)(cx - r)]; p1 = cell_start[row + (uint32_t)(cx - r) + 1]; }
             if (cx + r < (int)g.dim[0]) { q0 = cell_start[row + (uint32_t)(cx + r)]; q1 = cell_start[row + (uint32_t)(cx + r) + 1]; }
           }
-          for (int seg = 0; seg < 2; ++seg) {
-            scan(seg ? q0 : p0, seg ? q1 : p1);
-          }
+          scan2(p0, p1, q0, q1);
         } else {
           const int xstep = face ? 1 : (2 * r > 0 ? 2 * r : 1);  // interior rows of the shell: only the two end cells
           for (int dx = -r; dx <= r; dx += xstep) {
