@@ -477,9 +477,20 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             const uint64_t key = morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
             uint32_t p = lookup_cell(table, key);
             if (p == kNoIndex) continue;
-            for (; p < nf && skeys[p] == key; ++p) {
-              const double ddx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
-              best.insert(ddx * ddx + ddy * ddy + ddz * ddz, p);
+            // the cell's points two at a time: keys and coordinates of both are requested before anything is tested or inserted
+            for (; p < nf; p += 2) {
+              const uint32_t pb = p + 1 < nf ? p + 1 : p;
+              const uint64_t ka = skeys[p], kb = skeys[pb];
+              const double ax = sxyz[3 * (uint64_t)p], ay = sxyz[3 * (uint64_t)p + 1], az = sxyz[3 * (uint64_t)p + 2];
+              const double bx = sxyz[3 * (uint64_t)pb], by = sxyz[3 * (uint64_t)pb + 1], bz = sxyz[3 * (uint64_t)pb + 2];
+              if (ka != key) break;
+              const bool two = pb != p && kb == key;
+              const double adx = ax - qx, ady = ay - qy, adz = az - qz, bdx = bx - qx, bdy = by - qy, bdz = bz - qz;
+              const double da = adx * adx + ady * ady + adz * adz;
+              const double db = two ? bdx * bdx + bdy * bdy + bdz * bdz : __builtin_inf();
+#pragma nounroll
+              for (int u = 0; u < 2; ++u) best.insert(u ? db : da, u ? pb : p);
+              if (!two) break;
             }
           }
         }
