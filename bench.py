@@ -7,8 +7,12 @@ A "step" is one pass of the hot path over one batch of synthetic points already 
       10^8 points per GPU, columnar (HashMapBuffer) POSITION_3D Vec3f64
       -> BufferLayoutConverter with the LAS affine transformation (p*scale)+offset -> columnar POSITION_3D
       + calculate_bounds of the result, fused into ONE pass over HBM (24 B read + 24 B written per point).
-      N > 1: points shard by index range (weak scaling: 10^8 per GPU); the only exchange is one all-reduce (RCCL) of
-      the 6-double AABB record per step.
+      N > 1: points shard by index range; the only exchange is one all-reduce (RCCL) of the 6-double AABB record per step.
+      Two sharding modes: weak scaling (default: `--points` per GPU, global cloud of N x points) and BASELINE.json
+      configs[3] (`--global-points 1000000000`: ONE fixed cloud sharded N ways, rank r owns
+      [r*ceil(G/N), min(G, (r+1)*ceil(G/N))), "scaling": "strong").
+      `python bench.py --gpus N` without a launcher starts the N ranks itself (re-exec under torch.distributed.run) and
+      refuses to run when the box has fewer than N devices; under the driver's torchrun it uses the environment's ranks.
   other workloads (`--workload`): bounds (AABB only, 24 B/pt), las0_to_columns (configs[2]: 35 B interleaved LAS-0 ->
       10 columns, 70 B/pt), rawlas_to_columns (20 B raw records -> 10 columns with i32->f64 affine + bit fields, 55 B/pt).
 
@@ -62,18 +66,51 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    p.add_argument("--points", type=int, default=100_000_000, help="points per GPU (weak scaling)")
+    p.add_argument("--global-points", type=int, default=0,
+                   help="BASELINE.json configs[3]: ONE cloud of this many points sharded by index range over the ranks (strong scaling); overrides --points")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --launch-dry-run (CPU test of the launcher)")
+    p.add_argument("--launch-dry-run", action="store_true",
+                   help="start the ranks, count them with one all-reduce, print the census and exit: no GPU work (CPU test of the N>1 launcher)")
+    p.add_argument("--no-north-star", action="store_true", help="skip the 10^9-point single-GPU leg (north_star size) appended at N=1")
+    p.add_argument("--north-star-points", type=int, default=1_000_000_000)
     p.add_argument("--workload", default="convert_affine_bounds", choices=sorted(WORKLOADS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-points", type=int, default=100_000_000, help="CPU baseline sample (default: the whole 10^8-point workload, ~10 s of CPU work)")
     return p.parse_args()
 
 
+def _native_oracle():
+    """The oracle built for THIS host (`-O3 -march=native`, on the GPU box): oracle/_native/liboracle_native.so,
+    compiled here when g++ is present (about 8 s, cached by mtime).  Falls back to the travelling -march=x86-64-v2 build.
+    Returns (path, flags-description) or (None, None)."""
+    import shutil
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    generic = os.path.join(odir, "liboracle.so")
+    srcs = [os.path.join(odir, f) for f in ("oracle_capi.cpp", "oracle_capi.h", "pasture_oracle.hpp")]
+    gxx = shutil.which("g++")
+    if gxx and all(os.path.exists(f) for f in srcs):
+        out = os.path.join(odir, "_native", "liboracle_native.so")
+        try:
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            stale = not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(f) for f in srcs)
+            if stale:
+                subprocess.check_call([gxx, "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out + ".tmp", srcs[0]],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+                os.replace(out + ".tmp", out)
+            return out, "g++ -O3 -march=native, built on this host"
+        except Exception:
+            pass
+    if os.path.exists(generic):
+        return generic, "g++ -O3 -march=x86-64-v2 (no g++ on this host for a native build)" if not gxx else "g++ -O3 -march=x86-64-v2 (native build failed)"
+    return None, None
+
+
 def cpu_baseline(workload, sample_points):
     """Oracle timed on one pinned host core.  Only the checker lives under oracle/; it is never the thing shipped."""
-    from pasture_amd._capi import CApi  # binding class only
-    lib_path = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(lib_path):
+    lib_path, flags = _native_oracle()
+    if lib_path is None:
         return None
     lib = ctypes.CDLL(lib_path)
     aff = None
@@ -98,10 +135,15 @@ def cpu_baseline(workload, sample_points):
             "value": round(sample_points / med / 1e6, 3), "unit": "Mpoints/s", "cores": 1, "kind": "port",
             "sample": f"{sample_points} of the same synthetic points, same workload (columnar POSITION_3D affine convert + calculate_bounds), "
                       f"median of {reps} runs, single thread pinned to one core; oracle = faithful-shape C++ restatement of the Rust "
-                      f"reference (g++ -O3 -march=x86-64-v2), the reference itself is not buildable offline",
+                      f"reference ({flags}), the reference itself is not buildable offline",
             "effective_GBps": round(48 * sample_points / med / 1e9, 3),
             "bounds": list(bounds),
         }
+        # the same code at a tenth of the sample to show linearity
+        lin_n = max(1, sample_points // 10)
+        secs_l = (ctypes.c_double * reps)()
+        if lib.orc_bench_config2(lin_n, reps, SEED, sc, of, secs_l, bounds) == 0:
+            out["linearity"] = {"points": lin_n, "value": round(lin_n / statistics.median(list(secs_l)) / 1e6, 3), "unit": "Mpoints/s"}
         # BASELINE.json configs[0] exactly: 10^6 XYZ f64 points VectorBuffer -> HashMapBuffer + calculate_bounds, median of 10
         reps1 = 10
         secs1 = (ctypes.c_double * reps1)()
@@ -124,26 +166,92 @@ def cpu_baseline(workload, sample_points):
                 pass
 
 
+def _free_port():
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks of this file under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and hand back their exit code.  Refuses when the box has fewer than N devices."""
+    import subprocess
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; refusing to run fewer ranks "
+                             f"than asked (no silent 1-GPU run)\n")
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # does not return
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if args.gpus == 1:
+            args.gpus = world  # launched under torchrun without --gpus: the launcher's world size is the truth
+        else:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n")
+            sys.exit(2)
+    if args.launch_dry_run:
+        # CPU test of the launcher: every rank joins ONE all-reduce; the sum is the number of workers that really started
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        if dev == "cuda":
+            torch.cuda.set_device(local_rank)
+        census = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(census)
+        from pasture_amd.distributed import shard_range
+        g_pts = args.global_points or args.points * world
+        shard = shard_range(g_pts, rank, world) if args.global_points else range(rank * args.points, (rank + 1) * args.points)
+        mine = torch.tensor([shard.start, shard.stop, os.getpid()], dtype=torch.int64, device=dev)
+        allr = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        if rank == 0:
+            print(json.dumps({"launch_dry_run": True, "n_gpus": int(census.item()), "world_size": world, "backend": dist.get_backend(),
+                              "scaling": "strong" if args.global_points else "weak", "global_points": g_pts,
+                              "shards": [[int(t[0]), int(t[1])] for t in allr], "pids": [int(t[2]) for t in allr]}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU: pasture_amd has no CPU fallback"
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} wants device {local_rank} but this node has {torch.cuda.device_count()} GPUs\n")
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     # torchrun with one rank (or PASTURE_FORCE_DIST=1) still exercises the RCCL path: init, all-reduce, barrier
     distributed = world > 1 or (os.environ.get("PASTURE_FORCE_DIST") == "1" and "RANK" in os.environ)
+    n_ranks_seen = 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the 48-byte AABB collectives must not queue behind the 97k-workgroup conversion kernels: high-priority RCCL stream
         # (measured with one rank: step 0.806 -> 0.774 ms, kernel-only 0.767 ms; tools/exp_dist_overhead.py)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        census = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(census)  # n_gpus in the JSON line = the ranks RCCL really saw
+        n_ranks_seen = int(census.item())
+        if n_ranks_seen != world:
+            sys.stderr.write(f"bench.py: RCCL saw {n_ranks_seen} ranks, expected {world}\n")
+            sys.exit(2)
 
     import pasture_amd as pa
     from pasture_amd import las
@@ -155,8 +263,16 @@ def main():
     stream = torch.cuda.current_stream()
     api.set_stream(ctypes.c_void_p(stream.cuda_stream))  # kernels run on torch's current stream => torch events see them
 
-    n = args.points
-    first_index = rank * n  # weak scaling: every rank owns its own index range of one global synthetic cloud
+    if args.global_points:
+        # BASELINE.json configs[3]: ONE cloud sharded by index range; the ranks' shards differ by at most one tile
+        from pasture_amd.distributed import shard_range
+        shard = shard_range(args.global_points, rank, world)
+        n, first_index = len(shard), shard.start
+        global_points, scaling = args.global_points, "strong"
+    else:
+        n = args.points
+        first_index = rank * n  # weak scaling: every rank owns its own index range of one global synthetic cloud
+        global_points, scaling = n * world, "weak"
     bytes_per_point, desc = WORKLOADS[args.workload]
     # ring of AABB records: step i writes ring[i % 4]; with N > 1 its all-reduce runs asynchronously behind the next steps
     from pasture_amd.distributed import PipelinedBoundsReduce
@@ -367,34 +483,72 @@ def main():
     elif has_reduction and ring.i:
         rec = ring.recs[(ring.i - 1) % len(ring.recs)]
     result = bounds_from_record(rec.cpu())
+    # north_star size made driver-visible: the same fused convert + AABB over 10^9 points (24 GB in, 24 GB out) on ONE GPU, measured in this
+    # run after the timed region (N = 1, default workload only); reported beside the headline, never folded into `value`
+    north_star = None
+    if (world == 1 and not args.no_north_star and args.workload == "convert_affine_bounds" and not args.global_points
+            and args.north_star_points > n):
+        nn = args.north_star_points
+        free_b, _total_b = torch.cuda.mem_get_info()
+        if free_b > 2 * 24 * nn + (8 << 30):
+            del src, dst
+            big_src = pa.HashMapBuffer.new_from_layout(layout)
+            big_src.resize(nn)
+            big_src.synth_fill(SEED, 0)
+            big_dst = pa.HashMapBuffer.new_from_layout(layout)
+            big_dst.resize(nn)
+            big_rec = torch.empty(6, dtype=torch.float64, device="cuda")
+            ns_steps = 5
+            for _ in range(2):
+                conv.convert_into_with_bounds_async(big_src, big_dst, big_rec.data_ptr())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(ns_steps):
+                conv.convert_into_with_bounds_async(big_src, big_dst, big_rec.data_ptr())
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ns_ms = e0.elapsed_time(e1) / ns_steps
+            ns_gbs = bytes_per_point * nn / (ns_ms * 1e-3) / 1e9
+            north_star = {"points": nn, "steps": ns_steps, "ms_per_step": round(ns_ms, 4), "value": round(nn / (ns_ms * 1e-3) / 1e6, 2),
+                          "unit": "Mpoints/s", "achieved_GBps": round(ns_gbs, 1), "frac": round(ns_gbs / HBM_PEAK_GBS, 4),
+                          "bounds": bounds_from_record(big_rec.cpu()),
+                          "note": "north_star size (10^9 points, 1 GPU): same kernel, same fused step, HIP events over 5 back-to-back steps"}
+            del big_src, big_dst
+
     if rank == 0:
-        total_points = n * world * args.steps
+        total_points = global_points * args.steps
         value = total_points / elapsed / 1e6
         achieved = bytes_per_point * n / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath)).get(args.workload)
                 if t and t.get("points") == n:
                     traffic = t.get("bytes_per_launch")
+                    traffic_src = (f"profiles/hbm_traffic.json (round {t.get('round')}; separate rocprofv3 --pmc passes, fetch factor "
+                                   f"{t.get('fetch_factor', 2)}: {t.get('calibrated_on', 'wide coalesced reads')}); NOT measured in this run")
             except Exception:
                 pass
         line = {
             "metric": "Mpoints/sec + achieved HBM GB/s (% of peak), 10^8-pt POSITION_3D convert+AABB",
-            "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": n * world,
+            "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": global_points,
                        "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16") else "LAS format 0",
-                       "parallelism": f"index-range shard x{world}, one all-reduce of the 6-f64 AABB" if distributed else "1 GPU",
+                       "parallelism": (f"index-range shard x{world} of one {global_points}-point cloud (configs[3]), one all-reduce of the 6-f64 AABB" if args.global_points
+                                       else f"index-range shard x{world}, one all-reduce of the 6-f64 AABB") if distributed else "1 GPU",
                        "seed": SEED, "bounds": result},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_point": bytes_per_point, "kernel_ms_avg": round(kernel_ms_avg, 4),
                          "kernel_ms_min": round(min(kernel_ms), 4),
                          "note": "HIP events around one step's launches on the launch stream (conversion kernel + the AABB fold kernels where fused)"},
         }
+        if north_star is not None:
+            line["north_star_1e9"] = north_star
         if world == 1 and not args.no_cpu_baseline and args.workload == "convert_affine_bounds":
             cb = cpu_baseline(args.workload, args.cpu_sample_points)
             if cb is not None:

@@ -181,3 +181,42 @@ def test_sharded_filter_offsets_and_las_header_gloo(oracle):
     want_b = list(bounds[0]) + list(bounds[1])
     for g in got:
         assert g[4] == want_b and g[5] == counts
+
+
+# ---- bench.py's own N>1 launcher (`--gpus N` silently ran ONE rank) ---------------------------------------------
+def _run_bench(*argv, env_extra=None, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_launcher_spawns_n_workers_gloo_dry_run():
+    """WORLD_SIZE unset + --gpus 2: bench.py re-executes itself under torch.distributed.run; the census all-reduce counts 2 distinct
+    worker processes, and --global-points gives the configs[3] index-range shards (strong scaling)."""
+    import json
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--launch-dry-run", "--global-points", "1000000001")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["scaling"] == "strong"
+    assert line["shards"] == [[0, 500000001], [500000001, 1000000001]]
+    assert len(set(line["pids"])) == 2
+    # weak scaling (default): --points per GPU, rank r starts at r * points
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--launch-dry-run", "--points", "1000")
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["shards"] == [[0, 1000], [1000, 2000]] and line["global_points"] == 2000
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` on a box with fewer than N devices exits non-zero with a clear message (never a silent 1-GPU run)."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run_bench("--gpus", str(have + 1) if have + 1 > 1 else "2")
+    assert r.returncode != 0
+    assert "refusing to run fewer ranks" in r.stderr
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _run_bench("--gpus", "4", "--backend", "gloo", "--launch-dry-run",
+                   env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
