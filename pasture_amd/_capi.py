@@ -133,6 +133,7 @@ _PRODUCT_SIGNATURES = {
     "calculate_bounds_async": [_P, _P],
     "las_encode_range_async": [_P, _SZ, _SZ, C.c_uint32, _D3, _D3, _P, _SZ, _P, _P, C.c_uint32],
     "compute_normals_into": [_P, _SZ, _P],
+    "compute_normals_device": [_P, _SZ, _P, _P, _P],
 }
 
 PRODUCT_SYMBOLS = ["last_error"] + list(_SHARED_SIGNATURES) + list(_PRODUCT_SIGNATURES)

@@ -87,6 +87,13 @@ def compute_normals_into(point_cloud: _Buffer, k_nn: int, target: _Buffer) -> No
     point_cloud.api.compute_normals_into(point_cloud._h, k_nn, target._h)
 
 
+def compute_normals_device(point_cloud: _Buffer, k_nn: int, normals_ptr: int = 0, curvature_ptr: int = 0, knn_ptr: int = 0) -> None:
+    """The result of compute_normals in caller-owned DEVICE memory (addresses; 0 = not wanted): normals f64 [n][3], curvature f64 [n],
+    neighbour lists uint32 [n][k] in ascending distance."""
+    point_cloud.api.compute_normals_device(point_cloud._h, k_nn, C.c_void_p(normals_ptr or None), C.c_void_p(curvature_ptr or None),
+                                           C.c_void_p(knn_ptr or None))
+
+
 def voxelgrid_filter(buffer: _Buffer, leafsize_x: float, leafsize_y: float, leafsize_z: float, filtered_buffer: _Buffer) -> None:
     """voxel_grid.rs:109-166: down-samples `buffer` to one centroid per occupied voxel (cells centred on the axis markers),
     appended to `filtered_buffer` in (x, y, z) voxel order; per-attribute reductions of set_all_attributes (:459-689)."""

@@ -3,7 +3,9 @@
 // ExternalMemoryBuffer :1479-1708) — storage shape and accessor semantics (resize zero-fills, ranges are checked).
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 
+#include "device_sort.hpp"
 #include "runtime.hpp"
 
 namespace pst {
@@ -66,21 +68,64 @@ static bool pool_ready() {
   return state == 1;
 }
 
+// Pool blocks remember the stream they were allocated on.  hipFreeAsync orders the release behind THAT stream's work only, so a
+// buffer destroyed while another stream is current (a different thread whose stream is the default one, or after pst_set_stream)
+// first waits for the whole device: work enqueued by the asynchronous entry points may still be using the block.
+static std::mutex g_alloc_mu;
+static std::unordered_map<void*, hipStream_t> g_alloc_stream;
+
+hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s) {
+  *p = nullptr;
+  if (!pool_ready()) return hipMalloc(p, bytes);
+  const hipError_t e = hipMallocAsync(p, bytes, s);
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    g_alloc_stream[*p] = s;
+  }
+  return e;
+}
+void dev_free_stream(void* p, hipStream_t s) {
+  if (!p) return;
+  if (!pool_ready()) { (void)hipFree(p); return; }
+  hipStream_t owner = s;
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    auto it = g_alloc_stream.find(p);
+    if (it != g_alloc_stream.end()) { owner = it->second; g_alloc_stream.erase(it); }
+  }
+  if (owner != s) (void)hipDeviceSynchronize();
+  (void)hipFreeAsync(p, owner);
+}
+
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind) {
   if (bytes == 0) return nullptr;
   ensure_device();
   void* p = nullptr;
   if (memkind == PST_MEM_PINNED_HOST) PST_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
-  else if (pool_ready()) PST_HIP_CHECK(hipMallocAsync(&p, bytes, current_stream()));
-  else PST_HIP_CHECK(hipMalloc(&p, bytes));
+  else PST_HIP_CHECK(dev_alloc_stream(&p, bytes, current_stream()));
   return (uint8_t*)p;
 }
 void dev_free(uint8_t* p, uint32_t memkind) {
   if (!p) return;
   if (memkind == PST_MEM_PINNED_HOST) (void)hipHostFree(p);
-  else if (pool_ready()) (void)hipFreeAsync(p, current_stream());
-  else (void)hipFree(p);
+  else dev_free_stream(p, current_stream());
 }
+
+}  // namespace pst
+
+// scratch of the spatial-index builders (device_sort.hpp): same allocator, same PST_NO_POOL / no-pool fallback
+namespace pstk {
+hipError_t DevBuf::alloc(size_t bytes, hipStream_t stream) {
+  release();
+  return pst::dev_alloc_stream(&p, bytes ? bytes : 16, stream);
+}
+void DevBuf::release() {
+  if (p) pst::dev_free_stream(p, pst::current_stream());
+  p = nullptr;
+}
+}  // namespace pstk
+
+namespace pst {
 
 PlanEntry identity_entry(const Member& src, const Member& dst) {
   PlanEntry e{};

@@ -1,0 +1,22 @@
+// rocPRIM calls of the spatial-index builders, isolated in one translation unit (the headers are heavy).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device_sort.hpp"
+
+namespace pstk {
+
+hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                          size_t n, unsigned end_bit, hipStream_t stream) {
+  return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+}
+hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                          size_t n, unsigned end_bit, hipStream_t stream) {
+  return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+}
+hipError_t exclusive_sum_u32_u64(void* tmp, size_t& bytes, const uint32_t* in, unsigned long long* out, size_t n, hipStream_t stream) {
+  return rocprim::exclusive_scan(tmp, bytes, in, out, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+}
+
+}  // namespace pstk

@@ -1,0 +1,32 @@
+// Library plumbing shared by the spatial-index builders (normals.hip, voxel.hip): rocPRIM device primitives, called directly
+// (no CUB-shaped compatibility layer).  Every function follows rocPRIM's two-call convention: tmp == nullptr writes the scratch
+// size to `bytes` and does nothing else.  All of them are stream-ordered; none synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pstk {
+
+// stable LSD radix sort of (key, value) pairs on key bits [0, end_bit); n < 2^32
+hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                          size_t n, unsigned end_bit, hipStream_t stream);
+hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                          size_t n, unsigned end_bit, hipStream_t stream);
+// exclusive prefix sum of u32 counts into u64 offsets (out[0] = 0)
+hipError_t exclusive_sum_u32_u64(void* tmp, size_t& bytes, const uint32_t* in, unsigned long long* out, size_t n, hipStream_t stream);
+
+// stream-ordered scratch from the library's allocator (pst::dev_alloc / dev_free: HIP's stream-ordered pool, or plain hipMalloc
+// when the device has no pool support or PST_NO_POOL is set); freed in stream order by the destructor
+struct DevBuf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes, hipStream_t stream);
+  void release();
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  template <typename T> T* as() { return (T*)p; }
+};
+
+}  // namespace pstk

@@ -50,11 +50,12 @@ unsigned column_launch_grid(const PlanEntry& e, uint64_t n, bool with_bounds);
 bool launch_column(const PlanEntry& e, uint64_t n, double* bounds_partials, hipStream_t stream);
 
 // K4 kNN normal estimation (normals.hip).  Positions: Vec3f64 at pos_base + i*pos_stride.  Outputs (all optional, device
-// addresses): normals f64 [n][3], curvature f64 [n], knn int64 [n][k], NORMAL attribute (Vec3f32) and Curvature attribute (F64)
-// of a target buffer.  Returns 0, -1 on a HIP failure, or the number of neighbourhoods with < 3 usable points.
+// addresses): normals f64 [n][3], curvature f64 [n], knn int64 [n][k] and / or uint32 [n][k], NORMAL attribute (Vec3f32) and Curvature
+// attribute (F64) of a target buffer.  Returns 0, -1 on a HIP failure, -2 beyond 2^32 - 16 points, or the number of neighbourhoods with
+// < 3 usable points.
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
-                      long long* out_knn_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride,
-                      hipStream_t stream);
+                      long long* out_knn_dev, uint32_t* out_knn_u32_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr,
+                      uint64_t curv_stride, hipStream_t stream);
 
 // LAS record encoder (las_encode.hip)
 uint32_t las_raw_record_size(int format);

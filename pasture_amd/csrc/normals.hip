@@ -1,4 +1,4 @@
-// K4 — kNN normal estimation on the device (gfx950).
+// K4 — kNN normal estimation on the device (gfx950): spatial index, global-memory search kernels and the host driver.
 //
 // Replaces compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130): per point the k nearest neighbours
 // (exact, f64 squared Euclidean distance, the point itself included, ascending distance — the contract of
@@ -7,38 +7,32 @@
 // (eigenvalues of the unscaled matrix multiplied by the scale again :441-443; the diagonal subtraction :446-449 that
 // has no effect; normal = largest of three row cross products, NOT normalised :395-426).
 //
-// Neighbour search: points are binned into a uniform grid whose cell edge is chosen so that a sphere of one cell edge
-// holds about k points; cells are addressed by a 63-bit Morton key, the points are radix-sorted by key (hipCUB) and an
-// open-addressing hash table maps occupied cells to their first sorted point.  One lane per query walks Chebyshev
-// shells of cells around its own cell, keeps the k best candidates SORTED IN REGISTERS (fully unrolled insertion, no
-// scratch), and stops as soon as the k-th best distance is inside the searched cube.  Queries run in Morton order, so
-// neighbouring lanes touch the same cells and the gathers hit L2.
-//
+// Spatial index: points are binned into a uniform grid whose cell edge is chosen so that a sphere of one cell edge holds about k
+// points, radix-sorted by cell key (rocPRIM, device_sort.hip — library plumbing) and reordered once, so that every search reads
+// contiguous runs of sorted points.
+//   volume-like clouds (cells <= 4 n): keys are row-major cell numbers (x fastest, 32-bit) with a DENSE directory cell_start[];
+//       the search runs in normals_tile.hip (a box of cells staged in LDS per workgroup); queries it cannot finish come back as a list
+//       for knn_grid_kernel<K, true> below;
+//   sparse clouds: 63-bit Morton keys + an open-addressing hash table of occupied cells; knn_grid_kernel<K, false>: one lane per query
+//       walks Chebyshev shells of cells, k best candidates SORTED IN REGISTERS, stops when the k-th distance is inside the searched cube.
+// Search kernels write ONE aligned 32-byte result record per point at its original index (full-sector stores behind a compute-bound
+// search); split_results_kernel streams the records into the caller's outputs and narrows the normal to the NORMAL attribute (Vec3f32,
+// Rust `as`).
 // The reference allocates a HashMapBuffer per point and goes through DMatrix; none of that survives: the 3x3 moment
 // sums live in registers.  f64 throughout (sqrt / atan2 / cos / sin from the device math library); -ffp-contract=off.
-#include <hipcub/hipcub.hpp>
-
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-#include "device_common.hpp"
+#include "device_sort.hpp"
 #include "kernels.hpp"
+#include "normals_device.hpp"
+#include "normals_host.hpp"
 
-using namespace pstd;
+using namespace pstn;
 
 namespace {
-
-constexpr uint64_t kInvalidKey = ~0ull;
-constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
-
-struct GridParams {
-  double org[3];   // grid origin (min corner of the finite points)
-  double inv_h;    // 1 / cell edge
-  double h;        // cell edge
-  uint32_t dim[3]; // cells per axis (<= 2^21)
-  uint32_t dense;  // 1: keys are row-major cell numbers (x fastest) with a dense cell_start directory; 0: Morton keys + hash table
-};
 
 __device__ __forceinline__ uint64_t spread21(uint64_t v) {  // insert two zero bits between each of the low 21 bits
   v &= 0x1FFFFFull;
@@ -50,17 +44,6 @@ __device__ __forceinline__ uint64_t spread21(uint64_t v) {  // insert two zero b
   return v;
 }
 __device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z) { return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2); }
-
-__device__ __forceinline__ bool finite3(double x, double y, double z) {
-  return __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
-}
-__device__ __forceinline__ uint32_t cell_coord(double v, double org, double inv_h, uint32_t dim) {
-  double c = __builtin_floor((v - org) * inv_h);
-  if (!(c > 0.0)) c = 0.0;
-  const double top = (double)(dim - 1);
-  if (c > top) c = top;
-  return (uint32_t)c;
-}
 
 // positions (any stride) -> packed xyz f64 + finite-only bounds partials
 __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t* base, uint64_t stride, uint64_t n, double* __restrict__ xyz,
@@ -85,7 +68,8 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
   }
 }
 
-__global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, uint64_t* __restrict__ keys,
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, KeyT* __restrict__ keys,
                                                       uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite) {
   unsigned long long local = 0;
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
@@ -93,14 +77,14 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     uint64_t key = kInvalidKey;
     if (finite3(x, y, z)) {
-      const uint32_t cx = cell_coord(x, g.org[0], g.inv_h, g.dim[0]), cy = cell_coord(y, g.org[1], g.inv_h, g.dim[1]),
+      const uint32_t cx = cell_coord(x, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(y, g.org[1], g.inv_h, g.dim[1]),
                      cz = cell_coord(z, g.org[2], g.inv_h, g.dim[2]);
       key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
       local += 1;
     } else if (g.dense) {
       key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
     }
-    keys[i] = key;
+    keys[i] = (KeyT)key;
     idx[i] = (uint32_t)i;
   }
   if (local) atomicAdd(n_finite, local);  // the compiler folds this to one atomic per wave
@@ -157,7 +141,7 @@ __device__ __forceinline__ uint32_t lookup_cell(const CellTable& t, uint64_t k) 
 
 // Dense directory (volume-like clouds: cells <= a few n): cell_start[c] = first sorted point with key >= c, c in [0, cells].
 // Sorted keys are row-major cell numbers, so the cells x0..x1 of one grid row are ONE contiguous range of sorted points.
-__global__ __launch_bounds__(kBlock) void build_directory_kernel(const uint64_t* __restrict__ keys, uint64_t nf, uint64_t cells,
+__global__ __launch_bounds__(kBlock) void build_directory_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells,
                                                                  uint32_t* __restrict__ cell_start) {
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j <= nf; j += step) {
@@ -174,163 +158,11 @@ __global__ __launch_bounds__(kBlock) void build_directory_kernel(const uint64_t*
   }
 }
 
-// ---- k-best list, sorted ascending, fully in registers --------------------------------------------------------
-template <int K>
-struct KBest {
-  double d[K];
-  uint32_t i[K];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int t = 0; t < K; ++t) { d[t] = __builtin_inf(); i[t] = kNoIndex; }
-  }
-  // Insert (dist, index) keeping ascending order; an equal distance goes AFTER the existing ones (first found wins).
-  // Distances: new[t] = min(d[t], max(d[t-1], dist)) — two f64 ops per slot instead of compare + 64-bit selects (the search is
-  // VALU-bound: ~145 candidates per query, every accepted one walks all K slots).  Indices follow the same three cases through
-  // keep[t] = d[t] <= dist (monotone in t because the list is sorted).  Distances are never NaN here.
-  __device__ __forceinline__ void insert(double dist, uint32_t index) {
-    if (!(dist < d[K - 1])) return;
-    bool keep_prev = true;  // "d[-1] <= dist"
-    double d_prev = -__builtin_inf();
-    uint32_t i_prev = index;
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const double dt = d[t];
-      const uint32_t it = i[t];
-      const bool keep = dt <= dist;
-      d[t] = __builtin_fmin(dt, __builtin_fmax(d_prev, dist));
-      i[t] = keep ? it : (keep_prev ? index : i_prev);
-      keep_prev = keep;
-      d_prev = dt;
-      i_prev = it;
-    }
-  }
-  __device__ __forceinline__ double kth(uint32_t k) const {  // d[k-1] without dynamic register indexing
-    double v = d[K - 1];
-#pragma unroll
-    for (int t = 0; t < K; ++t) v = (uint32_t)t == k - 1 ? d[t] : v;
-    return v;
-  }
-};
-
-// ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
-struct Fit { double nx, ny, nz, curvature; int ok; };
-
-// KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
-// compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
-template <int KMAX = 0, typename GetPoint>
-__device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
-  Fit f{0, 0, 0, 0, 1};
-  auto for_each = [&](auto&& body) __attribute__((always_inline)) {
-    if constexpr (KMAX > 0) {
-#pragma unroll
-      for (int t = 0; t < KMAX; ++t) if ((uint32_t)t < m) body((uint32_t)t);
-    } else {
-      for (uint32_t t = 0; t < m; ++t) body(t);
-    }
-  };
-  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points) and compute_centroid :198-237 in ONE
-  // pass over the neighbours (each pass re-gathers 16 points): both candidate sums are accumulated in point order -- over all points
-  // (the dense path) and over the finite ones (the other path) -- and the one `dense` selects is used, so every sum is the same sequence
-  // of additions as in the reference.
-  bool dense = true;
-  double ax = 0, ay = 0, az = 0, fx = 0, fy = 0, fz = 0;
-  long long cnt = 0;
-  for_each([&](uint32_t t) __attribute__((always_inline)) {
-    double x, y, z; get(t, x, y, z);
-    if (x != x || y != y || z != z) dense = false;
-    ax += x; ay += y; az += z;
-    if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
-  });
-  const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
-  const double div = dense ? (double)m : (double)cnt;
-  const double cx = sx / div, cy = sy / div, cz = sz / div;
-  // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
-  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  long long used = 0;
-  for_each([&](uint32_t t) __attribute__((always_inline)) {
-    double x, y, z; get(t, x, y, z);
-    if (dense || finite3(x, y, z)) {
-      double d0 = x - cx, d1 = y - cy, d2 = z - cz;
-      c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
-      const double dx = d0;
-      d0 *= dx; d1 *= dx; d2 *= dx;
-      c00 += d0; c01 += d1; c02 += d2;
-      used += 1;
-    }
-  });
-  if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
-  const double c10 = c01, c20 = c02, c21 = c12;
-  // eigen_3x3 :429-453
-  double scale = __builtin_fabs(c00);  // covariance_matrix.abs().max(), column-major order
-  {
-    const double a[8] = {c10, c20, c01, c11, c21, c02, c12, c22};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const double v = __builtin_fabs(a[q]); if (v > scale) scale = v; }
-  }
-  const double s00 = c00 / scale, s01 = c01 / scale, s02 = c02 / scale, s10 = c10 / scale, s11 = c11 / scale, s12 = c12 / scale,
-               s20 = c20 / scale, s21 = c21 / scale, s22 = c22 / scale;
-  // solve_polynomial on the UNSCALED matrix :328-392
-  double ev0, ev1, ev2;
-  {
-    const double k0 = c00 * c11 * c22 + 2.0 * c01 * c02 * c12 - c00 * c12 * c12 - c11 * c02 * c02 - c22 * c01 * c01;
-    const double k1 = c00 * c11 - c01 * c01 + c00 * c22 - c02 * c02 + c11 * c22 - c12 * c12;
-    const double k2 = c00 + c11 + c22;
-    auto quadratic = [&]() {  // :308-325
-      ev0 = 0.0;
-      double delta = k2 * k2 - 4.0 * k1;
-      if (delta < 0.0) delta = 0.0;
-      const double sd = __builtin_sqrt(delta);
-      ev2 = 0.5 * (k2 + sd);
-      ev1 = 0.5 * (k2 - sd);
-    };
-    if (__builtin_fabs(k0) < 2.220446049250313e-16) {
-      quadratic();
-    } else {
-      const double one_third = 1.0 / 3.0;
-      const double sqrt_3 = __builtin_sqrt(3.0);
-      const double k2_third = k2 * one_third;
-      double alpha_third = (k1 - k2 * k2_third) * one_third;
-      if (alpha_third > 0.0) alpha_third = 0.0;
-      const double half_beta = 0.5 * (k0 + k2_third * (2.0 * k2_third * k2_third - k1));
-      double q = half_beta * half_beta + alpha_third * alpha_third * alpha_third;
-      if (q > 0.0) q = 0.0;
-      const double rho = __builtin_sqrt(-alpha_third);
-      const double theta = ::atan2(__builtin_sqrt(-q), half_beta) * one_third;
-      const double ct = ::cos(theta), st = ::sin(theta);
-      double a = k2_third + 2.0 * rho * ct;
-      double b = k2_third - rho * (ct + sqrt_3 * st);
-      double c = k2_third - rho * (ct - sqrt_3 * st);
-      // sort ascending (:384-386)
-      if (b < a) { const double t = a; a = b; b = t; }
-      if (c < b) { const double t = b; b = c; c = t; }
-      if (b < a) { const double t = a; a = b; b = t; }
-      ev0 = a; ev1 = b; ev2 = c;
-      if (ev0 <= 0.0) quadratic();
-    }
-    (void)ev1; (void)ev2;
-  }
-  const double eigen_value = ev0 * scale;  // "undo scale" :443 (sic)
-  // :446-449 subtracts ev0 from a COPY of the diagonal: no effect on the scaled matrix
-  // get_largest_eigen_vector :395-426: rows r0 x r1, r0 x r2, r1 x r2; first maximum of the L2 norm wins
-  const double a0 = s01 * s12 - s02 * s11, a1 = s02 * s10 - s00 * s12, a2 = s00 * s11 - s01 * s10;
-  const double b0 = s01 * s22 - s02 * s21, b1 = s02 * s20 - s00 * s22, b2 = s00 * s21 - s01 * s20;
-  const double d0 = s11 * s22 - s12 * s21, d1 = s12 * s20 - s10 * s22, d2 = s10 * s21 - s11 * s20;
-  const double na = __builtin_sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = __builtin_sqrt(b0 * b0 + b1 * b1 + b2 * b2),
-               nd = __builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-  f.nx = a0; f.ny = a1; f.nz = a2;
-  double best = na;
-  if (nb > best) { f.nx = b0; f.ny = b1; f.nz = b2; best = nb; }
-  if (nd > best) { f.nx = d0; f.ny = d1; f.nz = d2; }
-  // solve_plane_parameter :456-467
-  const double eigen_sum = c00 + c11 + c22;
-  f.curvature = eigen_sum != 0.0 ? __builtin_fabs(eigen_value / eigen_sum) : 0.0;
-  return f;
-}
-
 struct NormalsOut {
   double* normals_f64;    // [n][3] or null
   double* curvature_f64;  // [n] or null
-  long long* knn;         // [n][k] or null
+  long long* knn;         // [n][k] int64 or null
+  uint32_t* knn_u32;      // [n][k] uint32 (0xFFFFFFFF = no neighbour) or null
   uint64_t normal_attr;   // device address of the NORMAL (Vec3f32) attribute of point 0, or 0
   uint64_t normal_stride;
   uint64_t curv_attr;     // device address of the Curvature (F64) attribute of point 0, or 0
@@ -383,12 +215,13 @@ __global__ __launch_bounds__(kBlock) void knn_bruteforce_kernel(const double* __
     }
   }
   const uint32_t m = n < k ? n : k;
-  if (out.knn)
+  if (out.knn || out.knn_u32)
     for (uint32_t t = 0; t < k; ++t) {
       long long v = -1;
 #pragma unroll
       for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = (long long)best.i[u];
-      out.knn[(uint64_t)q * k + t] = v;
+      if (out.knn) out.knn[(uint64_t)q * k + t] = v;
+      if (out.knn_u32) out.knn_u32[(uint64_t)q * k + t] = (uint32_t)v;
     }
   const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
     uint32_t j = 0;
@@ -398,33 +231,35 @@ __global__ __launch_bounds__(kBlock) void knn_bruteforce_kernel(const double* __
   });
   write_result(out, q, f);
 }
-
-// ---- grid search ----------------------------------------------------------------------------------------------------
-// Termination test shared by both directory kinds: searched cube = cells [c - r, c + r]^3.  Anything outside is at least
-// `margin` away; a side that already reaches the grid boundary has nothing beyond it.  The slack absorbs the rounding of the
-// cell assignment.  Returns true when the k-th best distance is inside the searched cube (or the cube covers the grid).
-__device__ __forceinline__ bool shell_done(const GridParams& g, double qx, double qy, double qz, int cx, int cy, int cz, int r, double kth) {
-  double margin = __builtin_inf();
-  const double qa[3] = {qx, qy, qz};
-  const int ca[3] = {cx, cy, cz};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (ca[a] - r > 0) margin = __builtin_fmin(margin, qa[a] - (g.org[a] + (double)(ca[a] - r) * g.h));
-    if (ca[a] + r < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + r + 1) * g.h) - qa[a]);
+// ---- 32-byte result records (original point order) -> the caller's outputs ---------------------------------------------------------
+// Pure streaming: record i is read once (two 16-byte loads), every output is written coalesced.
+__global__ __launch_bounds__(kBlock) void split_results_kernel(const double* __restrict__ rec, uint64_t n, NormalsOut out) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2*>(rec + 4 * i));
+    const d2 b = __builtin_nontemporal_load(reinterpret_cast<const d2*>(rec + 4 * i + 2));
+    if (out.normals_f64) { out.normals_f64[3 * i] = a.x; out.normals_f64[3 * i + 1] = a.y; out.normals_f64[3 * i + 2] = b.x; }
+    if (out.curvature_f64) out.curvature_f64[i] = b.y;
+    if (out.normal_attr) {  // f64 -> f32 narrowing of the normal = Rust `as` (RNE, overflow -> inf)
+      gptr_t p = as_global(out.normal_attr) + i * out.normal_stride;
+      store_un<float>(p, (float)a.x); store_un<float>(p + 4, (float)a.y); store_un<float>(p + 8, (float)b.x);
+    }
+    if (out.curv_attr) store_un<double>(as_global(out.curv_attr) + i * out.curv_stride, b.y);
   }
-  if (margin == __builtin_inf()) return true;  // the cube covers the whole grid
-  margin = margin * (1.0 - 1e-12) - 1e-300;
-  return margin > 0.0 && kth <= margin * margin;
 }
 
-template <int K, bool DENSE>
-__global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys,
-                                                          const uint32_t* __restrict__ sidx, uint32_t nf, uint32_t k, GridParams g, CellTable table,
-                                                          const uint32_t* __restrict__ cell_start, NormalsOut out) {
-  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-  if (j >= nf) return;
+// ---- grid search over global memory -------------------------------------------------------------------------------------------------
+// LIST: the queries are the sorted indices qlist[0 .. nq) (what the box kernel could not finish); otherwise all nf sorted points.
+template <int K, bool DENSE, bool LIST>
+__global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
+                                                          GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
+                                                          const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out) {
+  const uint32_t t0 = blockIdx.x * kBlock + threadIdx.x;
+  if (t0 >= nq) return;
+  const uint32_t j = LIST ? qlist[t0] : t0;
   const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
-  const int cx = (int)cell_coord(qx, g.org[0], g.inv_h, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
+  const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
             cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
   KBest<K> best;
   best.init();
@@ -461,12 +296,14 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
           // up to two contiguous ranges of sorted points per row, scanned by ONE inlined copy of the insertion code (three call
           // sites cost 60 VGPRs: 167 -> 3 waves per SIMD)
           uint32_t p0 = 0, p1 = 0, q0 = 0, q1 = 0;
-          if (face) {  // the whole row segment [cx - r, cx + r] is one contiguous range
-            const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r >= (int)g.dim[0] ? (int)g.dim[0] - 1 : cx + r;
+          const int rr = r * (int)g.rx, ri = (r - 1) * (int)g.rx;  // shell r reaches r * rx fine cells along x
+          const int x0 = cx - rr < 0 ? 0 : cx - rr, x1 = cx + rr >= (int)g.dim[0] ? (int)g.dim[0] - 1 : cx + rr;
+          if (face) {  // the whole row segment [cx - rr, cx + rr] is one contiguous range
             p0 = cell_start[row + (uint32_t)x0]; p1 = cell_start[row + (uint32_t)x1 + 1];
-          } else {     // interior rows of the shell: only the two end cells
-            if (cx - r >= 0) { p0 = cell_start[row + (uint32_t)(cx - r)]; p1 = cell_start[row + (uint32_t)(cx - r) + 1]; }
-            if (cx + r < (int)g.dim[0]) { q0 = cell_start[row + (uint32_t)(cx + r)]; q1 = cell_start[row + (uint32_t)(cx + r) + 1]; }
+          } else {     // interior rows of the shell: only the two end slabs [cx - rr, cx - ri - 1] and [cx + ri + 1, cx + rr]
+            const int a1 = cx - ri - 1, b0 = cx + ri + 1;
+            if (a1 >= x0) { p0 = cell_start[row + (uint32_t)x0]; p1 = cell_start[row + (uint32_t)a1 + 1]; }
+            if (b0 <= x1) { q0 = cell_start[row + (uint32_t)b0]; q1 = cell_start[row + (uint32_t)x1 + 1]; }
           }
           scan2(p0, p1, q0, q1);
         } else {
@@ -499,13 +336,13 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
     if (shell_done(g, qx, qy, qz, cx, cy, cz, r, best.kth(k))) break;
   }
   const uint32_t m = nf < k ? nf : k;
-  const uint64_t orig = sidx[j];
-  if (out.knn)
+  const uint64_t orig = out.sidx[j];
+  if (out.knn || out.knn_u32)
     for (uint32_t t = 0; t < k; ++t) {
-      long long v = -1;
+      uint32_t v = kNoIndex;
 #pragma unroll
-      for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = (long long)sidx[best.i[u]];
-      out.knn[orig * k + t] = v;
+      for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = best.i[u];
+      write_knn(out, orig, k, t, v == kNoIndex ? kNoIndex : out.sidx[v]);
     }
   const Fit f = plane_fit<K>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
     uint32_t p = 0;
@@ -513,44 +350,36 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
     for (int u = 0; u < K; ++u) if ((uint32_t)u == t) p = best.i[u];
     x = sxyz[3 * (uint64_t)p]; y = sxyz[3 * (uint64_t)p + 1]; z = sxyz[3 * (uint64_t)p + 2];
   });
-  write_result(out, orig, f);
+  write_record(out, orig, f);
 }
 
 // non-finite query points (sorted positions [nf, n)): neighbourhood = itself + the first k-1 finite points
-__global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __restrict__ xyz, const double* __restrict__ sxyz,
-                                                               const uint32_t* __restrict__ sidx, uint32_t nf, uint32_t n, uint32_t k, NormalsOut out) {
+__global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __restrict__ xyz, const double* __restrict__ sxyz, uint32_t nf, uint32_t n,
+                                                               uint32_t k, RecOut out) {
   const uint32_t j = nf + blockIdx.x * kBlock + threadIdx.x;
   if (j >= n) return;
-  const uint64_t orig = sidx[j];
+  const uint64_t orig = out.sidx[j];
   const uint32_t m = (nf + 1 < k) ? nf + 1 : k;
-  if (out.knn)
-    for (uint32_t t = 0; t < k; ++t) out.knn[orig * k + t] = t == 0 ? (long long)orig : (t < m ? (long long)sidx[t - 1] : -1);
+  if (out.knn || out.knn_u32)
+    for (uint32_t t = 0; t < k; ++t) write_knn(out, orig, k, t, t == 0 ? (uint32_t)orig : (t < m ? out.sidx[t - 1] : kNoIndex));
   const Fit f = plane_fit(m, [&](uint32_t t, double& x, double& y, double& z) {
     if (t == 0) { x = xyz[3 * orig]; y = xyz[3 * orig + 1]; z = xyz[3 * orig + 2]; }
     else { x = sxyz[3 * (uint64_t)(t - 1)]; y = sxyz[3 * (uint64_t)(t - 1) + 1]; z = sxyz[3 * (uint64_t)(t - 1) + 2]; }
   });
-  write_result(out, orig, f);
+  write_record(out, orig, f);
 }
-
-// stream-ordered allocations from the device's default pool (release threshold raised by buffer.cpp): hipMalloc / hipFree of
-// gigabytes synchronise the device and cost milliseconds per call
-struct DevBuf {
-  void* p = nullptr;
-  hipStream_t s = nullptr;
-  hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return hipMallocAsync(&p, bytes ? bytes : 16, stream); }
-  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
-  template <typename T> T* as() { return (T*)p; }
-};
 
 }  // namespace
 
 namespace pstk {
 
-// Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), or the number of degenerate neighbourhoods (> 0).
+// Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,
+// or the number of degenerate neighbourhoods (> 0).
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
-                      long long* out_knn_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride,
-                      hipStream_t stream) {
+                      long long* out_knn_dev, uint32_t* out_knn_u32_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr,
+                      uint64_t curv_stride, hipStream_t stream) {
 #define NCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+  if (n >= 0xFFFFFFF0ull) return -2;  // sorted indices and directory entries are uint32_t
   const unsigned cus = (unsigned)device_cus();
   const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
   DevBuf xyz, partials, counters;
@@ -567,8 +396,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     for (int c = 0; c < 3; ++c) { mn[c] = std::fmin(mn[c], hp[b * 6 + c]); mx[c] = std::fmax(mx[c], hp[b * 6 + 3 + c]); }
 
   NormalsOut out{};
-  out.normals_f64 = out_normals_dev; out.curvature_f64 = out_curv_dev; out.knn = out_knn_dev;
+  out.normals_f64 = out_normals_dev; out.curvature_f64 = out_curv_dev; out.knn = out_knn_dev; out.knn_u32 = out_knn_u32_dev;
   out.normal_attr = normal_attr; out.normal_stride = normal_stride; out.curv_attr = curv_attr; out.curv_stride = curv_stride;
+  unsigned long long* n_finite = (unsigned long long*)counters.p;
+  unsigned long long* n_cells = n_finite + 1;
+  uint32_t* fb_count = (uint32_t*)((uint8_t*)counters.p + 16);
   out.error_count = (int*)((uint8_t*)counters.p + 32);
 
   const bool any_finite = mn[0] <= mx[0];
@@ -581,8 +413,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     else hipLaunchKernelGGL((K4), dim3(GRID), dim3(kBlock), 0, stream, __VA_ARGS__);                   \
   } while (0)
 #define KNN_DISPATCH(KERNEL, GRID, ...) KNN_DISPATCH_T(GRID, KERNEL<8>, KERNEL<16>, KERNEL<32>, KERNEL<64>, __VA_ARGS__)
-#define KNN_DISPATCH_GRID(DENSE, GRID, ...) \
-  KNN_DISPATCH_T(GRID, (knn_grid_kernel<8, DENSE>), (knn_grid_kernel<16, DENSE>), (knn_grid_kernel<32, DENSE>), (knn_grid_kernel<64, DENSE>), __VA_ARGS__)
+#define KNN_DISPATCH_GRID(DENSE, LIST, GRID, ...)                                                                                          \
+  KNN_DISPATCH_T(GRID, (knn_grid_kernel<8, DENSE, LIST>), (knn_grid_kernel<16, DENSE, LIST>), (knn_grid_kernel<32, DENSE, LIST>),          \
+                 (knn_grid_kernel<64, DENSE, LIST>), __VA_ARGS__)
   if (brute) {
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
     KNN_DISPATCH(knn_bruteforce_kernel, grid, xyz.as<double>(), (uint32_t)n, k, out);
@@ -596,83 +429,129 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     int dims_used = 0;
     for (int c = 0; c < 3; ++c) if (ext[c] > maxext * 1e-9) { vol *= ext[c]; dims_used += 1; }
     // Points per cell.  With the hash table every cell costs a probe, so few fat cells win: ~k/3 points per cell (the first
-    // shell of 27 cells almost always suffices).  With the dense directory a whole row of cells is one range scan, and small
-    // cells win because fewer candidates reach the VALU-bound sorted insert: ~k/12 points per cell, two shells
-    // (measured at k = 16, 10^8 points: 5.33 -> 126 ms, 2.2 -> 116, 1.3 -> 100, 0.8 -> 107, 0.4 -> 145).
-    auto grid_for = [&](double per_cell, GridParams& g) -> uint64_t {
-      double h = dims_used ? std::pow(vol * per_cell / (double)n, 1.0 / dims_used) : maxext;
+    // shell of 27 cells almost always suffices).  With the dense directory a whole row of cells is one range, and small cells win
+    // because the searched cube approximates the k-sphere better: ~k/12 points per cell, two shells
+    // (global-memory search at k = 16, 10^8 points: 5.33 -> 126 ms, 2.2 -> 116, 1.3 -> 100, 0.8 -> 107, 0.4 -> 145).
+    auto grid_for = [&](double h, uint32_t rx, GridParams& g) -> uint64_t {
       if (const char* e = std::getenv("PST_KNN_CELL")) { const double v = std::atof(e); if (v > 0) h = v; }
-      const double min_h = maxext / 2000000.0;  // <= 2^21 cells per axis
+      const double min_h = maxext * (double)rx / 2000000.0;  // <= 2^21 cells per axis
       if (!(h > min_h)) h = min_h;
+      g.h = h; g.inv_h = 1.0 / h; g.rx = rx; g.hx = h / (double)rx; g.inv_hx = (double)rx / h;
       for (int c = 0; c < 3; ++c) {
         g.org[c] = mn[c];
-        double d = std::floor(ext[c] / h) + 1.0;
+        double d = std::floor(ext[c] * (c == 0 ? g.inv_hx : g.inv_h)) + 1.0;
         if (d > 2097151.0) d = 2097151.0;
         g.dim[c] = (uint32_t)d;
       }
-      g.h = h;
-      g.inv_h = 1.0 / h;
       return (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];
     };
+    auto edge_for = [&](double per_cell) { return dims_used ? std::pow(vol * per_cell / (double)n, 1.0 / dims_used) : maxext; };
     double per_cell_env = 0.0;
     if (const char* e = std::getenv("PST_KNN_PER_CELL")) per_cell_env = std::atof(e);
     GridParams g{};
-    // dense directory when the grid is not much larger than the cloud (volume-like data); else Morton keys + hash table
-    uint64_t cells = grid_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0), g);
-    bool dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
-    if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
-    if (!dense) cells = grid_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0), g);
+    // 1. LDS box search (normals_tile.hip): cell edge h = R0, the radius of the sphere expected to hold M = 1.75 k points, so that the 3 x 3
+    //    rows around a query's row always cover its k-th distance when k points are found inside R0; along x the cells are rx times finer
+    //    (the points of a row are then sorted by x at that granularity and every row is trimmed to the ball).
+    // 2. otherwise the dense directory with ~k/12 points per cubic cell and two shells, when the grid is not much larger than the cloud
+    //    (volume-like data) -- 3. else Morton keys + hash table with ~k/3 points per cell.
+    TileShape shape;
+    bool tiled = false;
+    uint64_t cells = 0;
+    bool dense = false;
+    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE")) {
+      double m_target = 1.75 * (double)k;
+      if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
+      uint32_t rx = 4;
+      if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
+      // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
+      cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639), rx, g);
+      dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
+      tiled = dense && knn_tile_shape(g, n, cells, k, shape);
+    }
+    if (!tiled) {
+      cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0)), 1, g);
+      dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
+      if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
+      if (!dense) cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0)), 1, g);
+    }
     g.dense = dense ? 1u : 0u;
-    int key_bits = 64;
-    if (dense) { key_bits = 1; while (key_bits < 63 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells
-    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp;
-    NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream)); NCK(sorted_xyz.alloc(n * 24, stream));
-    unsigned long long* n_finite = (unsigned long long*)counters.p;
-    unsigned long long* n_cells = n_finite + 1;
-    hipLaunchKernelGGL(keys_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+    unsigned key_bits = 64;
+    if (dense) { key_bits = 1; while (key_bits < 32 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells (< 2^32)
+    const size_t key_size = dense ? 4 : 8;
+    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec;
+    NCK(keys.alloc(n * key_size, stream)); NCK(keys2.alloc(n * key_size, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
+    NCK(sorted_xyz.alloc(n * 24, stream));
     size_t tmp_bytes = 0;
-    NCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                           (int)n, 0, key_bits, stream));
-    NCK(tmp.alloc(tmp_bytes, stream));
-    NCK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(),
-                                           (int)n, 0, key_bits, stream));
+    if (dense) {
+      hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
+      NCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+      NCK(tmp.alloc(tmp_bytes, stream));
+      NCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+    } else {
+      hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+      NCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+      NCK(tmp.alloc(tmp_bytes, stream));
+      NCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+    }
     hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
     unsigned long long h_counts[2] = {0, 0};
     NCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
     NCK(hipStreamSynchronize(stream));
     const uint64_t nf = h_counts[0];
-    DevBuf tkeys, tstarts, directory;
+    NCK(rec.alloc(n * 32, stream));
+    RecOut sorted{rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count};
+    DevBuf tkeys, tstarts, directory, fb_list;
     CellTable table{nullptr, nullptr, 0};
-    if (dense) {
-      NCK(directory.alloc((cells + 2) * 4, stream));
-      hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, cells, directory.as<uint32_t>());
-    } else {
-      hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
-      NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
-      NCK(hipStreamSynchronize(stream));
-      uint64_t cap = 64;
-      while (cap < 2 * h_counts[1]) cap <<= 1;
-      NCK(tkeys.alloc(cap * 8, stream)); NCK(tstarts.alloc(cap * 4, stream));
-      NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
-      table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
-      hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
-    }
     if (nf) {
-      const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
-      if (dense)
-        KNN_DISPATCH_GRID(true, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)directory.as<uint32_t>(), out);
-      else
-        KNN_DISPATCH_GRID(false, grid, sorted_xyz.as<double>(), keys2.as<uint64_t>(), idx2.as<uint32_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)nullptr, out);
+      if (dense) {
+        NCK(directory.alloc((cells + 2) * 4, stream));
+        hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
+        const uint32_t* cell_start = directory.as<uint32_t>();
+        if (tiled) {
+          // box kernel first; what it hands back (k-th distance beyond its halo, boxes denser than its LDS budget) goes to the
+          // global-memory search as a list
+          NCK(fb_list.alloc(nf * 4, stream));
+          launch_knn_tile(shape, sorted_xyz.as<double>(), cell_start, g, k, (uint32_t)nf, sorted, fb_list.as<uint32_t>(), fb_count, stream);
+          uint32_t n_fb = 0;
+          NCK(hipMemcpyAsync(&n_fb, fb_count, 4, hipMemcpyDeviceToHost, stream));
+          NCK(hipStreamSynchronize(stream));
+          if (std::getenv("PST_KNN_DEBUG"))
+            fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
+                    (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.threads,
+                    shape.cap, n_fb);
+          if (n_fb) {
+            const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
+            KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
+                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted);
+          }
+        } else {
+          const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
+          KNN_DISPATCH_GRID(true, false, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
+                            (const uint32_t*)nullptr, (uint32_t)nf, sorted);
+        }
+      } else {
+        hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
+        NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
+        NCK(hipStreamSynchronize(stream));
+        uint64_t cap = 64;
+        while (cap < 2 * h_counts[1]) cap <<= 1;
+        NCK(tkeys.alloc(cap * 8, stream)); NCK(tstarts.alloc(cap * 4, stream));
+        NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
+        table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
+        hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
+        const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
+        KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted);
+      }
     }
     if (nf < n) {
       // non-finite query points: every distance is NaN (-> +inf), so "the k nearest" is the reference's kd-tree tie order
-      // (unpinned).  Chosen here: the point itself, then the first k-1 finite points in Morton order.
+      // (unpinned).  Chosen here: the point itself, then the first k-1 finite points in sorted order.
       const unsigned grid = (unsigned)((n - nf + kBlock - 1) / kBlock);
-      hipLaunchKernelGGL(knn_nonfinite_kernel, dim3(grid), dim3(kBlock), 0, stream, xyz.as<double>(), sorted_xyz.as<double>(), idx2.as<uint32_t>(),
-                         (uint32_t)nf, (uint32_t)n, k, out);
+      hipLaunchKernelGGL(knn_nonfinite_kernel, dim3(grid), dim3(kBlock), 0, stream, xyz.as<double>(), sorted_xyz.as<double>(), (uint32_t)nf, (uint32_t)n, k,
+                         sorted);
     }
+    hipLaunchKernelGGL(split_results_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const double*)rec.as<double>(), n, out);
     NCK(hipGetLastError());  // the temporaries are released stream-ordered (DevBuf): no host round trip here
   }
   NCK(hipGetLastError());

@@ -21,11 +21,13 @@ const Member& checked_position(const pst_buffer& b, size_t k) {
   const Member* m = b.layout.find(pos);  // view_attribute::<Vector3<f64>>(&POSITION_3D): exact (name, datatype) :97
   if (!m) throw Error(PST_ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
   if (k > 64) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: k > 64 is not supported by the register-resident k-best list");
-  if (b.len >= (1ull << 31)) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: more than 2^31-1 points per call");
+  if (b.len >= 0xFFFFFFF0ull)  // sorted indices and directory entries of the spatial index are uint32_t
+    throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: more than 2^32 - 17 points per call");
   return *m;
 }
 
 void raise_degenerate(long long rc) {
+  if (rc == -2) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: more than 2^32 - 17 points per call");
   if (rc < 0) throw Error(PST_ERR_HIP, std::string("normal estimation failed: ") + hipGetErrorString(hipGetLastError()));
   if (rc > 0)  // compute_covariance_matrix Err(..) :293-295, unwrapped at :471
     throw Error(PST_ERR_NOT_ENOUGH_NEIGHBOURS,
@@ -49,7 +51,7 @@ int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, doub
   const uint64_t stride = b->columnar ? pm.size : b->layout.size;
   TempDev d_normals(n * 24), d_curv(n * 8), d_knn(out_knn ? n * k * 8 : 0);
   raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, n, (uint32_t)k, (double*)d_normals.p, (double*)d_curv.p,
-                                     (long long*)d_knn.p, 0, 0, 0, 0, s));
+                                     (long long*)d_knn.p, nullptr, 0, 0, 0, 0, s));
   PST_HIP_CHECK(hipMemcpyAsync(not_null(out_normals, "out_normals"), d_normals.p, n * 24, hipMemcpyDeviceToHost, s));
   PST_HIP_CHECK(hipMemcpyAsync(not_null(out_curvature, "out_curvature"), d_curv.p, n * 8, hipMemcpyDeviceToHost, s));
   if (out_knn) PST_HIP_CHECK(hipMemcpyAsync(out_knn, d_knn.p, n * k * 8, hipMemcpyDeviceToHost, s));
@@ -84,7 +86,23 @@ int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst) {
   uint64_t na, nst, ca, cst;
   attr_addr(ns, na, nst);
   attr_addr(cs, ca, cst);
-  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, b->len, (uint32_t)k, nullptr, nullptr, nullptr, na, nst, ca, cst, s));
+  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, b->len, (uint32_t)k, nullptr, nullptr, nullptr, nullptr, na, nst, ca, cst, s));
+  PST_API_END
+}
+
+// Device-resident raw outputs (any of them may be null): normals f64 [n][3], curvature f64 [n], neighbour lists uint32 [n][k] in
+// ascending distance (0xFFFFFFFF where the cloud has fewer than k points).  Same checks and panics as pst_compute_normals.
+int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals, double* d_curvature, uint32_t* d_knn) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  const Member& pm = checked_position(*b, k);
+  if (!d_normals && !d_curvature && !d_knn) throw Error(PST_ERR_INVALID_ARGUMENT, "pst_compute_normals_device: no output requested");
+  ensure_device();
+  hipStream_t s = current_stream();
+  const size_t slot = (size_t)(&pm - b->layout.members.data());
+  const uint64_t base = b->columnar ? col_addr(*b, slot, 0) : aos_addr(*b, 0) + pm.offset;
+  const uint64_t stride = b->columnar ? pm.size : b->layout.size;
+  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, b->len, (uint32_t)k, d_normals, d_curvature, nullptr, d_knn, 0, 0, 0, 0, s));
   PST_API_END
 }
 

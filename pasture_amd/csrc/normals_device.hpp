@@ -1,0 +1,230 @@
+// Device code shared by the kNN normal-estimation kernels (normals.hip: search over global memory; normals_tile.hip: search over an
+// LDS-staged box of grid cells): the uniform grid, the register-resident k-best list and the plane fit of
+// pasture-algorithms/src/normal_estimation.rs:198-467.
+#pragma once
+#include "device_common.hpp"
+
+namespace pstn {
+
+using namespace pstd;
+
+constexpr uint64_t kInvalidKey = ~0ull;
+constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
+
+struct GridParams {
+  double org[3];   // grid origin (min corner of the finite points)
+  double inv_h;    // 1 / cell edge along y and z
+  double h;        // cell edge along y and z
+  double inv_hx;   // 1 / cell edge along x
+  double hx;       // cell edge along x = h / rx: with the dense directory the points of a grid row are sorted by x at this granularity
+  uint32_t rx;     // fine x cells per cell edge h (1 = cubic cells)
+  uint32_t dim[3]; // cells per axis (<= 2^21)
+  uint32_t dense;  // 1: keys are row-major cell numbers (x fastest) with a dense cell_start directory; 0: Morton keys + hash table
+};
+__device__ __forceinline__ double grid_edge(const GridParams& g, int axis) { return axis == 0 ? g.hx : g.h; }
+
+__device__ __forceinline__ bool finite3(double x, double y, double z) {
+  return __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+}
+__device__ __forceinline__ uint32_t cell_coord(double v, double org, double inv_h, uint32_t dim) {
+  double c = __builtin_floor((v - org) * inv_h);
+  if (!(c > 0.0)) c = 0.0;
+  const double top = (double)(dim - 1);
+  if (c > top) c = top;
+  return (uint32_t)c;
+}
+
+// ---- k-best list, sorted ascending, fully in registers --------------------------------------------------------
+template <int K>
+struct KBest {
+  double d[K];
+  uint32_t i[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < K; ++t) { d[t] = __builtin_inf(); i[t] = kNoIndex; }
+  }
+  // Insert (dist, index) keeping ascending order; an equal distance goes AFTER the existing ones (first found wins).
+  // Distances: new[t] = min(d[t], max(d[t-1], dist)) — two f64 ops per slot instead of compare + 64-bit selects (the search is
+  // VALU-bound: ~145 candidates per query, every accepted one walks all K slots).  Indices follow the same three cases through
+  // keep[t] = d[t] <= dist (monotone in t because the list is sorted).  Distances are never NaN here.
+  __device__ __forceinline__ void insert(double dist, uint32_t index) {
+    if (!(dist < d[K - 1])) return;
+    bool keep_prev = true;  // "d[-1] <= dist"
+    double d_prev = -__builtin_inf();
+    uint32_t i_prev = index;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      const double dt = d[t];
+      const uint32_t it = i[t];
+      const bool keep = dt <= dist;
+      d[t] = __builtin_fmin(dt, __builtin_fmax(d_prev, dist));
+      i[t] = keep ? it : (keep_prev ? index : i_prev);
+      keep_prev = keep;
+      d_prev = dt;
+      i_prev = it;
+    }
+  }
+  __device__ __forceinline__ double kth(uint32_t k) const {  // d[k-1] without dynamic register indexing
+    double v = d[K - 1];
+#pragma unroll
+    for (int t = 0; t < K; ++t) v = (uint32_t)t == k - 1 ? d[t] : v;
+    return v;
+  }
+};
+
+// ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
+struct Fit { double nx, ny, nz, curvature; int ok; };
+
+// KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
+// compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
+template <int KMAX = 0, typename GetPoint>
+__device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
+  Fit f{0, 0, 0, 0, 1};
+  auto for_each = [&](auto&& body) __attribute__((always_inline)) {
+    if constexpr (KMAX > 0) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) if ((uint32_t)t < m) body((uint32_t)t);
+    } else {
+      for (uint32_t t = 0; t < m; ++t) body(t);
+    }
+  };
+  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points) and compute_centroid :198-237 in ONE
+  // pass over the neighbours (each pass re-gathers 16 points): both candidate sums are accumulated in point order -- over all points
+  // (the dense path) and over the finite ones (the other path) -- and the one `dense` selects is used, so every sum is the same sequence
+  // of additions as in the reference.
+  bool dense = true;
+  double ax = 0, ay = 0, az = 0, fx = 0, fy = 0, fz = 0;
+  long long cnt = 0;
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
+    double x, y, z; get(t, x, y, z);
+    if (x != x || y != y || z != z) dense = false;
+    ax += x; ay += y; az += z;
+    if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
+  });
+  const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
+  const double div = dense ? (double)m : (double)cnt;
+  const double cx = sx / div, cy = sy / div, cz = sz / div;
+  // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  long long used = 0;
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
+    double x, y, z; get(t, x, y, z);
+    if (dense || finite3(x, y, z)) {
+      double d0 = x - cx, d1 = y - cy, d2 = z - cz;
+      c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+      const double dx = d0;
+      d0 *= dx; d1 *= dx; d2 *= dx;
+      c00 += d0; c01 += d1; c02 += d2;
+      used += 1;
+    }
+  });
+  if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
+  const double c10 = c01, c20 = c02, c21 = c12;
+  // eigen_3x3 :429-453
+  double scale = __builtin_fabs(c00);  // covariance_matrix.abs().max(), column-major order
+  {
+    const double a[8] = {c10, c20, c01, c11, c21, c02, c12, c22};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const double v = __builtin_fabs(a[q]); if (v > scale) scale = v; }
+  }
+  const double s00 = c00 / scale, s01 = c01 / scale, s02 = c02 / scale, s10 = c10 / scale, s11 = c11 / scale, s12 = c12 / scale,
+               s20 = c20 / scale, s21 = c21 / scale, s22 = c22 / scale;
+  // solve_polynomial on the UNSCALED matrix :328-392
+  double ev0, ev1, ev2;
+  {
+    const double k0 = c00 * c11 * c22 + 2.0 * c01 * c02 * c12 - c00 * c12 * c12 - c11 * c02 * c02 - c22 * c01 * c01;
+    const double k1 = c00 * c11 - c01 * c01 + c00 * c22 - c02 * c02 + c11 * c22 - c12 * c12;
+    const double k2 = c00 + c11 + c22;
+    auto quadratic = [&]() {  // :308-325
+      ev0 = 0.0;
+      double delta = k2 * k2 - 4.0 * k1;
+      if (delta < 0.0) delta = 0.0;
+      const double sd = __builtin_sqrt(delta);
+      ev2 = 0.5 * (k2 + sd);
+      ev1 = 0.5 * (k2 - sd);
+    };
+    if (__builtin_fabs(k0) < 2.220446049250313e-16) {
+      quadratic();
+    } else {
+      const double one_third = 1.0 / 3.0;
+      const double sqrt_3 = __builtin_sqrt(3.0);
+      const double k2_third = k2 * one_third;
+      double alpha_third = (k1 - k2 * k2_third) * one_third;
+      if (alpha_third > 0.0) alpha_third = 0.0;
+      const double half_beta = 0.5 * (k0 + k2_third * (2.0 * k2_third * k2_third - k1));
+      double q = half_beta * half_beta + alpha_third * alpha_third * alpha_third;
+      if (q > 0.0) q = 0.0;
+      const double rho = __builtin_sqrt(-alpha_third);
+      const double theta = ::atan2(__builtin_sqrt(-q), half_beta) * one_third;
+      const double ct = ::cos(theta), st = ::sin(theta);
+      double a = k2_third + 2.0 * rho * ct;
+      double b = k2_third - rho * (ct + sqrt_3 * st);
+      double c = k2_third - rho * (ct - sqrt_3 * st);
+      // sort ascending (:384-386)
+      if (b < a) { const double t = a; a = b; b = t; }
+      if (c < b) { const double t = b; b = c; c = t; }
+      if (b < a) { const double t = a; a = b; b = t; }
+      ev0 = a; ev1 = b; ev2 = c;
+      if (ev0 <= 0.0) quadratic();
+    }
+    (void)ev1; (void)ev2;
+  }
+  const double eigen_value = ev0 * scale;  // "undo scale" :443 (sic)
+  // :446-449 subtracts ev0 from a COPY of the diagonal: no effect on the scaled matrix
+  // get_largest_eigen_vector :395-426: rows r0 x r1, r0 x r2, r1 x r2; first maximum of the L2 norm wins
+  const double a0 = s01 * s12 - s02 * s11, a1 = s02 * s10 - s00 * s12, a2 = s00 * s11 - s01 * s10;
+  const double b0 = s01 * s22 - s02 * s21, b1 = s02 * s20 - s00 * s22, b2 = s00 * s21 - s01 * s20;
+  const double d0 = s11 * s22 - s12 * s21, d1 = s12 * s20 - s10 * s22, d2 = s10 * s21 - s11 * s20;
+  const double na = __builtin_sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = __builtin_sqrt(b0 * b0 + b1 * b1 + b2 * b2),
+               nd = __builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  f.nx = a0; f.ny = a1; f.nz = a2;
+  double best = na;
+  if (nb > best) { f.nx = b0; f.ny = b1; f.nz = b2; best = nb; }
+  if (nd > best) { f.nx = d0; f.ny = d1; f.nz = d2; }
+  // solve_plane_parameter :456-467
+  const double eigen_sum = c00 + c11 + c22;
+  f.curvature = eigen_sum != 0.0 ? __builtin_fabs(eigen_value / eigen_sum) : 0.0;
+  return f;
+}
+
+// Results leave the search kernels as ONE aligned 32-byte record {normal xyz, curvature} per point, written at the point's ORIGINAL
+// index: a full-sector store (no read-modify-write of partial sectors, which is what separate 12-byte and 8-byte stores into the
+// caller's columns cost), hidden behind the compute-bound search.  split_results_kernel (normals.hip) then streams the records into the
+// caller's outputs (f64 arrays / NORMAL Vec3f32 attribute with the Rust `as` narrowing / Curvature attribute), fully coalesced.
+struct RecOut {
+  double* rec;              // [n][4] f64: nx, ny, nz, curvature, indexed by ORIGINAL point index
+  const uint32_t* sidx;     // sorted position -> original index
+  long long* knn;           // [n][k] int64 (-1 = none), original indices, or null
+  uint32_t* knn_u32;        // [n][k] uint32 (0xFFFFFFFF = none) or null
+  int* error_count;         // neighbourhoods with fewer than 3 usable points
+};
+
+__device__ __forceinline__ void write_record(const RecOut& o, uint64_t orig, const Fit& f) {
+  if (!f.ok) { atomicAdd(o.error_count, 1); return; }
+  double* r = o.rec + 4 * orig;
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<d2*>(r) = d2{f.nx, f.ny};
+  *reinterpret_cast<d2*>(r + 2) = d2{f.nz, f.curvature};
+}
+__device__ __forceinline__ void write_knn(const RecOut& o, uint64_t orig, uint32_t k, uint32_t t, uint32_t neighbour_orig) {  // kNoIndex = none
+  if (o.knn) o.knn[orig * k + t] = neighbour_orig == kNoIndex ? -1ll : (long long)neighbour_orig;
+  if (o.knn_u32) o.knn_u32[orig * k + t] = neighbour_orig;
+}
+
+__device__ __forceinline__ bool shell_done(const GridParams& g, double qx, double qy, double qz, int cx, int cy, int cz, int r, double kth) {
+  double margin = __builtin_inf();
+  const double qa[3] = {qx, qy, qz};
+  const int ca[3] = {cx, cy, cz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int ra = a == 0 ? r * (int)g.rx : r;  // shell r spans r * rx fine cells along x: the same distance as r cells along y and z
+    const double ha = grid_edge(g, a);
+    if (ca[a] - ra > 0) margin = __builtin_fmin(margin, qa[a] - (g.org[a] + (double)(ca[a] - ra) * ha));
+    if (ca[a] + ra < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + ra + 1) * ha) - qa[a]);
+  }
+  if (margin == __builtin_inf()) return true;  // the cube covers the whole grid
+  margin = margin * (1.0 - 1e-12) - 1e-300;
+  return margin > 0.0 && kth <= margin * margin;
+}
+
+}  // namespace pstn

@@ -1,0 +1,462 @@
+// K4 (dense-directory regime) — kNN search over an LDS-staged box of grid cells, gfx950.
+//
+// compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130) needs, per point, the k nearest neighbours in ascending
+// distance (:103-108) and a plane fit over them (:198-467).
+//
+// Grid (normals.hip): cell edge h along y and z = R0, the radius of the sphere expected to hold ~1.75 k points; along x the cells are rx
+// (4) times finer.  Sorted points are row-major by cell, so the fine cells x0..x1 of one grid row are ONE contiguous range of sorted
+// points, ordered by x at granularity h / rx.  tau0 = h^2 is an a-priori bound on the squared k-th distance: a query that finds k points
+// inside tau0 needs only the 3 x 3 rows around its own row, and in each of them only the x interval the ball of that radius cuts out.
+//
+// A workgroup owns a BOX of bx * by * bz query cells.  It stages the points of the box plus its halo -- (by + 2)(bz + 2) row segments of
+// bx + 2 (rx + 1) fine cells, each a coalesced copy -- into LDS ONCE, with a 16-bit local copy of the cell directory, and every query
+// of the box finds its candidates there:
+//   * no dependent global loads in the search (the first version of this kernel issued one per candidate and lane: 30x the algorithmic
+//     HBM traffic and an L2 / HBM round trip per candidate);
+//   * 9 row segments per query, each TRIMMED to the ball (tau0, later the running k-th best) in f32 with upward slack: ~70 candidates
+//     instead of the ~170 of a 5 x 5 x 5 block of cubic cells;
+//   * four candidates per step: their 12 coordinate reads (one array per coordinate: neighbouring slots never share a bank) are
+//     issued together, one LDS round trip per four distance tests;
+//   * a candidate is only QUEUED (its 16-bit slot, per-lane LDS queue) when it beats tau0 and the lane's current (k+1)-th best key;
+//     the sorted insertion -- which a wave pays for whenever ANY lane inserts -- runs in batches when a queue fills, software-
+//     pipelined, on keys that carry the slot in their low 11 bits: two f64 operations per list entry;
+//   * the plane fit reads its neighbours from LDS; the result leaves as one aligned 32-byte record at the point's original index
+//     (a full-sector store) and split_results_kernel streams the records into the caller's outputs.
+//
+// A query that does not find k points inside tau0 (sparse neighbourhoods), whose packed keys are ambiguous (see the end of the
+// search), and every query of a box whose halo does not fit the LDS budget (locally dense clouds) is appended to a fallback list and
+// searched by knn_grid_kernel (normals.hip) over global memory: the box kernel is the fast path, not the only path.
+// f64 throughout, -ffp-contract=off; no MFMA (no contraction here).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "kernels.hpp"
+#include "normals_device.hpp"
+#include "normals_host.hpp"
+
+using namespace pstn;
+
+namespace {
+
+constexpr int kHalo = 1;          // halo rows on each side of a query row (the cell edge h is the a-priori bound on the k-th distance)
+constexpr int kMaxRows = 144;     // halo rows per box: (by + 2)(bz + 2)
+constexpr int kMaxQRows = 64;     // query rows per box: by * bz (one lane each in the prefix sum)
+constexpr int kMaxRowCells = 31;  // halo cells per row: bx + 2 (rx + 1) (directory rows have one more entry, one lane each)
+constexpr int kMaxDir = 3072;     // directory entries per box: rows * (cells per row + 1)
+constexpr int kQueue = 16;        // queued candidates per lane
+constexpr int kBatch = 4;         // candidates tested per lane and step (their 12 LDS reads are issued together)
+constexpr int kSegs = 9;          // row segments per query: the 3 x 3 rows around its own, each trimmed to the ball along x
+
+struct TileArgs {
+  const double* sxyz;          // sorted positions
+  const uint32_t* cell_start;  // dense directory
+  GridParams g;
+  uint32_t bx, by, bz;         // box size in cells
+  uint32_t nbx, nby, n_boxes;  // boxes along x, along y, in total
+  uint32_t k, nf;
+  RecOut out;
+  uint32_t* fb_list;           // queries left to the global-memory search ...
+  uint32_t* fb_count;          // ... and how many
+  double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
+  uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t& total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
+  }
+  total = (uint32_t)__shfl((int)inc, 63, 64);
+  return inc - v;
+}
+
+// ---- k-best list with the LDS slot of the candidate packed into the low bits of its f64 squared distance ---------------------------
+// One register pair per entry and two f64 operations per entry and insertion (v_max_f64 + v_min_f64) instead of five with a separate
+// index array: the sorted insertion is what a query wave spends most of its VALU time on.  11 bits of slot (CAP <= 2048) leave 41
+// mantissa bits; the kernel verifies afterwards that the dropped bits could not have changed the order (see the end of the search).
+constexpr uint32_t kSlotBits = 11, kSlotMask = (1u << kSlotBits) - 1u;
+__device__ __forceinline__ double pack_key(double d, uint32_t slot) {
+  d = __builtin_fmin(d, kF64Max);  // +inf would turn into a NaN pattern once slot bits are inserted
+  uint64_t b = __builtin_bit_cast(uint64_t, d);
+  b = (b & ~(uint64_t)kSlotMask) | slot;
+  return __builtin_bit_cast(double, b);
+}
+__device__ __forceinline__ uint32_t key_slot(double key) { return (uint32_t)__builtin_bit_cast(uint64_t, key) & kSlotMask; }
+__device__ __forceinline__ bool same_masked(double a, double b) {
+  return ((__builtin_bit_cast(uint64_t, a) ^ __builtin_bit_cast(uint64_t, b)) >> kSlotBits) == 0;
+}
+__device__ __forceinline__ double key_upper(double key) {  // >= the exact distance the key was made from
+  return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, key) | (uint64_t)kSlotMask);
+}
+template <int K>
+struct KBestPacked {
+  double key[K + 1];  // ascending; one entry more than needed: the (k+1)-th key decides whether the k-th is unambiguous
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t <= K; ++t) key[t] = __builtin_inf();
+  }
+  __device__ __forceinline__ void insert(double x) {  // new[t] = min(old[t], max(old[t-1], x))
+    if (!(x < key[K])) return;
+    // v_max_f64 / v_min_f64 written out: __builtin_fmin / fmax make hipcc canonicalise every operand first (one extra v_max_f64 per
+    // entry; keys come out of integer bit operations, which it cannot prove to be canonical) -- half again as many f64 operations
+    double prev = -__builtin_inf();
+#pragma unroll
+    for (int t = 0; t <= K; ++t) {
+      const double kt = key[t];
+      double hi, lo;
+      asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(prev), "v"(x));
+      asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(kt), "v"(hi));
+      key[t] = lo;
+      prev = kt;
+    }
+  }
+  __device__ __forceinline__ double kth(uint32_t k) const {  // key[k-1] without dynamic register indexing
+    double v = key[K - 1];
+#pragma unroll
+    for (int t = 0; t < K; ++t) v = (uint32_t)t == k - 1 ? key[t] : v;
+    return v;
+  }
+};
+
+// The halo of a box is addressed WITHOUT clipping: rows and cells outside the grid exist in the local directory as empty ranges, so
+// the search loop has no boundary tests: halo row r = (z - (Z0-2)) * HY + (y - (Y0-2)), halo cell c = x - (X0-2), and the candidates of
+// a query in halo cell (lx, ly, lz) in the row (dy, dz) away are the LDS slots [ldir[B + D], ldir[B + D + 5]) with
+// B = (lz * HY + ly) * NC1 + lx - 2 (per lane) and D = (dz * HY + dy) * NC1 (per segment, from a 25-entry table).
+template <int K, int THREADS, int CAP, bool WITH_KNN>
+__global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void knn_tile_kernel(const TileArgs a) {
+  __shared__ double PX[CAP], PY[CAP], PZ[CAP];  // staged points, one array per coordinate (8-byte stride: neighbouring slots never share a bank)
+  __shared__ uint16_t ldir[kMaxDir];            // ldir[r * NC1 + c] = first LDS slot of halo cell c of halo row r
+  __shared__ uint32_t g0[kMaxRows];             // first sorted point of every halo row
+  __shared__ uint32_t rbase[kMaxRows + 1];      // first LDS slot of every halo row (exclusive prefix sum of the row lengths)
+  __shared__ uint32_t qpre[kMaxQRows + 1];      // exclusive prefix sum of the query counts of the query rows
+  __shared__ uint16_t qbuf[kQueue * THREADS];
+  __shared__ uint32_t s_next;
+  constexpr int NW = THREADS / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t box = xcd_block_id();
+  if (box >= a.n_boxes) return;
+  const GridParams& g = a.g;
+  const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2];
+  const int bxi = (int)(box % a.nbx), byi = (int)((box / a.nbx) % a.nby), bzi = (int)(box / (a.nbx * a.nby));
+  const int X0 = bxi * (int)a.bx, Y0 = byi * (int)a.by, Z0 = bzi * (int)a.bz;  // first query cell
+  const int XH = (int)g.rx + 1;  // halo cells along x: the ball of radius < h reaches at most rx fine cells + the query's own partial cell
+  const int HX = (int)a.bx + 2 * XH, HY = (int)a.by + 2 * kHalo, HZ = (int)a.bz + 2 * kHalo;
+  const int NC1 = HX + 1, NR = HY * HZ, nqy = (int)a.by, nqr = (int)(a.by * a.bz);
+  auto row_in_grid = [&](int r, uint64_t& cell0) {
+    const int y = Y0 - kHalo + r % HY, z = Z0 - kHalo + r / HY;
+    cell0 = ((uint64_t)z * (uint64_t)dim1 + (uint64_t)y) * (uint64_t)dim0;
+    return y >= 0 && y < dim1 && z >= 0 && z < dim2;
+  };
+  auto clamp_x = [&](int x) { return (uint32_t)(x < 0 ? 0 : (x > dim0 ? dim0 : x)); };
+
+  // ---- A: the directory entries of every halo row (half a wave per row, one lane per cell boundary): ONE global round trip; the raw
+  //         32-bit entries are parked in the coordinate arrays, which are not in use yet --------------------------------------------
+  uint32_t* raw = reinterpret_cast<uint32_t*>(PX);  // [NR][32]; 3 * CAP * 8 bytes >= kMaxRows * 32 * 4 is asserted below
+  static_assert(3 * CAP * 8 >= kMaxRows * 32 * 4, "raw directory does not fit the coordinate arrays");
+  for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
+    const int c = (int)(tid & 31u);
+    if (c < NC1) {
+      uint64_t c0;
+      raw[r * 32 + c] = row_in_grid(r, c0) ? a.cell_start[c0 + clamp_x(X0 - XH + c)] : 0u;
+    }
+  }
+  if (tid == 0) s_next = 0;
+  __syncthreads();
+  for (int r = (int)tid; r < NR; r += THREADS) { g0[r] = raw[r * 32]; rbase[r] = raw[r * 32 + HX] - raw[r * 32]; }
+  __syncthreads();
+  if (wave == 0) {  // exclusive prefix sum of the row lengths: NR <= 144 = 3 entries per lane
+    uint32_t v[3], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; v[u] = r < NR ? rbase[r] : 0u; sum += v[u]; }
+    uint32_t total;
+    uint32_t run = wave_excl_scan(sum, lane, total);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; if (r < NR) rbase[r] = run; run += v[u]; }
+    if (lane == 0) rbase[NR] = total;
+  }
+  __syncthreads();
+  const uint32_t total = rbase[NR];
+  if (total == 0) return;
+  if (total > (uint32_t)CAP) {
+    // the halo does not fit: every query of the box goes to the global-memory search
+    for (int qr = (int)wave; qr < nqr; qr += NW) {
+      const int r = (kHalo + qr / nqy) * HY + kHalo + qr % nqy;
+      const uint32_t s0 = raw[r * 32 + XH], s1 = raw[r * 32 + XH + (int)a.bx];
+      for (uint32_t j = s0 + lane; j < s1; j += 64) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
+    }
+    return;
+  }
+  // ---- B: local 16-bit directory ----------------------------------------------------------------------------------------------------
+  for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
+    const int c = (int)(tid & 31u);
+    if (c < NC1) ldir[r * NC1 + c] = (uint16_t)(raw[r * 32 + c] - g0[r] + rbase[r]);
+  }
+  __syncthreads();  // the raw directory is dead: the coordinate arrays can be filled
+  // ---- C: coalesced copy of the row segments, xyz de-interleaved; kRows rows x kChunks 64-double chunks in flight per wave ----------
+  {
+    constexpr int kRows = 4, kChunks = 4;  // (16-byte loads were measured slower here: 9.0 against 7.0 ms for staging + output alone)
+    auto put = [&](uint32_t base, uint32_t e, double v) __attribute__((always_inline)) {
+      const uint32_t pt = e / 3u, c = e - 3u * pt;
+      double* dst = c == 0 ? PX : (c == 1 ? PY : PZ);
+      dst[base + pt] = v;
+    };
+    for (int r0 = (int)wave * kRows; r0 < NR; r0 += NW * kRows) {
+      double v[kRows][kChunks];
+      uint32_t len3[kRows];
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = r0 + u;
+        len3[u] = r < NR ? 3u * (rbase[r + 1] - rbase[r]) : 0u;
+        const double* src = a.sxyz + 3ull * (r < NR ? g0[r] : 0u);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) v[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = r0 + u;
+        if (r >= NR) continue;
+        const uint32_t base = rbase[r];
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) if (lane + 64u * c < len3[u]) put(base, lane + 64u * c, v[u][c]);
+        if (len3[u] > 64u * kChunks) {
+          const double* src = a.sxyz + 3ull * g0[r];
+          for (uint32_t e = lane + 64u * kChunks; e < len3[u]; e += 64) put(base, e, src[e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- D: queries of the box = the points of its bx cells in each of its by * bz rows ----------------------------------------------
+  auto qrow_halo = [&](int qr) { return (kHalo + qr / nqy) * HY + kHalo + qr % nqy; };
+  if (wave == 0) {
+    uint32_t cnt = 0;
+    if ((int)lane < nqr) { const int r = qrow_halo((int)lane); cnt = (uint32_t)ldir[r * NC1 + XH + (int)a.bx] - (uint32_t)ldir[r * NC1 + XH]; }
+    uint32_t tot;
+    const uint32_t ex = wave_excl_scan(cnt, lane, tot);
+    if ((int)lane < nqr) qpre[lane] = ex;
+    if (lane == 0) qpre[nqr] = tot;
+  }
+  __syncthreads();
+  const uint32_t Q = qpre[nqr];
+  const uint32_t m = a.nf < a.k ? a.nf : a.k;
+
+  for (;;) {
+    uint32_t c0 = 0;
+    if (lane == 0) c0 = atomicAdd(&s_next, 64u);
+    c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+    if (c0 >= Q) break;
+    const uint32_t q = c0 + lane;
+    const bool active = q < Q;
+    int qr = 0;
+    {
+      int lo = 0, hi = nqr;  // largest qr with qpre[qr] <= q
+      const uint32_t qq = active ? q : 0u;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qpre[mid] <= qq) lo = mid; else hi = mid; }
+      qr = lo;
+    }
+    const int hr = qrow_halo(qr);
+    const uint32_t slot = active ? (uint32_t)ldir[hr * NC1 + XH] + (q - qpre[qr]) : 0u;
+    const double qx = PX[slot], qy = PY[slot], qz = PZ[slot];
+    const uint32_t j = g0[hr] + (slot - rbase[hr]);  // index among the sorted points
+    // the row (y, z) is the query row; the cell along x comes from the coordinate (same arithmetic as keys_kernel)
+    const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
+    const int B = hr * NC1 + (cx - X0 + XH);  // directory entry of the query's own cell
+
+    KBestPacked<K> best;
+    best.init();
+    uint32_t qn = 0;  // queued candidates of this lane
+    auto key_of = [&](double x, double y, double z, uint32_t p) __attribute__((always_inline)) {
+      const double dx = x - qx, dy = y - qy, dz = z - qz;
+      return pack_key(dx * dx + dy * dy + dz * dz, p);
+    };
+    // Batched insertion, software-pipelined: the slot of entry i+2 and the coordinates of entry i+1 are requested before entry i is
+    // inserted, so the LDS round trips hide behind the insertion's VALU work.
+    auto flush = [&]() __attribute__((always_inline)) {
+      uint32_t p0 = qn > 0 ? qbuf[tid] : 0u;
+      uint32_t p1 = qn > 1 ? qbuf[THREADS + tid] : 0u;
+      double x0 = PX[p0], y0 = PY[p0], z0 = PZ[p0];
+      for (uint32_t i = 0; i < (uint32_t)kQueue; ++i) {
+        const bool has = i < qn;
+        if (!__any(has)) break;
+        const uint32_t p2 = i + 2 < qn ? qbuf[(i + 2) * THREADS + tid] : 0u;
+        const double x1 = PX[p1], y1 = PY[p1], z1 = PZ[p1];
+        if (has && !(a.ablate & 1u)) best.insert(key_of(x0, y0, z0, p0));
+        p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
+      }
+      qn = 0;
+    };
+    // Scan.  Every lane walks its own 9 row segments (the 3 x 3 rows around its cell).  BALL TRIMMING per segment, in units of h and f32
+    // with upward slack: a row whose (y, z) slab is farther from the query than the current bound (the a-priori tau0 < h^2, later the
+    // k-th best key) is skipped; the others are cut to the fine x cells that intersect the ball.  kBatch candidates per step: their 12
+    // coordinate reads are issued together, so one LDS round trip serves four distance tests.
+    const float fx = (float)((qx - g.org[0]) * g.inv_hx - (double)cx), fy = (float)((qy - g.org[1]) * g.inv_h - (double)cy),
+                fz = (float)((qz - g.org[2]) * g.inv_h - (double)cz);
+    const float inv_h2 = (float)(g.inv_h * g.inv_h) * 1.00001f, rxf = (float)g.rx * 1.00001f, xh = (float)XH;
+    int seg = active && !(a.ablate & 4u) ? 0 : kSegs;
+    uint32_t p = 0, pe = 0;
+    for (;;) {
+      while (p >= pe && seg < kSegs) {
+        const int dz = seg / 3 - 1, dy = seg - (seg / 3) * 3 - 1;
+        seg += 1;
+        // distance (in units of h) from the query to the slab [dy, dy + 1) x [dz, dz + 1) of rows, relative to its own row
+        const float ty = (float)dy - fy, tz = (float)dz - fz;
+        const float gy = fmaxf(0.0f, fmaxf(ty, -ty - 1.0f)), gz = fmaxf(0.0f, fmaxf(tz, -tz - 1.0f));
+        const float bound = (float)__builtin_fmin(key_upper(best.key[K]), a.tau0) * inv_h2;
+        const float r2 = bound - (gy * gy + gz * gz);
+        if (!(r2 > 0.0f)) continue;
+        const float ext = __builtin_sqrtf(r2) * rxf;  // half-width of the ball in this row, in fine x cells
+        const float lo_f = fmaxf(floorf(fx - ext), -xh), hi_f = fminf(floorf(fx + ext), xh);
+        const int Bd = B + (dz * HY + dy) * NC1;
+        p = ldir[Bd + (int)lo_f]; pe = ldir[Bd + (int)hi_f + 1];  // fine cells [lo, hi] of the row, relative to the query's cell
+      }
+      const uint32_t rem = p < pe ? pe - p : 0u;
+      const bool any_has = __any(rem != 0u);
+      if (any_has) {
+        double cx_[kBatch], cy_[kBatch], cz_[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const uint32_t pu = (uint32_t)u < rem ? p + (uint32_t)u : 0u;
+          cx_[u] = PX[pu]; cy_[u] = PY[pu]; cz_[u] = PZ[pu];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          if ((uint32_t)u < rem) {
+            const double key = key_of(cx_[u], cy_[u], cz_[u], p + (uint32_t)u);
+            if (key < __builtin_fmin(best.key[K], a.tau0) && !(a.ablate & 8u)) { qbuf[qn * THREADS + tid] = (uint16_t)(p + (uint32_t)u); qn += 1; }
+          }
+        }
+        p += rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch;
+      }
+      // ONE inlined copy of the insertion code: batches when some lane's queue could overflow in the next step, and the leftovers after
+      // the last candidate
+      if (__any(qn > (uint32_t)(kQueue - kBatch)) || (!any_has && __any(qn != 0u))) flush();
+      if (!any_has) break;
+    }
+    // Packed keys order candidates by (distance with its low 11 bits dropped, slot).  That IS the exact ascending-distance order, ties
+    // broken by slot, unless two of the best k+1 keys agree in every kept bit: then the pair is compared exactly -- an exact tie is
+    // already in its final order; a near-tie inside the list, or any agreement across the k / k+1 boundary (a candidate that was
+    // dropped might belong in front), sends the query to the exact search.
+    bool exact = true;
+    {
+      const uint32_t kk = a.k;
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        if ((uint32_t)t < kk && same_masked(best.key[t], best.key[t + 1])) {
+          if ((uint32_t)t + 1 == kk) exact = false;
+          else {
+            const uint32_t s0 = key_slot(best.key[t]), s1 = key_slot(best.key[t + 1]);
+            const double dx0 = PX[s0] - qx, dy0 = PY[s0] - qy, dz0 = PZ[s0] - qz, dx1 = PX[s1] - qx, dy1 = PY[s1] - qy, dz1 = PZ[s1] - qz;
+            if (dx0 * dx0 + dy0 * dy0 + dz0 * dz0 != dx1 * dx1 + dy1 * dy1 + dz1 * dz1) exact = false;
+          }
+        }
+      }
+    }
+    // k candidates inside tau0 < h^2: everything at most that far from the query lies in the 3 x 3 rows (each at least h deep beyond
+    // the query's cell) and inside the trims, which were cut with bounds that only shrank afterwards -- the list is complete
+    const bool done = a.ablate ? true : exact && best.kth(a.k) < a.tau0;
+    if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
+    if (active && done) {
+      const uint64_t orig = a.out.sidx[j];
+      if constexpr (WITH_KNN) {
+        for (uint32_t t = 0; t < a.k; ++t) {
+          uint32_t v = kNoIndex;
+          uint32_t pl = 0;
+#pragma unroll
+          for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = key_slot(best.key[u]);
+          if (t < m) {
+            int lo = 0, hi = NR;  // halo row of LDS slot pl: the last row that starts at or before it
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rbase[mid] <= pl) lo = mid; else hi = mid; }
+            v = a.out.sidx[g0[lo] + (pl - rbase[lo])];
+          }
+          write_knn(a.out, orig, a.k, t, v);
+        }
+      }
+      Fit f{0, 0, 0, 0, 1};
+      if (!(a.ablate & 2u)) f = plane_fit<K>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+        uint32_t pl = 0;
+#pragma unroll
+        for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = key_slot(best.key[u]);
+        x = PX[pl]; y = PY[pl]; z = PZ[pl];
+      });
+      write_record(a.out, orig, f);
+    }
+  }
+}
+
+}  // namespace
+
+namespace pstk {
+
+// Picks the box: least halo amplification (staged points / query points) whose expected number of staged points fits the LDS budget.
+// bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
+bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, TileShape& t) {
+  if (k > 32 || cells == 0 || nf == 0) return false;
+  t.threads = 256;
+  t.cap = 1536;
+  const uint32_t xh = g.rx + 1;
+  const double rho = (double)nf / (double)cells;  // points per fine cell
+  const double budget = 0.90 * (double)t.cap;
+  auto fits = [&](uint32_t bx, uint32_t by, uint32_t bz) {
+    const uint32_t hx = bx + 2 * xh, hy = by + 2 * kHalo, hz = bz + 2 * kHalo;
+    return bx <= g.dim[0] && by <= g.dim[1] && bz <= g.dim[2] && hx <= (uint32_t)kMaxRowCells && by * bz <= (uint32_t)kMaxQRows &&
+           hy * hz <= (uint32_t)kMaxRows && (hx + 1) * hy * hz <= (uint32_t)kMaxDir;
+  };
+  double best_amp = 1e300;
+  bool found = false;
+  for (uint32_t bz = 1; bz <= 8; ++bz)
+    for (uint32_t by = 1; by <= 8; ++by)
+      for (uint32_t bx = 1; bx <= (uint32_t)kMaxRowCells; ++bx) {
+        if (!fits(bx, by, bz)) continue;
+        // the halo is addressed unclipped (rows and cells outside the grid are empty), only its POINTS are clipped by the grid
+        const uint32_t px = std::min(bx + 2 * xh, g.dim[0]), py = std::min(by + 2 * kHalo, g.dim[1]), pz = std::min(bz + 2 * kHalo, g.dim[2]);
+        if (rho * px * py * pz > budget) continue;
+        const double amp = (double)(px * py * pz) / (double)(bx * by * bz);
+        if (amp < best_amp - 1e-12) { best_amp = amp; t.bx = bx; t.by = by; t.bz = bz; found = true; }
+      }
+  if (const char* e = std::getenv("PST_KNN_TILE")) {  // "bx,by,bz"
+    unsigned x = 0, y = 0, z = 0;
+    if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z && fits(x, y, z)) { t.bx = x; t.by = y; t.bz = z; found = true; }
+  }
+  return found;
+}
+
+void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,
+                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, hipStream_t stream) {
+  TileArgs a{};
+  a.sxyz = sxyz; a.cell_start = cell_start; a.g = g;
+  a.bx = t.bx; a.by = t.by; a.bz = t.bz;
+  a.nbx = (g.dim[0] + t.bx - 1) / t.bx; a.nby = (g.dim[1] + t.by - 1) / t.by;
+  const uint32_t nbz = (g.dim[2] + t.bz - 1) / t.bz;
+  a.n_boxes = a.nbx * a.nby * nbz;
+  a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
+  if (const char* e = std::getenv("PST_KNN_ABLATE")) a.ablate = (uint32_t)std::atoi(e);
+  // A-priori bound on the squared k-th distance: the grid's cell edge h was chosen as the radius of the sphere expected to hold about
+  // 1.75 k points (normals.hip), and candidates beyond tau0 = h^2 (less a few ulps for the packed keys) are not even queued.  Without
+  // it every candidate passes the "closer than the current k-th" test until a lane's list is full, and about k (1 + ln(N / k)) of N
+  // candidates pass overall -- each pass is a sorted insertion the whole wave waits for.  The result stays exact: a query that finds
+  // fewer than k candidates inside tau0 goes to the exact global-memory search like any other unfinished query (about 1 % of a uniform
+  // cloud's queries), and tau0 < h^2 is also what makes 3 x 3 rows of cells enough.
+  a.tau0 = g.h * g.h * (1.0 - 4e-9);
+  const unsigned grid = (a.n_boxes + 7u) & ~7u;
+  const bool knn = out.knn != nullptr || out.knn_u32 != nullptr;
+#define PST_TILE_LAUNCH(KK, TT, CC)                                                                                          \
+  do {                                                                                                                       \
+    if (knn) hipLaunchKernelGGL((knn_tile_kernel<KK, TT, CC, true>), dim3(grid), dim3(TT), 0, stream, a);                   \
+    else hipLaunchKernelGGL((knn_tile_kernel<KK, TT, CC, false>), dim3(grid), dim3(TT), 0, stream, a);                      \
+  } while (0)
+#define PST_TILE_K(TT, CC)                                                                                                   \
+  do {                                                                                                                       \
+    if (k <= 8) PST_TILE_LAUNCH(8, TT, CC);                                                                                  \
+    else if (k <= 16) PST_TILE_LAUNCH(16, TT, CC);                                                                           \
+    else PST_TILE_LAUNCH(32, TT, CC);                                                                                        \
+  } while (0)
+  PST_TILE_K(256, 1536);
+#undef PST_TILE_K
+#undef PST_TILE_LAUNCH
+}
+
+}  // namespace pstk

@@ -40,6 +40,9 @@ Workspace& workspace();
 
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind);
 void dev_free(uint8_t* p, uint32_t memkind);
+// no-throw forms on an explicit stream (stream-ordered pool, or hipMalloc / hipFree without pool support or with PST_NO_POOL)
+hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s);
+void dev_free_stream(void* p, hipStream_t s);
 
 // address helpers
 inline uint64_t aos_addr(const pst_buffer& b, size_t point) { return (uint64_t)(uintptr_t)b.data + (uint64_t)point * b.layout.size; }

@@ -354,6 +354,73 @@ def test_compute_normals_1e6_properties(hip):
         assert np.array_equal(knn[q], want)
 
 
+def test_full_size_1e8_knn_normals_properties(hip, oracle):
+    """configs[4] at its full size: 10^8 uniform points, k = 16, raw results in device memory (pst_compute_normals_device).
+    Checked on the device: every point is its own nearest neighbour, every list is sorted by distance and free of repeats,
+    normals / curvatures finite; 2 048 sampled queries against an on-device brute force over all 10^8 points; 256 of them against the
+    ORACLE's plane fit (the 16 neighbours in ascending distance, as a 16-point cloud with k = 16: the fit of point 0 is the same
+    sequence of floating-point operations as in the full computation); and NORMAL / Curvature columns written by
+    pst_compute_normals_into equal the f64 results narrowed with `as`."""
+    import torch
+    from pasture_amd.algorithms import compute_normals, compute_normals_device, compute_normals_into
+    n, k = 100_000_000, 16
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(42, 0)
+    normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    curv = torch.empty(n, dtype=torch.float64, device="cuda")
+    knn = torch.empty((n, k), dtype=torch.int32, device="cuda")  # uint32 bit patterns; n < 2^31 so they read as int32
+    compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
+    pts = _torch_view(src.column_ptr(A.POSITION_3D), n * 24).view(torch.float64).view(n, 3)
+    assert bool(torch.isfinite(normals).all()) and bool(torch.isfinite(curv).all()) and bool((curv >= 0).all())
+    chunk = 10_000_000
+    for first in range(0, n, chunk):
+        kk = knn[first:first + chunk].long()
+        assert bool((kk[:, 0] == torch.arange(first, first + chunk, device="cuda")).all()), "a point is not its own nearest neighbour"
+        assert bool(((kk >= 0) & (kk < n)).all())
+        d = ((pts[kk.reshape(-1)].view(chunk, k, 3) - pts[first:first + chunk, None, :]) ** 2).sum(dim=2)
+        assert bool((d[:, 1:] >= d[:, :-1]).all()), "a neighbour list is not in ascending distance"
+        assert bool((d[:, 1:] > 0).all()), "a neighbour repeats the query point"
+        del kk, d
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7)
+    sample = torch.randint(0, n, (2048,), generator=g)
+    # the cloud's corners and faces are where the search clips its cell neighbourhood: add the extreme points of every axis
+    extremes = torch.cat([pts.argmin(dim=0), pts.argmax(dim=0)]).cpu()
+    sample = torch.cat([sample, extremes])
+    host_nb = {}
+    for q in sample.tolist():
+        d = ((pts - pts[q]) ** 2).sum(dim=1)
+        dist, want = torch.topk(d, k, largest=False, sorted=True)
+        got = knn[q].long()
+        if not bool((want == got).all()):
+            # equal distances may be listed in either order (tie order is the un-vendored kd-tree crate's: unpinned)
+            dg = ((pts[got] - pts[q]) ** 2).sum(dim=1)
+            assert bool((dg == dist).all()), f"query {q}: neighbour distances {dg.tolist()} != brute force {dist.tolist()}"
+        if len(host_nb) < 256:
+            host_nb[q] = pts[got].cpu().numpy()
+        del d
+    hn, hc = normals.cpu(), curv.cpu()
+    for q, nb in host_nb.items():
+        ob = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=oracle))
+        ob.resize(k)
+        ob.set_attribute_range(A.POSITION_3D, range(0, k), nb)
+        on, oc = compute_normals(ob, k)
+        dev = nb - nb.mean(axis=0)
+        bad, cbad = _compare_normals(hn[q:q + 1].numpy(), hc[q:q + 1].numpy(), on[:1], oc[:1], scales=np.array([np.abs(dev.T @ dev).max()]))
+        assert not bad.any() and not cbad.any(), f"query {q}: normal {hn[q].tolist()} vs oracle {on[0].tolist()}, curvature {float(hc[q])} vs {float(oc[0])}"
+    # the north star's output form: NORMAL (Vec3f32) + Curvature (F64) columns
+    curv_def = PointAttributeDefinition("Curvature", T.F64)
+    out = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.NORMAL, curv_def], api=hip))
+    out.resize(n)
+    del knn
+    compute_normals_into(src, k, out)
+    n32 = _torch_view(out.column_ptr(A.NORMAL), n * 12).view(torch.float32).view(n, 3)
+    assert torch.equal(n32, normals.to(torch.float32))
+    assert torch.equal(_torch_view(out.column_ptr(curv_def), n * 8).view(torch.float64), curv)
+
+
 # ---- buffer kinds of the boundary: external memory, pinned host memory, explicit stream --------------------------
 
 def test_external_memory_buffers_over_torch_tensors(hip):
