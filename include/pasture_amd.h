@@ -97,7 +97,9 @@ typedef struct pst_mapping_info { /* AttributeMapping, buffer_conversion.rs:41-5
 
 typedef struct pst_layout pst_layout;       /* PointLayout,           point_layout.rs:648-997 */
 typedef struct pst_buffer pst_buffer;       /* VectorBuffer :659 / HashMapBuffer :1031 / ExternalMemoryBuffer :1479 (point_buffer.rs) */
-typedef struct pst_converter pst_converter; /* BufferLayoutConverter, buffer_conversion.rs:98-663 */
+typedef struct pst_converter pst_converter;
+typedef struct pst_comm pst_comm;           /* RCCL communicator(s) of the sharded path */
+typedef struct pst_comm_id { uint8_t bytes[128]; } pst_comm_id;  /* rendezvous token (RCCL unique id), shared out of band */ /* BufferLayoutConverter, buffer_conversion.rs:98-663 */
 
 const char* pst_last_error(void);
 
@@ -231,6 +233,25 @@ int pst_las_encode_points(const pst_buffer* src, uint32_t point_format, const do
 int pst_las_encode_range_async(const pst_buffer* src, size_t src_first, size_t count, uint32_t point_format, const double scale[3],
                                const double offset[3], pst_buffer* dst, size_t dst_first, double* device_bounds6, uint64_t* device_counts16,
                                uint32_t max_return);
+
+/* ---- multi-GPU: points shard by index range, the ONLY exchange is the global AABB ------------------------------
+ * The reference has no distributed code: its own index-range processing (convert_into_range buffer_conversion.rs:292; 1 MiB chunks
+ * raw_readers.rs:309-349) is what shards without a data-path collective, and the seeds of calculate_bounds (bounds.rs:31-32,
+ * +f64::MAX / f64::MIN) are the identities an EMPTY shard contributes.  One process per GPU: rank 0 calls pst_comm_unique_id, ships
+ * the 128 bytes to the other ranks (any channel), every rank calls pst_comm_init_rank with its device selected (pst_set_device).
+ * pst_comm_init is the single-process form (one handle driving GPUs 0..n-1, ncclCommInitAll).  RCCL is bound at run time; without
+ * it these entry points return PST_ERR_UNSUPPORTED. */
+int pst_comm_unique_id(pst_comm_id* out_id);
+int pst_comm_init_rank(int n_ranks, int rank, const pst_comm_id* id, pst_comm** out);
+int pst_comm_init(int n_gpus, pst_comm** out);
+int pst_comm_size(const pst_comm* comm, int* out_n_ranks);
+int pst_comm_destroy(pst_comm* comm);
+/* global AABB, in place, stream-ordered (no host synchronisation): device_rec6 = {min xyz, max xyz} as written by
+ * pst_calculate_bounds_async / pst_converter_convert_into_range_with_bounds_async.  ONE ncclAllReduce of 6 x f64 with ncclMin over
+ * {min xyz, -max xyz} (48 bytes over xGMI: latency-bound).  All-empty input leaves the seeds, i.e. None (bounds.rs:12-14). */
+int pst_bounds_allreduce(pst_comm* comm, double* device_rec6);
+/* the same for a pst_comm_init handle: device_recs[d] lives on GPU d, streams[d] (array nullable = default streams) is its stream */
+int pst_bounds_allreduce_multi(pst_comm* comm, double* const* device_recs, void* const* streams);
 
 #ifdef __cplusplus
 }

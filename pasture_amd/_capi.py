@@ -134,6 +134,13 @@ _PRODUCT_SIGNATURES = {
     "las_encode_range_async": [_P, _SZ, _SZ, C.c_uint32, _D3, _D3, _P, _SZ, _P, _P, C.c_uint32],
     "compute_normals_into": [_P, _SZ, _P],
     "compute_normals_device": [_P, _SZ, _P, _P, _P],
+    "comm_unique_id": [_P],
+    "comm_init_rank": [C.c_int, C.c_int, _P, _PP],
+    "comm_init": [C.c_int, _PP],
+    "comm_size": [_P, C.POINTER(C.c_int)],
+    "comm_destroy": [_P],
+    "bounds_allreduce": [_P, _P],
+    "bounds_allreduce_multi": [_P, _PP, _PP],
 }
 
 PRODUCT_SYMBOLS = ["last_error"] + list(_SHARED_SIGNATURES) + list(_PRODUCT_SIGNATURES)

@@ -113,3 +113,84 @@ def bounds_from_record(rec) -> Optional[Tuple[Tuple[float, float, float], Tuple[
     if any(a > b for a, b in zip(mn, mx)):
         raise PasturePanic(ERR_BOUNDS_INVALID, "AABB::from_min_max: Minimum position must be <= maximum position!")
     return tuple(mn), tuple(mx)
+
+
+class Communicator:
+    """pst_comm: the C ABI's own RCCL communicator (include/pasture_amd.h, "multi-GPU"), for hosts that do not run torch.distributed.
+
+    `Communicator.from_unique_id` is the one-process-per-GPU form (rank 0 creates the id with `Communicator.unique_id()` and ships the 128
+    bytes to the other ranks over any channel -- `from_torch_group` uses a torch.distributed broadcast for that); `single_process(n)`
+    drives GPUs 0..n-1 from one process.  `allreduce_bounds(ptr)` is ONE ncclAllReduce of the 6-double record, in place, stream-ordered."""
+
+    def __init__(self, handle, api):
+        self._h, self.api = handle, api
+
+    @staticmethod
+    def unique_id(api=None) -> bytes:
+        import ctypes as C
+        from ._capi import product_api
+        api = api or product_api()
+        buf = (C.c_uint8 * 128)()
+        api.comm_unique_id(buf)
+        return bytes(buf)
+
+    @classmethod
+    def from_unique_id(cls, n_ranks: int, rank: int, uid: bytes, api=None) -> "Communicator":
+        import ctypes as C
+        from ._capi import product_api
+        api = api or product_api()
+        assert len(uid) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        h = C.c_void_p()
+        api.comm_init_rank(n_ranks, rank, buf, C.byref(h))
+        return cls(h, api)
+
+    @classmethod
+    def from_torch_group(cls, group=None, api=None) -> "Communicator":
+        """Bootstraps over an existing torch.distributed group (any backend): rank 0's id is broadcast as 128 bytes."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t = torch.tensor(list(cls.unique_id(api)), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        return cls.from_unique_id(world, rank, bytes(t.cpu().tolist()), api)
+
+    @classmethod
+    def single_process(cls, n_gpus: int, api=None) -> "Communicator":
+        import ctypes as C
+        from ._capi import product_api
+        api = api or product_api()
+        h = C.c_void_p()
+        api.comm_init(n_gpus, C.byref(h))
+        return cls(h, api)
+
+    def size(self) -> int:
+        import ctypes as C
+        n = C.c_int()
+        self.api.comm_size(self._h, C.byref(n))
+        return n.value
+
+    def allreduce_bounds(self, device_rec6_ptr: int) -> None:
+        import ctypes as C
+        self.api.bounds_allreduce(self._h, C.c_void_p(device_rec6_ptr))
+
+    def allreduce_bounds_multi(self, device_rec_ptrs, streams=None) -> None:
+        import ctypes as C
+        n = len(device_rec_ptrs)
+        recs = (C.c_void_p * n)(*device_rec_ptrs)
+        st = (C.c_void_p * n)(*streams) if streams is not None else None
+        self.api.bounds_allreduce_multi(self._h, recs, st)
+
+    def destroy(self) -> None:
+        if self._h is not None:
+            self.api.comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

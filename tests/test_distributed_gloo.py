@@ -220,3 +220,58 @@ def test_bench_rejects_world_size_mismatch():
     r = _run_bench("--gpus", "4", "--backend", "gloo", "--launch-dry-run",
                    env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+# ---- the C ABI's own collective (pst_comm_*, pst_bounds_allreduce: RCCL bound directly) ------------------------------------------------
+def test_comm_entry_points_fail_loudly_without_a_device():
+    """No GPU in the CPU suite: the multi-GPU entry points are exported and answer with PST_ERR_NO_DEVICE, never a silent no-op."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pasture_amd._capi import PastureError
+    from pasture_amd.distributed import Communicator
+    with pytest.raises(PastureError) as e:
+        Communicator.unique_id()
+    assert e.value.code == 21
+    with pytest.raises(PastureError) as e:
+        Communicator.single_process(1)
+    assert e.value.code == 21
+
+
+@pytest.mark.gpu
+def test_capi_bounds_allreduce_world_size_1_rccl(hip):
+    """pst_comm_unique_id -> pst_comm_init_rank(1, 0) -> pst_bounds_allreduce on the record pst_calculate_bounds_async wrote: with ONE rank
+    the global AABB is the local one (the encode / ncclAllReduce(ncclMin) / decode sequence really ran on the device: the record is
+    poisoned first); an all-empty shard keeps the seeds = None; and the single-process handle (pst_comm_init(1)) gives the same."""
+    import torch
+    from pasture_amd.algorithms import calculate_bounds, calculate_bounds_async
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.distributed import Communicator, bounds_from_record
+    from pasture_amd.layout import PointLayout, attributes as A
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    buf.resize(1_000_003)
+    buf.synth_fill(42, 5)
+    want = calculate_bounds(buf)
+    comm = Communicator.from_unique_id(1, 0, Communicator.unique_id())
+    assert comm.size() == 1
+    rec = torch.full((6,), float("nan"), dtype=torch.float64, device="cuda")
+    calculate_bounds_async(buf, rec.data_ptr())
+    comm.allreduce_bounds(rec.data_ptr())
+    torch.cuda.synchronize()
+    assert bounds_from_record(rec.cpu()) == (want.min(), want.max())
+    empty = torch.tensor([F64] * 3 + [-F64] * 3, dtype=torch.float64, device="cuda")
+    comm.allreduce_bounds(empty.data_ptr())
+    torch.cuda.synchronize()
+    assert bounds_from_record(empty.cpu()) is None
+    comm.destroy()
+    multi = Communicator.single_process(1)
+    rec2 = torch.empty(6, dtype=torch.float64, device="cuda")
+    calculate_bounds_async(buf, rec2.data_ptr())
+    torch.cuda.synchronize()
+    multi.allreduce_bounds_multi([rec2.data_ptr()])
+    torch.cuda.synchronize()
+    assert bounds_from_record(rec2.cpu()) == (want.min(), want.max())
+    multi.destroy()
+
+
+F64 = 1.7976931348623157e308
