@@ -98,6 +98,7 @@ typedef struct pst_mapping_info { /* AttributeMapping, buffer_conversion.rs:41-5
 typedef struct pst_layout pst_layout;       /* PointLayout,           point_layout.rs:648-997 */
 typedef struct pst_buffer pst_buffer;       /* VectorBuffer :659 / HashMapBuffer :1031 / ExternalMemoryBuffer :1479 (point_buffer.rs) */
 typedef struct pst_converter pst_converter;
+typedef struct pst_point_converter pst_point_converter;
 typedef struct pst_comm pst_comm;           /* RCCL communicator(s) of the sharded path */
 typedef struct pst_comm_id { uint8_t bytes[128]; } pst_comm_id;  /* rendezvous token (RCCL unique id), shared out of band */ /* BufferLayoutConverter, buffer_conversion.rs:98-663 */
 
@@ -162,6 +163,16 @@ int pst_buffer_filter_into(const pst_buffer* src, pst_buffer* dst, const uint8_t
 /* HashMapBuffer::filter::<B, _> (point_buffer.rs:1064-1076): new buffer of out_storage holding exactly the matching points */
 int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, pst_buffer** out);
 
+/* RawPointConverter::{from_to, convert}, pasture-core/src/layout/conversion/attribute_conversion.rs:62-109 — the point-major variant:
+ * one `as` converter per attribute present in BOTH layouts (matched by name, in the order of `from`) whose datatypes differ.
+ * Attributes with equal datatypes get no converter and are SKIPPED, not copied (:73-90); an impossible pair is the panic of :267-269
+ * (PST_ERR_INVALID_CONVERSION).  `convert` runs the converters on `count` interleaved points (the reference converts one point slice
+ * per call); bytes of the target points that no converter writes keep their values.  Both buffers must be interleaved and carry the
+ * layouts given to create (the reference's `unsafe` contract, checked here: PST_ERR_LAYOUT_MISMATCH). */
+int pst_point_converter_create(const pst_layout* from, const pst_layout* to, pst_point_converter** out);
+int pst_point_converter_destroy(pst_point_converter* c);
+int pst_point_converter_num_converters(const pst_point_converter* c, size_t* out);
+int pst_point_converter_convert(const pst_point_converter* c, const pst_buffer* src, size_t src_first, pst_buffer* dst, size_t dst_first, size_t count);
 /* ---- BufferLayoutConverter ------------------------------------------------------------------------- */
 int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_default, pst_converter** out); /* for_layouts :112 / for_layouts_with_default :126 */
 int pst_converter_destroy(pst_converter* c);

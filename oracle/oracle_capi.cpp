@@ -11,6 +11,7 @@ using namespace orc;
 struct orc_layout { PointLayout l; };
 struct orc_buffer { std::unique_ptr<Buffer> b; };
 struct orc_converter { BufferLayoutConverter c; std::vector<TransformDesc> xf; /* parallel to c.mappings */ };
+struct orc_point_converter { RawPointConverter c; PointLayout from, to; };
 
 static thread_local std::string g_last_error;
 
@@ -332,6 +333,30 @@ int orc_buffer_synth_fill(orc_buffer* b, uint64_t seed, uint64_t first_index) {
       buf.set_attribute(attrs[slot].def, i, tmp.data());
     }
   }
+  ORC_CATCH
+}
+
+// RawPointConverter (attribute_conversion.rs:62-109) applied to `count` interleaved points, one `convert` call per point
+int orc_point_converter_create(const orc_layout* from, const orc_layout* to, orc_point_converter** out) {
+  ORC_TRY
+  *need(out, "out") = new orc_point_converter{RawPointConverter::from_to(need(from, "from")->l, need(to, "to")->l), from->l, to->l};
+  ORC_CATCH
+}
+int orc_point_converter_destroy(orc_point_converter* c) { delete c; return OK; }
+int orc_point_converter_num_converters(const orc_point_converter* c, size_t* out) { ORC_TRY *need(out, "out") = need(c, "converter")->c.attribute_converters.size(); ORC_CATCH }
+int orc_point_converter_convert(const orc_point_converter* c, const orc_buffer* src, size_t src_first, orc_buffer* dst, size_t dst_first, size_t count) {
+  ORC_TRY
+  need(c, "converter");
+  InterleavedBuffer* si = need(src, "src")->b->as_interleaved();
+  InterleavedBuffer* di = need(dst, "dst")->b->as_interleaved();
+  if (!si || !di) throw Panic(ERR_INVALID_ARGUMENT, "RawPointConverter::convert works on the bytes of one interleaved point");
+  if (!(src->b->point_layout() == c->from)) throw Panic(ERR_LAYOUT_MISMATCH, "source point does not have the PointLayout passed to RawPointConverter::from_to");
+  if (!(dst->b->point_layout() == c->to)) throw Panic(ERR_LAYOUT_MISMATCH, "target point does not have the PointLayout passed to RawPointConverter::from_to");
+  if (src_first + count > src->b->len() || dst_first + count > dst->b->len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  const uint64_t ss = c->from.size_of_point_entry(), ds = c->to.size_of_point_entry();
+  const uint8_t* sp = count ? si->get_point_range_ref({src_first, src_first + count}) : nullptr;
+  uint8_t* dp = count ? di->get_point_range_mut({dst_first, dst_first + count}) : nullptr;
+  for (size_t i = 0; i < count; ++i) c->c.convert(sp + i * ss, dp + i * ds);
   ORC_CATCH
 }
 

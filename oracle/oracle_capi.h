@@ -86,6 +86,13 @@ int orc_buffer_filter_into(const orc_buffer* src, orc_buffer* dst, const uint8_t
                            size_t* out_matches);
 int orc_buffer_filter(const orc_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, orc_buffer** out);
 
+/* RawPointConverter::{from_to, convert}, attribute_conversion.rs:62-109 (point-major; same-datatype attributes are skipped) */
+typedef struct orc_point_converter orc_point_converter;
+int orc_point_converter_create(const orc_layout* from, const orc_layout* to, orc_point_converter** out);
+int orc_point_converter_destroy(orc_point_converter* c);
+int orc_point_converter_num_converters(const orc_point_converter* c, size_t* out);
+int orc_point_converter_convert(const orc_point_converter* c, const orc_buffer* src, size_t src_first, orc_buffer* dst, size_t dst_first, size_t count);
+
 int orc_converter_create(const orc_layout* from, const orc_layout* to, int with_default, orc_converter** out);
 int orc_converter_destroy(orc_converter* c);
 int orc_converter_set_custom_mapping(orc_converter* c, const char* from_name, const orc_datatype* from_dt, const char* to_name,

@@ -500,6 +500,39 @@ inline AttributeConversionFn get_generic_converter(const DataType& from, const D
     throw Panic(ERR_INVALID_CONVERSION, "Invalid conversion " + from.display() + " -> " + to.display());
   return f;
 }
+// get_converter_for_attributes — attribute_conversion.rs:122-132: None for equal datatypes (the caller copies or, in RawPointConverter,
+// SKIPS the attribute), the generic converter otherwise; panics for an impossible pair.
+inline AttributeConversionFn get_converter_for_attributes(const AttributeDef& from, const AttributeDef& to) {
+  if (from.name != to.name) throw Panic(ERR_INVALID_ARGUMENT, "assertion `left == right` failed: from_attribute.name() == to_attribute.name()");
+  if (from.datatype == to.datatype) return nullptr;
+  return get_generic_converter(from.datatype, to.datatype);
+}
+
+// RawAttributeConverter + RawPointConverter — attribute_conversion.rs:21-109.  Point-major: converts ONE interleaved point; only
+// attributes present in both layouts (matched by name, in the order of `from_layout`) whose datatypes DIFFER get a converter --
+// same-datatype attributes are skipped, not copied (:73-90: filter_map over an Option that is None for equal datatypes).
+struct RawAttributeConverter {
+  AttributeConversionFn conversion_fn;
+  uint64_t source_offset, source_size, target_offset, target_size;
+  void convert(const uint8_t* source_point, uint8_t* target_point) const { conversion_fn(source_point + source_offset, target_point + target_offset); }  // :45-58
+};
+struct RawPointConverter {
+  std::vector<RawAttributeConverter> attribute_converters;
+  static RawPointConverter from_to(const PointLayout& from_layout, const PointLayout& to_layout) {  // :69-96
+    RawPointConverter c;
+    for (const AttributeMember& from_attribute : from_layout.attributes) {
+      const AttributeMember* to_attribute = to_layout.get_attribute_by_name(from_attribute.def.name);
+      if (!to_attribute) continue;
+      AttributeConversionFn fn = get_converter_for_attributes(from_attribute.def, to_attribute->def);
+      if (fn) c.attribute_converters.push_back({fn, from_attribute.offset, from_attribute.def.datatype.size(), to_attribute->offset, to_attribute->def.datatype.size()});
+    }
+    return c;
+  }
+  void convert(const uint8_t* source_point, uint8_t* target_point) const {  // :104-108
+    for (const RawAttributeConverter& a : attribute_converters) a.convert(source_point, target_point);
+  }
+};
+
 // convert_unit — attribute_conversion.rs:297-299 (only used through AttributeViewConverting)
 
 // ----------------------------------------------------------------------------------

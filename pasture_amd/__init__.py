@@ -8,7 +8,7 @@ from ._capi import PastureError, PasturePanic, product_api, LIB_PATH  # noqa: F4
 from .layout import (FieldAlignment, PointAttributeDataType, PointAttributeDefinition, PointAttributeMember, PointLayout,  # noqa: F401
                      attributes)
 from .buffers import ExternalColumnsBuffer, ExternalMemoryBuffer, HashMapBuffer, VectorBuffer  # noqa: F401
-from .conversion import BufferLayoutConverter, Transform  # noqa: F401
+from .conversion import BufferLayoutConverter, RawPointConverter, Transform  # noqa: F401
 from .algorithms import (AABB, calculate_bounds, calculate_bounds_async, compute_normals, compute_normals_into, minmax_attribute, voxelgrid_filter,  # noqa: F401
                          transform_attribute)
 

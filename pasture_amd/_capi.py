@@ -106,6 +106,10 @@ _SHARED_SIGNATURES = {
     "converter_get_mapping": [_P, _SZ, C.POINTER(MappingInfoStruct)],
     "converter_convert_into_range": [_P, _P, _SZ, _SZ, _P, _SZ, _SZ],
     "converter_convert": [_P, _P, C.c_uint32, _PP],
+    "point_converter_create": [_P, _P, _PP],
+    "point_converter_destroy": [_P],
+    "point_converter_num_converters": [_P, C.POINTER(_SZ)],
+    "point_converter_convert": [_P, _P, _SZ, _P, _SZ, _SZ],
     "calculate_bounds": [_P, _D3, _D3, C.POINTER(C.c_int)],
     "minmax_attribute": [_P, C.c_char_p, _DT, _P, _P, C.POINTER(C.c_int)],
     "transform_attribute": [_P, C.c_char_p, _DT, C.POINTER(TransformStruct)],

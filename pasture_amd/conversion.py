@@ -70,6 +70,38 @@ class MappingInfo:
     apply_to_source: bool
 
 
+class RawPointConverter:
+    """attribute_conversion.rs:62-109 — the point-major converter: `from_to` collects one `as` converter per attribute present in both
+    layouts whose datatypes differ (equal datatypes: no converter, the attribute is SKIPPED, not copied); `convert` runs them on
+    interleaved points.  The reference converts one point slice per call; `convert` here takes point indices and a count."""
+
+    def __init__(self, from_layout: PointLayout, to_layout: PointLayout):
+        assert from_layout.api is to_layout.api
+        self.api = from_layout.api
+        h = C.c_void_p()
+        self.api.point_converter_create(from_layout._h, to_layout._h, C.byref(h))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.api.point_converter_destroy(self._h)
+        except Exception:
+            pass
+
+    @classmethod
+    def from_to(cls, from_layout: PointLayout, to_layout: PointLayout) -> "RawPointConverter":  # :69-96
+        return cls(from_layout, to_layout)
+
+    def num_converters(self) -> int:
+        n = C.c_size_t()
+        self.api.point_converter_num_converters(self._h, C.byref(n))
+        return n.value
+
+    def convert(self, source, source_point: int, target, target_point: int, count: int = 1) -> None:  # :104-108
+        self.api.point_converter_convert(self._h, source._h, source_point, target._h, target_point, count)
+
+
 class BufferLayoutConverter:
     def __init__(self, from_layout: PointLayout, to_layout: PointLayout, with_default: bool):
         assert from_layout.api is to_layout.api

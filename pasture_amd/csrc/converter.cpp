@@ -1,5 +1,6 @@
 // BufferLayoutConverter on the device: mapping construction (host), plan flattening, kernel selection.
 // Reference: pasture-core/src/layout/conversion/buffer_conversion.rs:98-663 and attribute_conversion.rs:184-271.
+#include <atomic>
 #include <cstdlib>
 #include <optional>
 
@@ -63,14 +64,22 @@ static void validate_transform(const XfDesc& x) {
 
 }  // namespace pst
 
+// RawPointConverter, attribute_conversion.rs:62-109: one converter per attribute present in both layouts (matched by name, in the order
+// of from_layout) whose datatypes DIFFER; same-datatype attributes get none and are therefore skipped, not copied (:73-90)
+struct pst_point_converter {
+  pst::Layout from, to;
+  std::vector<PlanEntry> entries;
+};
+
 struct pst_converter {
   pst::Layout from, to;
   std::vector<pst::Mapping> mappings;
   // plan recognition cache for the specialised LAS record decoder (las_decode.hip): -2 = not examined yet, -1 = generic plan,
   // 0..10 = "raw LAS records of this format -> its typed default layout with the mappings of get_default_las_converter"
-  mutable int las_decode_format = -2;
-  mutable int identity_records = -2;
-  mutable int las_typed_format = -2;  // -2 not examined, -1 no, 0..10: identity plan over LasPointFormatN::layout() (las_transpose.hip)  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
+  // (atomics: two threads may share one converter, each on its own stream; both compute the same value, either store wins)
+  mutable std::atomic<int> las_decode_format{-2};
+  mutable std::atomic<int> identity_records{-2};
+  mutable std::atomic<int> las_typed_format{-2};  // -2 not examined, -1 no, 0..10: identity plan over LasPointFormatN::layout() (las_transpose.hip)  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
 };
 
 namespace pst {
@@ -381,6 +390,53 @@ static void install_mapping(pst_converter& c, Mapping&& m, const AttributeDef& t
 }
 
 extern "C" {
+
+int pst_point_converter_create(const pst_layout* from, const pst_layout* to, pst_point_converter** out) {
+  PST_API_BEGIN
+  auto c = std::make_unique<pst_point_converter>();
+  c->from = not_null(from, "from")->l;
+  c->to = not_null(to, "to")->l;
+  for (const Member& from_attr : c->from.members) {  // :70-91
+    const Member* to_attr = c->to.find_by_name(from_attr.def.name);
+    if (!to_attr) continue;                                       // .filter(has_attribute_with_name)
+    if (from_attr.def.datatype == to_attr->def.datatype) continue;  // get_converter_for_attributes -> None -> filter_map drops it
+    require_convertible(from_attr.def.datatype, to_attr->def.datatype);  // "Invalid conversion X -> Y" :267-269
+    PlanEntry e = identity_entry(from_attr, *to_attr);
+    e.dst_ct = (uint8_t)to_attr->def.datatype.comp_type();
+    e.convert = 1u;
+    c->entries.push_back(e);
+  }
+  *not_null(out, "out") = c.release();
+  PST_API_END
+}
+int pst_point_converter_destroy(pst_point_converter* c) {
+  delete c;
+  return PST_OK;
+}
+int pst_point_converter_num_converters(const pst_point_converter* c, size_t* out) {
+  PST_API_BEGIN
+  *not_null(out, "out") = not_null(c, "converter")->entries.size();
+  PST_API_END
+}
+// RawPointConverter::convert (:104-108) applied to `count` points: target bytes no converter writes keep their values
+int pst_point_converter_convert(const pst_point_converter* c, const pst_buffer* src, size_t src_first, pst_buffer* dst, size_t dst_first, size_t count) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  not_null(src, "src");
+  not_null(dst, "dst");
+  if (src->columnar || dst->columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "RawPointConverter::convert works on the bytes of one interleaved point");
+  // the reference's safety contract ("source_point must ... have the exact same PointLayout as the one passed to from_to") is checked here
+  if (src->layout != c->from) throw Error(PST_ERR_LAYOUT_MISMATCH, "source point does not have the PointLayout passed to RawPointConverter::from_to");
+  if (dst->layout != c->to) throw Error(PST_ERR_LAYOUT_MISMATCH, "target point does not have the PointLayout passed to RawPointConverter::from_to");
+  if (src_first + count < src_first || src_first + count > src->len || dst_first + count < dst_first || dst_first + count > dst->len)
+    throw Error(PST_ERR_RANGE, "point range out of bounds");
+  if (count && !c->entries.empty()) {
+    hipStream_t s = current_stream();
+    execute_entries(true, aos_addr(*src, src_first), (uint32_t)c->from.size, true, aos_addr(*dst, dst_first), (uint32_t)c->to.size, count, c->entries, true, s);
+    stream_sync(s);
+  }
+  PST_API_END
+}
 
 int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_default, pst_converter** out) {
   PST_API_BEGIN

@@ -269,3 +269,62 @@ def test_empty_layout_converter(api):
     src = make_buffer("V", big, random_records(big, 10, seed=1))
     out = conv.convert(src, VectorBuffer)
     assert out.len() == 10 and out.point_layout().size_of_point_entry() == 0
+
+
+# ---- RawPointConverter (attribute_conversion.rs:62-109): point-major, same-datatype attributes are SKIPPED --------------------------
+def _bench_source_layout(api):  # layout_conversion_bench.rs:15-26
+    return PointLayout.from_attributes_packed([A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY, A.GPS_TIME], 1, api=api)
+
+
+def _bench_target_layout(api):  # layout_conversion_bench.rs:28-39, plus an attribute the source does not have
+    return PointLayout.from_attributes_packed([A.GPS_TIME, A.POSITION_3D.with_custom_datatype(T.Vec3f32), A.CLASSIFICATION.with_custom_datatype(T.U32),
+                                               A.INTENSITY.with_custom_datatype(T.U8), A.RETURN_NUMBER], 1, api=api)
+
+
+@pytest.mark.parametrize("n,first,count", [(1, 0, 1), (1000, 17, 600), (5003, 0, 5003), (64, 10, 0)])
+def test_raw_point_converter_skips_equal_datatypes(api, n, first, count):
+    from pasture_amd.conversion import RawPointConverter
+    src_l, dst_l = _bench_source_layout(api), _bench_target_layout(api)
+    conv = RawPointConverter.from_to(src_l, dst_l)
+    assert conv.num_converters() == 3  # Position3D f64->f32, Classification u8->u32, Intensity u16->u8; GpsTime (F64 == F64) gets none
+    rec = random_records(src_l, n, seed=n)
+    rec["Position3D"] = rec["Position3D"] * 1e6 - 5e5
+    src = make_buffer("V", src_l, rec)
+    sentinel = np.zeros(n, dtype=dst_l.numpy_record_dtype())
+    sentinel.view(np.uint8)[:] = 0xAB
+    dst = make_buffer("V", dst_l, sentinel)
+    conv.convert(src, first, dst, first, count)
+    out = dst.get_point_range(range(0, n)).view(dst_l.numpy_record_dtype()).reshape(n)
+    want = sentinel.copy()
+    sl = slice(first, first + count)
+    want["Position3D"][sl] = rec["Position3D"][sl].astype(np.float32)
+    want["Classification"][sl] = rec["Classification"][sl].astype(np.uint32)
+    want["Intensity"][sl] = rec["Intensity"][sl].astype(np.uint8)  # `as u8` truncates (wraps)
+    # GpsTime: same datatype in both layouts -> NO converter -> the target keeps its bytes (attribute_conversion.rs:73-90);
+    # ReturnNumber: not in the source layout; points outside [first, first + count): untouched
+    assert out.tobytes() == want.tobytes()
+
+
+def test_raw_point_converter_panics_and_contract(api):
+    from pasture_amd._capi import PastureError
+    from pasture_amd.conversion import RawPointConverter
+    src_l = _bench_source_layout(api)
+    bad = PointLayout.from_attributes([A.POSITION_3D.with_custom_datatype(T.U8)], api=api)  # Vec3f64 -> U8: not in the `as` table
+    with pytest.raises(PasturePanic) as e:
+        RawPointConverter.from_to(src_l, bad)
+    assert e.value.code == 5 and "Invalid conversion" in str(e.value)
+    disjoint = PointLayout.from_attributes([A.NORMAL], api=api)
+    assert RawPointConverter.from_to(src_l, disjoint).num_converters() == 0
+    assert RawPointConverter.from_to(src_l, src_l).num_converters() == 0  # every datatype equal: nothing to do (and nothing is copied)
+    dst_l = _bench_target_layout(api)
+    conv = RawPointConverter.from_to(src_l, dst_l)
+    src = make_buffer("V", src_l, random_records(src_l, 8, seed=1))
+    dst = make_buffer("V", dst_l, np.zeros(8, dtype=dst_l.numpy_record_dtype()))
+    with pytest.raises(PasturePanic) as e:  # the reference's `unsafe` contract, checked
+        conv.convert(dst, 0, dst, 0, 1)
+    assert e.value.code == 2
+    with pytest.raises(PastureError):
+        conv.convert(src, 4, dst, 0, 5)  # range
+    col = make_buffer("H", src_l, random_records(src_l, 8, seed=1))
+    with pytest.raises(PastureError):  # a point is one interleaved byte slice
+        conv.convert(col, 0, dst, 0, 1)

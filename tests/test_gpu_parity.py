@@ -1162,3 +1162,61 @@ def test_two_threads_two_streams(hip):
         t.join()
     assert not errors, errors
     assert got[1] == want[1] and got[2] == want[2]
+
+
+def test_two_threads_share_one_converter(hip):
+    """ONE BufferLayoutConverter used from two threads at once, each with its own stream and its own buffers (the reference's converter is
+    only read by convert_into_range: buffer_conversion.rs:292 takes &self).  The plan-recognition caches inside the converter are atomics;
+    every recognised path is exercised: the LAS decoder plan (columnar and interleaved targets), the typed transposition and the plain
+    record copy, from the cold cache of a fresh converter each round."""
+    import ctypes
+    import threading
+    import torch
+    n = 300_000
+    raw = las.point_layout_from_las_point_format(las.Format(3), True, api=hip)
+    typed = las.point_layout_from_las_point_format(las.Format(3), False, api=hip)
+    src_raw = VectorBuffer.new_from_layout(raw)
+    src_raw.resize(n)
+    src_raw.synth_fill(9, 0)
+    hip.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def run(decode, ident, out):
+        cols = HashMapBuffer.new_from_layout(typed)
+        cols.resize(n)
+        decode.convert_into(src_raw, cols)                      # raw records -> typed columns (las_decode plan)
+        recs = VectorBuffer.new_from_layout(typed)
+        recs.resize(n)
+        decode.convert_into(src_raw, recs)                      # raw records -> typed records (interleaved decoder)
+        back = VectorBuffer.new_from_layout(typed)
+        back.resize(n)
+        ident.convert_into(cols, back)                          # typed columns -> typed records (transposition plan)
+        copy = VectorBuffer.new_from_layout(typed)
+        copy.resize(n)
+        ident.convert_into(recs, copy)                          # records -> records, identity (one byte copy)
+        out.append((recs.get_point_range(range(0, n)).tobytes(), back.get_point_range(range(0, n)).tobytes(), copy.get_point_range(range(0, n)).tobytes()))
+    ref = []
+    run(las.get_default_las_converter(raw, typed, SCALE, OFFSET), BufferLayoutConverter.for_layouts(typed, typed), ref)
+    assert ref[0][0] == ref[0][1] == ref[0][2]
+    for _round in range(4):
+        decode = las.get_default_las_converter(raw, typed, SCALE, OFFSET)   # fresh converters: caches start unexamined
+        ident = BufferLayoutConverter.for_layouts(typed, typed)
+        results, errors = {0: [], 1: []}, []
+        barrier = threading.Barrier(2)
+
+        def runner(i):
+            try:
+                stream = torch.cuda.Stream()
+                hip.set_stream(ctypes.c_void_p(stream.cuda_stream))
+                with torch.cuda.stream(stream):
+                    barrier.wait()
+                    run(decode, ident, results[i])
+                stream.synchronize()
+            except Exception as e:  # pragma: no cover
+                errors.append(repr(e))
+        threads = [threading.Thread(target=runner, args=(i,)) for i in (0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert results[0] == ref and results[1] == ref
