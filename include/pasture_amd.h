@@ -108,6 +108,7 @@ const char* pst_last_error(void);
 int pst_device_count(int* out);
 int pst_set_device(int device);
 int pst_set_stream(void* hip_stream); /* hipStream_t; thread-local; NULL = null stream */
+int pst_get_stream(void** out_hip_stream); /* the calling thread's current stream (so that a helper can restore it) */
 int pst_stream_synchronize(void);
 
 /* ---- PointLayout ------------------------------------------------------------------------------------ */

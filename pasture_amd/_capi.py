@@ -126,6 +126,7 @@ _PRODUCT_SIGNATURES = {
     "device_count": [C.POINTER(C.c_int)],
     "set_device": [C.c_int],
     "set_stream": [_P],
+    "get_stream": [_PP],
     "stream_synchronize": [],
     "buffer_wrap_external": [_P, _P, _SZ, _PP],
     "buffer_wrap_external_columns": [_P, _PP, _SZ, _PP],

@@ -224,6 +224,7 @@ int pst_device_count(int* out) {
 }
 int pst_set_device(int device) { PST_API_BEGIN ensure_device(); PST_HIP_CHECK(hipSetDevice(device)); PST_API_END }
 int pst_set_stream(void* hip_stream) { pst::t_stream = (hipStream_t)hip_stream; return PST_OK; }
+int pst_get_stream(void** out_hip_stream) { PST_API_BEGIN *not_null(out_hip_stream, "out_hip_stream") = (void*)pst::t_stream; PST_API_END }
 int pst_stream_synchronize(void) { PST_API_BEGIN ensure_device(); stream_sync(current_stream()); PST_API_END }
 
 int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, pst_buffer** out) {

@@ -5,8 +5,9 @@
 //
 //   voxel_keys_kernel    per point: find_leaf (:21-52) = lower_bound over the axis markers + "better fitting marker" step;
 //                        key = x | y | z packed x-major in as few bits as the marker counts need (fewer radix passes)
-//   hipCUB radix sort    (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library)
-//   hipCUB run-length    unique keys -> points per voxel; exclusive sum -> voxel starts                         (library)
+//   rocPRIM radix sort   (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library plumbing,
+//                        device_sort.hip)
+//   voxel_heads_*        run heads of the sorted keys: per-tile counts, exclusive scan, voxel starts (two light passes over the keys)
 //   voxel_reduce_kernel  a wave per 64 voxels: averages / max-pools of small voxels one voxel per LANE (sequential loop = the
 //                        reference's loop); most-common attributes and large voxels one voxel per WAVE (set_all_attributes :459-689):
 //                          average:     64 values fetched in parallel, then ONE sequential f64 addition chain in point order
@@ -16,12 +17,11 @@
 //                                       larger voxels: voxel_mode_big_kernel (one block per voxel, 65536-bin histogram)
 //                                       ties -> smallest value (the reference's HashMap iteration order is random)
 // Gather-bound (points of a voxel are scattered in the source) + sort-bound: no MFMA.
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <vector>
 
 #include "device_common.hpp"
+#include "device_sort.hpp"
 #include "kernels.hpp"
 
 using namespace pstd;
@@ -64,9 +64,20 @@ __device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __res
 
 struct AxisGrid { const double* markers; uint32_t n; uint32_t shift; double origin, inv_leaf; };
 
-template <typename KeyT>
+// LDS_MARKERS: the three marker arrays are staged in LDS first (they are walked twice per point and axis: the arithmetic guess is
+// usually off by at most one, but every step is a dependent load); grids with more markers than kLdsMarkers read them from global memory.
+constexpr uint32_t kLdsMarkers = 6144;  // 48 KiB
+template <typename KeyT, bool LDS_MARKERS>
 __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy,
                                                             AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx) {
+  __shared__ double lds_markers[LDS_MARKERS ? kLdsMarkers : 1];
+  if constexpr (LDS_MARKERS) {
+    // gx.markers, gy.markers, gz.markers are consecutive in one device array (voxel_grid_build)
+    const uint32_t total = gx.n + gy.n + gz.n;
+    for (uint32_t i = threadIdx.x; i < total; i += kBlock) lds_markers[i] = gx.markers[i];
+    __syncthreads();
+    gx.markers = lds_markers; gy.markers = lds_markers + gx.n; gz.markers = lds_markers + gx.n + gy.n;
+  }
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
     const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
@@ -74,6 +85,51 @@ __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __res
                    kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
     keys[i] = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
     idx[i] = (uint32_t)i;
+  }
+}
+
+// ---- voxel segmentation: run heads of the sorted keys -------------------------------------------------------------------------------
+// A tile = kBlock * kHeadsPerThread consecutive sorted keys.  Pass 1 counts the heads of every tile; an exclusive scan of the counts
+// gives every tile the rank of its first voxel; pass 2 writes starts[rank] = position for every head, and starts[n_voxels] = n.
+constexpr int kHeadsPerThread = 8;
+template <typename KeyT, bool WRITE>
+__global__ __launch_bounds__(kBlock) void voxel_heads_kernel(const KeyT* __restrict__ keys, uint64_t n, uint32_t* __restrict__ tile_counts,
+                                                             const unsigned long long* __restrict__ tile_first, unsigned long long* __restrict__ starts) {
+  __shared__ uint32_t wave_sums[kBlock / 64];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * (kBlock * kHeadsPerThread);
+  const uint64_t j0 = tile0 + (uint64_t)threadIdx.x * kHeadsPerThread;
+  uint32_t flags = 0, cnt = 0;
+  KeyT prev = j0 > 0 && j0 <= n ? keys[j0 - 1] : KeyT(0);
+#pragma unroll
+  for (int u = 0; u < kHeadsPerThread; ++u) {
+    const uint64_t j = j0 + u;
+    if (j < n) {
+      const KeyT k = keys[j];
+      if (j == 0 || k != prev) { flags |= 1u << u; cnt += 1; }
+      prev = k;
+    }
+  }
+  // block exclusive scan of cnt
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) { if ((uint32_t)w < wave) before += wave_sums[w]; total += wave_sums[w]; }
+  if constexpr (!WRITE) {
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+  } else {
+    unsigned long long rank = tile_first[blockIdx.x] + before + (inc - cnt);
+#pragma unroll
+    for (int u = 0; u < kHeadsPerThread; ++u)
+      if (flags & (1u << u)) starts[rank++] = j0 + u;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) starts[tile_first[blockIdx.x] + total] = n;
   }
 }
 
@@ -336,22 +392,12 @@ __global__ __launch_bounds__(kBlock) void voxel_mode_big_kernel(const VoxelArgs 
   }
 }
 
-// stream-ordered allocations from the device's default pool (release threshold raised by buffer.cpp): no device-wide
-// synchronisation per call, unlike hipMalloc / hipFree of gigabytes
-struct DevBuf {
-  void* p = nullptr;
-  hipStream_t s = nullptr;
-  hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return hipMallocAsync(&p, bytes ? bytes : 16, stream); }
-  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
-  template <typename T> T* as() { return (T*)p; }
-};
-
 }  // namespace
 
 namespace pstk {
 
 struct VoxelGridState {
-  DevBuf keys, keys2, idx, idx2, tmp, markers, unique, counts, starts, nruns, big_list, big_count, hist;
+  DevBuf keys, keys2, idx, idx2, tmp, markers, unique, counts, starts, big_list, big_count, hist;
   uint64_t n = 0, n_voxels = 0;
 };
 
@@ -359,34 +405,42 @@ struct VoxelGridState {
 // KeyT = uint32_t when the packed (x, y, z) key fits 32 bits (half the key traffic of the radix sort), else uint64_t.
 template <typename KeyT>
 static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy, AxisGrid gz,
-                                        int end_bit, hipStream_t stream) {
+                                        unsigned end_bit, hipStream_t stream) {
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
   VCK(st->keys.alloc(n * sizeof(KeyT), stream)); VCK(st->keys2.alloc(n * sizeof(KeyT), stream));
-  VCK(st->idx.alloc((n + 1) * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
+  VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)device_cus() * 16));
-  hipLaunchKernelGGL((voxel_keys_kernel<KeyT>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
-                     st->idx.as<uint32_t>());
-  size_t tmp_sort = 0, tmp_rle = 0, tmp_scan = 0;
-  VCK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, st->keys.as<KeyT>(), st->keys2.as<KeyT>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(),
-                                         (int)n, 0, end_bit, stream));
-  // unique/counts reuse the unsorted key / index arrays after the sort (n entries each)
-  VCK(st->nruns.alloc(16, stream));
-  VCK(st->starts.alloc((n + 1) * 8, stream));
-  VCK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, st->keys2.as<KeyT>(), st->keys.as<KeyT>(), st->idx.as<uint32_t>(), st->nruns.as<uint32_t>(),
-                                            (int)n, stream));
-  VCK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)n + 1, stream));
-  VCK(st->tmp.alloc(std::max(tmp_sort, std::max(tmp_rle, tmp_scan)), stream));
-  VCK(hipcub::DeviceRadixSort::SortPairs(st->tmp.p, tmp_sort, st->keys.as<KeyT>(), st->keys2.as<KeyT>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(),
-                                         (int)n, 0, end_bit, stream));
-  VCK(hipcub::DeviceRunLengthEncode::Encode(st->tmp.p, tmp_rle, st->keys2.as<KeyT>(), st->keys.as<KeyT>(), st->idx.as<uint32_t>(), st->nruns.as<uint32_t>(),
-                                            (int)n, stream));
-  uint32_t runs = 0;
-  VCK(hipMemcpyAsync(&runs, st->nruns.p, 4, hipMemcpyDeviceToHost, stream));
+  if (gx.n + gy.n + gz.n <= kLdsMarkers)
+    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, true>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
+                       st->idx.as<uint32_t>());
+  else
+    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, false>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
+                       st->idx.as<uint32_t>());
+  const uint64_t tiles = (n + (uint64_t)kBlock * kHeadsPerThread - 1) / ((uint64_t)kBlock * kHeadsPerThread);
+  size_t tmp_sort = 0, tmp_scan = 0;
+  auto sort = [&](void* tmp, size_t& bytes) {
+    if constexpr (sizeof(KeyT) == 4)
+      return sort_pairs_u32(tmp, bytes, st->keys.as<uint32_t>(), st->keys2.as<uint32_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream);
+    else
+      return sort_pairs_u64(tmp, bytes, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream);
+  };
+  VCK(sort(nullptr, tmp_sort));
+  VCK(st->counts.alloc((tiles + 1) * 4, stream));
+  VCK(st->unique.alloc((tiles + 1) * 8, stream));  // exclusive scan of the tile counts (+ the total)
+  VCK(exclusive_sum_u32_u64(nullptr, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
+  VCK(st->tmp.alloc(std::max(tmp_sort, tmp_scan), stream));
+  VCK(sort(st->tmp.p, tmp_sort));
+  VCK(hipMemsetAsync(st->counts.as<uint32_t>() + tiles, 0, 4, stream));
+  hipLaunchKernelGGL((voxel_heads_kernel<KeyT, false>), dim3((unsigned)tiles), dim3(kBlock), 0, stream, (const KeyT*)st->keys2.as<KeyT>(), n,
+                     st->counts.as<uint32_t>(), (const unsigned long long*)nullptr, (unsigned long long*)nullptr);
+  VCK(exclusive_sum_u32_u64(st->tmp.p, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
+  unsigned long long runs = 0;
+  VCK(hipMemcpyAsync(&runs, st->unique.as<unsigned long long>() + tiles, 8, hipMemcpyDeviceToHost, stream));
   VCK(hipStreamSynchronize(stream));
   st->n_voxels = runs;
-  // starts[v] = exclusive sum of counts over runs + 1 items: starts[n_voxels] = n comes out of the same scan (the extra input
-  // element is never added to an output), so no host round trip is needed here
-  VCK(hipcub::DeviceScan::ExclusiveSum(st->tmp.p, tmp_scan, st->idx.as<uint32_t>(), st->starts.as<unsigned long long>(), (int)runs + 1, stream));
+  VCK(st->starts.alloc((runs + 1) * 8, stream));
+  hipLaunchKernelGGL((voxel_heads_kernel<KeyT, true>), dim3((unsigned)tiles), dim3(kBlock), 0, stream, (const KeyT*)st->keys2.as<KeyT>(), n,
+                     (uint32_t*)nullptr, (const unsigned long long*)st->unique.as<unsigned long long>(), st->starts.as<unsigned long long>());
   return (long long)runs;
 #undef VCK
 }
@@ -403,7 +457,7 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
   if (nz && hipMemcpyAsync(dm + nx + ny, markers_z, (size_t)nz * 8, hipMemcpyHostToDevice, stream) != hipSuccess) return -1;
   auto bits_for = [](uint32_t count) { uint32_t b = 1; while (b < 21 && (1u << b) < count) ++b; return b; };  // indices 0 .. count-1
   const uint32_t bz = bits_for(nz), by = bits_for(ny), bx = bits_for(nx);
-  const int end_bit = (int)(bx + by + bz);
+  const unsigned end_bit = bx + by + bz;
   AxisGrid gx{dm, nx, by + bz, origin[0], 1.0 / leaf[0]}, gy{dm + nx, ny, bz, origin[1], 1.0 / leaf[1]}, gz{dm + nx + ny, nz, 0, origin[2], 1.0 / leaf[2]};
   return end_bit <= 32 ? voxel_grid_build_typed<uint32_t>(st, pos_base, pos_stride, n, gx, gy, gz, end_bit, stream)
                        : voxel_grid_build_typed<uint64_t>(st, pos_base, pos_stride, n, gx, gy, gz, end_bit, stream);

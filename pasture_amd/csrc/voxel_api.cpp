@@ -67,7 +67,7 @@ extern "C" int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x,
                 "The PointBuffer does not have the attribute attributes::POSITION_3D which is needed for the creation of the voxel grid.");
   const size_t n = buffer->len;
   if (n == 0) throw Error(PST_ERR_BOUNDS_INVALID, "called `Option::unwrap()` on a `None` value");  // :125 calculate_bounds(buffer).unwrap()
-  if (n > (size_t)INT_MAX) throw Error(PST_ERR_UNSUPPORTED, "voxelgrid_filter: more than 2^31 - 1 points");
+  if (n >= 0xFFFFFFF0ull) throw Error(PST_ERR_UNSUPPORTED, "voxelgrid_filter: more than 2^32 - 17 points per call (sorted point indices are uint32_t)");
   ensure_device();
   hipStream_t s = current_stream();
   Workspace& ws = workspace();

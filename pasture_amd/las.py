@@ -190,7 +190,22 @@ def read_records_into(records, point_format: int, scale, offset, target, chunk_p
     bounce = None if records.is_pinned() else [torch.empty(chunk * rs, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
     copied = [torch.cuda.Event() for _ in range(2)]
     decoded = [torch.cuda.Event() for _ in range(2)]
+    # the staging tensors were allocated on the compute stream: torch's allocator may hand out blocks that queued compute-stream work
+    # is still using, so the copy stream starts behind the compute stream and the blocks are marked as used by both
+    copier.wait_stream(compute)
+    for t in staging:
+        t.record_stream(copier)
+    prev_stream = C.c_void_p()
+    api.get_stream(C.byref(prev_stream))
     api.set_stream(C.c_void_p(compute.cuda_stream))
+    try:
+        return _read_chunks(api, records, rs, n, chunk, staging, views, bounce, copied, decoded, compute, copier, converter, target)
+    finally:
+        api.set_stream(prev_stream)  # the caller's pst stream is left as it was
+
+
+def _read_chunks(api, records, rs, n, chunk, staging, views, bounce, copied, decoded, compute, copier, converter, target):
+    import torch
     for c, first in enumerate(range(0, n, chunk)):
         b = c & 1
         cnt = min(chunk, n - first)
@@ -239,8 +254,31 @@ def write_records_from(points, point_format: int, scale, offset, records_out, he
     encoded = [torch.cuda.Event() for _ in range(2)]
     copied = [torch.cuda.Event() for _ in range(2)]
     sc, of = (C.c_double * 3)(*scale), (C.c_double * 3)(*offset)
+    copier.wait_stream(compute)  # staging was allocated on the compute stream (see read_records_into)
+    for t in staging:
+        t.record_stream(copier)
+    prev_stream = C.c_void_p()
+    api.get_stream(C.byref(prev_stream))
     api.set_stream(C.c_void_p(compute.cuda_stream))
     pending = [None, None]  # (bounce buffer, destination slice) whose D2H copy is in flight
+    try:
+        _write_chunks(api, points, point_format, sc, of, max_return, records_out, rs, n, chunk, n_chunks, staging, views, bounce, dev_bounds, dev_counts,
+                      encoded, copied, compute, copier, pending)
+    finally:
+        api.set_stream(prev_stream)  # the caller's pst stream is left as it was
+    copier.synchronize()
+    compute.synchronize()
+    for b in range(2):
+        if pending[b] is not None:
+            pending[b][1].copy_(pending[b][0][:pending[b][1].numel()])
+    return _fold_header(header_bounds, max_return, n_chunks, dev_bounds, dev_counts)
+
+
+def _write_chunks(api, points, point_format, sc, of, max_return, records_out, rs, n, chunk, n_chunks, staging, views, bounce, dev_bounds, dev_counts, encoded,
+                  copied, compute, copier, pending):
+    import ctypes as C
+
+    import torch
     for c in range(n_chunks):
         b = c & 1
         first = c * chunk
@@ -263,11 +301,10 @@ def write_records_from(points, point_format: int, scale, offset, records_out, he
                 bounce[b][:cnt * rs].copy_(staging[b][:cnt * rs], non_blocking=True)
                 pending[b] = (bounce[b], dst)
             copied[b].record(copier)
-    copier.synchronize()
-    compute.synchronize()
-    for b in range(2):
-        if pending[b] is not None:
-            pending[b][1].copy_(pending[b][0][:pending[b][1].numel()])
+
+
+def _fold_header(header_bounds, max_return, n_chunks, dev_bounds, dev_counts):
+    from ._capi import ERR_RANGE, PasturePanic
     hb = list(header_bounds) if header_bounds is not None else [1.7976931348623157e308] * 3 + [-1.7976931348623157e308] * 3
     counts = [0] * max_return
     if n_chunks:
