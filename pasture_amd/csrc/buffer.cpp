@@ -27,8 +27,11 @@ void ensure_device() {
 
 void stream_sync(hipStream_t s) { PST_HIP_CHECK(hipStreamSynchronize(s)); }
 
+// One workspace per (thread, stream): the asynchronous entry points of one thread may run on several streams at once (a compute and
+// a copy stream, the pipelined LAS reader / writer), and their per-block partial records and result records must not alias.
 Workspace& workspace() {
-  static thread_local Workspace ws;
+  static thread_local std::unordered_map<hipStream_t, Workspace> by_stream;
+  Workspace& ws = by_stream[current_stream()];
   if (!ws.dev) {
     ensure_device();
     PST_HIP_CHECK(hipMalloc((void**)&ws.dev, Workspace::kWorkspaceBytes));
@@ -42,7 +45,7 @@ uint8_t* Workspace::partials(size_t bytes) {
     if (partials_buf) (void)hipFree(partials_buf);  // implicit device synchronisation: nothing in flight uses it afterwards
     partials_buf = nullptr;
     partials_cap = 0;
-    const size_t want = std::max<size_t>(bytes, 8u << 20);
+    const size_t want = std::max<size_t>(bytes, 16u << 20);  // pre-sized for the largest launch geometry in use: growth mid-pipeline would stall it
     PST_HIP_CHECK(hipMalloc((void**)&partials_buf, want));
     partials_cap = want;
   }

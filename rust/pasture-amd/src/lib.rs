@@ -52,7 +52,21 @@ impl LayoutHandle {
     }
 }
 impl Drop for LayoutHandle { fn drop(&mut self) { unsafe { pst_layout_destroy(self.0) }; } }
-fn layout_alignment(_layout: &PointLayout) -> u64 { unimplemented!("needs an accessor for memory_layout.align() upstream") }
+/// pasture-core 0.5 keeps `memory_layout` private, so the alignment is reconstructed: the largest power of two that is at most the
+/// largest `min_alignment` of the attribute datatypes and divides the point size and every attribute offset.  This is the value
+/// `add_attribute` / the derive macro produce for `repr(C)` and `repr(packed(n))` layouts whose packing is visible in the offsets; a
+/// `packed(1)` layout whose fields happen to sit at naturally aligned offsets is indistinguishable from its unpacked twin here (the two
+/// then compare equal on the device side although `PointLayout::eq` separates them) -- an upstream accessor would remove the guess.
+fn layout_alignment(layout: &PointLayout) -> u64 {
+    let max_field = layout.attributes().map(|a| a.datatype().min_alignment()).max().unwrap_or(1).max(1);
+    let mut align = 1u64;
+    while align * 2 <= max_field
+        && layout.size_of_point_entry() % (align * 2) == 0
+        && layout.attributes().all(|a| a.offset() % (align * 2) == 0) {
+        align *= 2;
+    }
+    align
+}
 
 macro_rules! device_buffer {
     ($name:ident, $storage:expr) => {
@@ -168,7 +182,10 @@ pub fn calculate_bounds(buffer: &impl DeviceBuffer) -> Option<AABB<f64>> {
 }
 
 /// pasture-algorithms/src/normal_estimation.rs:79
-pub fn compute_normals(buffer: &impl DeviceBuffer, n_points: usize, k_nn: usize) -> Vec<(Vector3<f64>, f64)> {
+pub fn compute_normals(buffer: &impl DeviceBuffer, k_nn: usize) -> Vec<(Vector3<f64>, f64)> {
+    // the output length comes from the buffer itself: a caller-supplied count smaller than it would let the C side write past the Vecs
+    let mut n_points = 0usize;
+    check(unsafe { pst_buffer_len(buffer.handle(), &mut n_points) });
     let (mut normals, mut curvature) = (vec![0f64; 3 * n_points], vec![0f64; n_points]);
     check(unsafe { pst_compute_normals(buffer.handle(), k_nn, normals.as_mut_ptr(), curvature.as_mut_ptr(), std::ptr::null_mut()) });
     (0..n_points).map(|i| (Vector3::new(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]), curvature[i])).collect()
@@ -181,7 +198,9 @@ pub fn voxelgrid_filter(buffer: &impl DeviceBuffer, leafsize_x: f64, leafsize_y:
 
 impl DeviceHashMapBuffer {
     /// HashMapBuffer::filter_into (point_buffer.rs:1082-1136); the closure is evaluated into a byte mask once.
-    pub fn filter_into<F: Fn(usize) -> bool>(&self, buffer: &mut impl DeviceBuffer, predicate: F, num_matches_hint: Option<usize>, len: usize) -> usize {
+    pub fn filter_into<F: Fn(usize) -> bool>(&self, buffer: &mut impl DeviceBuffer, predicate: F, num_matches_hint: Option<usize>) -> usize {
+        let mut len = 0usize;  // the mask must cover every point of `self`: its length is read from the buffer, never taken from the caller
+        check(unsafe { pst_buffer_len(self.raw(), &mut len) });
         let mask: Vec<u8> = (0..len).map(|i| predicate(i) as u8).collect();
         let mut matches = 0usize;
         check(unsafe { pst_buffer_filter_into(self.raw(), buffer.handle(), mask.as_ptr(), /* host memory */ 1,
