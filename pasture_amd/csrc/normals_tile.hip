@@ -40,6 +40,13 @@ using namespace pstn;
 
 namespace {
 
+// step / candidate statistics of the search (a build with -DPST_KNN_STATS prints them per launch; off: the counters cost registers)
+#ifdef PST_KNN_STATS
+#define PST_KNN_STAT(...) __VA_ARGS__
+#else
+#define PST_KNN_STAT(...)
+#endif
+
 constexpr int kHalo = 1;          // halo rows on each side of a query row (the cell edge h is the a-priori bound on the k-th distance)
 constexpr int kMaxRows = 144;     // halo rows per box: (by + 2)(bz + 2)
 constexpr int kMaxQRows = 64;     // query rows per box: by * bz (one lane each in the prefix sum)
@@ -60,6 +67,7 @@ struct TileArgs {
   uint32_t* fb_list;           // queries left to the global-memory search ...
   uint32_t* fb_count;          // ... and how many
   double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
+  unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan
 };
 
@@ -80,7 +88,8 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 // mantissa bits; the kernel verifies afterwards that the dropped bits could not have changed the order (see the end of the search).
 constexpr uint32_t kSlotBits = 11, kSlotMask = (1u << kSlotBits) - 1u;
 __device__ __forceinline__ double pack_key(double d, uint32_t slot) {
-  d = __builtin_fmin(d, kF64Max);  // +inf would turn into a NaN pattern once slot bits are inserted
+  // a squared distance that overflowed to +inf becomes a NaN pattern here and then fails every `<`: the candidate is ignored, the
+  // query cannot reach k neighbours inside tau0 through it, and the completion test sends it to the exact search
   uint64_t b = __builtin_bit_cast(uint64_t, d);
   b = (b & ~(uint64_t)kSlotMask) | slot;
   return __builtin_bit_cast(double, b);
@@ -128,7 +137,9 @@ struct KBestPacked {
 // B = (lz * HY + ly) * NC1 + lx - 2 (per lane) and D = (dz * HY + dy) * NC1 (per segment, from a 25-entry table).
 template <int K, int THREADS, int CAP, bool WITH_KNN>
 __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void knn_tile_kernel(const TileArgs a) {
-  __shared__ double PX[CAP], PY[CAP], PZ[CAP];  // staged points, one array per coordinate (8-byte stride: neighbouring slots never share a bank)
+  // staged points, one array per coordinate (8-byte stride: neighbouring slots never share a bank); + kBatch: a batch may read past a range
+  constexpr int CS = CAP + kBatch;
+  __shared__ double P3[3 * CS];  // x of slot s = P3[s], y = P3[CS + s], z = P3[2 * CS + s]
   __shared__ uint16_t ldir[kMaxDir];            // ldir[r * NC1 + c] = first LDS slot of halo cell c of halo row r
   __shared__ uint32_t g0[kMaxRows];             // first sorted point of every halo row
   __shared__ uint32_t rbase[kMaxRows + 1];      // first LDS slot of every halo row (exclusive prefix sum of the row lengths)
@@ -155,8 +166,8 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
 
   // ---- A: the directory entries of every halo row (half a wave per row, one lane per cell boundary): ONE global round trip; the raw
   //         32-bit entries are parked in the coordinate arrays, which are not in use yet --------------------------------------------
-  uint32_t* raw = reinterpret_cast<uint32_t*>(PX);  // [NR][32]; 3 * CAP * 8 bytes >= kMaxRows * 32 * 4 is asserted below
-  static_assert(3 * CAP * 8 >= kMaxRows * 32 * 4, "raw directory does not fit the coordinate arrays");
+  uint32_t* raw = reinterpret_cast<uint32_t*>(P3);  // [NR][32]
+  static_assert(sizeof(P3) >= kMaxRows * 32 * 4, "raw directory does not fit the coordinate arrays");
   for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
     const int c = (int)(tid & 31u);
     if (c < NC1) {
@@ -201,8 +212,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     constexpr int kRows = 4, kChunks = 4;  // (16-byte loads were measured slower here: 9.0 against 7.0 ms for staging + output alone)
     auto put = [&](uint32_t base, uint32_t e, double v) __attribute__((always_inline)) {
       const uint32_t pt = e / 3u, c = e - 3u * pt;
-      double* dst = c == 0 ? PX : (c == 1 ? PY : PZ);
-      dst[base + pt] = v;
+      P3[c * CS + base + pt] = v;
     };
     for (int r0 = (int)wave * kRows; r0 < NR; r0 += NW * kRows) {
       double v[kRows][kChunks];
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     if (c0 >= Q) break;
     const uint32_t q = c0 + lane;
     const bool active = q < Q;
+    PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 2, 1ull);)
     int qr = 0;
     {
       int lo = 0, hi = nqr;  // largest qr with qpre[qr] <= q
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     }
     const int hr = qrow_halo(qr);
     const uint32_t slot = active ? (uint32_t)ldir[hr * NC1 + XH] + (q - qpre[qr]) : 0u;
-    const double qx = PX[slot], qy = PY[slot], qz = PZ[slot];
+    const double qx = P3[slot], qy = P3[CS + slot], qz = P3[2 * CS + slot];
     const uint32_t j = g0[hr] + (slot - rbase[hr]);  // index among the sorted points
     // the row (y, z) is the query row; the cell along x comes from the coordinate (same arithmetic as keys_kernel)
     const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
@@ -278,12 +289,13 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     auto flush = [&]() __attribute__((always_inline)) {
       uint32_t p0 = qn > 0 ? qbuf[tid] : 0u;
       uint32_t p1 = qn > 1 ? qbuf[THREADS + tid] : 0u;
-      double x0 = PX[p0], y0 = PY[p0], z0 = PZ[p0];
+      double x0 = P3[p0], y0 = P3[CS + p0], z0 = P3[2 * CS + p0];
       for (uint32_t i = 0; i < (uint32_t)kQueue; ++i) {
         const bool has = i < qn;
         if (!__any(has)) break;
+        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 1, 1ull);)
         const uint32_t p2 = i + 2 < qn ? qbuf[(i + 2) * THREADS + tid] : 0u;
-        const double x1 = PX[p1], y1 = PY[p1], z1 = PZ[p1];
+        const double x1 = P3[p1], y1 = P3[CS + p1], z1 = P3[2 * CS + p1];
         if (has && !(a.ablate & 1u)) best.insert(key_of(x0, y0, z0, p0));
         p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
       }
@@ -313,28 +325,33 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         const int Bd = B + (dz * HY + dy) * NC1;
         p = ldir[Bd + (int)lo_f]; pe = ldir[Bd + (int)hi_f + 1];  // fine cells [lo, hi] of the row, relative to the query's cell
       }
-      const uint32_t rem = p < pe ? pe - p : 0u;
-      const bool any_has = __any(rem != 0u);
-      if (any_has) {
+      // A lane whose queue could overflow WAITS (it tests nothing this step) instead of forcing the whole wave into a half-empty
+      // insertion round: the queues are emptied only when no lane can go on scanning, i.e. when nearly every lane holds a full queue
+      // or has finished (measured at 26 queued candidates per query: 71 insertion steps per query wave with flush-on-first-full).
+      const bool room = qn <= (uint32_t)(kQueue - kBatch);
+      const uint32_t rem = (p < pe && room) ? pe - p : 0u;
+      if (__any(rem != 0u)) {
+        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch));)
         double cx_[kBatch], cy_[kBatch], cz_[kBatch];
+        const uint32_t pb = rem ? p : 0u;  // slots beyond the lane's range are read too (one base address, immediate offsets) and ignored
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const uint32_t pu = (uint32_t)u < rem ? p + (uint32_t)u : 0u;
-          cx_[u] = PX[pu]; cy_[u] = PY[pu]; cz_[u] = PZ[pu];
-        }
+        for (int u = 0; u < kBatch; ++u) { cx_[u] = P3[pb + u]; cy_[u] = P3[CS + pb + u]; cz_[u] = P3[2 * CS + pb + u]; }
+        const double thr = __builtin_fmin(best.key[K], a.tau0);
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
           if ((uint32_t)u < rem) {
             const double key = key_of(cx_[u], cy_[u], cz_[u], p + (uint32_t)u);
-            if (key < __builtin_fmin(best.key[K], a.tau0) && !(a.ablate & 8u)) { qbuf[qn * THREADS + tid] = (uint16_t)(p + (uint32_t)u); qn += 1; }
+            if (key < thr && !(a.ablate & 8u)) {
+              qbuf[qn * THREADS + tid] = (uint16_t)(p + (uint32_t)u); qn += 1;
+              PST_KNN_STAT(atomicAdd(a.dbg + 4, 1ull);)
+            }
           }
         }
         p += rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch;
+      } else {
+        if (__any(qn != 0u)) flush();  // ONE inlined copy of the insertion code
+        if (!__any(p < pe)) break;
       }
-      // ONE inlined copy of the insertion code: batches when some lane's queue could overflow in the next step, and the leftovers after
-      // the last candidate
-      if (__any(qn > (uint32_t)(kQueue - kBatch)) || (!any_has && __any(qn != 0u))) flush();
-      if (!any_has) break;
     }
     // Packed keys order candidates by (distance with its low 11 bits dropped, slot).  That IS the exact ascending-distance order, ties
     // broken by slot, unless two of the best k+1 keys agree in every kept bit: then the pair is compared exactly -- an exact tie is
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
           if ((uint32_t)t + 1 == kk) exact = false;
           else {
             const uint32_t s0 = key_slot(best.key[t]), s1 = key_slot(best.key[t + 1]);
-            const double dx0 = PX[s0] - qx, dy0 = PY[s0] - qy, dz0 = PZ[s0] - qz, dx1 = PX[s1] - qx, dy1 = PY[s1] - qy, dz1 = PZ[s1] - qz;
+            const double dx0 = P3[s0] - qx, dy0 = P3[CS + s0] - qy, dz0 = P3[2 * CS + s0] - qz, dx1 = P3[s1] - qx, dy1 = P3[CS + s1] - qy, dz1 = P3[2 * CS + s1] - qz;
             if (dx0 * dx0 + dy0 * dy0 + dz0 * dz0 != dx1 * dx1 + dy1 * dy1 + dz1 * dz1) exact = false;
           }
         }
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         uint32_t pl = 0;
 #pragma unroll
         for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = key_slot(best.key[u]);
-        x = PX[pl]; y = PY[pl]; z = PZ[pl];
+        x = P3[pl]; y = P3[CS + pl]; z = P3[2 * CS + pl];
       });
       write_record(a.out, orig, f);
     }
@@ -441,6 +458,14 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   // fewer than k candidates inside tau0 goes to the exact global-memory search like any other unfinished query (about 1 % of a uniform
   // cloud's queries), and tau0 < h^2 is also what makes 3 x 3 rows of cells enough.
   a.tau0 = g.h * g.h * (1.0 - 4e-9);
+#ifdef PST_KNN_STATS
+  static unsigned long long* dbg_dev = nullptr;
+  {
+    if (!dbg_dev) (void)hipMalloc((void**)&dbg_dev, 64);
+    (void)hipMemsetAsync(dbg_dev, 0, 64, stream);
+    a.dbg = dbg_dev;
+  }
+#endif
   const unsigned grid = (a.n_boxes + 7u) & ~7u;
   const bool knn = out.knn != nullptr || out.knn_u32 != nullptr;
 #define PST_TILE_LAUNCH(KK, TT, CC)                                                                                          \
@@ -457,6 +482,15 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   PST_TILE_K(256, 1536);
 #undef PST_TILE_K
 #undef PST_TILE_LAUNCH
+#ifdef PST_KNN_STATS
+  {
+    unsigned long long h[8] = {};
+    (void)hipMemcpyAsync(h, a.dbg, 64, hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    fprintf(stderr, "[pst knn tile] query waves %llu: scan steps %.1f, insertion steps %.1f per wave; candidates tested %.1f, queued %.1f per query\n", h[2],
+            (double)h[0] / (double)(h[2] ? h[2] : 1), (double)h[1] / (double)(h[2] ? h[2] : 1), (double)h[3] / (double)nf, (double)h[4] / (double)nf);
+  }
+#endif
 }
 
 }  // namespace pstk
