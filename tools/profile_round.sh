@@ -14,7 +14,7 @@ for w in "$@"; do
       write) args="--kernel-trace --pmc WRITE_SIZE" ;;
     esac
     steps=5; [ "$pass" != kt ] && steps=3
-    timeout 600 rocprofv3 $args -d "$out" -o bench -- python bench.py --no-cpu-baseline --workload "$w" --steps $steps --warmup 1 > "$out/bench.log" 2>&1
+    timeout 600 rocprofv3 $args -d "$out" -o bench -- python bench.py --no-cpu-baseline --no-north-star --workload "$w" --steps $steps --warmup 1 > "$out/bench.log" 2>&1
     echo "$w $pass rc=$? $(tail -c 300 "$out/bench.log" | tr '\n' ' ' | cut -c1-200)"
   done
 done
