@@ -68,6 +68,27 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
   }
 }
 
+// Does the cloud fill its bounding box?  A 32^3 occupancy bitmask (per-block in LDS, OR-ed into global memory): the LDS box search is
+// laid out for volume-like clouds; a surface in a 3-D box (a few percent of the coarse cells occupied) keeps the global-memory search.
+constexpr uint32_t kOccBins = 32, kOccWords = kOccBins * kOccBins * kOccBins / 32;
+__global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restrict__ xyz, uint64_t n, double ox, double oy, double oz, double sx, double sy,
+                                                           double sz, uint32_t* __restrict__ bits) {
+  __shared__ uint32_t local[kOccWords];
+  for (uint32_t i = threadIdx.x; i < kOccWords; i += kBlock) local[i] = 0;
+  __syncthreads();
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!finite3(x, y, z)) continue;
+    const uint32_t bx = min((uint32_t)((x - ox) * sx), kOccBins - 1), by = min((uint32_t)((y - oy) * sy), kOccBins - 1),
+                   bz = min((uint32_t)((z - oz) * sz), kOccBins - 1);
+    const uint32_t bit = (bz * kOccBins + by) * kOccBins + bx;
+    atomicOr(&local[bit >> 5], 1u << (bit & 31u));
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kOccWords; i += kBlock) if (local[i]) atomicOr(&bits[i], local[i]);
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, KeyT* __restrict__ keys,
                                                       uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite) {
@@ -446,76 +467,141 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       return (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];
     };
     auto edge_for = [&](double per_cell) { return dims_used ? std::pow(vol * per_cell / (double)n, 1.0 / dims_used) : maxext; };
+    auto is_dense = [&](uint64_t cells) { return cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull; };
     double per_cell_env = 0.0;
     if (const char* e = std::getenv("PST_KNN_PER_CELL")) per_cell_env = std::atof(e);
+    const bool debug = std::getenv("PST_KNN_DEBUG") != nullptr;
+
+    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, tkeys, tstarts, fb_list;
+    NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
+    NCK(sorted_xyz.alloc(n * 24, stream));
+    NCK(rec.alloc(n * 32, stream));
     GridParams g{};
-    // 1. LDS box search (normals_tile.hip): cell edge h = R0, the radius of the sphere expected to hold M = 1.75 k points, so that the 3 x 3
+    uint64_t cells = 0, nf = 0;
+    CellTable table{nullptr, nullptr, 0};
+    // The spatial index for a given grid: keys, radix sort, reorder, and the dense directory or the hash table.  Returns false on a HIP failure.
+    auto build_index = [&](double h, uint32_t rx, bool dense) -> bool {
+#define BCK(x) do { if ((x) != hipSuccess) return false; } while (0)
+      cells = grid_for(h, rx, g);
+      g.dense = dense ? 1u : 0u;
+      unsigned key_bits = 64;
+      if (dense) { key_bits = 1; while (key_bits < 32 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells (< 2^32)
+      BCK(hipMemsetAsync(counters.p, 0, 16, stream));
+      size_t tmp_bytes = 0;
+      if (dense) {
+        hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
+        BCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        BCK(tmp.alloc(tmp_bytes, stream));
+        BCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+      } else {
+        hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+        BCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        BCK(tmp.alloc(tmp_bytes, stream));
+        BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+      }
+      hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
+      unsigned long long h_counts[2] = {0, 0};
+      BCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
+      BCK(hipStreamSynchronize(stream));
+      nf = h_counts[0];
+      if (!nf) return true;
+      if (dense) {
+        BCK(directory.alloc((cells + 2) * 4, stream));
+        hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
+      } else {
+        hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
+        BCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
+        BCK(hipStreamSynchronize(stream));
+        uint64_t cap = 64;
+        while (cap < 2 * h_counts[1]) cap <<= 1;
+        BCK(tkeys.alloc(cap * 8, stream)); BCK(tstarts.alloc(cap * 4, stream));
+        BCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
+        table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
+        hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
+      }
+      return true;
+#undef BCK
+    };
+
+    // 1. LDS box search (normals_tile.hip): cell edge h = R0, the radius of the ball expected to hold M = 1.75 k points, so that the 3 x 3
     //    rows around a query's row always cover its k-th distance when k points are found inside R0; along x the cells are rx times finer
-    //    (the points of a row are then sorted by x at that granularity and every row is trimmed to the ball).
+    //    (the points of a row are then sorted by x at that granularity and every row is trimmed to the ball).  R0 starts from the density
+    //    of the bounding box and is CORRECTED by a probe of the built index (knn_probe: mean number of points within h / 2 and h of a
+    //    sampled point, power law through the two): a surface in a 3-D box holds several times M points in the first guess.
     // 2. otherwise the dense directory with ~k/12 points per cubic cell and two shells, when the grid is not much larger than the cloud
     //    (volume-like data) -- 3. else Morton keys + hash table with ~k/3 points per cell.
     TileShape shape;
     bool tiled = false;
-    uint64_t cells = 0;
-    bool dense = false;
+    unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
+    // fraction of the 32^3 coarse cells of the bounding box that hold a point (flat axes count as one layer)
+    double occupancy = 0.0;
     if (k <= 32 && !std::getenv("PST_KNN_NO_TILE")) {
+      DevBuf occ;
+      NCK(occ.alloc(kOccWords * 4, stream));
+      NCK(hipMemsetAsync(occ.p, 0, kOccWords * 4, stream));
+      double sc[3];
+      for (int c = 0; c < 3; ++c) sc[c] = ext[c] > maxext * 1e-9 ? (double)kOccBins / ext[c] * (1.0 - 1e-12) : 0.0;
+      hipLaunchKernelGGL(occupancy_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], sc[0], sc[1], sc[2],
+                         occ.as<uint32_t>());
+      std::vector<uint32_t> hb(kOccWords);
+      NCK(hipMemcpyAsync(hb.data(), occ.p, kOccWords * 4, hipMemcpyDeviceToHost, stream));
+      NCK(hipStreamSynchronize(stream));
+      uint64_t set = 0;
+      for (uint32_t w : hb) set += (uint64_t)__builtin_popcount(w);
+      double bins = 1.0;
+      for (int c = 0; c < 3; ++c) bins *= sc[c] > 0 ? (double)kOccBins : 1.0;
+      occupancy = (double)set / bins;
+      if (debug) fprintf(stderr, "[pst knn] occupancy of the bounding box at 32^3: %.3f\n", occupancy);
+    }
+    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && occupancy >= 0.5) {
       double m_target = 1.75 * (double)k;
       if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
       uint32_t rx = 4;
       if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
-      cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639), rx, g);
-      dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
-      tiled = dense && knn_tile_shape(g, n, cells, k, shape);
+      double h = edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
+      for (int round = 0; round < 3; ++round) {
+        GridParams trial{};
+        // (clustered clouds leave cells empty: 4 bytes each, up to 8 per point are accepted here)
+        const uint64_t trial_cells = grid_for(h, rx, trial);
+        if (!(trial_cells <= std::max<uint64_t>(8 * n, 1u << 20) && trial_cells < 0xFFFFFFF0ull)) break;
+        if (!build_index(h, rx, true)) return -1;
+        if (!nf) break;
+        double m_half = 0, m_full = 0;
+        if (!knn_probe(sorted_xyz.as<double>(), directory.as<uint32_t>(), g, (uint32_t)nf, scratch3, stream, m_half, m_full)) return -1;
+        // N(r) ~ r^D through (h/2, m_half) and (h, m_full); the radius that holds M points
+        const double D = std::fmin(3.0, std::fmax(1.0, std::log2(std::fmax(m_full, 1.0) / std::fmax(m_half, 1.0))));
+        const double h_new = g.h * std::pow(m_target / std::fmax(m_full, 1.0), 1.0 / D);
+        if (debug) fprintf(stderr, "[pst knn probe] h=%g: %.1f points within h/2, %.1f within h (target %.1f), dimension %.2f -> h=%g\n", g.h, m_half, m_full, m_target, D, h_new);
+        if (round == 2 || std::fabs(h_new / g.h - 1.0) <= 0.10 || per_cell_env > 0 || std::getenv("PST_KNN_CELL")) {
+          tiled = knn_tile_shape(g, nf, cells, k, directory.as<uint32_t>(), scratch3, stream, shape);
+          break;
+        }
+        h = h_new;
+      }
     }
+    bool dense = tiled;
     if (!tiled) {
-      cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0)), 1, g);
-      dense = cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull;
+      const double h_vol = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0));
+      GridParams trial{};
+      dense = is_dense(grid_for(h_vol, 1, trial));
       if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
-      if (!dense) cells = grid_for(edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0)), 1, g);
+      if (!build_index(dense ? h_vol : edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0)), 1, dense)) return -1;
     }
-    g.dense = dense ? 1u : 0u;
-    unsigned key_bits = 64;
-    if (dense) { key_bits = 1; while (key_bits < 32 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells (< 2^32)
-    const size_t key_size = dense ? 4 : 8;
-    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec;
-    NCK(keys.alloc(n * key_size, stream)); NCK(keys2.alloc(n * key_size, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
-    NCK(sorted_xyz.alloc(n * 24, stream));
-    size_t tmp_bytes = 0;
-    if (dense) {
-      hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
-      NCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
-      NCK(tmp.alloc(tmp_bytes, stream));
-      NCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
-    } else {
-      hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
-      NCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
-      NCK(tmp.alloc(tmp_bytes, stream));
-      NCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
-    }
-    hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
-    unsigned long long h_counts[2] = {0, 0};
-    NCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
-    NCK(hipStreamSynchronize(stream));
-    const uint64_t nf = h_counts[0];
-    NCK(rec.alloc(n * 32, stream));
     RecOut sorted{rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count};
-    DevBuf tkeys, tstarts, directory, fb_list;
-    CellTable table{nullptr, nullptr, 0};
     if (nf) {
       if (dense) {
-        NCK(directory.alloc((cells + 2) * 4, stream));
-        hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
         const uint32_t* cell_start = directory.as<uint32_t>();
         if (tiled) {
-          // box kernel first; what it hands back (k-th distance beyond its halo, boxes denser than its LDS budget) goes to the
-          // global-memory search as a list
+          // box kernel first; what it hands back (k-th distance beyond tau0, ambiguous packed keys, boxes denser than its LDS budget) goes to
+          // the global-memory search as a list
           NCK(fb_list.alloc(nf * 4, stream));
+          NCK(hipMemsetAsync(fb_count, 0, 4, stream));
           launch_knn_tile(shape, sorted_xyz.as<double>(), cell_start, g, k, (uint32_t)nf, sorted, fb_list.as<uint32_t>(), fb_count, stream);
           uint32_t n_fb = 0;
           NCK(hipMemcpyAsync(&n_fb, fb_count, 4, hipMemcpyDeviceToHost, stream));
           NCK(hipStreamSynchronize(stream));
-          if (std::getenv("PST_KNN_DEBUG"))
+          if (debug)
             fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
                     (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.threads,
                     shape.cap, n_fb);
@@ -530,15 +616,6 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
                             (const uint32_t*)nullptr, (uint32_t)nf, sorted);
         }
       } else {
-        hipLaunchKernelGGL(count_cells_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, n_cells);
-        NCK(hipMemcpyAsync(&h_counts[1], n_cells, 8, hipMemcpyDeviceToHost, stream));
-        NCK(hipStreamSynchronize(stream));
-        uint64_t cap = 64;
-        while (cap < 2 * h_counts[1]) cap <<= 1;
-        NCK(tkeys.alloc(cap * 8, stream)); NCK(tstarts.alloc(cap * 4, stream));
-        NCK(hipMemsetAsync(tkeys.p, 0xFF, cap * 8, stream));
-        table = CellTable{tkeys.as<uint64_t>(), tstarts.as<uint32_t>(), (uint32_t)(cap - 1)};
-        hipLaunchKernelGGL(build_table_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint64_t>(), nf, table);
         const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
         KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted);

@@ -9,7 +9,12 @@ namespace pstk {
 
 struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; };
 // false: no box fits (k > 32, or even a single query row with its halo exceeds the LDS budget at this density)
-bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, TileShape& t);
+// (measured: census kernels over the dense directory; scratch3 = 24 bytes of device memory; synchronises the stream)
+bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, const uint32_t* cell_start, unsigned long long* scratch3,
+                    hipStream_t stream, TileShape& t);
+// mean number of points within h / 2 and within h of a sampled point of the sorted cloud (synchronises the stream); false on failure
+bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t nf, unsigned long long* scratch3, hipStream_t stream,
+               double& mean_half, double& mean_full);
 // Searches every query whose 5x5x5-cell neighbourhood fits the box kernel; the others are appended to fb_list / *fb_count
 // (sorted indices) for knn_grid_kernel.  *fb_count must be zero on entry; fb_list must hold nf entries.
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,

@@ -404,41 +404,149 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
   }
 }
 
+// ---- density probe: how many points does a ball of radius h (and h / 2) around a typical point hold? ---------------------------------
+// The grid's cell edge h should be the radius R0 of the ball expected to hold M points.  The volume of the bounding box gives that only
+// for clouds that fill their box: a surface in a 3-D box (the LiDAR case) has far more points inside R0 than n * ball / box.  The probe
+// counts, for a sample of the sorted points, the points within h / 2 and within h (exact: the 3 x 3 rows around a point cover radius h),
+// and the host fits a power law through the two means (normals.hip).
+__global__ __launch_bounds__(kBlock) void knn_probe_kernel(const double* __restrict__ sxyz, const uint32_t* __restrict__ cell_start, GridParams g, uint32_t nf,
+                                                           uint32_t stride, unsigned long long* __restrict__ sums) {
+  const uint32_t j = (blockIdx.x * kBlock + threadIdx.x) * stride;
+  unsigned long long c_half = 0, c_full = 0, one = 0;
+  if (j < nf) {
+    const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+    const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
+              cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    const double r2 = g.h * g.h, r2h = 0.25 * r2;
+    const int x0 = max(cx - (int)g.rx, 0), x1 = min(cx + (int)g.rx, (int)g.dim[0] - 1);
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int y = cy + dy, z = cz + dz;
+        if (y < 0 || y >= (int)g.dim[1] || z < 0 || z >= (int)g.dim[2]) continue;
+        const uint64_t row = ((uint64_t)z * g.dim[1] + (uint64_t)y) * g.dim[0];
+        const uint32_t p0 = cell_start[row + (uint32_t)x0], p1 = cell_start[row + (uint32_t)x1 + 1];
+        for (uint32_t p = p0; p < p1; ++p) {
+          const double dx = sxyz[3 * (uint64_t)p] - qx, ddy = sxyz[3 * (uint64_t)p + 1] - qy, ddz = sxyz[3 * (uint64_t)p + 2] - qz;
+          const double d = dx * dx + ddy * ddy + ddz * ddz;
+          c_half += d < r2h;
+          c_full += d < r2;
+        }
+      }
+    one = 1;
+  }
+  // wave sums, one atomic per wave and counter
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    c_half += shfl_xor_any(c_half, off); c_full += shfl_xor_any(c_full, off); one += shfl_xor_any(one, off);
+  }
+  if ((threadIdx.x & 63u) == 0 && one) { atomicAdd(sums, c_half); atomicAdd(sums + 1, c_full); atomicAdd(sums + 2, one); }
+}
+
+// ---- box census: what would a box shape stage?  One thread per box: staged points (halo) and queries, from the directory alone.
+// sums: [0] queries, [1] staged points over non-empty boxes, [2] queries of boxes whose halo exceeds the capacity
+__global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __restrict__ cell_start, GridParams g, uint32_t bx, uint32_t by, uint32_t bz,
+                                                            uint32_t nbx, uint32_t nby, uint32_t n_boxes, uint32_t cap, unsigned long long* __restrict__ sums) {
+  const uint32_t box = blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long q = 0, staged = 0, lost = 0;
+  if (box < n_boxes) {
+    const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2], XH = (int)g.rx + 1;
+    const int X0 = (int)(box % nbx) * (int)bx, Y0 = (int)((box / nbx) % nby) * (int)by, Z0 = (int)(box / (nbx * nby)) * (int)bz;
+    auto cl = [&](int x) { return (uint32_t)(x < 0 ? 0 : (x > dim0 ? dim0 : x)); };
+    for (int z = Z0 - kHalo; z < Z0 + (int)bz + kHalo; ++z)
+      for (int y = Y0 - kHalo; y < Y0 + (int)by + kHalo; ++y) {
+        if (y < 0 || y >= dim1 || z < 0 || z >= dim2) continue;
+        const uint64_t row = ((uint64_t)z * dim1 + (uint64_t)y) * dim0;
+        staged += cell_start[row + cl(X0 + (int)bx + XH)] - cell_start[row + cl(X0 - XH)];
+        if (y >= Y0 && y < Y0 + (int)by && z >= Z0 && z < Z0 + (int)bz) q += cell_start[row + cl(X0 + (int)bx)] - cell_start[row + cl(X0)];
+      }
+    if (q == 0) staged = 0;
+    if (staged > cap) lost = q;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { q += shfl_xor_any(q, off); staged += shfl_xor_any(staged, off); lost += shfl_xor_any(lost, off); }
+  if ((threadIdx.x & 63u) == 0 && q) { atomicAdd(sums, q); atomicAdd(sums + 1, staged); atomicAdd(sums + 2, lost); }
+}
+
 }  // namespace
 
 namespace pstk {
 
-// Picks the box: least halo amplification (staged points / query points) whose expected number of staged points fits the LDS budget.
-// bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
-bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, TileShape& t) {
-  if (k > 32 || cells == 0 || nf == 0) return false;
-  t.threads = 256;
-  t.cap = 1536;
+namespace {
+bool tile_fits(const pstn::GridParams& g, uint32_t bx, uint32_t by, uint32_t bz) {
+  const uint32_t hx = bx + 2 * (g.rx + 1), hy = by + 2 * kHalo, hz = bz + 2 * kHalo;
+  return bx <= g.dim[0] && by <= g.dim[1] && bz <= g.dim[2] && hx <= (uint32_t)kMaxRowCells && by * bz <= (uint32_t)kMaxQRows &&
+         hy * hz <= (uint32_t)kMaxRows && (hx + 1) * hy * hz <= (uint32_t)kMaxDir;
+}
+// least geometric halo amplification among the boxes whose halo has at most `max_halo_cells` fine cells
+bool best_box(const pstn::GridParams& g, double max_halo_cells, pstk::TileShape& t) {
   const uint32_t xh = g.rx + 1;
-  const double rho = (double)nf / (double)cells;  // points per fine cell
-  const double budget = 0.90 * (double)t.cap;
-  auto fits = [&](uint32_t bx, uint32_t by, uint32_t bz) {
-    const uint32_t hx = bx + 2 * xh, hy = by + 2 * kHalo, hz = bz + 2 * kHalo;
-    return bx <= g.dim[0] && by <= g.dim[1] && bz <= g.dim[2] && hx <= (uint32_t)kMaxRowCells && by * bz <= (uint32_t)kMaxQRows &&
-           hy * hz <= (uint32_t)kMaxRows && (hx + 1) * hy * hz <= (uint32_t)kMaxDir;
-  };
   double best_amp = 1e300;
   bool found = false;
   for (uint32_t bz = 1; bz <= 8; ++bz)
     for (uint32_t by = 1; by <= 8; ++by)
       for (uint32_t bx = 1; bx <= (uint32_t)kMaxRowCells; ++bx) {
-        if (!fits(bx, by, bz)) continue;
+        if (!tile_fits(g, bx, by, bz)) continue;
         // the halo is addressed unclipped (rows and cells outside the grid are empty), only its POINTS are clipped by the grid
         const uint32_t px = std::min(bx + 2 * xh, g.dim[0]), py = std::min(by + 2 * kHalo, g.dim[1]), pz = std::min(bz + 2 * kHalo, g.dim[2]);
-        if (rho * px * py * pz > budget) continue;
+        if ((double)px * py * pz > max_halo_cells) continue;
         const double amp = (double)(px * py * pz) / (double)(bx * by * bz);
         if (amp < best_amp - 1e-12) { best_amp = amp; t.bx = bx; t.by = by; t.bz = bz; found = true; }
       }
+  return found;
+}
+}  // namespace
+
+// Density probe (knn_probe_kernel): mean number of points within h / 2 and within h of a sampled point.  false on a HIP failure.
+bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t nf, unsigned long long* scratch3, hipStream_t stream,
+               double& mean_half, double& mean_full) {
+  const uint32_t samples = 1u << 16;
+  const uint32_t stride = std::max<uint32_t>(1u, nf / samples);
+  const uint32_t n_s = (nf + stride - 1) / stride;
+  if (hipMemsetAsync(scratch3, 0, 24, stream) != hipSuccess) return false;
+  hipLaunchKernelGGL(knn_probe_kernel, dim3((n_s + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sxyz, cell_start, g, nf, stride, scratch3);
+  unsigned long long h[3] = {};
+  if (hipMemcpyAsync(h, scratch3, 24, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
+  if (!h[2]) return false;
+  mean_half = (double)h[0] / (double)h[2];
+  mean_full = (double)h[1] / (double)h[2];
+  return true;
+}
+
+// Picks the box by MEASUREMENT: candidates from large to small (least geometric halo amplification for a shrinking halo budget); the first
+// whose census (knn_census_kernel: staged points and queries of every box, read off the directory) loses at most 2 % of the queries to boxes
+// that exceed the LDS capacity wins.  Average density would do for a cloud that fills its bounding box; a surface in a 3-D box puts all
+// its points into a few boxes.  bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
+bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, const uint32_t* cell_start, unsigned long long* scratch3,
+                    hipStream_t stream, TileShape& t) {
+  if (k > 32 || cells == 0 || nf == 0) return false;
+  t.threads = 256;
+  t.cap = 1536;
   if (const char* e = std::getenv("PST_KNN_TILE")) {  // "bx,by,bz"
     unsigned x = 0, y = 0, z = 0;
-    if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z && fits(x, y, z)) { t.bx = x; t.by = y; t.bz = z; found = true; }
+    if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z && tile_fits(g, x, y, z)) { t.bx = x; t.by = y; t.bz = z; return true; }
   }
-  return found;
+  const double rho = (double)nf / (double)cells;  // points per fine cell, averaged over the whole grid: the first guess
+  double budget = 0.90 * (double)t.cap / rho;
+  TileShape last{};
+  for (int attempt = 0; attempt < 8; ++attempt, budget *= 0.7) {
+    TileShape c = t;
+    if (!best_box(g, budget, c)) break;
+    if (c.bx == last.bx && c.by == last.by && c.bz == last.bz) continue;
+    last = c;
+    const uint32_t nbx = (g.dim[0] + c.bx - 1) / c.bx, nby = (g.dim[1] + c.by - 1) / c.by, nbz = (g.dim[2] + c.bz - 1) / c.bz;
+    const uint64_t n_boxes = (uint64_t)nbx * nby * nbz;
+    if (n_boxes >= 0x7FFFFFFFull) break;
+    if (hipMemsetAsync(scratch3, 0, 24, stream) != hipSuccess) return false;
+    hipLaunchKernelGGL(knn_census_kernel, dim3((unsigned)((n_boxes + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cell_start, g, c.bx, c.by, c.bz, nbx, nby,
+                       (uint32_t)n_boxes, t.cap, scratch3);
+    unsigned long long h[3] = {};
+    if (hipMemcpyAsync(h, scratch3, 24, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
+    if (std::getenv("PST_KNN_DEBUG"))
+      fprintf(stderr, "[pst knn census] box %ux%ux%u: halo amplification %.2f, %.2f %% of the queries in boxes over capacity\n", c.bx, c.by, c.bz,
+              h[0] ? (double)h[1] / (double)h[0] : 0.0, h[0] ? 100.0 * (double)h[2] / (double)h[0] : 0.0);
+    if (h[0] && (double)h[2] <= 0.02 * (double)h[0]) { t.bx = c.bx; t.by = c.by; t.bz = c.bz; return true; }
+  }
+  return false;
 }
 
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,

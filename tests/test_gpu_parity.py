@@ -270,6 +270,10 @@ def _normals_inputs(n, seed, shape):
         xy = rng.random((n, 2)) * 500.0
         z = 20.0 * np.sin(xy[:, 0] / 40.0) * np.cos(xy[:, 1] / 55.0) + rng.normal(0, 0.05, n)
         return np.column_stack([xy, z])
+    if shape == "clustered":  # volume-like (every coarse cell occupied) but the density varies 9-fold: the density probe must re-grid
+        a = rng.random((n // 2, 3)) * np.array([400.0, 400.0, 400.0])
+        b = rng.random((n - n // 2, 3)) * np.array([200.0, 200.0, 200.0]) + np.array([50.0, 100.0, 150.0])
+        return np.concatenate([a, b])[rng.permutation(n)]
     raise ValueError(shape)
 
 
@@ -297,7 +301,8 @@ def _compare_normals(hn, hc, on, oc, rel=1e-9, scales=None):
     return bad, cerr
 
 
-@pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5)])
+@pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5),
+                                       ("clustered", 40_000, 16), ("clustered", 30_000, 24)])
 @pytest.mark.parametrize("kind", ["V", "H"])
 def test_compute_normals_vs_oracle(hip, oracle, shape, n, k, kind):
     from pasture_amd.algorithms import compute_normals
