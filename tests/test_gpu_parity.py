@@ -426,6 +426,43 @@ def test_full_size_1e8_knn_normals_properties(hip, oracle):
     assert torch.equal(_torch_view(out.column_ptr(curv_def), n * 8).view(torch.float64), curv)
 
 
+@pytest.mark.parametrize("n_side,k", [(48, 16), (40, 8), (36, 27)])
+def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
+    """LAS coordinates are integers times a scale: equal distances are the rule, not the exception.  On a jittered-then-quantised lattice
+    (every point has 6 neighbours at exactly the same distance, 12 at the next, ...) the tie ORDER is unpinned (kd-tree crate), but the
+    multiset of neighbour distances is not: every list must hold the k smallest distances in ascending order, start with the point itself
+    and contain no point twice.  Covers the packed-key ambiguity handling of the LDS box search (exact ties stay, boundary ties go to the
+    exact search) and the global-memory search behind it."""
+    import torch
+    from pasture_amd.algorithms import compute_normals_device
+    rng = np.random.default_rng(n_side)
+    g = np.arange(n_side, dtype=np.float64)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    # a third of the points leaves the lattice by a multiple of 1/4: ties between DIFFERENT offsets, duplicates excluded
+    move = rng.random(len(pts)) < 0.33
+    pts[move] += rng.integers(1, 4, size=(move.sum(), 3)) * 0.25
+    pts = pts[rng.permutation(len(pts))] * 0.5
+    n = len(pts)
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    buf.resize(n)
+    buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+    knn = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    curv = torch.empty(n, dtype=torch.float64, device="cuda")
+    compute_normals_device(buf, k, 0, curv.data_ptr(), knn.data_ptr())
+    tp = torch.as_tensor(pts, device="cuda")
+    kk = knn.long()
+    assert bool((kk[:, 0] == torch.arange(n, device="cuda")).all())
+    assert bool((kk.sort(dim=1).values[:, 1:] != kk.sort(dim=1).values[:, :-1]).all()), "a neighbour is listed twice"
+    got = ((tp[kk.reshape(-1)].view(n, k, 3) - tp[:, None, :]) ** 2).sum(dim=2)
+    assert bool((got[:, 1:] >= got[:, :-1]).all())
+    for first in range(0, n, 8192):
+        q = tp[first:first + 8192]
+        d = ((q[:, None, :] - tp[None, :, :]) ** 2).sum(dim=2)
+        want = torch.topk(d, k, dim=1, largest=False, sorted=True).values
+        assert torch.equal(got[first:first + 8192], want), "neighbour distances differ from the brute-force k smallest"
+    assert bool(torch.isfinite(curv).all())
+
+
 # ---- buffer kinds of the boundary: external memory, pinned host memory, explicit stream --------------------------
 
 def test_external_memory_buffers_over_torch_tensors(hip):
