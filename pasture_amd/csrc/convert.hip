@@ -26,6 +26,7 @@ namespace pstk {
 void launch_convert_tile_tt(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
 void launch_convert_tile_tf(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
 void launch_convert_tile_ft(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
+bool launch_convert_static(const ConvertPlan& plan, bool src_aos, bool dst_aos, unsigned grid, size_t lds_bytes, const PlanEntry* entries, hipStream_t stream);
 
 int device_cus() {
   static int cus = [] {
@@ -95,6 +96,7 @@ bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool us
   if (use_lds && (src_aos || dst_aos)) {
     const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
     // 256-thread blocks: 512 / 1024 measured 15-60 % slower (per-wave interpretation cost is amortised over fewer points)
+    if (launch_convert_static(plan, src_aos, dst_aos, grid, lds_bytes, entries, stream)) return hipGetLastError() == hipSuccess;
     if (src_aos && dst_aos) launch_convert_tile_tt(grid, lds_bytes, stream, h, entries);
     else if (src_aos) launch_convert_tile_tf(grid, lds_bytes, stream, h, entries);
     else launch_convert_tile_ft(grid, lds_bytes, stream, h, entries);
