@@ -1262,3 +1262,44 @@ def test_two_threads_share_one_converter(hip):
             t.join()
         assert not errors, errors
         assert results[0] == ref and results[1] == ref
+
+
+@pytest.mark.parametrize("n", [1, 1023, 1024, 1025, 100_003])
+def test_compile_time_plans_match_numpy(hip, n):
+    """The plans that take the compile-time kernels (static_plans.hpp): CustomPointTypeBig columns <-> records, typed LAS-1 records ->
+    {Position3D, Intensity, Classification}, CustomPointTypeBig compaction into a VectorBuffer -- ragged sizes around the static tile,
+    expectations from numpy on the host (byte-exact)."""
+    from harness import custom_point_type_big
+    big = custom_point_type_big(hip)
+    rec = random_records_like(big, n, seed=n)
+    cols = make_buffer_like("H", big, rec)
+    conv = BufferLayoutConverter.for_layouts(big, big)
+    recs = conv.convert(cols, VectorBuffer)                     # columns -> records (static plan BigColumnsToRecords)
+    assert recs.get_point_range(range(0, n)).tobytes() == rec.tobytes()
+    back = conv.convert(recs, HashMapBuffer)                    # records -> columns (BigRecordsToColumns)
+    for a in big.attributes():
+        assert back.view_attribute(a.attribute_definition()).tobytes() == np.ascontiguousarray(rec[a.name()]).tobytes(), a.name()
+    # LAS-1 typed records -> 27-byte records
+    las1 = las.point_layout_from_las_point_format(las.Format(1), False, api=hip)
+    small = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], 1, api=hip)
+    r1 = random_records_like(las1, n, seed=n + 7)
+    src = make_buffer_like("V", las1, r1)
+    out = BufferLayoutConverter.for_layouts(las1, small).convert(src, VectorBuffer)
+    got = out.get_point_range(range(0, n)).view(small.numpy_record_dtype()).reshape(n)
+    for name in ("Position3D", "Intensity", "Classification"):
+        assert np.ascontiguousarray(got[name]).tobytes() == np.ascontiguousarray(r1[name]).tobytes(), name
+    # compaction of CustomPointTypeBig columns into a VectorBuffer (buffer_filter_bench.rs:71-74)
+    mask = np.random.default_rng(n).random(n) < 0.5
+    kept = cols.filter(VectorBuffer, mask)
+    assert kept.len() == int(mask.sum())
+    assert kept.get_point_range(range(0, kept.len())).tobytes() == rec[mask].tobytes()
+
+
+def random_records_like(layout, n, seed):
+    from harness import random_records
+    return random_records(layout, n, seed)
+
+
+def make_buffer_like(kind, layout, records):
+    from harness import make_buffer
+    return make_buffer(kind, layout, records)
