@@ -15,6 +15,7 @@
 // HBM-bound gather/scatter: no MFMA.
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "las_device.hpp"
 #include "tile_io.hpp"
 
 #include <algorithm>
@@ -360,6 +361,84 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DST_AOS 
   }
 }
 
+// Point-major form for the same layout: ONE lane gathers the seven pieces of a selected point (all loads in flight together) and writes
+// one 41-byte record image, assembled in registers at compile-time offsets, into the LDS record tile.  Nine granule copies per point
+// (each with its own index arithmetic and LDS store) become seven loads and eleven dword stores.
+template <int PPL>
+__global__ __launch_bounds__(kBlock) void filter_big_records_kernel(const FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  uint16_t* sel = (uint16_t*)lds_raw;
+  lptr_t lds = (lptr_t)lds_raw + ((a.tile * 2u + 15u) & ~15u);
+  __shared__ uint32_t wave_tot[kBlock / 64];
+  constexpr uint32_t STRIDE = 41;
+  const uint64_t first = (uint64_t)blockIdx.x * a.tile;
+  const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
+  const uint64_t out0 = a.offsets[blockIdx.x];
+  uint32_t m = a.counts[blockIdx.x];
+  if (m == 0 || out0 >= a.limit) return;
+  const uint32_t p0 = threadIdx.x * PPL;
+  uint8_t mb[PPL];
+  cgptr_t mp = (cgptr_t)((uint64_t)(uintptr_t)a.mask + first);
+  if (p0 + PPL <= cnt) {
+    static_assert(PPL == 8, "2048-point tiles");
+    const uint64_t w = load_un<uint64_t>(mp + p0);
+    for (int i = 0; i < 8; ++i) mb[i] = (uint8_t)(w >> (8 * i));
+  } else {
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) mb[i] = p0 + i < cnt ? mp[p0 + i] : (uint8_t)0;
+  }
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) c += mb[i] != 0;
+  uint32_t incl = c;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t r = incl - c;
+  for (uint32_t w = 0; w < wave; ++w) r += wave_tot[w];
+#pragma unroll
+  for (int i = 0; i < PPL; ++i) if (mb[i] != 0) sel[r++] = (uint16_t)(p0 + i);
+  if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
+  m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+  cgptr_t gps = (cgptr_t)as_global(a.attrs[0].src), col = (cgptr_t)as_global(a.attrs[1].src), pos = (cgptr_t)as_global(a.attrs[2].src),
+          cls = (cgptr_t)as_global(a.attrs[3].src), inten = (cgptr_t)as_global(a.attrs[4].src);
+  const uint32_t nch = (m + a.chunk - 1) / a.chunk;
+  const uint32_t mc = ((m + nch - 1) / nch + 15u) & ~15u;
+  __syncthreads();
+  for (uint32_t j0 = 0; j0 < m; j0 += mc) {
+    const uint32_t cm = (m - j0) < mc ? (m - j0) : mc;
+    const uint64_t ga = a.dst_aos + (out0 + j0) * STRIDE;
+    const uint32_t mis = (uint32_t)(ga & 15u);
+    for (uint32_t j = threadIdx.x; j < cm; j += kBlock) {
+      const uint64_t i = first + sel[j0 + j];
+      const uint64_t g = load_un<uint64_t>(gps + i * 8);
+      const uint32_t c0 = load_un<uint32_t>(col + i * 6);
+      const uint16_t c1 = load_un<uint16_t>(col + i * 6 + 4);
+      const u32x4 pa = load_un<u32x4>(pos + i * 24);
+      const uint64_t pz = load_un<uint64_t>(pos + i * 24 + 16);
+      const uint8_t cl = load_un<uint8_t>(cls + i);
+      const uint16_t in = load_un<uint16_t>(inten + i * 2);
+      pstlas::RecordImage<STRIDE> img;
+      img.put(0, 8, g);
+      img.put(8, 6, (uint64_t)c0 | ((uint64_t)c1 << 32));
+      img.put(14, 8, (uint64_t)pa.x | ((uint64_t)pa.y << 32));
+      img.put(22, 8, (uint64_t)pa.z | ((uint64_t)pa.w << 32));
+      img.put(30, 8, pz);
+      img.put(38, 1, cl);
+      img.put(39, 2, in);
+      img.store(lds + (mis + j * STRIDE));
+    }
+    __syncthreads();
+    tile_store<kBlock>(lds, as_global(ga - mis), mis, cm * STRIDE);
+    if (j0 + mc < m) __syncthreads();
+  }
+}
+
 template <typename SP>
 static bool filter_plan_equals(const FilterArgs& a, bool dst_aos) {
   if (a.n_attrs != (uint32_t)SP::n || a.tile != 2048u) return false;
@@ -386,8 +465,9 @@ uint32_t filter_tile(bool, uint32_t) { return 2048; }
 // Interleaved targets: records per LDS chunk -- about 15 KiB of records (same-box sweep, 41-byte records: 8 KiB 3.99, 12 KiB 4.51,
 // 16 KiB 4.60, 21 KiB 4.43, 32 KiB 3.76 TB/s; 15 KiB + the 4 KiB index list leave room for eight blocks per CU, which the kernel's
 // register budget -- amdgpu_waves_per_eu(8) -- matches: +3 %), a multiple of 16.  PST_FILTER_TILE_LDS overrides the byte budget (tuning).
-static uint32_t filter_chunk(uint32_t dst_stride) {
-  static const long budget = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 15L * 1024L; }();
+static uint32_t filter_chunk(uint32_t dst_stride, long default_budget = 15L * 1024L) {
+  static const long forced = [] { const char* v = std::getenv("PST_FILTER_TILE_LDS"); return v && *v ? std::strtol(v, nullptr, 10) : 0L; }();
+  const long budget = forced > 0 ? forced : default_budget;
   uint64_t c = (uint64_t)budget / (dst_stride ? dst_stride : 1u);
   c = c / 16 * 16;
   if (c < 16) c = 16;
@@ -448,7 +528,17 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
     static const bool static_plans = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
     // interleaved targets only: same-box A/B 0.6075 -> 0.6267 of peak; the columnar target LOST with constants (0.663 -> 0.626) and stays interpreted
     if (static_plans && dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, dst_aos)) {
-      hipLaunchKernelGGL((filter_scatter_static_kernel<8, true, BigFilterPlan>), dim3(n_tiles), dim3(kBlock), lds_bytes, stream, a);
+      // point-major record assembly (filter_big_records_kernel): same-box A/B against the granule-major constants 0.657 -> 0.673 of peak
+      // (PST_FILTER_PM=0 switches back), 0.680 with a 24 KiB record tile (8 / 16 / 24 / 32 KiB: 0.671 / 0.674 / 0.680 / 0.676)
+      static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 1; }();
+      if (pm) {
+        FilterArgs b = a;
+        b.chunk = filter_chunk(dst_stride, 24L * 1024L);
+        const size_t lds_pm = (((size_t)tile * 2 + 15) & ~(size_t)15) + (size_t)b.chunk * dst_stride + 48;
+        hipLaunchKernelGGL((filter_big_records_kernel<8>), dim3(n_tiles), dim3(kBlock), lds_pm, stream, b);
+      } else {
+        hipLaunchKernelGGL((filter_scatter_static_kernel<8, true, BigFilterPlan>), dim3(n_tiles), dim3(kBlock), lds_bytes, stream, a);
+      }
       continue;
     }
     switch (tile / kBlock) {
