@@ -31,7 +31,23 @@ void stream_sync(hipStream_t s) { PST_HIP_CHECK(hipStreamSynchronize(s)); }
 // a copy stream, the pipelined LAS reader / writer), and their per-block partial records and result records must not alias.
 Workspace& workspace() {
   static thread_local std::unordered_map<hipStream_t, Workspace> by_stream;
-  Workspace& ws = by_stream[current_stream()];
+  const hipStream_t cur = current_stream();
+  auto it = by_stream.find(cur);
+  if (it == by_stream.end()) {
+    // a thread that keeps creating streams (one per request, say) must not keep a workspace for each of them for ever: beyond eight
+    // the idle ones are released (after a device synchronisation: their last launches may still be reading them)
+    if (by_stream.size() >= 8) {
+      (void)hipDeviceSynchronize();
+      for (auto& kv : by_stream) {
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
+        if (kv.second.pinned) (void)hipHostFree(kv.second.pinned);
+        if (kv.second.partials_buf) (void)hipFree(kv.second.partials_buf);
+      }
+      by_stream.clear();
+    }
+    it = by_stream.emplace(cur, Workspace{}).first;
+  }
+  Workspace& ws = it->second;
   if (!ws.dev) {
     ensure_device();
     PST_HIP_CHECK(hipMalloc((void**)&ws.dev, Workspace::kWorkspaceBytes));
