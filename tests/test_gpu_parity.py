@@ -426,6 +426,39 @@ def test_full_size_1e8_knn_normals_properties(hip, oracle):
     assert torch.equal(_torch_view(out.column_ptr(curv_def), n * 8).view(torch.float64), curv)
 
 
+def _degenerate_cloud(name):
+    rng = np.random.default_rng(3)
+    if name == "flat_plane":   # one grid layer: every halo row above and below is outside the grid
+        return np.column_stack([rng.random((20000, 2)) * 300.0, np.full(20000, 7.25)])
+    if name == "line_x":       # a single grid row
+        return np.column_stack([rng.random(6000) * 1000.0, np.full(6000, 1.0), np.full(6000, -2.0)])
+    if name == "two_planes":   # 6 % of the bounding box occupied: the occupancy test keeps the global-memory search
+        return np.concatenate([np.column_stack([rng.random((15000, 2)) * 200.0, np.zeros(15000)]),
+                               np.column_stack([rng.random((15000, 2)) * 200.0, np.full(15000, 150.0)])])
+    if name == "utm_offsets":  # coordinates of ~5e6 with metre-scale neighbourhoods: the f32 ball trimming works on cell-relative values
+        return rng.random((30000, 3)) * np.array([300.0, 300.0, 30.0]) + np.array([5.4e6, 5.0e5, 100.0])
+    if name == "cluster_and_outlier":  # one far point stretches the bounding box by nine orders of magnitude
+        return np.concatenate([rng.random((9000, 3)) * 1e-3, np.array([[1e6, 1e6, 1e6]])])
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("name", ["flat_plane", "line_x", "two_planes", "utm_offsets", "cluster_and_outlier"])
+def test_compute_normals_degenerate_clouds_vs_oracle(hip, oracle, name):
+    from pasture_amd.algorithms import compute_normals
+    pts = _degenerate_cloud(name)
+    n, k = len(pts), 16
+
+    def run(api):
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    assert np.array_equal(hk, ok)
+    bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
+    assert bad.sum() == 0 and cbad.sum() == 0
+
+
 @pytest.mark.parametrize("n_side,k", [(48, 16), (40, 8), (36, 27)])
 def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
     """LAS coordinates are integers times a scale: equal distances are the rule, not the exception.  On a jittered-then-quantised lattice
