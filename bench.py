@@ -49,6 +49,10 @@ WORKLOADS = {
                                 "generic tile kernel, four points per lane"),
     "las1_records_to_custom27": (70, "INTERPRETED plan: typed LAS-1 records (43 B) -> packed records {Position3D, Intensity, Classification} "
                                      "(27 B): 43 R + 27 W; generic interleaved -> interleaved tile kernel"),
+    "benchlayout_records_to_columns": (60, "layout_conversion_bench.rs: PointTypeSource (35 B packed) VectorBuffer -> PointTypeTarget (25 B) HashMapBuffer, "
+                                           "three `as` casts (Vec3f64->Vec3f32, u8->u32, u16->u8): 35 R + 25 W"),
+    "benchlayout_columns_to_records": (60, "the same conversion HashMapBuffer -> VectorBuffer"),
+    "benchlayout_records_to_records": (60, "the same conversion VectorBuffer -> VectorBuffer"),
     "las0_encode": (55, "LAS writer: 10 SoA columns (typed LAS-0) -> raw LAS-0 records + header AABB + per-return counts, fused (35 R + 20 W)"),
     "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
                                   "resident in HBM (2 mask reads + 41 R + 20.5 W per input point)"),
@@ -381,6 +385,22 @@ def main():
         dst = pa.VectorBuffer.new_from_layout(big)
         dst.resize(n)
         conv = pa.BufferLayoutConverter.for_layouts(big, big)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload.startswith("benchlayout_"):
+        src_layout = pa.PointLayout.from_attributes_packed([A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY, A.GPS_TIME], 1)
+        dst_layout = pa.PointLayout.from_attributes_packed([A.GPS_TIME, A.POSITION_3D.with_custom_datatype(T.Vec3f32), A.CLASSIFICATION.with_custom_datatype(T.U32),
+                                                            A.INTENSITY.with_custom_datatype(T.U8)], 1)
+        src_kind = pa.VectorBuffer if args.workload.split("_")[1] == "records" else pa.HashMapBuffer
+        dst_kind = pa.VectorBuffer if args.workload.endswith("_records") else pa.HashMapBuffer
+        src = src_kind.new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = dst_kind.new_from_layout(dst_layout)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(src_layout, dst_layout)
         pa.calculate_bounds_async(src, rec.data_ptr())
 
         def step():

@@ -56,6 +56,16 @@ bool launch_convert_static(const ConvertPlan& plan, bool src_aos, bool dst_aos, 
     launch_static<true, true, pststatic::Las1RecordsToXyzIC>(grid, lds_bytes, stream, plan.h, entries);
     return true;
   }
+  {
+    using namespace pststatic;
+    // same-box A/B against the interpreter: records -> columns 0.762 -> 0.766, columns -> records 0.697 -> 0.742, records -> records 0.582 -> 0.716
+    if (src_aos && !dst_aos && plan_equals<BenchSourceToTarget<0, 1024>>(plan)) { launch_static<true, false, BenchSourceToTarget<0, 1024>>(grid, lds_bytes, stream, plan.h, entries); return true; }
+    if (!src_aos && dst_aos && plan_equals<BenchSourceToTarget<1, 1024>>(plan)) { launch_static<false, true, BenchSourceToTarget<1, 1024>>(grid, lds_bytes, stream, plan.h, entries); return true; }
+    if (src_aos && dst_aos && plan_equals<BenchSourceToTarget<2, 1024>>(plan)) {
+      launch_static<true, true, BenchSourceToTarget<2, 512>>(grid, lds_bytes, stream, plan.h, entries);  // same-box sweep: 256 0.564, 384 0.667, 512 0.716, 1024 0.572, 2048 0.370
+      return true;
+    }
+  }
   if (std::getenv("PST_STATIC_DEBUG")) {
     const ConvertHeader& h = plan.h;
     fprintf(stderr, "[pst static] no match: aos %d->%d strides %u %u tile %u quad %u covered %u n %u masks %x %x %x %x %x\n", (int)src_aos, (int)dst_aos, h.src_stride,
