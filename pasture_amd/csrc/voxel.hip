@@ -100,11 +100,24 @@ __global__ __launch_bounds__(kBlock) void voxel_heads_kernel(const KeyT* __restr
   const uint64_t j0 = tile0 + (uint64_t)threadIdx.x * kHeadsPerThread;
   uint32_t flags = 0, cnt = 0;
   KeyT prev = j0 > 0 && j0 <= n ? keys[j0 - 1] : KeyT(0);
+  KeyT kk[kHeadsPerThread];
+  if (j0 + kHeadsPerThread <= n) {  // the thread's eight keys as 16-byte vector loads (32 / 64 contiguous bytes per lane)
+    typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+    const u32x4v* v = reinterpret_cast<const u32x4v*>(keys + j0);
+    constexpr int NV = (int)(sizeof(KeyT) * kHeadsPerThread / 16);
+    u32x4v w[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) w[q] = v[q];
+    __builtin_memcpy(kk, w, sizeof(kk));
+  } else {
+#pragma unroll
+    for (int u = 0; u < kHeadsPerThread; ++u) kk[u] = j0 + u < n ? keys[j0 + u] : KeyT(0);
+  }
 #pragma unroll
   for (int u = 0; u < kHeadsPerThread; ++u) {
     const uint64_t j = j0 + u;
     if (j < n) {
-      const KeyT k = keys[j];
+      const KeyT k = kk[u];
       if (j == 0 || k != prev) { flags |= 1u << u; cnt += 1; }
       prev = k;
     }
