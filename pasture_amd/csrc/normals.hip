@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
     cgptr_t p = (cgptr_t)(uint64_t)base + i * stride;
     const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
-    xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z;
+    if (xyz) { xyz[3 * i] = x; xyz[3 * i + 1] = y; xyz[3 * i + 2] = z; }  // null: the source already is a packed Vec3f64 array
     if (finite3(x, y, z)) {
       mn[0] = __builtin_fmin(mn[0], x); mx[0] = __builtin_fmax(mx[0], x);
       mn[1] = __builtin_fmin(mn[1], y); mx[1] = __builtin_fmax(mx[1], y);
@@ -113,10 +113,15 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
 
 __global__ __launch_bounds__(kBlock) void reorder_kernel(const double* __restrict__ xyz, const uint32_t* __restrict__ idx, uint64_t n,
                                                          double* __restrict__ sorted_xyz) {
+  // one random 24-byte read per point (8-byte aligned): a 16-byte + an 8-byte load, the store side is lane-contiguous
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += step) {
     const uint64_t i = idx[j];
-    sorted_xyz[3 * j] = xyz[3 * i]; sorted_xyz[3 * j + 1] = xyz[3 * i + 1]; sorted_xyz[3 * j + 2] = xyz[3 * i + 2];
+    const d2u xy = *reinterpret_cast<const d2u*>(xyz + 3 * i);
+    const double z = xyz[3 * i + 2];
+    *reinterpret_cast<d2u*>(sorted_xyz + 3 * j) = xy;
+    sorted_xyz[3 * j + 2] = z;
   }
 }
 
@@ -394,6 +399,8 @@ __global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __r
 
 namespace pstk {
 
+namespace { struct XyzRef { const double* p; template <typename T> const T* as() const { return (const T*)p; } }; }
+
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,
 // or the number of degenerate neighbourhoods (> 0).
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
@@ -403,12 +410,16 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   if (n >= 0xFFFFFFF0ull) return -2;  // sorted indices and directory entries are uint32_t
   const unsigned cus = (unsigned)device_cus();
   const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
-  DevBuf xyz, partials, counters;
-  NCK(xyz.alloc(n * 24, stream));
+  // a packed, 8-byte aligned Vec3f64 array (a HashMapBuffer column, an XYZ-only VectorBuffer) is searched in place: no 24 n-byte copy
+  const bool packed_source = pos_stride == 24 && ((uintptr_t)pos_base & 7u) == 0;
+  DevBuf xyz_own, partials, counters;
+  if (!packed_source) NCK(xyz_own.alloc(n * 24, stream));
+  XyzRef xyz{packed_source ? (const double*)pos_base : (const double*)xyz_own.p};
   NCK(partials.alloc((size_t)sgrid * 48, stream));
   NCK(counters.alloc(64, stream));
   NCK(hipMemsetAsync(counters.p, 0, 64, stream));
-  hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, xyz.as<double>(), partials.as<double>());
+  hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, packed_source ? (double*)nullptr : xyz_own.as<double>(),
+                     partials.as<double>());
   std::vector<double> hp((size_t)sgrid * 6);
   NCK(hipMemcpyAsync(hp.data(), partials.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
   NCK(hipStreamSynchronize(stream));
