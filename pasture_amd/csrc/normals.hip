@@ -20,9 +20,11 @@
 // Rust `as`).
 // The reference allocates a HashMapBuffer per point and goes through DMatrix; none of that survives: the 3x3 moment
 // sums live in registers.  f64 throughout (sqrt / atan2 / cos / sin from the device math library); -ffp-contract=off.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "device_sort.hpp"
@@ -399,7 +401,55 @@ __global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __r
 
 namespace pstk {
 
-namespace { struct XyzRef { const double* p; template <typename T> const T* as() const { return (const T*)p; } }; }
+namespace {
+struct XyzRef { const double* p; template <typename T> const T* as() const { return (const T*)p; } };
+
+// Scratch of one compute_normals call (~90 bytes per point in a dozen arrays).  The arrays of a call have the same sizes as those of the
+// previous call on the same cloud, so they are kept in a per-thread cache of device blocks keyed by size and handed out again: the driver is
+// not asked for memory in the steady state.  (Measured with hipMallocAsync / hipFreeAsync per array instead: every ~14th call of a 10^8-point
+// cloud stalled for 0.7-0.9 s inside one of the allocations -- three per stalled call -- with the GPU idle; rocprofv3 showed no long kernel.)
+// Blocks are only reused after the call that used them has synchronised its stream (run_normals ends with a read-back), blocks that went
+// unused while the cache holds more than twice what the last call needed are returned to the driver.
+struct ScratchCache {
+  struct Block { void* p; size_t bytes; bool busy; unsigned idle_calls; };
+  std::vector<Block> blocks;
+  void* take(size_t bytes) {
+    bytes = bytes ? (bytes + 255) & ~(size_t)255 : 256;
+    Block* best = nullptr;
+    for (Block& b : blocks)
+      if (!b.busy && b.bytes >= bytes && b.bytes <= bytes + bytes / 8 + 4096 && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; best->idle_calls = 0; return best->p; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    blocks.push_back(Block{p, bytes, true, 0});
+    return p;
+  }
+  void end_call() {
+    size_t used = 0, held = 0;
+    for (Block& b : blocks) { held += b.bytes; if (b.busy) used += b.bytes; else b.idle_calls += 1; b.busy = false; }
+    if (held > 2 * used) {
+      for (size_t i = 0; i < blocks.size();) {
+        if (blocks[i].idle_calls >= 2) { (void)hipFree(blocks[i].p); blocks[i] = blocks.back(); blocks.pop_back(); }
+        else ++i;
+      }
+    }
+  }
+  ~ScratchCache() { for (Block& b : blocks) (void)hipFree(b.p); }
+};
+ScratchCache& scratch_cache() {
+  static thread_local ScratchCache c;
+  return c;
+}
+struct CacheBuf {  // same surface as DevBuf
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes, hipStream_t) { p = scratch_cache().take(bytes); return p ? hipSuccess : hipErrorOutOfMemory; }
+  template <typename T> T* as() { return (T*)p; }
+};
+struct CallGuard {
+  hipStream_t stream;
+  ~CallGuard() { (void)hipStreamSynchronize(stream); scratch_cache().end_call(); }  // blocks go back only when nothing in flight uses them
+};
+}  // namespace
 
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,
 // or the number of degenerate neighbourhoods (> 0).
@@ -412,7 +462,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
   // a packed, 8-byte aligned Vec3f64 array (a HashMapBuffer column, an XYZ-only VectorBuffer) is searched in place: no 24 n-byte copy
   const bool packed_source = pos_stride == 24 && ((uintptr_t)pos_base & 7u) == 0;
-  DevBuf xyz_own, partials, counters;
+  CallGuard scratch_guard{stream};  // every exit of this function hands the scratch blocks back to the cache (all of them synchronise the stream or fail)
+  CacheBuf xyz_own, partials, counters;
   if (!packed_source) NCK(xyz_own.alloc(n * 24, stream));
   XyzRef xyz{packed_source ? (const double*)pos_base : (const double*)xyz_own.p};
   NCK(partials.alloc((size_t)sgrid * 48, stream));
@@ -482,8 +533,20 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     double per_cell_env = 0.0;
     if (const char* e = std::getenv("PST_KNN_PER_CELL")) per_cell_env = std::atof(e);
     const bool debug = std::getenv("PST_KNN_DEBUG") != nullptr;
+    const bool trace = std::getenv("PST_KNN_TRACE") != nullptr;  // host wall time of every phase (each mark synchronises the stream)
+    auto t_prev = std::chrono::steady_clock::now();
+    std::string trace_line;
+    auto mark = [&](const char* what) {
+      if (!trace) return;
+      (void)hipStreamSynchronize(stream);
+      const auto now = std::chrono::steady_clock::now();
+      char buf[64];
+      snprintf(buf, sizeof buf, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+      trace_line += buf;
+      t_prev = now;
+    };
 
-    DevBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, tkeys, tstarts, fb_list;
+    CacheBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, tkeys, tstarts, fb_list;
     NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
     NCK(sorted_xyz.alloc(n * 24, stream));
     NCK(rec.alloc(n * 32, stream));
@@ -547,7 +610,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // fraction of the 32^3 coarse cells of the bounding box that hold a point (flat axes count as one layer)
     double occupancy = 0.0;
     if (k <= 32 && !std::getenv("PST_KNN_NO_TILE")) {
-      DevBuf occ;
+      CacheBuf occ;
       NCK(occ.alloc(kOccWords * 4, stream));
       NCK(hipMemsetAsync(occ.p, 0, kOccWords * 4, stream));
       double sc[3];
@@ -563,6 +626,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       for (int c = 0; c < 3; ++c) bins *= sc[c] > 0 ? (double)kOccBins : 1.0;
       occupancy = (double)set / bins;
       if (debug) fprintf(stderr, "[pst knn] occupancy of the bounding box at 32^3: %.3f\n", occupancy);
+      mark("occupancy");
     }
     if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && occupancy >= 0.5) {
       double m_target = 1.75 * (double)k;
@@ -577,15 +641,18 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const uint64_t trial_cells = grid_for(h, rx, trial);
         if (!(trial_cells <= std::max<uint64_t>(8 * n, 1u << 20) && trial_cells < 0xFFFFFFF0ull)) break;
         if (!build_index(h, rx, true)) return -1;
+        mark("index");
         if (!nf) break;
         double m_half = 0, m_full = 0;
         if (!knn_probe(sorted_xyz.as<double>(), directory.as<uint32_t>(), g, (uint32_t)nf, scratch3, stream, m_half, m_full)) return -1;
         // N(r) ~ r^D through (h/2, m_half) and (h, m_full); the radius that holds M points
+        mark("probe");
         const double D = std::fmin(3.0, std::fmax(1.0, std::log2(std::fmax(m_full, 1.0) / std::fmax(m_half, 1.0))));
         const double h_new = g.h * std::pow(m_target / std::fmax(m_full, 1.0), 1.0 / D);
         if (debug) fprintf(stderr, "[pst knn probe] h=%g: %.1f points within h/2, %.1f within h (target %.1f), dimension %.2f -> h=%g\n", g.h, m_half, m_full, m_target, D, h_new);
         if (round == 2 || std::fabs(h_new / g.h - 1.0) <= 0.10 || per_cell_env > 0 || std::getenv("PST_KNN_CELL")) {
           tiled = knn_tile_shape(g, nf, cells, k, directory.as<uint32_t>(), scratch3, stream, shape);
+          mark("census");
           break;
         }
         h = h_new;
@@ -612,6 +679,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           uint32_t n_fb = 0;
           NCK(hipMemcpyAsync(&n_fb, fb_count, 4, hipMemcpyDeviceToHost, stream));
           NCK(hipStreamSynchronize(stream));
+          mark("box-search");
           if (debug)
             fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
                     (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.threads,
@@ -639,8 +707,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       hipLaunchKernelGGL(knn_nonfinite_kernel, dim3(grid), dim3(kBlock), 0, stream, xyz.as<double>(), sorted_xyz.as<double>(), (uint32_t)nf, (uint32_t)n, k,
                          sorted);
     }
+    mark("fallback");
     hipLaunchKernelGGL(split_results_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const double*)rec.as<double>(), n, out);
-    NCK(hipGetLastError());  // the temporaries are released stream-ordered (DevBuf): no host round trip here
+    mark("split");
+    if (trace) fprintf(stderr, "[pst knn trace]%s\n", trace_line.c_str());
+    NCK(hipGetLastError());
   }
   NCK(hipGetLastError());
   int errors = 0;
