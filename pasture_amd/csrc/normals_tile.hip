@@ -68,6 +68,7 @@ struct TileArgs {
   uint32_t* fb_count;          // ... and how many
   double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
   unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
+  uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 16
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan
 };
 
@@ -326,11 +327,15 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         p = ldir[Bd + (int)lo_f]; pe = ldir[Bd + (int)hi_f + 1];  // fine cells [lo, hi] of the row, relative to the query's cell
       }
       // A lane whose queue could overflow WAITS (it tests nothing this step) instead of forcing the whole wave into a half-empty
-      // insertion round: the queues are emptied only when no lane can go on scanning, i.e. when nearly every lane holds a full queue
-      // or has finished (measured at 26 queued candidates per query: 71 insertion steps per query wave with flush-on-first-full).
+      // insertion round: the queues are emptied only when (almost) no lane can go on scanning, i.e. when nearly every lane holds a full
+      // queue or has finished (measured at 26 queued candidates per query: 71 insertion steps per query wave with flush-on-first-full).
       const bool room = qn <= (uint32_t)(kQueue - kBatch);
       const uint32_t rem = (p < pe && room) ? pe - p : 0u;
-      if (__any(rem != 0u)) {
+      // With lanes waiting, the wave scans on only while more than flush_at lanes can still scan: waiting for the last stragglers costs
+      // more scan steps than their few queue entries save in the insertion round (same-box sweep of flush_at, box search per 10^8
+      // points: 0: 45.2 ms, 4: 43.5, 8: 43.0, 16: 42.5, 32: 42.6, 48: 43.5, 56: 44.5).
+      const uint64_t can = __ballot(rem != 0u), waiting = __ballot(p < pe && !room);
+      if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch));)
         double cx_[kBatch], cy_[kBatch], cz_[kBatch];
         const uint32_t pb = rem ? p : 0u;  // slots beyond the lane's range are read too (one base address, immediate offsets) and ignored
@@ -559,6 +564,8 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   a.n_boxes = a.nbx * a.nby * nbz;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
   if (const char* e = std::getenv("PST_KNN_ABLATE")) a.ablate = (uint32_t)std::atoi(e);
+  a.flush_at = 16;
+  if (const char* e = std::getenv("PST_KNN_FLUSH_AT")) a.flush_at = (uint32_t)std::atoi(e);
   // A-priori bound on the squared k-th distance: the grid's cell edge h was chosen as the radius of the sphere expected to hold about
   // 1.75 k points (normals.hip), and candidates beyond tau0 = h^2 (less a few ulps for the packed keys) are not even queued.  Without
   // it every candidate passes the "closer than the current k-th" test until a lane's list is full, and about k (1 + ln(N / k)) of N
