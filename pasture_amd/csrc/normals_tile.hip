@@ -112,17 +112,15 @@ struct KBestPacked {
   __device__ __forceinline__ void insert(double x) {  // new[t] = min(old[t], max(old[t-1], x))
     if (!(x < key[K])) return;
     // v_max_f64 / v_min_f64 written out: __builtin_fmin / fmax make hipcc canonicalise every operand first (one extra v_max_f64 per
-    // entry; keys come out of integer bit operations, which it cannot prove to be canonical) -- half again as many f64 operations
-    double prev = -__builtin_inf();
+    // entry; keys come out of integer bit operations, which it cannot prove to be canonical) -- half again as many f64 operations.
+    // From the top down, so that entry t-1 still holds its old value when entry t is rewritten: in place, no register copies.
 #pragma unroll
-    for (int t = 0; t <= K; ++t) {
-      const double kt = key[t];
-      double hi, lo;
-      asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(prev), "v"(x));
-      asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(kt), "v"(hi));
-      key[t] = lo;
-      prev = kt;
+    for (int t = K; t >= 1; --t) {
+      double hi;
+      asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(key[t - 1]), "v"(x));
+      asm("v_min_f64 %0, %1, %2" : "=v"(key[t]) : "v"(key[t]), "v"(hi));
     }
+    asm("v_min_f64 %0, %1, %2" : "=v"(key[0]) : "v"(key[0]), "v"(x));
   }
   __device__ __forceinline__ double kth(uint32_t k) const {  // key[k-1] without dynamic register indexing
     double v = key[K - 1];
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     uint32_t p = 0, pe = 0;
     for (;;) {
       while (p >= pe && seg < kSegs) {
-        const int dz = seg / 3 - 1, dy = seg - (seg / 3) * 3 - 1;
+        const int sz = (seg * 11) >> 5, dz = sz - 1, dy = seg - 3 * sz - 1;  // seg / 3 and seg % 3 for seg < 9, without the integer division
         seg += 1;
         // distance (in units of h) from the query to the slab [dy, dy + 1) x [dz, dz + 1) of rows, relative to its own row
         const float ty = (float)dy - fy, tz = (float)dz - fz;
@@ -321,9 +319,11 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         const float bound = (float)__builtin_fmin(key_upper(best.key[K]), a.tau0) * inv_h2;
         const float r2 = bound - (gy * gy + gz * gz);
         if (!(r2 > 0.0f)) continue;
-        const float ext = __builtin_sqrtf(r2) * rxf;  // half-width of the ball in this row, in fine x cells
+        // half-width of the ball in this row, in fine x cells: the raw v_sqrt_f32 (1 ulp; sqrtf expands into a 20-instruction
+        // correctly-rounded sequence) under the 1e-5 relative slack of rxf and an absolute one for arguments near zero
+        const float ext = __builtin_amdgcn_sqrtf(r2) * rxf + 1e-6f;
         const float lo_f = fmaxf(floorf(fx - ext), -xh), hi_f = fminf(floorf(fx + ext), xh);
-        const int Bd = B + (dz * HY + dy) * NC1;
+        const int Bd = B + __mul24(__mul24(dz, HY) + dy, NC1);  // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
         p = ldir[Bd + (int)lo_f]; pe = ldir[Bd + (int)hi_f + 1];  // fine cells [lo, hi] of the row, relative to the query's cell
       }
       // A lane whose queue could overflow WAITS (it tests nothing this step) instead of forcing the whole wave into a half-empty
@@ -343,13 +343,11 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         for (int u = 0; u < kBatch; ++u) { cx_[u] = P3[pb + u]; cy_[u] = P3[CS + pb + u]; cz_[u] = P3[2 * CS + pb + u]; }
         const double thr = __builtin_fmin(best.key[K], a.tau0);
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          if ((uint32_t)u < rem) {
-            const double key = key_of(cx_[u], cy_[u], cz_[u], p + (uint32_t)u);
-            if (key < thr && !(a.ablate & 8u)) {
-              qbuf[qn * THREADS + tid] = (uint16_t)(p + (uint32_t)u); qn += 1;
-              PST_KNN_STAT(atomicAdd(a.dbg + 4, 1ull);)
-            }
+        for (int u = 0; u < kBatch; ++u) {  // all four keys are computed (no branch per candidate); those past the lane's range never queue
+          const double key = key_of(cx_[u], cy_[u], cz_[u], pb + (uint32_t)u);
+          if ((uint32_t)u < rem && key < thr && !(a.ablate & 8u)) {
+            qbuf[qn * THREADS + tid] = (uint16_t)(pb + (uint32_t)u); qn += 1;
+            PST_KNN_STAT(atomicAdd(a.dbg + 4, 1ull);)
           }
         }
         p += rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch;
