@@ -333,7 +333,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     uint32_t left = kSegs;
     uint32_t p = 0, pe = 0;
     for (;;) {
-      while (p >= pe && left != 0u) {
+      if (p >= pe && left != 0u) {  // ONE shift per step: a lane that drew an empty range idles this step and draws again in the next
         const uint32_t e = ent[0];
 #pragma unroll
         for (int s = 0; s + 1 < kSegs; ++s) ent[s] = ent[s + 1];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
       // With lanes waiting, the wave scans on only while more than flush_at lanes can still scan: waiting for the last stragglers costs
       // more scan steps than their few queue entries save in the insertion round (same-box sweep of flush_at, box search per 10^8
       // points: 0: 45.2 ms, 4: 43.5, 8: 43.0, 16: 42.5, 32: 42.6, 48: 43.5, 56: 44.5).
-      const uint64_t can = __ballot(rem != 0u), waiting = __ballot(p < pe && !room);
+      const uint64_t can = __ballot(rem != 0u || (p >= pe && left != 0u)), waiting = __ballot(p < pe && !room);
       if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch));)
         double cx_[kBatch], cy_[kBatch], cz_[kBatch];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         p += rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch;
       } else {
         if (__any(qn != 0u)) flush();  // ONE inlined copy of the insertion code
-        if (!__any(p < pe)) break;
+        if (!__any(p < pe || left != 0u)) break;
       }
     }
     // Packed keys order candidates by (distance with its low 11 bits dropped, slot).  That IS the exact ascending-distance order, ties
