@@ -279,6 +279,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     KBestPacked<K> best;
     best.init();
     uint32_t qn = 0;  // queued candidates of this lane
+    double thr = a.tau0;  // a candidate is queued when it beats the a-priori bound and the (k+1)-th best key as of the last insertion round
     auto key_of = [&](double x, double y, double z, uint32_t p) __attribute__((always_inline)) {
       const double dx = x - qx, dy = y - qy, dz = z - qz;
       return pack_key(dx * dx + dy * dy + dz * dz, p);
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
       uint32_t p0 = qn > 0 ? qbuf[tid] : 0u;
       uint32_t p1 = qn > 1 ? qbuf[THREADS + tid] : 0u;
       double x0 = P3[p0], y0 = P3[CS + p0], z0 = P3[2 * CS + p0];
+#pragma unroll 2
       for (uint32_t i = 0; i < (uint32_t)kQueue; ++i) {
         const bool has = i < qn;
         if (!__any(has)) break;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
       }
       qn = 0;
+      asm("v_min_f64 %0, %1, %2" : "=v"(thr) : "v"(best.key[K]), "v"(thr));
     };
     // Scan.  Every lane walks its own 9 row segments (the 3 x 3 rows around its cell), own row first, then the four rows that share a
     // face with it, then the diagonals.  BALL TRIMMING per segment, in units of h and f32 with upward slack: a row whose (y, z) slab is
@@ -355,7 +358,6 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         const uint32_t pb = rem ? p : 0u;  // slots beyond the lane's range are read too (one base address, immediate offsets) and ignored
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) { cx_[u] = P3[pb + u]; cy_[u] = P3[CS + pb + u]; cz_[u] = P3[2 * CS + pb + u]; }
-        const double thr = __builtin_fmin(best.key[K], a.tau0);
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {  // all four keys are computed (no branch per candidate); those past the lane's range never queue
           const double key = key_of(cx_[u], cy_[u], cz_[u], pb + (uint32_t)u);
