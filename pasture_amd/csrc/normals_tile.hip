@@ -69,7 +69,7 @@ struct TileArgs {
   double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
   unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
   uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 16
-  uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan
+  uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan, 8 = nothing queued, 16 = no copy, 32 = no records, 64 = empty kernel
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t& total) {
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t box = xcd_block_id();
   if (box >= a.n_boxes) return;
+  if (a.ablate & 64u) return;
   const GridParams& g = a.g;
   const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2];
   const int bxi = (int)(box % a.nbx), byi = (int)((box / a.nbx) % a.nby), bzi = (int)(box / (a.nbx * a.nby));
@@ -175,81 +176,95 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     }
   }
   if (tid == 0) s_next = 0;
-  __syncthreads();
-  for (int r = (int)tid; r < NR; r += THREADS) { g0[r] = raw[r * 32]; rbase[r] = raw[r * 32 + HX] - raw[r * 32]; }
-  __syncthreads();
-  if (wave == 0) {  // exclusive prefix sum of the row lengths: NR <= 144 = 3 entries per lane
+  __syncthreads();  // (1) raw directory in LDS
+  // Every wave works out the row prefix sums for itself (NR <= 144 = 3 rows per lane): the total decides the path without another
+  // barrier, and the wave can request its share of the points before the local directory is written.  Wave 0 publishes the sums.
+  auto qrow_halo = [&](int qr) { return (kHalo + qr / nqy) * HY + kHalo + qr % nqy; };
+  uint32_t total;
+  {
     uint32_t v[3], sum = 0;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; v[u] = r < NR ? rbase[r] : 0u; sum += v[u]; }
-    uint32_t total;
+    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; v[u] = r < NR ? raw[r * 32 + HX] - raw[r * 32] : 0u; sum += v[u]; }
     uint32_t run = wave_excl_scan(sum, lane, total);
+    if (wave == 0) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; if (r < NR) rbase[r] = run; run += v[u]; }
-    if (lane == 0) rbase[NR] = total;
+      for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; if (r < NR) { rbase[r] = run; g0[r] = raw[r * 32]; } run += v[u]; }
+      if (lane == 0) rbase[NR] = total;
+      // D: queries of the box = the points of its bx cells in each of its by * bz rows
+      uint32_t cnt = 0;
+      if ((int)lane < nqr) { const int r = qrow_halo((int)lane); cnt = raw[r * 32 + XH + (int)a.bx] - raw[r * 32 + XH]; }
+      uint32_t tot;
+      const uint32_t ex = wave_excl_scan(cnt, lane, tot);
+      if ((int)lane < nqr) qpre[lane] = ex;
+      if (lane == 0) qpre[nqr] = tot;
+    }
   }
-  __syncthreads();
-  const uint32_t total = rbase[NR];
   if (total == 0) return;
   if (total > (uint32_t)CAP) {
     // the halo does not fit: every query of the box goes to the global-memory search
     for (int qr = (int)wave; qr < nqr; qr += NW) {
-      const int r = (kHalo + qr / nqy) * HY + kHalo + qr % nqy;
+      const int r = qrow_halo(qr);
       const uint32_t s0 = raw[r * 32 + XH], s1 = raw[r * 32 + XH + (int)a.bx];
       for (uint32_t j = s0 + lane; j < s1; j += 64) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
     }
     return;
   }
+  // ---- C: coalesced copy of the row segments, xyz de-interleaved; kRows rows x kChunks 64-double chunks in flight per wave.  The loads
+  //         of the first pass (all rows of a typical box: NW * kRows = 32) are requested HERE, off the raw directory, and land while the
+  //         local directory is written (16-byte loads were measured slower: 9.0 against 7.0 ms for staging + output alone) -------------
+  constexpr int kRows = 8, kChunks = 4;
+  double cv[kRows][kChunks];
+  uint32_t len3[kRows];
+  const bool copy_on = !(a.ablate & 16u);
+#pragma unroll
+  for (int u = 0; u < kRows; ++u) {
+    const int r = (int)wave * kRows + u;
+    const uint32_t first = r < NR ? raw[r * 32] : 0u;
+    len3[u] = r < NR && copy_on ? 3u * (raw[r * 32 + HX] - first) : 0u;
+    const double* src = a.sxyz + 3ull * first;
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) cv[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
+  }
+  __syncthreads();  // (2) row sums published
   // ---- B: local 16-bit directory ----------------------------------------------------------------------------------------------------
   for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
     const int c = (int)(tid & 31u);
     if (c < NC1) ldir[r * NC1 + c] = (uint16_t)(raw[r * 32 + c] - g0[r] + rbase[r]);
   }
-  __syncthreads();  // the raw directory is dead: the coordinate arrays can be filled
-  // ---- C: coalesced copy of the row segments, xyz de-interleaved; kRows rows x kChunks 64-double chunks in flight per wave ----------
+  __syncthreads();  // (3) the raw directory is dead: the coordinate arrays can be filled
   {
-    constexpr int kRows = 4, kChunks = 4;  // (16-byte loads were measured slower here: 9.0 against 7.0 ms for staging + output alone)
     auto put = [&](uint32_t base, uint32_t e, double v) __attribute__((always_inline)) {
       const uint32_t pt = e / 3u, c = e - 3u * pt;
       P3[c * CS + base + pt] = v;
     };
-    for (int r0 = (int)wave * kRows; r0 < NR; r0 += NW * kRows) {
-      double v[kRows][kChunks];
-      uint32_t len3[kRows];
-#pragma unroll
-      for (int u = 0; u < kRows; ++u) {
-        const int r = r0 + u;
-        len3[u] = r < NR ? 3u * (rbase[r + 1] - rbase[r]) : 0u;
-        const double* src = a.sxyz + 3ull * (r < NR ? g0[r] : 0u);
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) v[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
-      }
+    auto store_rows = [&](int r0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < kRows; ++u) {
         const int r = r0 + u;
         if (r >= NR) continue;
         const uint32_t base = rbase[r];
 #pragma unroll
-        for (int c = 0; c < kChunks; ++c) if (lane + 64u * c < len3[u]) put(base, lane + 64u * c, v[u][c]);
+        for (int c = 0; c < kChunks; ++c) if (lane + 64u * c < len3[u]) put(base, lane + 64u * c, cv[u][c]);
         if (len3[u] > 64u * kChunks) {
           const double* src = a.sxyz + 3ull * g0[r];
           for (uint32_t e = lane + 64u * kChunks; e < len3[u]; e += 64) put(base, e, src[e]);
         }
       }
+    };
+    store_rows((int)wave * kRows);
+    for (int r0 = (NW + (int)wave) * kRows; r0 < NR && copy_on; r0 += NW * kRows) {  // boxes with more than NW * kRows rows
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = r0 + u;
+        len3[u] = r < NR ? 3u * (rbase[r + 1] - rbase[r]) : 0u;
+        const double* src = a.sxyz + 3ull * (r < NR ? g0[r] : 0u);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) cv[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
+      }
+      store_rows(r0);
     }
   }
-  __syncthreads();
-  // ---- D: queries of the box = the points of its bx cells in each of its by * bz rows ----------------------------------------------
-  auto qrow_halo = [&](int qr) { return (kHalo + qr / nqy) * HY + kHalo + qr % nqy; };
-  if (wave == 0) {
-    uint32_t cnt = 0;
-    if ((int)lane < nqr) { const int r = qrow_halo((int)lane); cnt = (uint32_t)ldir[r * NC1 + XH + (int)a.bx] - (uint32_t)ldir[r * NC1 + XH]; }
-    uint32_t tot;
-    const uint32_t ex = wave_excl_scan(cnt, lane, tot);
-    if ((int)lane < nqr) qpre[lane] = ex;
-    if (lane == 0) qpre[nqr] = tot;
-  }
-  __syncthreads();
+  __syncthreads();  // (4) points staged
   const uint32_t Q = qpre[nqr];
   const uint32_t m = a.nf < a.k ? a.nf : a.k;
 
@@ -272,6 +287,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     const uint32_t slot = active ? (uint32_t)ldir[hr * NC1 + XH] + (q - qpre[qr]) : 0u;
     const double qx = P3[slot], qy = P3[CS + slot], qz = P3[2 * CS + slot];
     const uint32_t j = g0[hr] + (slot - rbase[hr]);  // index among the sorted points
+    const uint32_t orig = active ? a.out.sidx[j] : 0u;  // requested now: the round trip hides behind the search
     // the row (y, z) is the query row; the cell along x comes from the coordinate (same arithmetic as keys_kernel)
     const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
     const int B = hr * NC1 + (active ? cx - X0 + XH : XH);  // directory entry of the query's own cell (idle lanes: any valid one)
@@ -395,8 +411,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     // the query's cell) and inside the trims, which were cut with bounds that only shrank afterwards -- the list is complete
     const bool done = a.ablate ? true : exact && best.kth(a.k) < a.tau0;
     if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
-    if (active && done) {
-      const uint64_t orig = a.out.sidx[j];
+    if (active && done && !(a.ablate & 32u)) {
       if constexpr (WITH_KNN) {
         for (uint32_t t = 0; t < a.k; ++t) {
           uint32_t v = kNoIndex;
@@ -547,7 +562,7 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
   const double rho = (double)nf / (double)cells;  // points per fine cell, averaged over the whole grid: the first guess
   double budget = 0.90 * (double)t.cap / rho;
   TileShape last{};
-  for (int attempt = 0; attempt < 8; ++attempt, budget *= 0.7) {
+  for (int attempt = 0; attempt < 14; ++attempt, budget *= 0.85) {
     TileShape c = t;
     if (!best_box(g, budget, c)) break;
     if (c.bx == last.bx && c.by == last.by && c.bz == last.bz) continue;
