@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
       for (int u = 0; u < K; ++u) if ((uint32_t)u == t && t < m) v = best.i[u];
       write_knn(out, orig, k, t, v == kNoIndex ? kNoIndex : out.sidx[v]);
     }
-  const Fit f = plane_fit<K>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+  const Fit f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
     uint32_t p = 0;
 #pragma unroll
     for (int u = 0; u < K; ++u) if ((uint32_t)u == t) p = best.i[u];

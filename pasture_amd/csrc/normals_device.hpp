@@ -77,7 +77,9 @@ struct Fit { double nx, ny, nz, curvature; int ok; };
 
 // KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
 // compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
-template <int KMAX = 0, typename GetPoint>
+// FINITE: the caller guarantees finite coordinates (the grid search only ever sees the finite points): the NaN / finiteness tests per
+// neighbour, which then cannot change anything, are not compiled in.
+template <int KMAX = 0, bool FINITE = false, typename GetPoint>
 __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   Fit f{0, 0, 0, 0, 1};
   auto for_each = [&](auto&& body) __attribute__((always_inline)) {
@@ -97,9 +99,11 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   long long cnt = 0;
   for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
-    if (x != x || y != y || z != z) dense = false;
     ax += x; ay += y; az += z;
-    if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
+    if constexpr (!FINITE) {
+      if (x != x || y != y || z != z) dense = false;
+      if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
+    }
   });
   const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
   const double div = dense ? (double)m : (double)cnt;
@@ -109,7 +113,7 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   long long used = 0;
   for_each([&](uint32_t t) __attribute__((always_inline)) {
     double x, y, z; get(t, x, y, z);
-    if (dense || finite3(x, y, z)) {
+    if (FINITE || dense || finite3(x, y, z)) {
       double d0 = x - cx, d1 = y - cy, d2 = z - cz;
       c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
       const double dx = d0;

@@ -68,7 +68,8 @@ struct TileArgs {
   uint32_t* fb_count;          // ... and how many
   double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
   unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
-  uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 16
+  double tau0_below;           // the largest double below tau0
+  uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 48
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan, 8 = nothing queued, 16 = no copy, 32 = no records, 64 = empty kernel
 };
 
@@ -295,7 +296,10 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     KBestPacked<K> best;
     best.init();
     uint32_t qn = 0;  // queued candidates of this lane
-    double thr = a.tau0;  // a candidate is queued when it beats the a-priori bound and the (k+1)-th best key as of the last insertion round
+    // A candidate is queued when its squared distance is below the a-priori bound AND not above the (k+1)-th best key as of the last
+    // insertion round with its slot bits set (key_upper: every distance whose packed key could still be smaller).  The plain f64
+    // distance is compared: packing happens in the insertion round only.
+    double lim = a.tau0_below;
     auto key_of = [&](double x, double y, double z, uint32_t p) __attribute__((always_inline)) {
       const double dx = x - qx, dy = y - qy, dz = z - qz;
       return pack_key(dx * dx + dy * dy + dz * dz, p);
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
       }
       qn = 0;
-      asm("v_min_f64 %0, %1, %2" : "=v"(thr) : "v"(best.key[K]), "v"(thr));
+      const double ku = best.key[K] < __builtin_inf() ? key_upper(best.key[K]) : lim;  // (+inf with the slot bits set would be a NaN)
+      asm("v_min_f64 %0, %1, %2" : "=v"(lim) : "v"(ku), "v"(lim));
     };
     // Scan.  Every lane walks its own 9 row segments (the 3 x 3 rows around its cell), own row first, then the four rows that share a
     // face with it, then the diagonals.  BALL TRIMMING per segment, in units of h and f32 with upward slack: a row whose (y, z) slab is
@@ -370,16 +375,19 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
       const uint64_t can = __ballot(rem != 0u || (p >= pe && left != 0u)), waiting = __ballot(p < pe && !room);
       if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch));)
-        double cx_[kBatch], cy_[kBatch], cz_[kBatch];
-        const uint32_t pb = rem ? p : 0u;  // slots beyond the lane's range are read too (one base address, immediate offsets) and ignored
+        if (rem != 0u) {  // ONE predicate per step; inside, nothing branches and the execution mask stays put
+          double cx_[kBatch], cy_[kBatch], cz_[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) { cx_[u] = P3[pb + u]; cy_[u] = P3[CS + pb + u]; cz_[u] = P3[2 * CS + pb + u]; }
+          for (int u = 0; u < kBatch; ++u) { cx_[u] = P3[p + u]; cy_[u] = P3[CS + p + u]; cz_[u] = P3[2 * CS + p + u]; }  // (past the range: read, then ignored)
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {  // all four keys are computed (no branch per candidate); those past the lane's range never queue
-          const double key = key_of(cx_[u], cy_[u], cz_[u], pb + (uint32_t)u);
-          if ((uint32_t)u < rem && key < thr && !(a.ablate & 8u)) {
-            qbuf[qn * THREADS + tid] = (uint16_t)(pb + (uint32_t)u); qn += 1;
-            PST_KNN_STAT(atomicAdd(a.dbg + 4, 1ull);)
+          for (int u = 0; u < kBatch; ++u) {
+            const double dx = cx_[u] - qx, dy = cy_[u] - qy, dz = cz_[u] - qz;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            // the slot is written in any case (a scanning lane has room for kBatch entries) and kept if the candidate passes
+            qbuf[qn * THREADS + tid] = (uint16_t)(p + (uint32_t)u);
+            const bool pass = ((uint32_t)u < rem) & (d2 <= lim) & !(a.ablate & 8u);
+            PST_KNN_STAT(if (pass) atomicAdd(a.dbg + 4, 1ull);)
+            qn += pass ? 1u : 0u;
           }
         }
         p += rem < (uint32_t)kBatch ? rem : (uint32_t)kBatch;
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
         }
       }
       Fit f{0, 0, 0, 0, 1};
-      if (!(a.ablate & 2u)) f = plane_fit<K>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+      if (!(a.ablate & 2u)) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
         uint32_t pl = 0;
 #pragma unroll
         for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = key_slot(best.key[u]);
@@ -593,7 +601,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   a.n_boxes = a.nbx * a.nby * nbz;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
   if (const char* e = std::getenv("PST_KNN_ABLATE")) a.ablate = (uint32_t)std::atoi(e);
-  a.flush_at = 16;
+  a.flush_at = 48;
   if (const char* e = std::getenv("PST_KNN_FLUSH_AT")) a.flush_at = (uint32_t)std::atoi(e);
   // A-priori bound on the squared k-th distance: the grid's cell edge h was chosen as the radius of the sphere expected to hold about
   // 1.75 k points (normals.hip), and candidates beyond tau0 = h^2 (less a few ulps for the packed keys) are not even queued.  Without
@@ -602,6 +610,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   // fewer than k candidates inside tau0 goes to the exact global-memory search like any other unfinished query (about 1 % of a uniform
   // cloud's queries), and tau0 < h^2 is also what makes 3 x 3 rows of cells enough.
   a.tau0 = g.h * g.h * (1.0 - 4e-9);
+  a.tau0_below = std::nextafter(a.tau0, 0.0);
 #ifdef PST_KNN_STATS
   static unsigned long long* dbg_dev = nullptr;
   {
