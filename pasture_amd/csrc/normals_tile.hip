@@ -123,6 +123,15 @@ struct KBestPacked {
     }
     asm("v_min_f64 %0, %1, %2" : "=v"(key[0]) : "v"(key[0]), "v"(x));
   }
+  __device__ __forceinline__ void insert_always(double x) {  // the same without the early exit (x = +inf is a no-op): no execution-mask traffic
+#pragma unroll
+    for (int t = K; t >= 1; --t) {
+      double hi;
+      asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(key[t - 1]), "v"(x));
+      asm("v_min_f64 %0, %1, %2" : "=v"(key[t]) : "v"(key[t]), "v"(hi));
+    }
+    asm("v_min_f64 %0, %1, %2" : "=v"(key[0]) : "v"(key[0]), "v"(x));
+  }
   __device__ __forceinline__ double kth(uint32_t k) const {  // key[k-1] without dynamic register indexing
     double v = key[K - 1];
 #pragma unroll
@@ -177,6 +186,8 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     }
   }
   if (tid == 0) s_next = 0;
+#pragma unroll
+  for (int i = 0; i < kQueue; ++i) qbuf[i * THREADS + tid] = 0;  // stale queue entries are read (never used): they must be valid slots
   __syncthreads();  // (1) raw directory in LDS
   // Every wave works out the row prefix sums for itself (NR <= 144 = 3 rows per lane): the total decides the path without another
   // barrier, and the wave can request its share of the points before the local directory is written.  Wave 0 publishes the sums.
@@ -307,17 +318,19 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     // Batched insertion, software-pipelined: the slot of entry i+2 and the coordinates of entry i+1 are requested before entry i is
     // inserted, so the LDS round trips hide behind the insertion's VALU work.
     auto flush = [&]() __attribute__((always_inline)) {
-      uint32_t p0 = qn > 0 ? qbuf[tid] : 0u;
-      uint32_t p1 = qn > 1 ? qbuf[THREADS + tid] : 0u;
+      // nothing here is predicated per lane: a lane without an entry reads a stale (valid) slot and inserts +inf, which changes nothing
+      uint32_t p0 = qbuf[tid];
+      uint32_t p1 = qbuf[THREADS + tid];
       double x0 = P3[p0], y0 = P3[CS + p0], z0 = P3[2 * CS + p0];
 #pragma unroll 2
       for (uint32_t i = 0; i < (uint32_t)kQueue; ++i) {
         const bool has = i < qn;
         if (!__any(has)) break;
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 1, 1ull);)
-        const uint32_t p2 = i + 2 < qn ? qbuf[(i + 2) * THREADS + tid] : 0u;
+        const uint32_t p2 = qbuf[(i + 2 < (uint32_t)kQueue ? i + 2 : (uint32_t)kQueue - 1u) * THREADS + tid];
         const double x1 = P3[p1], y1 = P3[CS + p1], z1 = P3[2 * CS + p1];
-        if (has && !(a.ablate & 1u)) best.insert(key_of(x0, y0, z0, p0));
+        const double key = key_of(x0, y0, z0, p0);
+        if (!(a.ablate & 1u)) best.insert_always(has ? key : __builtin_inf());
         p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
       }
       qn = 0;
