@@ -1,5 +1,6 @@
 // rocPRIM calls of the spatial-index builders, isolated in one translation unit (the headers are heavy).
 #include <cstring>
+#include <iterator>
 
 #include <rocprim/rocprim.hpp>
 
@@ -17,6 +18,10 @@ hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uin
 }
 hipError_t exclusive_sum_u32_u64(void* tmp, size_t& bytes, const uint32_t* in, unsigned long long* out, size_t n, hipStream_t stream) {
   return rocprim::exclusive_scan(tmp, bytes, in, out, 0ull, n, rocprim::plus<unsigned long long>(), stream);
+}
+hipError_t suffix_min_u32(void* tmp, size_t& bytes, uint32_t* data, size_t n, hipStream_t stream) {
+  auto rev = std::make_reverse_iterator(data + n);
+  return rocprim::inclusive_scan(tmp, bytes, rev, rev, n, rocprim::minimum<uint32_t>(), stream);
 }
 
 }  // namespace pstk

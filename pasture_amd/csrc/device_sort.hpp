@@ -16,6 +16,9 @@ hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uin
 // exclusive prefix sum of u32 counts into u64 offsets (out[0] = 0)
 hipError_t exclusive_sum_u32_u64(void* tmp, size_t& bytes, const uint32_t* in, unsigned long long* out, size_t n, hipStream_t stream);
 
+// in place: data[i] = min(data[i], data[i + 1], ..., data[n - 1])  (a directory whose run heads were scattered into a 0xFFFFFFFF-filled array)
+hipError_t suffix_min_u32(void* tmp, size_t& bytes, uint32_t* data, size_t n, hipStream_t stream);
+
 // stream-ordered scratch from the library's allocator (pst::dev_alloc / dev_free: HIP's stream-ordered pool, or plain hipMalloc
 // when the device has no pool support or PST_NO_POOL is set); freed in stream order by the destructor
 struct DevBuf {
