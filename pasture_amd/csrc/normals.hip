@@ -565,8 +565,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     uint64_t cells = 0, nf = 0;
     CellTable table{nullptr, nullptr, 0};
     // The spatial index for a given grid: keys, radix sort, reorder, and the dense directory or the hash table.  Returns false on a HIP failure.
-    auto build_index = [&](double h, uint32_t rx, bool dense) -> bool {
+    // (src, cnt): the points to index -- all of them, or the subsample the density estimate below works on
+    auto build_index = [&](double h, uint32_t rx, bool dense, const double* src = nullptr, uint64_t cnt = 0) -> bool {
 #define BCK(x) do { if ((x) != hipSuccess) return false; } while (0)
+      if (!src) { src = xyz.as<double>(); cnt = n; }
       cells = grid_for(h, rx, g);
       g.dense = dense ? 1u : 0u;
       unsigned key_bits = 64;
@@ -574,17 +576,17 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       BCK(hipMemsetAsync(counters.p, 0, 16, stream));
       size_t tmp_bytes = 0;
       if (dense) {
-        hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
-        BCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
+        BCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
         BCK(tmp.alloc(tmp_bytes, stream));
-        BCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        BCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
       } else {
-        hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
-        BCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+        BCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
         BCK(tmp.alloc(tmp_bytes, stream));
-        BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, key_bits, stream));
+        BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
       }
-      hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), idx2.as<uint32_t>(), n, sorted_xyz.as<double>());
+      hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
       unsigned long long h_counts[2] = {0, 0};
       BCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
       BCK(hipStreamSynchronize(stream));
@@ -648,18 +650,51 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (debug) fprintf(stderr, "[pst knn] occupancy of the bounding box at 32^3: %.3f\n", occupancy);
       mark("occupancy");
     }
-    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || std::getenv("PST_KNN_FORCE_TILE"))) {
+    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
       double m_target = 1.75 * (double)k;
       if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
-      uint32_t rx = 4;
+      // fine x cells per h: 4 for clouds that fill their box; 2 for the others (a surface: the same box holds fewer points, the 31-cell limit of a
+      // box row then makes boxes too short at rx = 4: 6.3 against 3.9 ms per 10^7 points of the sheet in tools/exp_normals_surface.py)
+      uint32_t rx = occupancy < 0.5 ? 2 : 4;
       if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
       double h = edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
+      // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
+      // times too large, and an index built with it is thrown away) the density is measured first on a 1-in-16 SUBSAMPLE: a small index
+      // with the subsample's own first guess, the probe's power law N_s(r) = N_s(h_s) (r / h_s)^D through h_s / 2 and h_s, and the radius
+      // at which the FULL cloud (16 N_s) holds M points.  A sixteenth of the index cost instead of a wasted index.
+      if (occupancy < 0.9 && n >= (1u << 20) && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL")) {
+        const uint64_t S = 16, n_s = n / S;
+        CacheBuf xyz_s;
+        NCK(xyz_s.alloc(n_s * 24, stream));
+        hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_s, xyz_s.as<double>(),
+                           partials.as<double>());
+        double h_s = h * std::cbrt((double)S);
+        for (int round = 0; round < 2; ++round) {
+          GridParams trial{};
+          uint32_t rx_s = 1;
+          if (!(grid_for(h_s, rx_s, trial) <= std::max<uint64_t>(8 * n_s, 1u << 20))) break;
+          if (!build_index(h_s, rx_s, true, xyz_s.as<double>(), n_s)) return -1;
+          if (!nf) break;
+          double m_half = 0, m_full = 0;
+          if (!knn_probe(sorted_xyz.as<double>(), directory.as<uint32_t>(), g, (uint32_t)nf, scratch3, stream, m_half, m_full)) return -1;
+          const double D = std::fmin(3.0, std::fmax(1.0, std::log2(std::fmax(m_full, 1.0) / std::fmax(m_half, 1.0))));
+          // N_full(r) = S * m_full * (r / h_s)^D = M
+          const double h_full = g.h * std::pow(m_target / ((double)S * std::fmax(m_full, 1.0)), 1.0 / D);
+          if (debug) fprintf(stderr, "[pst knn subsample] h_s=%g: %.1f points within h_s/2, %.1f within h_s, dimension %.2f -> h=%g (volume guess %g)\n", g.h, m_half, m_full, D, h_full, h);
+          // a probe that sees fewer than ~4 or more than ~200 points is off the power law's useful range: once more with a better h_s
+          if (round == 0 && (m_full < 4.0 || m_full > 200.0)) { h_s = g.h * std::pow(16.0 / std::fmax(m_full, 0.25), 1.0 / D); continue; }
+          h = h_full;
+          break;
+        }
+        mark("subsample");
+      }
       for (int round = 0; round < 3; ++round) {
         GridParams trial{};
-        // (clustered clouds leave cells empty: 4 bytes each, up to 8 per point are accepted here)
+        // (clustered clouds and surfaces leave cells empty: 4 bytes each, up to 12 per point are accepted here)
         uint64_t trial_cells = grid_for(h, rx, trial);
-        static const uint64_t budget_mult = [] { const char* e = std::getenv("PST_KNN_CELL_BUDGET"); const long v = e ? std::atol(e) : 0; return (uint64_t)(v > 0 ? v : 8); }();
+        const char* budget_env = std::getenv("PST_KNN_CELL_BUDGET");  // cells per point the dense directory may take (default 12: 48 bytes per point)
+        const uint64_t budget_mult = budget_env && std::atol(budget_env) > 0 ? (uint64_t)std::atol(budget_env) : 12;
         const uint64_t cell_budget = std::max<uint64_t>(budget_mult * n, 1u << 20);
         while (rx > 1 && !(trial_cells <= cell_budget && trial_cells < 0xFFFFFFF0ull)) { rx >>= 1; trial_cells = grid_for(h, rx, trial); }  // coarser x cells before giving up
         if (!(trial_cells <= cell_budget && trial_cells < 0xFFFFFFF0ull)) break;

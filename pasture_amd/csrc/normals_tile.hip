@@ -583,7 +583,9 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
   const double rho = (double)nf / (double)cells;  // points per fine cell, averaged over the whole grid: the first guess
   double budget = 0.90 * (double)t.cap / rho;
   TileShape last{};
-  for (int attempt = 0; attempt < 14; ++attempt, budget *= 0.85) {
+  double shrink = 1.0;
+  for (int attempt = 0; attempt < 14; ++attempt) {
+    budget *= shrink;
     TileShape c = t;
     if (!best_box(g, budget, c)) break;
     if (c.bx == last.bx && c.by == last.by && c.bz == last.bz) continue;
@@ -600,6 +602,8 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
       fprintf(stderr, "[pst knn census] box %ux%ux%u: halo amplification %.2f, %.2f %% of the queries in boxes over capacity\n", c.bx, c.by, c.bz,
               h[0] ? (double)h[1] / (double)h[0] : 0.0, h[0] ? 100.0 * (double)h[2] / (double)h[0] : 0.0);
     if (h[0] && (double)h[2] <= 0.02 * (double)h[0]) { t.bx = c.bx; t.by = c.by; t.bz = c.bz; return true; }
+    // most queries lost: the cloud is locally several times denser than its grid average (a surface): big steps down; otherwise fine ones
+    shrink = h[0] && (double)h[2] > 0.5 * (double)h[0] ? 0.6 : 0.85;
   }
   return false;
 }

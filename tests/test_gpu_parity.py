@@ -459,6 +459,29 @@ def test_compute_normals_degenerate_clouds_vs_oracle(hip, oracle, name):
     assert bad.sum() == 0 and cbad.sum() == 0
 
 
+@pytest.mark.parametrize("shape,n,budget", [("surface", 60_000, None), ("surface", 60_000, "2"), ("two_planes", 30_000, None)])
+def test_box_search_forced_on_sparse_clouds_vs_oracle(hip, oracle, monkeypatch, shape, n, budget):
+    """Clouds that leave most cells of their bounding box empty normally keep the global-memory search (occupancy test).  Forced through the
+    box search (PST_KNN_FORCE_TILE) they exercise what that path does for sparse grids: the directory built from scattered run heads + a
+    suffix minimum, and -- with a small cell budget -- the coarser x cells (rx 4 -> 2 -> 1).  Lists and normals must not change."""
+    from pasture_amd.algorithms import compute_normals
+    pts = _degenerate_cloud(shape) if shape == "two_planes" else _normals_inputs(n, 5, shape)
+    n, k = len(pts), 16
+    monkeypatch.setenv("PST_KNN_FORCE_TILE", "1")
+    if budget:
+        monkeypatch.setenv("PST_KNN_CELL_BUDGET", budget)
+
+    def run(api):
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    assert np.array_equal(hk, ok)
+    bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
+    assert bad.sum() == 0 and cbad.sum() == 0
+
+
 @pytest.mark.parametrize("n_side,k", [(48, 16), (40, 8), (36, 27)])
 def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
     """LAS coordinates are integers times a scale: equal distances are the rule, not the exception.  On a jittered-then-quantised lattice
