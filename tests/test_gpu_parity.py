@@ -426,6 +426,55 @@ def test_full_size_1e8_knn_normals_properties(hip, oracle):
     assert torch.equal(_torch_view(out.column_ptr(curv_def), n * 8).view(torch.float64), curv)
 
 
+def test_surface_cloud_4e6_knn_normals_properties(hip, oracle):
+    """A LiDAR-like sheet (2-D manifold in a 3-D box, 23 % of the coarse cells occupied) large enough for the box search: the cell edge comes
+    from the density probe of a 1-in-16 subsample (the bounding box's volume is 2-3 times off), the directory is the sparse build, rx = 2.
+    Same checks as the 10^8-point test: self first, sorted lists, 1 024 sampled queries against an on-device brute force, 128 of them
+    against the oracle's plane fit."""
+    import torch
+    from pasture_amd.algorithms import compute_normals, compute_normals_device
+    from pasture_amd.buffers import ExternalColumnsBuffer
+    n, k = 4_000_000, 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    xy = torch.rand(n, 2, device="cuda", dtype=torch.float64, generator=g) * 1000.0
+    z = 10.0 * torch.sin(xy[:, 0] / 50.0) * torch.cos(xy[:, 1] / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+    pts = torch.cat([xy, z[:, None]], dim=1).contiguous()
+    src = ExternalColumnsBuffer([pts], PointLayout.from_attributes([A.POSITION_3D], api=hip), n)
+    normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    curv = torch.empty(n, dtype=torch.float64, device="cuda")
+    knn = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
+    assert bool(torch.isfinite(normals).all()) and bool(torch.isfinite(curv).all()) and bool((curv >= 0).all())
+    kk = knn.long()
+    assert bool((kk[:, 0] == torch.arange(n, device="cuda")).all()), "a point is not its own nearest neighbour"
+    d = ((pts[kk.reshape(-1)].view(n, k, 3) - pts[:, None, :]) ** 2).sum(dim=2)
+    assert bool((d[:, 1:] >= d[:, :-1]).all()) and bool((d[:, 1:] > 0).all())
+    del d
+    gc = torch.Generator(device="cpu")
+    gc.manual_seed(9)
+    sample = torch.cat([torch.randint(0, n, (1024,), generator=gc), pts.argmin(dim=0).cpu(), pts.argmax(dim=0).cpu()])
+    hn, hc = normals.cpu(), curv.cpu()
+    checked = 0
+    for q in sample.tolist():
+        dq = ((pts - pts[q]) ** 2).sum(dim=1)
+        dist, want = torch.topk(dq, k, largest=False, sorted=True)
+        got = kk[q]
+        if not bool((want == got).all()):
+            dg = ((pts[got] - pts[q]) ** 2).sum(dim=1)
+            assert bool((dg == dist).all()), f"query {q}: neighbour distances differ from brute force"
+        if checked < 128:
+            checked += 1
+            nb = pts[got].cpu().numpy()
+            ob = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=oracle))
+            ob.resize(k)
+            ob.set_attribute_range(A.POSITION_3D, range(0, k), nb)
+            on, oc = compute_normals(ob, k)
+            dev = nb - nb.mean(axis=0)
+            bad, cbad = _compare_normals(hn[q:q + 1].numpy(), hc[q:q + 1].numpy(), on[:1], oc[:1], scales=np.array([np.abs(dev.T @ dev).max()]))
+            assert not bad.any() and not cbad.any(), f"query {q}: normal {hn[q].tolist()} vs oracle {on[0].tolist()}"
+
+
 def _degenerate_cloud(name):
     rng = np.random.default_rng(3)
     if name == "flat_plane":   # one grid layer: every halo row above and below is outside the grid
