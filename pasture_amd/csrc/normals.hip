@@ -628,6 +628,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     //    (volume-like data) -- 3. else Morton keys + hash table with ~k/3 points per cell.
     TileShape shape;
     bool tiled = false;
+    double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
     // fraction of the 32^3 coarse cells of the bounding box that hold a point (flat axes count as one layer)
     double occupancy = 0.0;
@@ -660,34 +661,27 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
       double h = edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
       // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
-      // times too large, and an index built with it is thrown away) the density is measured first on a 1-in-16 SUBSAMPLE: a small index
-      // with the subsample's own first guess, the probe's power law N_s(r) = N_s(h_s) (r / h_s)^D through h_s / 2 and h_s, and the radius
-      // at which the FULL cloud (16 N_s) holds M points.  A sixteenth of the index cost instead of a wasted index.
-      if (occupancy < 0.9 && n >= (1u << 20) && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL")) {
-        const uint64_t S = 16, n_s = n / S;
-        CacheBuf xyz_s;
+      // times too large; separate clusters: orders of magnitude) the scale is MEASURED first, without an index (normals_scale.hip): distance
+      // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
+      // around a typical point, and its local dimension.
+      if (occupancy < 0.9 && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+        // the subsample: a sixteenth of the cloud, at least 2^20 and at most 2^22 points (the further the thinning, the longer the extrapolation
+        // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
+        const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
+        const uint64_t S = (n + cap_s - 1) / cap_s, n_s = n / S;
+        CacheBuf xyz_s, hist_s;
         NCK(xyz_s.alloc(n_s * 24, stream));
+        NCK(hist_s.alloc(knn_scale_scratch_bytes(), stream));
         hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_s, xyz_s.as<double>(),
                            partials.as<double>());
-        double h_s = h * std::cbrt((double)S);
-        for (int round = 0; round < 2; ++round) {
-          GridParams trial{};
-          uint32_t rx_s = 1;
-          if (!(grid_for(h_s, rx_s, trial) <= std::max<uint64_t>(8 * n_s, 1u << 20))) break;
-          if (!build_index(h_s, rx_s, true, xyz_s.as<double>(), n_s)) return -1;
-          if (!nf) break;
-          double m_half = 0, m_full = 0;
-          if (!knn_probe(sorted_xyz.as<double>(), directory.as<uint32_t>(), g, (uint32_t)nf, scratch3, stream, m_half, m_full)) return -1;
-          const double D = std::fmin(3.0, std::fmax(1.0, std::log2(std::fmax(m_full, 1.0) / std::fmax(m_half, 1.0))));
-          // N_full(r) = S * m_full * (r / h_s)^D = M
-          const double h_full = g.h * std::pow(m_target / ((double)S * std::fmax(m_full, 1.0)), 1.0 / D);
-          if (debug) fprintf(stderr, "[pst knn subsample] h_s=%g: %.1f points within h_s/2, %.1f within h_s, dimension %.2f -> h=%g (volume guess %g)\n", g.h, m_half, m_full, D, h_full, h);
-          // a probe that sees fewer than ~4 or more than ~200 points is off the power law's useful range: once more with a better h_s
-          if (round == 0 && (m_full < 4.0 || m_full > 200.0)) { h_s = g.h * std::pow(16.0 / std::fmax(m_full, 0.25), 1.0 / D); continue; }
-          h = h_full;
-          break;
+        double h_m = 0, dim_m = 3;
+        if (knn_scale_estimate(xyz_s.as<double>(), (uint32_t)n_s, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_s.as<unsigned int>(), stream,
+                               h_m, dim_m)) {
+          if (debug) fprintf(stderr, "[pst knn scale] %llu of %llu points: %.1f points within h=%g, dimension %.2f (volume guess %g)\n", (unsigned long long)n_s,
+                             (unsigned long long)n, m_target, h_m, dim_m, h);
+          h = h_m; h_est = h_m; d_est = dim_m;
         }
-        mark("subsample");
+        mark("scale");
       }
       for (int round = 0; round < 3; ++round) {
         GridParams trial{};
@@ -718,11 +712,24 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     }
     bool dense = tiled;
     if (!tiled) {
-      const double h_vol = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0));
+      // Cubic cells of ~k/12 points (dense directory) or ~k/3 points (hash table) -- by the bounding box's volume, or, where the scale was
+      // MEASURED above (a cloud that does not fill its box and did not fit the box search's directory budget either), by that: the ball of
+      // radius h_est holds M points and N(r) ~ r^D; a cubic cell of edge h holds about what a ball of radius c_D h does (c = 0.62 in 3-D,
+      // 0.56 in 2-D, 0.5 in 1-D).  A cloud of dimension D occupies 3^D of the 27 cells of the first shell, so the cell's share is scaled by
+      // 3^(3-D): the first shell then holds the same number of candidates whatever the dimension.
+      double h_dense = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0));
+      double h_hash = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0));
+      if (h_est > 0.0 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL")) {
+        const double c_d = 0.44 + 0.06 * d_est, shells = std::pow(3.0, 3.0 - d_est), m_ball = 1.75 * (double)k;
+        const double hd = h_est / c_d * std::pow(std::fmax(0.5, (double)k / 12.0) * shells / m_ball, 1.0 / d_est);
+        const double hh = h_est / c_d * std::pow(std::fmax(1.0, (double)k / 3.0) * shells / m_ball, 1.0 / d_est);
+        if (debug) fprintf(stderr, "[pst knn] measured scale: cell edge %g (dense) / %g (hash) instead of %g / %g from the bounding box\n", hd, hh, h_dense, h_hash);
+        h_dense = hd; h_hash = hh;
+      }
       GridParams trial{};
-      dense = is_dense(grid_for(h_vol, 1, trial));
+      dense = is_dense(grid_for(h_dense, 1, trial));
       if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
-      if (!build_index(dense ? h_vol : edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0)), 1, dense)) return -1;
+      if (!build_index(dense ? h_dense : h_hash, 1, dense)) return -1;
     }
     RecOut sorted{rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count};
     if (nf) {

@@ -502,12 +502,26 @@ def _large_sparse_cloud(name, n):
 
 @pytest.mark.parametrize("name,n", [("sheet", 4_000_000), ("two_clusters", 2_100_000), ("tilted_plane", 2_100_000), ("helix", 1_100_000), ("lattice_sheet", 1_500_000)])
 def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
-    """Clouds of more than 2^20 points that leave most of their bounding box empty take the box search with a cell edge measured on a
-    1-in-16 subsample (the box's volume is several times off for them), the sparse directory build and rx = 2 (or coarser).  Whatever path a
-    shape ends on -- a helix or two far-apart clusters exceed the directory's cell budget and fall back to the global-memory search --
-    the lists must be the exact k nearest and the fits the oracle's."""
+    """Clouds that leave most of their bounding box empty are gridded by their MEASURED scale (normals_scale.hip: nearest-neighbour distance
+    histograms of 512 sampled points against a subsample), not by the box's volume; the large ones take the box search with the sparse
+    directory build and rx = 2 (or coarser).  Whatever path a shape ends on -- a helix, a tilted plane or two far-apart clusters exceed the
+    directory's cell budget and use the global-memory search over a hash directory -- the lists must be the exact k nearest and the fits
+    the oracle's."""
+    import time
+    import torch
     pts = _large_sparse_cloud(name, n)
     _check_knn_on_device(hip, oracle, pts, 16, n_samples=512 if name != "sheet" else 1024)
+    if name == "two_clusters":
+        # gridded by the bounding box's volume every cluster is ONE cell and the search a brute force (2.2 s here); with the measured scale 6 ms
+        from pasture_amd.algorithms import compute_normals_device
+        from pasture_amd.buffers import ExternalColumnsBuffer
+        src = ExternalColumnsBuffer([pts], PointLayout.from_attributes([A.POSITION_3D], api=hip), n)
+        curv = torch.empty(n, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        compute_normals_device(src, 16, 0, curv.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.5, "the search degenerated on a clustered cloud"
 
 
 def _degenerate_cloud(name):
