@@ -13,13 +13,14 @@
 // of the box finds its candidates there:
 //   * no dependent global loads in the search (the first version of this kernel issued one per candidate and lane: 30x the algorithmic
 //     HBM traffic and an L2 / HBM round trip per candidate);
-//   * 9 row segments per query, each TRIMMED to the ball (tau0, later the running k-th best) in f32 with upward slack: ~70 candidates
-//     instead of the ~170 of a 5 x 5 x 5 block of cubic cells;
+//   * 9 row segments per query, each TRIMMED to the ball of the a-priori bound tau0 in f32 with upward slack (~97 candidates instead of the
+//     ~170 of a 5 x 5 x 5 block of cubic cells); all nine ranges are worked out up front into a register table that a lane shifts down;
 //   * four candidates per step: their 12 coordinate reads (one array per coordinate: neighbouring slots never share a bank) are
 //     issued together, one LDS round trip per four distance tests;
-//   * a candidate is only QUEUED (its 16-bit slot, per-lane LDS queue) when it beats tau0 and the lane's current (k+1)-th best key;
-//     the sorted insertion -- which a wave pays for whenever ANY lane inserts -- runs in batches when a queue fills, software-
-//     pipelined, on keys that carry the slot in their low 11 bits: two f64 operations per list entry;
+//   * a candidate is only QUEUED (its 16-bit slot, per-lane LDS queue) when it beats tau0 and the lane's (k+1)-th best key as of the last
+//     insertion round; the sorted insertion -- which a wave pays for whenever ANY lane inserts -- runs in rounds when queues fill,
+//     software-pipelined, on keys that carry the slot in their low 11 bits: two f64 operations per list entry;
+//   * no per-lane predication in the two inner loops (masked arithmetic and +inf insertions instead of execution-mask changes);
 //   * the plane fit reads its neighbours from LDS; the result leaves as one aligned 32-byte record at the point's original index
 //     (a full-sector store) and split_results_kernel streams the records into the caller's outputs.
 //
@@ -143,7 +144,7 @@ struct KBestPacked {
 // The halo of a box is addressed WITHOUT clipping: rows and cells outside the grid exist in the local directory as empty ranges, so
 // the search loop has no boundary tests: halo row r = (z - (Z0-2)) * HY + (y - (Y0-2)), halo cell c = x - (X0-2), and the candidates of
 // a query in halo cell (lx, ly, lz) in the row (dy, dz) away are the LDS slots [ldir[B + D], ldir[B + D + 5]) with
-// B = (lz * HY + ly) * NC1 + lx - 2 (per lane) and D = (dz * HY + dy) * NC1 (per segment, from a 25-entry table).
+// B = (lz * HY + ly) * NC1 + lx - XH (per lane) and D = (dz * HY + dy) * NC1 (per segment: a compile-time pair (dy, dz)).
 template <int K, int THREADS, int CAP, bool WITH_KNN>
 __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void knn_tile_kernel(const TileArgs a) {
   // staged points, one array per coordinate (8-byte stride: neighbouring slots never share a bank); + kBatch: a batch may read past a range
