@@ -288,12 +288,22 @@ __global__ __launch_bounds__(kBlock) void split_results_kernel(const double* __r
   }
 }
 
+// sorted positions (of the CURRENT index) of the queries flagged as unresolved by original index; the flags are cleared on the way
+__global__ __launch_bounds__(kBlock) void collect_unresolved_kernel(const uint32_t* __restrict__ sidx, uint32_t nf, uint8_t* __restrict__ flag,
+                                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= nf) return;
+  const uint32_t o = sidx[j];
+  if (flag[o]) { flag[o] = 0; list[atomicAdd(count, 1u)] = j; }
+}
+
 // ---- grid search over global memory -------------------------------------------------------------------------------------------------
 // LIST: the queries are the sorted indices qlist[0 .. nq) (what the box kernel could not finish); otherwise all nf sorted points.
 template <int K, bool DENSE, bool LIST>
 __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
-                                                          const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out) {
+                                                          const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out, int shell_cap,
+                                                          uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count) {
   const uint32_t t0 = blockIdx.x * kBlock + threadIdx.x;
   if (t0 >= nq) return;
   const uint32_t j = LIST ? qlist[t0] : t0;
@@ -373,6 +383,13 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
       }
     }
     if (shell_done(g, qx, qy, qz, cx, cy, cz, r, best.kth(k))) break;
+    // shell_cap > 0: a query that is still open after that many shells (an outlier, a point of a region far sparser than the grid was made
+    // for: shell r costs (2 r + 1)^2 rows) is handed back -- flagged by its original index -- and searched again on a coarser grid
+    if (shell_cap > 0 && r == shell_cap && r < max_r) {
+      unres_flag[out.sidx[j]] = 1;
+      atomicAdd(unres_count, 1u);
+      return;
+    }
   }
   const uint32_t m = nf < k ? nf : k;
   const uint64_t orig = out.sidx[j];
@@ -478,8 +495,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   if (!packed_source) NCK(xyz_own.alloc(n * 24, stream));
   XyzRef xyz{packed_source ? (const double*)pos_base : (const double*)xyz_own.p};
   NCK(partials.alloc((size_t)sgrid * 48, stream));
-  NCK(counters.alloc(64, stream));
-  NCK(hipMemsetAsync(counters.p, 0, 64, stream));
+  NCK(counters.alloc(128, stream));
+  NCK(hipMemsetAsync(counters.p, 0, 128, stream));
   hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, packed_source ? (double*)nullptr : xyz_own.as<double>(),
                      partials.as<double>());
   std::vector<double> hp((size_t)sgrid * 6);
@@ -626,13 +643,14 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     //    sampled point, power law through the two): a surface in a 3-D box holds several times M points in the first guess.
     // 2. otherwise the dense directory with ~k/12 points per cubic cell and two shells, when the grid is not much larger than the cloud
     //    (volume-like data) -- 3. else Morton keys + hash table with ~k/3 points per cell.
+    constexpr int kShellCap = 6;  // shells a global-memory search walks before it hands a query to a coarser grid
     TileShape shape;
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
     // fraction of the 32^3 coarse cells of the bounding box that hold a point (flat axes count as one layer)
     double occupancy = 0.0;
-    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE")) {
+    {
       CacheBuf occ;
       NCK(occ.alloc(kOccWords * 4, stream));
       NCK(hipMemsetAsync(occ.p, 0, kOccWords * 4, stream));
@@ -651,38 +669,38 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (debug) fprintf(stderr, "[pst knn] occupancy of the bounding box at 32^3: %.3f\n", occupancy);
       mark("occupancy");
     }
+    double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
+    if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
+    // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
+    // times too large; separate clusters: orders of magnitude) the scale is MEASURED first, without an index (normals_scale.hip): distance
+    // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
+    // around a typical point, and its local dimension.
+    if (occupancy < 0.9 && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+      // the subsample: a sixteenth of the cloud, at least 2^20 and at most 2^22 points (the further the thinning, the longer the extrapolation
+      // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
+      const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
+      const uint64_t S = (n + cap_s - 1) / cap_s, n_s = n / S;
+      CacheBuf xyz_s, hist_s;
+      NCK(xyz_s.alloc(n_s * 24, stream));
+      NCK(hist_s.alloc(knn_scale_scratch_bytes(), stream));
+      hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_s, xyz_s.as<double>(),
+                         partials.as<double>());
+      double h_m = 0, dim_m = 3;
+      if (knn_scale_estimate(xyz_s.as<double>(), (uint32_t)n_s, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_s.as<unsigned int>(), stream,
+                             h_m, dim_m)) {
+        if (debug) fprintf(stderr, "[pst knn scale] %llu of %llu points: %.1f points within h=%g, dimension %.2f (by the box's volume: %g)\n", (unsigned long long)n_s,
+                           (unsigned long long)n, m_target, h_m, dim_m, edge_for(m_target / 4.18879020478639));
+        h_est = h_m; d_est = dim_m;
+      }
+      mark("scale");
+    }
     if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
-      double m_target = 1.75 * (double)k;
-      if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
       // fine x cells per h: 4 for clouds that fill their box; 2 for the others (a surface: the same box holds fewer points, the 31-cell limit of a
       // box row then makes boxes too short at rx = 4: 6.3 against 3.9 ms per 10^7 points of the sheet in tools/exp_normals_surface.py)
       uint32_t rx = occupancy < 0.5 ? 2 : 4;
       if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
-      double h = edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
-      // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
-      // times too large; separate clusters: orders of magnitude) the scale is MEASURED first, without an index (normals_scale.hip): distance
-      // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
-      // around a typical point, and its local dimension.
-      if (occupancy < 0.9 && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
-        // the subsample: a sixteenth of the cloud, at least 2^20 and at most 2^22 points (the further the thinning, the longer the extrapolation
-        // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
-        const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
-        const uint64_t S = (n + cap_s - 1) / cap_s, n_s = n / S;
-        CacheBuf xyz_s, hist_s;
-        NCK(xyz_s.alloc(n_s * 24, stream));
-        NCK(hist_s.alloc(knn_scale_scratch_bytes(), stream));
-        hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_s, xyz_s.as<double>(),
-                           partials.as<double>());
-        double h_m = 0, dim_m = 3;
-        if (knn_scale_estimate(xyz_s.as<double>(), (uint32_t)n_s, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_s.as<unsigned int>(), stream,
-                               h_m, dim_m)) {
-          if (debug) fprintf(stderr, "[pst knn scale] %llu of %llu points: %.1f points within h=%g, dimension %.2f (volume guess %g)\n", (unsigned long long)n_s,
-                             (unsigned long long)n, m_target, h_m, dim_m, h);
-          h = h_m; h_est = h_m; d_est = dim_m;
-        }
-        mark("scale");
-      }
+      double h = h_est > 0.0 ? h_est : edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
       for (int round = 0; round < 3; ++round) {
         GridParams trial{};
         // (clustered clouds and surfaces leave cells empty: 4 bytes each, up to 12 per point are accepted here)
@@ -720,7 +738,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       double h_dense = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0));
       double h_hash = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0));
       if (h_est > 0.0 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL")) {
-        const double c_d = 0.44 + 0.06 * d_est, shells = std::pow(3.0, 3.0 - d_est), m_ball = 1.75 * (double)k;
+        const double c_d = 0.44 + 0.06 * d_est, shells = std::pow(3.0, 3.0 - d_est), m_ball = m_target;
         const double hd = h_est / c_d * std::pow(std::fmax(0.5, (double)k / 12.0) * shells / m_ball, 1.0 / d_est);
         const double hh = h_est / c_d * std::pow(std::fmax(1.0, (double)k / 3.0) * shells / m_ball, 1.0 / d_est);
         if (debug) fprintf(stderr, "[pst knn] measured scale: cell edge %g (dense) / %g (hash) instead of %g / %g from the bounding box\n", hd, hh, h_dense, h_hash);
@@ -731,6 +749,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
       if (!build_index(dense ? h_dense : h_hash, 1, dense)) return -1;
     }
+    CacheBuf unres;  // one byte per point, by ORIGINAL index: the query was handed back by a capped search
+    NCK(unres.alloc(n, stream));
+    NCK(hipMemsetAsync(unres.p, 0, n, stream));
+    uint32_t* unres_count = (uint32_t*)((uint8_t*)counters.p + 64);
     RecOut sorted{rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count};
     if (nf) {
       if (dense) {
@@ -752,17 +774,48 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           if (n_fb) {
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
             KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted);
+                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
           }
         } else {
           const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
           KNN_DISPATCH_GRID(true, false, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                            (const uint32_t*)nullptr, (uint32_t)nf, sorted);
+                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
         }
       } else {
         const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
         KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted);
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
+      }
+      // Queries the capped search handed back (outliers; regions far sparser than the grid was made for): again on a grid with six times the
+      // cell edge -- its first shell covers what six shells of the last one did -- until none is left; the last level is uncapped.
+      for (int level = 1; nf; ++level) {
+        uint32_t n_un = 0;
+        NCK(hipMemcpyAsync(&n_un, unres_count, 4, hipMemcpyDeviceToHost, stream));
+        NCK(hipStreamSynchronize(stream));
+        if (!n_un) break;
+        NCK(hipMemsetAsync(unres_count, 0, 4, stream));
+        const double h_up = g.h * (double)kShellCap;
+        GridParams trial{};
+        const uint64_t up_cells = grid_for(h_up, 1, trial);
+        const bool last = level >= 8 || std::max(trial.dim[0], std::max(trial.dim[1], trial.dim[2])) <= (uint32_t)kShellCap + 1u;
+        const bool up_dense = is_dense(up_cells);
+        if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries, cell edge %g (%s)%s\n", level, n_un, h_up, up_dense ? "dense" : "hash", last ? ", uncapped" : "");
+        if (!build_index(h_up, 1, up_dense)) return -1;
+        dense = up_dense;
+        NCK(fb_list.alloc((size_t)nf * 4, stream));
+        hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(), (uint32_t)nf,
+                           unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
+        NCK(hipMemsetAsync(unres_count, 0, 4, stream));  // (the list length is n_un; the counter now counts what this level hands back)
+        const unsigned grid = (unsigned)((n_un + kBlock - 1) / kBlock);
+        const int cap = last ? 0 : kShellCap;
+        if (up_dense) {
+          KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, (const uint32_t*)directory.as<uint32_t>(),
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count);
+        } else {
+          KNN_DISPATCH_GRID(false, true, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table, (const uint32_t*)nullptr,
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count);
+        }
+        mark("coarser");
       }
     }
     if (nf < n) {

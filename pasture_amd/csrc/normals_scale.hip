@@ -1,5 +1,5 @@
 // Local scale of a point cloud, measured without an index: for 512 sampled points, a histogram of their squared distances to
-// a subsample of the cloud (two bins per octave, 64 bins below the bounding box's diagonal).  From each histogram: the radius at which the
+// a subsample of the cloud (one bin per octave of d^2 -- the f32 exponent --, 80 bins below the bounding box's diagonal: 2^40 in distance).  From each histogram: the radius at which the
 // subsample holds T points around that query, the local dimension D (how fast the count grows from T to 4 T), and from those the radius at
 // which the FULL cloud holds M points, r_M = r_T (M / (T f))^(1/D) with f = points per subsample point.  The MEDIAN over the queries is the
 // cell edge the kNN search grids with.
@@ -18,8 +18,9 @@
 
 namespace {
 
-constexpr int kBins = 64;          // two per octave of the squared distance: a factor 65536 in distance below the diagonal
-constexpr int kTile = 1024;        // candidates staged per step
+constexpr int kBins = 80;          // one per octave of the squared distance: a factor 2^40 in distance below the diagonal (at two per octave a
+                                   // cluster 10^-9 of the box across fell into bin 0 whole)
+constexpr int kTile = 768;         // candidates staged per step
 constexpr int kQPerBlock = 256;    // one query per thread
 
 // cand: packed xyz of the subsample.  Query j is candidate j * q_stride.  Block (x, y): queries [256 x, 256 x + 256) against the candidate
@@ -44,9 +45,9 @@ __global__ __launch_bounds__(kQPerBlock) void knn_scale_kernel(const double* __r
     for (uint32_t c = 0; c < cnt; ++c) {  // every lane reads the same candidate: LDS broadcast
       const double dx = tile[3 * c] - qx, dy = tile[3 * c + 1] - qy, dz = tile[3 * c + 2] - qz;
       const float d2 = (float)(dx * dx + dy * dy + dz * dz);
-      // bits >> 22 = 2 * biased exponent + the top mantissa bit: bin edges at 2^e and 1.5 * 2^e.  0 (the query itself, duplicates) and
-      // everything below the range go to bin 0; NaN / inf (non-finite coordinates) come out above the range and are not counted.
-      const int b = (int)(__float_as_uint(d2) >> 22) - bin_off;
+      // bits >> 23 = the biased exponent: bin edges at powers of two.  0 (the query itself, duplicates) and everything below the range go
+      // to bin 0; NaN / inf (non-finite coordinates) come out above the range and are not counted.
+      const int b = (int)(__float_as_uint(d2) >> 23) - bin_off;
       if (b < kBins) H[(b < 0 ? 0 : b) * kQPerBlock + t] += 1;
     }
   }
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(kQPerBlock) void knn_scale_kernel(const double* __r
 }
 
 float bin_upper_edge(int b, int bin_off) {  // d^2 values below this fall into bins 0 .. b
-  const uint32_t bits = (uint32_t)(b + bin_off + 1) << 22;
+  const uint32_t bits = (uint32_t)(b + bin_off + 1) << 23;
   float f;
   std::memcpy(&f, &bits, 4);
   return f;
@@ -82,7 +83,7 @@ bool knn_scale_estimate(const double* cand, uint32_t n_c, double thinning, doubl
   const float top = (float)diag2;
   uint32_t top_bits;
   std::memcpy(&top_bits, &top, 4);
-  const int bin_off = (int)(top_bits >> 22) - (kBins - 1);  // the diagonal falls into the last bin
+  const int bin_off = (int)(top_bits >> 23) - (kBins - 1);  // the diagonal falls into the last bin
   if (hipMemsetAsync(scratch, 0, (size_t)n_q * kBins * sizeof(unsigned int), stream) != hipSuccess) return false;
   const uint32_t slice = 4096;
   hipLaunchKernelGGL(knn_scale_kernel, dim3((n_q + kQPerBlock - 1) / kQPerBlock, (n_c + slice - 1) / slice), dim3(kQPerBlock), 0, stream, cand, n_c, n_q, q_stride,
