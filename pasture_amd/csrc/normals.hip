@@ -409,6 +409,66 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   write_record(out, orig, f);
 }
 
+// ---- exact search of a FEW queries against all finite points: one workgroup per query ---------------------------------------------------
+// The terminal fallback for queries no grid level resolves cheaply (far outliers: on a grid coarse enough to reach their neighbours a cell
+// holds millions of points, and a grid search walks a cell with ONE lane).  Every thread keeps the k best of its share of the points, then
+// k rounds of a workgroup-wide minimum over the threads' list heads (ties: lower sorted index) pick the result in ascending order.
+template <int K>
+__global__ __launch_bounds__(kBlock) void knn_brute_list_kernel(const double* __restrict__ sxyz, uint32_t nf, uint32_t k, const uint32_t* __restrict__ qlist, uint32_t nq,
+                                                                RecOut out) {
+  __shared__ double wd[kBlock / 64];
+  __shared__ uint32_t wi[kBlock / 64];
+  __shared__ uint32_t res[64];
+  __shared__ uint32_t win;
+  if (blockIdx.x >= nq) return;
+  const uint32_t j = qlist[blockIdx.x];
+  const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+  KBest<K> best;
+  best.init();
+  for (uint32_t p = threadIdx.x; p < nf; p += kBlock) {
+    const double dx = sxyz[3 * (uint64_t)p] - qx, dy = sxyz[3 * (uint64_t)p + 1] - qy, dz = sxyz[3 * (uint64_t)p + 2] - qz;
+    const double d = dx * dx + dy * dy + dz * dz;
+    if (d < best.kth(k)) best.insert(d, p);
+  }
+  const uint32_t m = nf < k ? nf : k;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t t = 0; t < m; ++t) {
+    double d = best.d[0];
+    uint32_t i = best.i[0];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = shfl_xor_any(d, off);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)i, off, 64);
+      if (od < d || (od == d && oi < i)) { d = od; i = oi; }
+    }
+    if (lane == 0) { wd[wave] = d; wi[wave] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double bd = wd[0];
+      uint32_t bi = wi[0];
+      for (int w = 1; w < kBlock / 64; ++w) if (wd[w] < bd || (wd[w] == bd && wi[w] < bi)) { bd = wd[w]; bi = wi[w]; }
+      res[t] = bi;
+      win = bi;
+    }
+    __syncthreads();
+    if (best.i[0] == win && win != kNoIndex) {  // the winner drops its head
+#pragma unroll
+      for (int u = 0; u + 1 < K; ++u) { best.d[u] = best.d[u + 1]; best.i[u] = best.i[u + 1]; }
+      best.d[K - 1] = __builtin_inf(); best.i[K - 1] = kNoIndex;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const uint64_t orig = out.sidx[j];
+  if (out.knn || out.knn_u32)
+    for (uint32_t t = 0; t < k; ++t) write_knn(out, orig, k, t, t < m ? out.sidx[res[t]] : kNoIndex);
+  const Fit f = plane_fit<0, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+    const uint32_t p = res[t];
+    x = sxyz[3 * (uint64_t)p]; y = sxyz[3 * (uint64_t)p + 1]; z = sxyz[3 * (uint64_t)p + 2];
+  });
+  write_record(out, orig, f);
+}
+
 // non-finite query points (sorted positions [nf, n)): neighbourhood = itself + the first k-1 finite points
 __global__ __launch_bounds__(kBlock) void knn_nonfinite_kernel(const double* __restrict__ xyz, const double* __restrict__ sxyz, uint32_t nf, uint32_t n,
                                                                uint32_t k, RecOut out) {
@@ -794,10 +854,22 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         NCK(hipStreamSynchronize(stream));
         if (!n_un) break;
         NCK(hipMemsetAsync(unres_count, 0, 4, stream));
+        // Two coarser levels at most, and none at all for a handful of queries: on a grid coarse enough for a far outlier a cell holds
+        // millions of points and a grid search walks a cell with one lane (64 outliers around 10^7 points: 67 s on the fourth level).  What
+        // is left is searched exactly against all points, one workgroup per query (knn_brute_list_kernel).
+        if (level >= 3 || (double)n_un * (double)nf <= 4e9) {
+          NCK(fb_list.alloc((size_t)nf * 4, stream));
+          hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(),
+                             (uint32_t)nf, unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
+          if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries against all %llu points\n", level, n_un, (unsigned long long)nf);
+          KNN_DISPATCH(knn_brute_list_kernel, n_un, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted);
+          mark("all-points");
+          break;
+        }
         const double h_up = g.h * (double)kShellCap;
         GridParams trial{};
         const uint64_t up_cells = grid_for(h_up, 1, trial);
-        const bool last = level >= 8 || std::max(trial.dim[0], std::max(trial.dim[1], trial.dim[2])) <= (uint32_t)kShellCap + 1u;
+        const bool last = std::max(trial.dim[0], std::max(trial.dim[1], trial.dim[2])) <= (uint32_t)kShellCap + 1u;
         const bool up_dense = is_dense(up_cells);
         if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries, cell edge %g (%s)%s\n", level, n_un, h_up, up_dense ? "dense" : "hash", last ? ", uncapped" : "");
         if (!build_index(h_up, 1, up_dense)) return -1;
