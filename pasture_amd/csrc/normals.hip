@@ -72,23 +72,32 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
 
 // Does the cloud fill its bounding box?  A 32^3 occupancy bitmask (per-block in LDS, OR-ed into global memory): the LDS box search is
 // laid out for volume-like clouds; a surface in a 3-D box (a few percent of the coarse cells occupied) keeps the global-memory search.
+constexpr uint32_t kAxisBins = 256;  // slices per axis of the point-count histograms behind the trimmed box
 constexpr uint32_t kOccBins = 32, kOccWords = kOccBins * kOccBins * kOccBins / 32;
 __global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restrict__ xyz, uint64_t n, double ox, double oy, double oz, double sx, double sy,
-                                                           double sz, uint32_t* __restrict__ bits) {
+                                                           double sz, uint32_t* __restrict__ bits, double ax, double ay, double az, uint32_t* __restrict__ axis_hist) {
   __shared__ uint32_t local[kOccWords];
+  __shared__ uint32_t hist[3 * kAxisBins];  // points per slice of the box along every axis (ax/ay/az = slices per unit; outside -> end slices)
   for (uint32_t i = threadIdx.x; i < kOccWords; i += kBlock) local[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 3 * kAxisBins; i += kBlock) hist[i] = 0;
   __syncthreads();
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     if (!finite3(x, y, z)) continue;
-    const uint32_t bx = min((uint32_t)((x - ox) * sx), kOccBins - 1), by = min((uint32_t)((y - oy) * sy), kOccBins - 1),
-                   bz = min((uint32_t)((z - oz) * sz), kOccBins - 1);
+    const double fx = (x - ox) * sx, fy = (y - oy) * sy, fz = (z - oz) * sz;
+    auto slice = [](double t) { return (uint32_t)(t < 0.0 ? 0.0 : t > (double)(kAxisBins - 1) ? (double)(kAxisBins - 1) : t); };
+    atomicAdd(&hist[slice((x - ox) * ax)], 1u);
+    atomicAdd(&hist[kAxisBins + slice((y - oy) * ay)], 1u);
+    atomicAdd(&hist[2 * kAxisBins + slice((z - oz) * az)], 1u);
+    if (fx < 0.0 || fy < 0.0 || fz < 0.0 || fx >= (double)kOccBins || fy >= (double)kOccBins || fz >= (double)kOccBins) continue;  // outside a trimmed box
+    const uint32_t bx = min((uint32_t)fx, kOccBins - 1), by = min((uint32_t)fy, kOccBins - 1), bz = min((uint32_t)fz, kOccBins - 1);
     const uint32_t bit = (bz * kOccBins + by) * kOccBins + bx;
     atomicOr(&local[bit >> 5], 1u << (bit & 31u));
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kOccWords; i += kBlock) if (local[i]) atomicOr(&bits[i], local[i]);
+  for (uint32_t i = threadIdx.x; i < 3 * kAxisBins; i += kBlock) if (hist[i]) atomicAdd(&axis_hist[i], hist[i]);
 }
 
 template <typename KeyT>
@@ -409,30 +418,27 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   write_record(out, orig, f);
 }
 
-// ---- exact search of a FEW queries against all finite points: one workgroup per query ---------------------------------------------------
-// The terminal fallback for queries no grid level resolves cheaply (far outliers: on a grid coarse enough to reach their neighbours a cell
-// holds millions of points, and a grid search walks a cell with ONE lane).  Every thread keeps the k best of its share of the points, then
-// k rounds of a workgroup-wide minimum over the threads' list heads (ties: lower sorted index) pick the result in ascending order.
-template <int K>
-__global__ __launch_bounds__(kBlock) void knn_brute_list_kernel(const double* __restrict__ sxyz, uint32_t nf, uint32_t k, const uint32_t* __restrict__ qlist, uint32_t nq,
-                                                                RecOut out) {
+// ---- exact search of the queries no grid resolves cheaply (far outliers), against all finite points: bound, filter, select -----------------
+// On a grid coarse enough to reach a far outlier's neighbours a cell holds millions of points, and a grid search walks a cell with ONE
+// lane (64 outliers around 10^7 points: 67 s on the fourth level).  Instead:
+//   1. knn_bound_kernel: the exact k-th distance of every open query within a SUBSAMPLE of the cloud -- an upper bound of the true one;
+//   2. knn_filter_kernel: every point against every open query, points in registers, queries broadcast from LDS, ~10 instructions per
+//      pair; a point inside a query's bound is appended to that query's candidate list (about k times the thinning of the subsample);
+//   3. knn_select_kernel: one workgroup per query picks the k nearest of its candidates (every thread the k best of its share, then k
+//      rounds of a workgroup-wide minimum over the list heads; ties: lower sorted index), fits the plane and writes the record.  A list
+//      that overflowed is replaced by a scan of all points.
+template <int K, typename Visit>
+__device__ __forceinline__ void block_select_and_fit(const double* __restrict__ sxyz, uint32_t nf, uint32_t k, uint32_t j, const RecOut& out, double* kth_out, Visit&& visit) {
   __shared__ double wd[kBlock / 64];
   __shared__ uint32_t wi[kBlock / 64];
   __shared__ uint32_t res[64];
   __shared__ uint32_t win;
-  if (blockIdx.x >= nq) return;
-  const uint32_t j = qlist[blockIdx.x];
-  const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
   KBest<K> best;
   best.init();
-  for (uint32_t p = threadIdx.x; p < nf; p += kBlock) {
-    const double dx = sxyz[3 * (uint64_t)p] - qx, dy = sxyz[3 * (uint64_t)p + 1] - qy, dz = sxyz[3 * (uint64_t)p + 2] - qz;
-    const double d = dx * dx + dy * dy + dz * dz;
-    if (d < best.kth(k)) best.insert(d, p);
-  }
-  const uint32_t m = nf < k ? nf : k;
+  visit([&](double d, uint32_t p) __attribute__((always_inline)) { if (d < best.kth(k)) best.insert(d, p); });
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  for (uint32_t t = 0; t < m; ++t) {
+  double last = __builtin_inf();
+  for (uint32_t t = 0; t < k; ++t) {
     double d = best.d[0];
     uint32_t i = best.i[0];
 #pragma unroll
@@ -449,16 +455,20 @@ __global__ __launch_bounds__(kBlock) void knn_brute_list_kernel(const double* __
       for (int w = 1; w < kBlock / 64; ++w) if (wd[w] < bd || (wd[w] == bd && wi[w] < bi)) { bd = wd[w]; bi = wi[w]; }
       res[t] = bi;
       win = bi;
+      wd[0] = bd;
     }
     __syncthreads();
+    last = wd[0];
     if (best.i[0] == win && win != kNoIndex) {  // the winner drops its head
 #pragma unroll
       for (int u = 0; u + 1 < K; ++u) { best.d[u] = best.d[u + 1]; best.i[u] = best.i[u + 1]; }
       best.d[K - 1] = __builtin_inf(); best.i[K - 1] = kNoIndex;
     }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x != 0) return;
+  if (kth_out) { *kth_out = last; return; }  // (+inf when fewer than k points were visited)
+  const uint32_t m = nf < k ? nf : k;
   const uint64_t orig = out.sidx[j];
   if (out.knn || out.knn_u32)
     for (uint32_t t = 0; t < k; ++t) write_knn(out, orig, k, t, t < m ? out.sidx[res[t]] : kNoIndex);
@@ -467,6 +477,76 @@ __global__ __launch_bounds__(kBlock) void knn_brute_list_kernel(const double* __
     x = sxyz[3 * (uint64_t)p]; y = sxyz[3 * (uint64_t)p + 1]; z = sxyz[3 * (uint64_t)p + 2];
   });
   write_record(out, orig, f);
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void knn_bound_kernel(const double* __restrict__ sxyz, const uint32_t* __restrict__ qlist, uint32_t nq, const double* __restrict__ sub,
+                                                           uint32_t n_sub, uint32_t k, double* __restrict__ bound) {
+  if (blockIdx.x >= nq) return;
+  const uint32_t j = qlist[blockIdx.x];
+  const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+  RecOut none{};
+  block_select_and_fit<K>(sxyz, n_sub, k, j, none, bound + blockIdx.x, [&](auto&& take) __attribute__((always_inline)) {
+    for (uint32_t p = threadIdx.x; p < n_sub; p += kBlock) {
+      const double dx = sub[3 * (uint64_t)p] - qx, dy = sub[3 * (uint64_t)p + 1] - qy, dz = sub[3 * (uint64_t)p + 2] - qz;
+      const double d = dx * dx + dy * dy + dz * dz;
+      if (d == d) take(d, p);  // (the subsample may hold non-finite points)
+    }
+  });
+}
+
+constexpr uint32_t kFilterPts = 4;     // points per thread of the filter
+constexpr uint32_t kFilterChunk = 256;  // queries staged per step
+__global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __restrict__ sxyz, uint32_t nf, const uint32_t* __restrict__ qlist, uint32_t nq,
+                                                            const double* __restrict__ bound, uint32_t cap, uint32_t* __restrict__ cand_count,
+                                                            uint32_t* __restrict__ cand) {
+  __shared__ double sq[4 * kFilterChunk];  // x, y, z, bound of the staged queries
+  const uint32_t p0 = (blockIdx.x * kBlock + threadIdx.x) * kFilterPts;
+  double px[kFilterPts], py[kFilterPts], pz[kFilterPts];
+#pragma unroll
+  for (uint32_t u = 0; u < kFilterPts; ++u) {
+    const uint32_t p = p0 + u < nf ? p0 + u : nf - 1;
+    px[u] = sxyz[3 * (uint64_t)p]; py[u] = sxyz[3 * (uint64_t)p + 1]; pz[u] = sxyz[3 * (uint64_t)p + 2];
+  }
+  for (uint32_t q0 = 0; q0 < nq; q0 += kFilterChunk) {
+    const uint32_t cnt = min(kFilterChunk, nq - q0);
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+      const uint32_t j = qlist[q0 + threadIdx.x];
+      sq[threadIdx.x] = sxyz[3 * (uint64_t)j]; sq[kFilterChunk + threadIdx.x] = sxyz[3 * (uint64_t)j + 1]; sq[2 * kFilterChunk + threadIdx.x] = sxyz[3 * (uint64_t)j + 2];
+      sq[3 * kFilterChunk + threadIdx.x] = bound[q0 + threadIdx.x];
+    }
+    __syncthreads();
+    for (uint32_t q = 0; q < cnt; ++q) {  // every lane reads the same query: LDS broadcast
+      const double qx = sq[q], qy = sq[kFilterChunk + q], qz = sq[2 * kFilterChunk + q], b = sq[3 * kFilterChunk + q];
+#pragma unroll
+      for (uint32_t u = 0; u < kFilterPts; ++u) {
+        const double dx = px[u] - qx, dy = py[u] - qy, dz = pz[u] - qz;
+        if (dx * dx + dy * dy + dz * dz <= b && p0 + u < nf) {
+          const uint32_t pos = atomicAdd(&cand_count[q0 + q], 1u);
+          if (pos < cap) cand[(uint64_t)(q0 + q) * cap + pos] = p0 + u;
+        }
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void knn_select_kernel(const double* __restrict__ sxyz, uint32_t nf, uint32_t k, const uint32_t* __restrict__ qlist, uint32_t nq,
+                                                            const uint32_t* __restrict__ cand_count, const uint32_t* __restrict__ cand, uint32_t cap, RecOut out) {
+  if (blockIdx.x >= nq) return;
+  const uint32_t j = qlist[blockIdx.x];
+  const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+  const uint32_t cnt = cand_count ? cand_count[blockIdx.x] : 0xFFFFFFFFu;
+  const bool listed = cnt <= cap && cnt >= (nf < k ? nf : k);  // (overflow, or no filter at all: every point is a candidate)
+  const uint32_t total = listed ? cnt : nf;
+  block_select_and_fit<K>(sxyz, nf, k, j, out, (double*)nullptr, [&](auto&& take) __attribute__((always_inline)) {
+    for (uint32_t c = threadIdx.x; c < total; c += kBlock) {
+      const uint32_t p = listed ? cand[(uint64_t)blockIdx.x * cap + c] : c;
+      const double dx = sxyz[3 * (uint64_t)p] - qx, dy = sxyz[3 * (uint64_t)p + 1] - qy, dz = sxyz[3 * (uint64_t)p + 2] - qz;
+      take(dx * dx + dy * dy + dz * dz, p);
+    }
+  });
 }
 
 // non-finite query points (sorted positions [nf, n)): neighbourhood = itself + the first k-1 finite points
@@ -592,13 +672,18 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     KNN_DISPATCH(knn_bruteforce_kernel, grid, xyz.as<double>(), (uint32_t)n, k, out);
   } else {
     // cell edge: a sphere of radius h should hold about k points  =>  (4/3 pi) h^3 * density ~ k
-    double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
-    double maxext = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
-    if (!(maxext > 0.0)) maxext = 1.0;
-    // treat flat axes (extent < 1e-6 of the largest) as thickness-free: density is per area / per length then
-    double vol = 1.0;
+    // the box the grids are laid over: the bounding box, or (below) a trimmed one when a few far points stretch it
+    double ext[3], maxext = 1.0, vol = 1.0;
     int dims_used = 0;
-    for (int c = 0; c < 3; ++c) if (ext[c] > maxext * 1e-9) { vol *= ext[c]; dims_used += 1; }
+    auto set_box = [&]() {
+      for (int c = 0; c < 3; ++c) ext[c] = mx[c] - mn[c];
+      maxext = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
+      if (!(maxext > 0.0)) maxext = 1.0;
+      // treat flat axes (extent < 1e-6 of the largest) as thickness-free: density is per area / per length then
+      vol = 1.0; dims_used = 0;
+      for (int c = 0; c < 3; ++c) if (ext[c] > maxext * 1e-9) { vol *= ext[c]; dims_used += 1; }
+    };
+    set_box();
     // Points per cell.  With the hash table every cell costs a probe, so few fat cells win: ~k/3 points per cell (the first
     // shell of 27 cells almost always suffices).  With the dense directory a whole row of cells is one range, and small cells win
     // because the searched cube approximates the k-sphere better: ~k/12 points per cell, two shells
@@ -708,27 +793,62 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
-    // fraction of the 32^3 coarse cells of the bounding box that hold a point (flat axes count as one layer)
+    // fraction of the 32^3 coarse cells of the box that hold a point (flat axes count as one layer), and -- from point counts per slice of
+    // every axis, taken in the same pass -- a TRIMMED box: the smallest slice ranges that hold all but 0.05 % of the points at either end,
+    // one slice added on each side.  It replaces the bounding box only when it is at least 8 times smaller, i.e. when a few far points
+    // stretch the bounding box (64 outliers around 10^7 points: the cloud filled 0.001 % of it, no dense directory fitted, 42 ms instead
+    // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
+    // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
     double occupancy = 0.0;
-    {
+    for (int pass = 0; pass < 3; ++pass) {
       CacheBuf occ;
-      NCK(occ.alloc(kOccWords * 4, stream));
-      NCK(hipMemsetAsync(occ.p, 0, kOccWords * 4, stream));
-      double sc[3];
-      for (int c = 0; c < 3; ++c) sc[c] = ext[c] > maxext * 1e-9 ? (double)kOccBins / ext[c] * (1.0 - 1e-12) : 0.0;
+      const size_t occ_bytes = (size_t)kOccWords * 4 + 3 * kAxisBins * 4;
+      NCK(occ.alloc(occ_bytes, stream));
+      NCK(hipMemsetAsync(occ.p, 0, occ_bytes, stream));
+      double sc[3], ax[3];
+      for (int c = 0; c < 3; ++c) {
+        sc[c] = ext[c] > maxext * 1e-9 ? (double)kOccBins / ext[c] * (1.0 - 1e-12) : 0.0;
+        ax[c] = ext[c] > maxext * 1e-9 ? (double)kAxisBins / ext[c] * (1.0 - 1e-12) : 0.0;
+      }
+      uint32_t* axis_hist = occ.as<uint32_t>() + kOccWords;
       hipLaunchKernelGGL(occupancy_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], sc[0], sc[1], sc[2],
-                         occ.as<uint32_t>());
-      std::vector<uint32_t> hb(kOccWords);
-      NCK(hipMemcpyAsync(hb.data(), occ.p, kOccWords * 4, hipMemcpyDeviceToHost, stream));
+                         occ.as<uint32_t>(), ax[0], ax[1], ax[2], axis_hist);
+      std::vector<uint32_t> hb(kOccWords + 3 * kAxisBins);
+      NCK(hipMemcpyAsync(hb.data(), occ.p, occ_bytes, hipMemcpyDeviceToHost, stream));
       NCK(hipStreamSynchronize(stream));
       uint64_t set = 0;
-      for (uint32_t w : hb) set += (uint64_t)__builtin_popcount(w);
+      for (uint32_t w = 0; w < kOccWords; ++w) set += (uint64_t)__builtin_popcount(hb[w]);
       double bins = 1.0;
       for (int c = 0; c < 3; ++c) bins *= sc[c] > 0 ? (double)kOccBins : 1.0;
       occupancy = (double)set / bins;
-      if (debug) fprintf(stderr, "[pst knn] occupancy of the bounding box at 32^3: %.3f\n", occupancy);
-      mark("occupancy");
+      if (debug) fprintf(stderr, "[pst knn] occupancy of the box at 32^3: %.3f\n", occupancy);
+      double tmn[3], tmx[3], shrink = 1.0;
+      for (int c = 0; c < 3; ++c) {
+        tmn[c] = mn[c]; tmx[c] = mx[c];
+        if (!(ax[c] > 0)) continue;
+        const uint32_t* hc = hb.data() + kOccWords + c * kAxisBins;
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < kAxisBins; ++i) total += hc[i];
+        const uint64_t cut = total / 2000;  // 0.05 %
+        uint32_t lo = 0, hi = kAxisBins - 1;
+        for (uint64_t acc = 0; lo < hi && acc + hc[lo] <= cut; ++lo) acc += hc[lo];
+        for (uint64_t acc = 0; hi > lo && acc + hc[hi] <= cut; --hi) acc += hc[hi];
+        lo = lo > 0 ? lo - 1 : 0; hi = hi + 1 < kAxisBins ? hi + 1 : kAxisBins - 1;
+        tmn[c] = std::fmax(mn[c], mn[c] + (double)lo / ax[c]);
+        tmx[c] = std::fmin(mx[c], mn[c] + (double)(hi + 1) / ax[c]);
+        shrink *= (tmx[c] - tmn[c]) / ext[c];
+      }
+      if (pass < 2 && shrink <= 0.125 && !std::getenv("PST_KNN_NO_TRIM")) {
+        if (debug) fprintf(stderr, "[pst knn] trimmed box: %.3g of the volume: [%g, %g] x [%g, %g] x [%g, %g]\n", shrink, tmn[0], tmx[0], tmn[1], tmx[1], tmn[2], tmx[2]);
+        for (int c = 0; c < 3; ++c) { mn[c] = tmn[c]; mx[c] = tmx[c]; }
+        set_box();
+        continue;
+      }
+      break;
     }
+    mark("occupancy");
+    CacheBuf xyz_s;  // a subsample of the cloud (packed xyz; may hold non-finite points): the scale estimate and the bounds of the all-points search
+    uint64_t n_sub = 0;
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
     if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
     // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
@@ -740,8 +860,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
       const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
       const uint64_t S = (n + cap_s - 1) / cap_s, n_s = n / S;
-      CacheBuf xyz_s, hist_s;
+      CacheBuf hist_s;
       NCK(xyz_s.alloc(n_s * 24, stream));
+      n_sub = n_s;
       NCK(hist_s.alloc(knn_scale_scratch_bytes(), stream));
       hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_s, xyz_s.as<double>(),
                          partials.as<double>());
@@ -854,15 +975,35 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         NCK(hipStreamSynchronize(stream));
         if (!n_un) break;
         NCK(hipMemsetAsync(unres_count, 0, 4, stream));
-        // Two coarser levels at most, and none at all for a handful of queries: on a grid coarse enough for a far outlier a cell holds
-        // millions of points and a grid search walks a cell with one lane (64 outliers around 10^7 points: 67 s on the fourth level).  What
-        // is left is searched exactly against all points, one workgroup per query (knn_brute_list_kernel).
-        if (level >= 3 || (double)n_un * (double)nf <= 4e9) {
+        // A coarser level only while MANY queries are open (a sparse region), and two at most; a few thousand (outliers) are searched
+        // exactly against all points instead (bound / filter / select above): on a grid coarse enough to reach a far outlier's neighbours
+        // a cell holds millions of points and a grid search walks a cell with one lane.
+        if (level >= 3 || n_un <= 8192) {
           NCK(fb_list.alloc((size_t)nf * 4, stream));
           hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(),
                              (uint32_t)nf, unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
           if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries against all %llu points\n", level, n_un, (unsigned long long)nf);
-          KNN_DISPATCH(knn_brute_list_kernel, n_un, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted);
+          if (!n_sub) {  // (clouds that fill their box had no scale estimate: take the subsample now)
+            const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
+            const uint64_t S = (n + cap_s - 1) / cap_s;
+            n_sub = n / S;
+            NCK(xyz_s.alloc(n_sub * 24, stream));
+            hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_sub, xyz_s.as<double>(),
+                               partials.as<double>());
+          }
+          const uint32_t cand_cap = 4096;
+          CacheBuf bound, cand_count, cand;
+          NCK(bound.alloc((size_t)n_un * 8, stream));
+          NCK(cand_count.alloc((size_t)n_un * 4, stream));
+          NCK(cand.alloc((size_t)n_un * cand_cap * 4, stream));
+          NCK(hipMemsetAsync(cand_count.p, 0, (size_t)n_un * 4, stream));
+          KNN_DISPATCH(knn_bound_kernel, n_un, sorted_xyz.as<double>(), (const uint32_t*)fb_list.as<uint32_t>(), n_un, (const double*)xyz_s.as<double>(), (uint32_t)n_sub, k,
+                       bound.as<double>());
+          hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
+                             (const double*)sorted_xyz.as<double>(), (uint32_t)nf, (const uint32_t*)fb_list.as<uint32_t>(), n_un, (const double*)bound.as<double>(), cand_cap,
+                             cand_count.as<uint32_t>(), cand.as<uint32_t>());
+          KNN_DISPATCH(knn_select_kernel, n_un, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_un,
+                       (const uint32_t*)cand_count.as<uint32_t>(), (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);
           mark("all-points");
           break;
         }

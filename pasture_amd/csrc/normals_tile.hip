@@ -304,6 +304,11 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     // the row (y, z) is the query row; the cell along x comes from the coordinate (same arithmetic as keys_kernel)
     const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
     const int B = hr * NC1 + (active ? cx - X0 + XH : XH);  // directory entry of the query's own cell (idle lanes: any valid one)
+    // A query OUTSIDE the grid's box (the box may be a trimmed one: normals.hip) was clamped into a boundary cell; the trims below take the
+    // query to lie in its cell.  It goes to the global-memory search, which is exact for it.  (On the box's upper faces the unclamped cell
+    // number equals dim: those are the box's own last points, inside.)
+    auto beyond = [](double v, double org, double inv, uint32_t dim) { const double u = __builtin_floor((v - org) * inv); return u < 0.0 || u > (double)dim; };
+    const bool outside = beyond(qx, g.org[0], g.inv_hx, g.dim[0]) || beyond(qy, g.org[1], g.inv_h, g.dim[1]) || beyond(qz, g.org[2], g.inv_h, g.dim[2]);
 
     KBestPacked<K> best;
     best.init();
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
       const float fx = (float)((qx - g.org[0]) * g.inv_hx - (double)cx), fy = (float)((qy - g.org[1]) * g.inv_h - (double)cy),
                   fz = (float)((qz - g.org[2]) * g.inv_h - (double)cz);
       const float bound = (float)a.tau0 * ((float)(g.inv_h * g.inv_h) * 1.00001f), rxf = (float)g.rx * 1.00001f, xh = (float)XH;
-      const bool on = active && !(a.ablate & 4u);
+      const bool on = active && !outside && !(a.ablate & 4u);
 #pragma unroll
       for (int s = 0; s < kSegs; ++s) {
         constexpr int kDy[kSegs] = {0, -1, 1, 0, 0, -1, 1, -1, 1}, kDz[kSegs] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     }
     // k candidates inside tau0 < h^2: everything at most that far from the query lies in the 3 x 3 rows (each at least h deep beyond
     // the query's cell) and inside the trims, which were cut with bounds that only shrank afterwards -- the list is complete
-    const bool done = a.ablate ? true : exact && best.kth(a.k) < a.tau0;
+    const bool done = a.ablate ? true : !outside && exact && best.kth(a.k) < a.tau0;
     if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
     if (active && done && !(a.ablate & 32u)) {
       if constexpr (WITH_KNN) {

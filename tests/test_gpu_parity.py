@@ -426,7 +426,7 @@ def test_full_size_1e8_knn_normals_properties(hip, oracle):
     assert torch.equal(_torch_view(out.column_ptr(curv_def), n * 8).view(torch.float64), curv)
 
 
-def _check_knn_on_device(hip, oracle, pts, k, n_samples=1024, n_fits=128, seed=9):
+def _check_knn_on_device(hip, oracle, pts, k, n_samples=1024, n_fits=128, seed=9, extra_queries=None):
     """compute_normals_device on a device-resident cloud `pts` [n][3] f64, checked on the device: self first, lists sorted by distance, `n_samples`
     sampled queries (+ the extreme points of every axis) against a brute force over all points, `n_fits` of them against the oracle's plane
     fit of the 16-point neighbourhood (the same sequence of floating-point operations as in the full computation)."""
@@ -448,6 +448,8 @@ def _check_knn_on_device(hip, oracle, pts, k, n_samples=1024, n_fits=128, seed=9
     gc = torch.Generator(device="cpu")
     gc.manual_seed(seed)
     sample = torch.cat([torch.randint(0, n, (n_samples,), generator=gc), pts.argmin(dim=0).cpu(), pts.argmax(dim=0).cpu()])
+    if extra_queries is not None:
+        sample = torch.cat([extra_queries, sample])  # first: they are among the fits checked against the oracle
     hn, hc = normals.cpu(), curv.cpu()
     checked = 0
     for q in sample.tolist():
@@ -493,6 +495,18 @@ def _large_sparse_cloud(name, n):
     if name == "helix":          # a 1-D curve in 3-D with a little noise
         t = r(n) * 600.0
         return (torch.stack([50.0 * torch.cos(t), 50.0 * torch.sin(t), 2.0 * t], dim=1) + 0.05 * torch.randn(n, 3, device="cuda", dtype=torch.float64, generator=g)).contiguous()
+    if name == "volume_with_outliers":  # 200 points far outside a cloud that fills its box: they stretch the bounding box 40-fold
+        pts = r(n, 3) * torch.tensor([1000.0, 1000.0, 100.0], device="cuda", dtype=torch.float64)
+        far = (r(200, 3) - 0.5) * 40000.0
+        pts[torch.randint(0, n, (200,), device="cuda", generator=g)] = far
+        return pts.contiguous()
+    if name == "sheet_with_outliers":   # the LiDAR case with stray returns far above and below
+        xy = r(n, 2) * 1000.0
+        z = 10.0 * torch.sin(xy[:, 0] / 50.0) * torch.cos(xy[:, 1] / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+        pts = torch.cat([xy, z[:, None]], dim=1)
+        idx = torch.randint(0, n, (300,), device="cuda", generator=g)
+        pts[idx, 2] = (r(300) - 0.5) * 6000.0
+        return pts.contiguous()
     if name == "lattice_sheet":  # a sheet on a coarse coordinate lattice: many exact distance ties and coincident points
         xy = torch.round(r(n, 2) * 2000.0) * 0.5
         z = torch.round(5.0 * torch.sin(xy[:, 0] / 60.0) * 4.0) * 0.25
@@ -500,7 +514,8 @@ def _large_sparse_cloud(name, n):
     raise ValueError(name)
 
 
-@pytest.mark.parametrize("name,n", [("sheet", 4_000_000), ("two_clusters", 2_100_000), ("tilted_plane", 2_100_000), ("helix", 1_100_000), ("lattice_sheet", 1_500_000)])
+@pytest.mark.parametrize("name,n", [("sheet", 4_000_000), ("two_clusters", 2_100_000), ("tilted_plane", 2_100_000), ("helix", 1_100_000), ("lattice_sheet", 1_500_000),
+                                    ("volume_with_outliers", 3_000_000), ("sheet_with_outliers", 3_000_000)])
 def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
     """Clouds that leave most of their bounding box empty are gridded by their MEASURED scale (normals_scale.hip: nearest-neighbour distance
     histograms of 512 sampled points against a subsample), not by the box's volume; the large ones take the box search with the sparse
@@ -510,7 +525,13 @@ def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
     import time
     import torch
     pts = _large_sparse_cloud(name, n)
-    _check_knn_on_device(hip, oracle, pts, 16, n_samples=512 if name != "sheet" else 1024)
+    extra = None
+    if name.endswith("_with_outliers"):  # every far point is checked, not only the samples: they take the bound / filter / select search
+        c = pts.median(dim=0).values
+        far = ((pts - c).abs() > torch.tensor([1500.0, 1500.0, 400.0], device="cuda", dtype=torch.float64)).any(dim=1)
+        extra = torch.nonzero(far).flatten().cpu()
+        assert 100 <= len(extra) <= 400
+    _check_knn_on_device(hip, oracle, pts, 16, n_samples=512 if name != "sheet" else 1024, extra_queries=extra)
     if name == "two_clusters":
         # gridded by the bounding box's volume every cluster is ONE cell and the search a brute force (2.2 s here); with the measured scale 6 ms
         from pasture_amd.algorithms import compute_normals_device
