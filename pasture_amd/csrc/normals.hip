@@ -800,7 +800,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
     // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
     double occupancy = 0.0;
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < 4; ++pass) {
       CacheBuf occ;
       const size_t occ_bytes = (size_t)kOccWords * 4 + 3 * kAxisBins * 4;
       NCK(occ.alloc(occ_bytes, stream));
@@ -838,7 +838,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         tmx[c] = std::fmin(mx[c], mn[c] + (double)(hi + 1) / ax[c]);
         shrink *= (tmx[c] - tmn[c]) / ext[c];
       }
-      if (pass < 2 && shrink <= 0.125 && !std::getenv("PST_KNN_NO_TRIM")) {
+      // (once a box has been trimmed, the slices are finer and a second and third look may tighten it further: any gain above 40 % is taken)
+      if (pass < 3 && shrink <= (pass == 0 ? 0.125 : 0.6) && !std::getenv("PST_KNN_NO_TRIM")) {
         if (debug) fprintf(stderr, "[pst knn] trimmed box: %.3g of the volume: [%g, %g] x [%g, %g] x [%g, %g]\n", shrink, tmn[0], tmx[0], tmn[1], tmx[1], tmn[2], tmx[2]);
         for (int c = 0; c < 3; ++c) { mn[c] = tmn[c]; mx[c] = tmx[c]; }
         set_box();
