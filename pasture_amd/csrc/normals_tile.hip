@@ -653,6 +653,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   do {                                                                                                                       \
     if (k <= 8) PST_TILE_LAUNCH(8, TT, CC);                                                                                  \
     else if (k <= 16) PST_TILE_LAUNCH(16, TT, CC);                                                                           \
+    else if (k <= 24) PST_TILE_LAUNCH(24, TT, CC);                                                                           \
     else PST_TILE_LAUNCH(32, TT, CC);                                                                                        \
   } while (0)
   PST_TILE_K(256, 1536);
