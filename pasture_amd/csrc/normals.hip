@@ -75,7 +75,8 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
 constexpr uint32_t kAxisBins = 256;  // slices per axis of the point-count histograms behind the trimmed box
 constexpr uint32_t kOccBins = 32, kOccWords = kOccBins * kOccBins * kOccBins / 32;
 __global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restrict__ xyz, uint64_t n, double ox, double oy, double oz, double sx, double sy,
-                                                           double sz, uint32_t* __restrict__ bits, double ax, double ay, double az, uint32_t* __restrict__ axis_hist) {
+                                                           double sz, uint32_t* __restrict__ bits, double ax, double ay, double az, uint32_t* __restrict__ axis_hist,
+                                                           GridParams frame) {
   __shared__ uint32_t local[kOccWords];
   __shared__ uint32_t hist[3 * kAxisBins];  // points per slice of the box along every axis (ax/ay/az = slices per unit; outside -> end slices)
   for (uint32_t i = threadIdx.x; i < kOccWords; i += kBlock) local[i] = 0;
@@ -83,8 +84,10 @@ __global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restr
   __syncthreads();
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
-    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    if (!finite3(x, y, z)) continue;
+    const double x0 = xyz[3 * i], y0 = xyz[3 * i + 1], z0 = xyz[3 * i + 2];
+    if (!finite3(x0, y0, z0)) continue;
+    double x, y, z;  // in the grid's frame
+    grid_frame(frame, x0, y0, z0, x, y, z);
     const double fx = (x - ox) * sx, fy = (y - oy) * sy, fz = (z - oz) * sz;
     auto slice = [](double t) { return (uint32_t)(t < 0.0 ? 0.0 : t > (double)(kAxisBins - 1) ? (double)(kAxisBins - 1) : t); };
     atomicAdd(&hist[slice((x - ox) * ax)], 1u);
@@ -100,6 +103,52 @@ __global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restr
   for (uint32_t i = threadIdx.x; i < 3 * kAxisBins; i += kBlock) if (hist[i]) atomicAdd(&axis_hist[i], hist[i]);
 }
 
+// First and second moments of the points of a subsample that lie inside a box (the principal axes of the cloud without its far points):
+// sums[0..2] = sum x, y, z; sums[3..8] = sum xx, xy, xz, yy, yz, zz (about `centre`, which keeps the sums small); sums[9] = count.
+__global__ __launch_bounds__(kBlock) void moments_kernel(const double* __restrict__ xyz, uint64_t n, uint64_t stride_pts, double bx0, double by0, double bz0, double bx1,
+                                                         double by1, double bz1, double cx, double cy, double cz, double* __restrict__ sums) {
+  double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    const uint64_t p = i * stride_pts;
+    const double x = xyz[3 * p], y = xyz[3 * p + 1], z = xyz[3 * p + 2];
+    if (!finite3(x, y, z) || x < bx0 || x > bx1 || y < by0 || y > by1 || z < bz0 || z > bz1) continue;
+    const double dx = x - cx, dy = y - cy, dz = z - cz;
+    acc[0] += dx; acc[1] += dy; acc[2] += dz;
+    acc[3] += dx * dx; acc[4] += dx * dy; acc[5] += dx * dz; acc[6] += dy * dy; acc[7] += dy * dz; acc[8] += dz * dz;
+    acc[9] += 1.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    double v = acc[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_any(v, off);
+    if ((threadIdx.x & 63u) == 0 && v != 0.0) atomicAdd(&sums[q], v);
+  }
+}
+
+// bounds, in the frame `f`, of the finite points inside an axis-aligned box (partials: six doubles per block, like gather_positions_kernel)
+__global__ __launch_bounds__(kBlock) void framed_bounds_kernel(const double* __restrict__ xyz, uint64_t n, double bx0, double by0, double bz0, double bx1, double by1,
+                                                               double bz1, GridParams f, double* __restrict__ partials) {
+  double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!finite3(x, y, z) || x < bx0 || x > bx1 || y < by0 || y > by1 || z < bz0 || z > bz1) continue;
+    double u, v, w;
+    grid_frame(f, x, y, z, u, v, w);
+    mn[0] = __builtin_fmin(mn[0], u); mx[0] = __builtin_fmax(mx[0], u);
+    mn[1] = __builtin_fmin(mn[1], v); mx[1] = __builtin_fmax(mx[1], v);
+    mn[2] = __builtin_fmin(mn[2], w); mx[2] = __builtin_fmax(mx[2], w);
+  }
+  __shared__ double scratch[(kBlock / 64) * 6];
+  block_reduce_minmax<double, 3>(mn, mx, scratch);
+  if (threadIdx.x == 0) {
+    double* o = partials + (uint64_t)blockIdx.x * 6;
+    o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx[0]; o[4] = mx[1]; o[5] = mx[2];
+  }
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, KeyT* __restrict__ keys,
                                                       uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite) {
@@ -109,8 +158,10 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     uint64_t key = kInvalidKey;
     if (finite3(x, y, z)) {
-      const uint32_t cx = cell_coord(x, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(y, g.org[1], g.inv_h, g.dim[1]),
-                     cz = cell_coord(z, g.org[2], g.inv_h, g.dim[2]);
+      double u, v, w;
+      grid_frame(g, x, y, z, u, v, w);
+      const uint32_t cx = cell_coord(u, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(v, g.org[1], g.inv_h, g.dim[1]),
+                     cz = cell_coord(w, g.org[2], g.inv_h, g.dim[2]);
       key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
       local += 1;
     } else if (g.dense) {
@@ -317,8 +368,10 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   if (t0 >= nq) return;
   const uint32_t j = LIST ? qlist[t0] : t0;
   const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
-  const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
-            cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+  double qu, qv, qw;  // the query in the grid's frame: cells and shell margins; distances use (qx, qy, qz)
+  grid_frame(g, qx, qy, qz, qu, qv, qw);
+  const int cx = (int)cell_coord(qu, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qv, g.org[1], g.inv_h, g.dim[1]),
+            cz = (int)cell_coord(qw, g.org[2], g.inv_h, g.dim[2]);
   KBest<K> best;
   best.init();
   // candidates in pairs: both coordinate triples are requested before the first insertion (the loop was waiting on one dependent load
@@ -391,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
         }
       }
     }
-    if (shell_done(g, qx, qy, qz, cx, cy, cz, r, best.kth(k))) break;
+    if (shell_done(g, qu, qv, qw, cx, cy, cz, r, best.kth(k))) break;
     // shell_cap > 0: a query that is still open after that many shells (an outlier, a point of a region far sparser than the grid was made
     // for: shell r costs (2 r + 1)^2 rows) is handed back -- flagged by its original index -- and searched again on a coarser grid
     if (shell_cap > 0 && r == shell_cap && r < max_r) {
@@ -672,6 +725,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     KNN_DISPATCH(knn_bruteforce_kernel, grid, xyz.as<double>(), (uint32_t)n, k, out);
   } else {
     // cell edge: a sphere of radius h should hold about k points  =>  (4/3 pi) h^3 * density ~ k
+    GridParams frame{};  // the frame the grids live in: the cloud's own axes, or (below) its principal axes
     // the box the grids are laid over: the bounding box, or (below) a trimmed one when a few far points stretch it
     double ext[3], maxext = 1.0, vol = 1.0;
     int dims_used = 0;
@@ -693,6 +747,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       const double min_h = maxext * (double)rx / 2000000.0;  // <= 2^21 cells per axis
       if (!(h > min_h)) h = min_h;
       g.h = h; g.inv_h = 1.0 / h; g.rx = rx; g.hx = h / (double)rx; g.inv_hx = (double)rx / h;
+      g.rotated = frame.rotated;
+      for (int c = 0; c < 9; ++c) g.rot[c] = frame.rot[c];
+      for (int c = 0; c < 3; ++c) g.rot_c[c] = frame.rot_c[c];
       for (int c = 0; c < 3; ++c) {
         g.org[c] = mn[c];
         double d = std::floor(ext[c] * (c == 0 ? g.inv_hx : g.inv_h)) + 1.0;
@@ -800,11 +857,13 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
     // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
     double occupancy = 0.0;
+    auto measure_box = [&]() -> bool {
+#define MCK(x) do { if ((x) != hipSuccess) return false; } while (0)
     for (int pass = 0; pass < 4; ++pass) {
       CacheBuf occ;
       const size_t occ_bytes = (size_t)kOccWords * 4 + 3 * kAxisBins * 4;
-      NCK(occ.alloc(occ_bytes, stream));
-      NCK(hipMemsetAsync(occ.p, 0, occ_bytes, stream));
+      MCK(occ.alloc(occ_bytes, stream));
+      MCK(hipMemsetAsync(occ.p, 0, occ_bytes, stream));
       double sc[3], ax[3];
       for (int c = 0; c < 3; ++c) {
         sc[c] = ext[c] > maxext * 1e-9 ? (double)kOccBins / ext[c] * (1.0 - 1e-12) : 0.0;
@@ -812,10 +871,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       uint32_t* axis_hist = occ.as<uint32_t>() + kOccWords;
       hipLaunchKernelGGL(occupancy_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], sc[0], sc[1], sc[2],
-                         occ.as<uint32_t>(), ax[0], ax[1], ax[2], axis_hist);
+                         occ.as<uint32_t>(), ax[0], ax[1], ax[2], axis_hist, frame);
       std::vector<uint32_t> hb(kOccWords + 3 * kAxisBins);
-      NCK(hipMemcpyAsync(hb.data(), occ.p, occ_bytes, hipMemcpyDeviceToHost, stream));
-      NCK(hipStreamSynchronize(stream));
+      MCK(hipMemcpyAsync(hb.data(), occ.p, occ_bytes, hipMemcpyDeviceToHost, stream));
+      MCK(hipStreamSynchronize(stream));
       uint64_t set = 0;
       for (uint32_t w = 0; w < kOccWords; ++w) set += (uint64_t)__builtin_popcount(hb[w]);
       double bins = 1.0;
@@ -847,7 +906,73 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       break;
     }
+    return true;
+#undef MCK
+    };
+    if (!measure_box()) return -1;
     mark("occupancy");
+    // PRINCIPAL AXES.  A cloud that is thin along a direction which is not a coordinate axis (a tilted facade, a diagonal flight strip, a
+    // helix) fills little of any axis-aligned box: the dense directory over that box would exceed its budget and the search fall back to
+    // the hash directory.  The covariance of a subsample (inside the trimmed box) gives the principal axes; if the box in THAT frame is
+    // at most a third of the volume, the grid is laid in it: cells, rows and trims use rotated coordinates (grid_frame), distances the
+    // original ones.
+    if (occupancy < 0.5 && n >= (1u << 16) && !std::getenv("PST_KNN_NO_ROTATE")) {
+      const uint64_t S_m = std::max<uint64_t>(1, n >> 20), n_m = n / S_m;
+      CacheBuf sums;
+      NCK(sums.alloc(80, stream));
+      NCK(hipMemsetAsync(sums.p, 0, 80, stream));
+      const double ctr[3] = {0.5 * (mn[0] + mx[0]), 0.5 * (mn[1] + mx[1]), 0.5 * (mn[2] + mx[2])};
+      hipLaunchKernelGGL(moments_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n_m, S_m, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], ctr[0],
+                         ctr[1], ctr[2], sums.as<double>());
+      double hs[10];
+      NCK(hipMemcpyAsync(hs, sums.p, 80, hipMemcpyDeviceToHost, stream));
+      NCK(hipStreamSynchronize(stream));
+      if (hs[9] >= 1000.0) {
+        const double c = hs[9], m0 = hs[0] / c, m1 = hs[1] / c, m2 = hs[2] / c;
+        double A[3][3] = {{hs[3] / c - m0 * m0, hs[4] / c - m0 * m1, hs[5] / c - m0 * m2}, {0, hs[6] / c - m1 * m1, hs[7] / c - m1 * m2}, {0, 0, hs[8] / c - m2 * m2}};
+        A[1][0] = A[0][1]; A[2][0] = A[0][2]; A[2][1] = A[1][2];
+        double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};  // columns = eigenvectors (cyclic Jacobi)
+        for (int sweep = 0; sweep < 30; ++sweep) {
+          const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+          if (!(off > 1e-300) || off < 1e-14 * (std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]))) break;
+          for (int pi = 0; pi < 2; ++pi)
+            for (int qi = pi + 1; qi < 3; ++qi) {
+              if (A[pi][qi] == 0.0) continue;
+              const double theta = (A[qi][qi] - A[pi][pi]) / (2.0 * A[pi][qi]);
+              const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0)), cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+              for (int r = 0; r < 3; ++r) { const double arp = A[r][pi], arq = A[r][qi]; A[r][pi] = cs * arp - sn * arq; A[r][qi] = sn * arp + cs * arq; }
+              for (int r = 0; r < 3; ++r) { const double apr = A[pi][r], aqr = A[qi][r]; A[pi][r] = cs * apr - sn * aqr; A[qi][r] = sn * apr + cs * aqr; }
+              for (int r = 0; r < 3; ++r) { const double vrp = V[r][pi], vrq = V[r][qi]; V[r][pi] = cs * vrp - sn * vrq; V[r][qi] = sn * vrp + cs * vrq; }
+            }
+        }
+        int order[3] = {0, 1, 2};  // largest variance first: the grid's rows (x) run along the cloud's longest direction
+        std::sort(order, order + 3, [&](int a, int b) { return A[a][a] > A[b][b]; });
+        GridParams cand{};
+        cand.rotated = 1;
+        for (int cc = 0; cc < 3; ++cc) cand.rot_c[cc] = ctr[cc];
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) cand.rot[3 * r + cc] = V[cc][order[r]];
+        hipLaunchKernelGGL(framed_bounds_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], cand, partials.as<double>());
+        NCK(hipMemcpyAsync(hp.data(), partials.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
+        NCK(hipStreamSynchronize(stream));
+        double rmn[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, rmx[3] = {-rmn[0], -rmn[0], -rmn[0]};
+        for (unsigned b = 0; b < sgrid; ++b)
+          for (int cc = 0; cc < 3; ++cc) { rmn[cc] = std::fmin(rmn[cc], hp[b * 6 + cc]); rmx[cc] = std::fmax(rmx[cc], hp[b * 6 + 3 + cc]); }
+        if (rmn[0] <= rmx[0]) {
+          double v_now = 1.0, v_rot = 1.0;
+          double rext = std::fmax(rmx[0] - rmn[0], std::fmax(rmx[1] - rmn[1], rmx[2] - rmn[2]));
+          for (int cc = 0; cc < 3; ++cc) { v_now *= std::fmax(ext[cc], 1e-6 * maxext); v_rot *= std::fmax(rmx[cc] - rmn[cc], 1e-6 * rext); }
+          if (debug) fprintf(stderr, "[pst knn] principal axes: box %.3g of the axis-aligned one (%g x %g x %g)\n", v_rot / v_now, rmx[0] - rmn[0], rmx[1] - rmn[1], rmx[2] - rmn[2]);
+          if (v_rot <= 0.35 * v_now) {
+            frame = cand;
+            for (int cc = 0; cc < 3; ++cc) { mn[cc] = rmn[cc]; mx[cc] = rmx[cc]; }
+            set_box();
+            if (!measure_box()) return -1;
+          }
+        }
+      }
+      mark("axes");
+    }
     CacheBuf xyz_s;  // a subsample of the cloud (packed xyz; may hold non-finite points): the scale estimate and the bounds of the all-points search
     uint64_t n_sub = 0;
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
@@ -857,9 +982,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
     // around a typical point, and its local dimension.
     if (occupancy < 0.9 && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
-      // the subsample: a sixteenth of the cloud, at least 2^20 and at most 2^22 points (the further the thinning, the longer the extrapolation
+      // the subsample: a sixteenth of the cloud, at least 2^18 and at most 2^22 points (the further the thinning, the longer the extrapolation
       // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
-      const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
+      const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 18, n / 16));
       const uint64_t S = (n + cap_s - 1) / cap_s, n_s = n / S;
       CacheBuf hist_s;
       NCK(xyz_s.alloc(n_s * 24, stream));
@@ -879,7 +1004,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
       // fine x cells per h: 4 for clouds that fill their box; 2 for the others (a surface: the same box holds fewer points, the 31-cell limit of a
       // box row then makes boxes too short at rx = 4: 6.3 against 3.9 ms per 10^7 points of the sheet in tools/exp_normals_surface.py)
-      uint32_t rx = occupancy < 0.5 ? 2 : 4;
+      uint32_t rx = (h_est > 0.0 ? d_est < 2.5 : occupancy < 0.5) ? 2 : 4;  // (the measured dimension where there is one: a sheet that fills a thin box is still a sheet)
       if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
       double h = h_est > 0.0 ? h_est : edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);

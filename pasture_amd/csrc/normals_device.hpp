@@ -20,7 +20,21 @@ struct GridParams {
   uint32_t rx;     // fine x cells per cell edge h (1 = cubic cells)
   uint32_t dim[3]; // cells per axis (<= 2^21)
   uint32_t dense;  // 1: keys are row-major cell numbers (x fastest) with a dense cell_start directory; 0: Morton keys + hash table
+  uint32_t rotated;  // 1: cells are assigned in a rotated frame (u, v, w) = rot * (x, y, z) -- the cloud's principal axes --, org / dim refer to it
+  double rot[9];     // row-major orthonormal matrix (distances are ALWAYS computed from the original coordinates)
+  double rot_c[3];   // the point the rotation turns about (near the cloud's centre: rotated coordinates are then of the size of the cloud, and
+                     // their rounding error -- a few ulps of that size -- stays far below the slack of every bound that uses them)
 };
+// The frame the grid lives in.  A rotation keeps every coordinate difference within the Euclidean distance, so all bounds of the searches
+// (a point within distance d of a query lies within d of it along every grid axis) hold in it as they do along the cloud's own axes.
+__device__ __forceinline__ void grid_frame(const GridParams& g, double x, double y, double z, double& u, double& v, double& w) {
+  if (g.rotated) {
+    const double dx = x - g.rot_c[0], dy = y - g.rot_c[1], dz = z - g.rot_c[2];
+    u = g.rot[0] * dx + g.rot[1] * dy + g.rot[2] * dz;
+    v = g.rot[3] * dx + g.rot[4] * dy + g.rot[5] * dz;
+    w = g.rot[6] * dx + g.rot[7] * dy + g.rot[8] * dz;
+  } else { u = x; v = y; w = z; }
+}
 __device__ __forceinline__ double grid_edge(const GridParams& g, int axis) { return axis == 0 ? g.hx : g.h; }
 
 __device__ __forceinline__ bool finite3(double x, double y, double z) {
@@ -227,7 +241,7 @@ __device__ __forceinline__ bool shell_done(const GridParams& g, double qx, doubl
     if (ca[a] + ra < (int)g.dim[a] - 1) margin = __builtin_fmin(margin, (g.org[a] + (double)(ca[a] + ra + 1) * ha) - qa[a]);
   }
   if (margin == __builtin_inf()) return true;  // the cube covers the whole grid
-  margin = margin * (1.0 - 1e-12) - 1e-300;
+  margin = margin * (g.rotated ? 1.0 - 1e-9 : 1.0 - 1e-12) - 1e-300;  // (rotated coordinates carry a rounding error of ~1e-13 of the cloud's size)
   return margin > 0.0 && kth <= margin * margin;
 }
 

@@ -302,13 +302,15 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     const uint32_t j = g0[hr] + (slot - rbase[hr]);  // index among the sorted points
     const uint32_t orig = active ? a.out.sidx[j] : 0u;  // requested now: the round trip hides behind the search
     // the row (y, z) is the query row; the cell along x comes from the coordinate (same arithmetic as keys_kernel)
-    const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
+    double qu, qv, qw;  // the query in the grid's frame (cells, trims); distances use (qx, qy, qz)
+    grid_frame(g, qx, qy, qz, qu, qv, qw);
+    const int cx = (int)cell_coord(qu, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
     const int B = hr * NC1 + (active ? cx - X0 + XH : XH);  // directory entry of the query's own cell (idle lanes: any valid one)
     // A query OUTSIDE the grid's box (the box may be a trimmed one: normals.hip) was clamped into a boundary cell; the trims below take the
     // query to lie in its cell.  It goes to the global-memory search, which is exact for it.  (On the box's upper faces the unclamped cell
     // number equals dim: those are the box's own last points, inside.)
     auto beyond = [](double v, double org, double inv, uint32_t dim) { const double u = __builtin_floor((v - org) * inv); return u < 0.0 || u > (double)dim; };
-    const bool outside = beyond(qx, g.org[0], g.inv_hx, g.dim[0]) || beyond(qy, g.org[1], g.inv_h, g.dim[1]) || beyond(qz, g.org[2], g.inv_h, g.dim[2]);
+    const bool outside = beyond(qu, g.org[0], g.inv_hx, g.dim[0]) || beyond(qv, g.org[1], g.inv_h, g.dim[1]) || beyond(qw, g.org[2], g.inv_h, g.dim[2]);
 
     KBestPacked<K> best;
     best.init();
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     // candidates per query, but the wave ran that ~55-instruction advance for some lane in nearly every scan step.)
     uint32_t ent[kSegs];
     {
-      const float fx = (float)((qx - g.org[0]) * g.inv_hx - (double)cx), fy = (float)((qy - g.org[1]) * g.inv_h - (double)cy),
-                  fz = (float)((qz - g.org[2]) * g.inv_h - (double)cz);
+      const float fx = (float)((qu - g.org[0]) * g.inv_hx - (double)cx), fy = (float)((qv - g.org[1]) * g.inv_h - (double)cy),
+                  fz = (float)((qw - g.org[2]) * g.inv_h - (double)cz);
       const float bound = (float)a.tau0 * ((float)(g.inv_h * g.inv_h) * 1.00001f), rxf = (float)g.rx * 1.00001f, xh = (float)XH;
       const bool on = active && !outside && !(a.ablate & 4u);
 #pragma unroll
@@ -476,8 +478,10 @@ __global__ __launch_bounds__(kBlock) void knn_probe_kernel(const double* __restr
   unsigned long long c_half = 0, c_full = 0, one = 0;
   if (j < nf) {
     const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
-    const int cx = (int)cell_coord(qx, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qy, g.org[1], g.inv_h, g.dim[1]),
-              cz = (int)cell_coord(qz, g.org[2], g.inv_h, g.dim[2]);
+    double qu, qv, qw;
+    grid_frame(g, qx, qy, qz, qu, qv, qw);
+    const int cx = (int)cell_coord(qu, g.org[0], g.inv_hx, g.dim[0]), cy = (int)cell_coord(qv, g.org[1], g.inv_h, g.dim[1]),
+              cz = (int)cell_coord(qw, g.org[2], g.inv_h, g.dim[2]);
     const double r2 = g.h * g.h, r2h = 0.25 * r2;
     const int x0 = max(cx - (int)g.rx, 0), x1 = min(cx + (int)g.rx, (int)g.dim[0] - 1);
     for (int dz = -1; dz <= 1; ++dz)

@@ -507,6 +507,12 @@ def _large_sparse_cloud(name, n):
         idx = torch.randint(0, n, (300,), device="cuda", generator=g)
         pts[idx, 2] = (r(300) - 0.5) * 6000.0
         return pts.contiguous()
+    if name == "diagonal_strip":  # a flight strip at 40 degrees to the axes, at UTM-sized coordinates: the grid is laid along its principal axes
+        import math
+        a, b = r(n) * 6000.0, r(n) * 250.0
+        z = 10.0 * torch.sin(a / 50.0) * torch.cos(b / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+        c, s_ = math.cos(math.radians(40.0)), math.sin(math.radians(40.0))
+        return torch.stack([c * a - s_ * b + 500000.0, s_ * a + c * b + 5400000.0, z], dim=1).contiguous()
     if name == "lattice_sheet":  # a sheet on a coarse coordinate lattice: many exact distance ties and coincident points
         xy = torch.round(r(n, 2) * 2000.0) * 0.5
         z = torch.round(5.0 * torch.sin(xy[:, 0] / 60.0) * 4.0) * 0.25
@@ -515,13 +521,13 @@ def _large_sparse_cloud(name, n):
 
 
 @pytest.mark.parametrize("name,n", [("sheet", 4_000_000), ("two_clusters", 2_100_000), ("tilted_plane", 2_100_000), ("helix", 1_100_000), ("lattice_sheet", 1_500_000),
-                                    ("volume_with_outliers", 3_000_000), ("sheet_with_outliers", 3_000_000)])
+                                    ("volume_with_outliers", 3_000_000), ("sheet_with_outliers", 3_000_000), ("diagonal_strip", 3_000_000)])
 def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
     """Clouds that leave most of their bounding box empty are gridded by their MEASURED scale (normals_scale.hip: nearest-neighbour distance
     histograms of 512 sampled points against a subsample), not by the box's volume; the large ones take the box search with the sparse
     directory build and rx = 2 (or coarser).  Whatever path a shape ends on -- a helix, a tilted plane or two far-apart clusters exceed the
-    directory's cell budget and use the global-memory search over a hash directory -- the lists must be the exact k nearest and the fits
-    the oracle's."""
+    directory's cell budget and use the global-memory search over a hash directory; a tilted plane and a diagonal strip are gridded along
+    their principal axes -- the lists must be the exact k nearest and the fits the oracle's."""
     import time
     import torch
     pts = _large_sparse_cloud(name, n)
