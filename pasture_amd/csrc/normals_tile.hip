@@ -636,7 +636,8 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   // candidates pass overall -- each pass is a sorted insertion the whole wave waits for.  The result stays exact: a query that finds
   // fewer than k candidates inside tau0 goes to the exact global-memory search like any other unfinished query (about 1 % of a uniform
   // cloud's queries), and tau0 < h^2 is also what makes 3 x 3 rows of cells enough.
-  a.tau0 = g.h * g.h * (1.0 - 4e-9);
+  // (in a rotated frame the cell coordinates carry a rounding error of up to ~1e-9 h at the largest grids: ten times the margin there)
+  a.tau0 = g.h * g.h * (1.0 - (g.rotated ? 4e-8 : 4e-9));
   a.tau0_below = std::nextafter(a.tau0, 0.0);
 #ifdef PST_KNN_STATS
   static unsigned long long* dbg_dev = nullptr;
