@@ -952,6 +952,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         for (int cc = 0; cc < 3; ++cc) cand.rot_c[cc] = ctr[cc];
         for (int r = 0; r < 3; ++r)
           for (int cc = 0; cc < 3; ++cc) cand.rot[3 * r + cc] = V[cc][order[r]];
+        double align = 1.0;  // the smallest of the rows' largest components: 1 = the principal axes ARE the coordinate axes (in some order)
+        for (int r = 0; r < 3; ++r) align = std::fmin(align, std::fmax(std::fabs(cand.rot[3 * r]), std::fmax(std::fabs(cand.rot[3 * r + 1]), std::fabs(cand.rot[3 * r + 2]))));
+        if (align >= 0.995) { mark("axes"); goto axes_done; }  // within 6 degrees: nothing to gain, no pass over the points
         hipLaunchKernelGGL(framed_bounds_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], cand, partials.as<double>());
         NCK(hipMemcpyAsync(hp.data(), partials.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
         NCK(hipStreamSynchronize(stream));
@@ -973,6 +976,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       mark("axes");
     }
+    axes_done:;
     CacheBuf xyz_s;  // a subsample of the cloud (packed xyz; may hold non-finite points): the scale estimate and the bounds of the all-points search
     uint64_t n_sub = 0;
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
