@@ -94,6 +94,13 @@ def compute_normals_device(point_cloud: _Buffer, k_nn: int, normals_ptr: int = 0
                                            C.c_void_p(knn_ptr or None))
 
 
+def release_scratch(api=None) -> None:
+    """Frees the device scratch the calling thread's compute_normals* calls keep between calls (about 100 bytes per point of the largest
+    recent cloud).  Never needed for correctness."""
+    from ._capi import product_api
+    (api or product_api()).release_scratch()
+
+
 def voxelgrid_filter(buffer: _Buffer, leafsize_x: float, leafsize_y: float, leafsize_z: float, filtered_buffer: _Buffer) -> None:
     """voxel_grid.rs:109-166: down-samples `buffer` to one centroid per occupied voxel (cells centred on the axis markers),
     appended to `filtered_buffer` in (x, y, z) voxel order; per-attribute reductions of set_all_attributes (:459-689)."""

@@ -53,6 +53,7 @@ bool launch_column(const PlanEntry& e, uint64_t n, double* bounds_partials, hipS
 // addresses): normals f64 [n][3], curvature f64 [n], knn int64 [n][k] and / or uint32 [n][k], NORMAL attribute (Vec3f32) and Curvature
 // attribute (F64) of a target buffer.  Returns 0, -1 on a HIP failure, -2 beyond 2^32 - 16 points, or the number of neighbourhoods with
 // < 3 usable points.
+void release_normals_scratch();
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
                       long long* out_knn_dev, uint32_t* out_knn_u32_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr,
                       uint64_t curv_stride, hipStream_t stream);

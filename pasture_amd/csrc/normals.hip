@@ -655,7 +655,11 @@ struct ScratchCache {
       }
     }
   }
-  ~ScratchCache() { for (Block& b : blocks) (void)hipFree(b.p); }
+  void release_all() {  // (no call of this thread is in flight: every call synchronises its stream before it returns)
+    for (Block& b : blocks) (void)hipFree(b.p);
+    blocks.clear();
+  }
+  ~ScratchCache() { release_all(); }
 };
 ScratchCache& scratch_cache() {
   static thread_local ScratchCache c;
@@ -671,6 +675,9 @@ struct CallGuard {
   ~CallGuard() { (void)hipStreamSynchronize(stream); scratch_cache().end_call(); }  // blocks go back only when nothing in flight uses them
 };
 }  // namespace
+
+// Frees the device blocks the calling thread's kNN calls keep between calls (about 100 bytes per point of the largest recent cloud).
+void release_normals_scratch() { scratch_cache().release_all(); }
 
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,
 // or the number of degenerate neighbourhoods (> 0).

@@ -340,6 +340,28 @@ def test_compute_normals_into_device_columns(hip, oracle):
         assert not out.view_attribute(A.CLASSIFICATION).any()
 
 
+def test_release_scratch_returns_the_knn_cache(hip):
+    """pst_release_scratch: the kNN search keeps ~100 bytes of device scratch per point between calls (per thread); releasing it gives the
+    memory back and the next call simply allocates again."""
+    import torch
+    from pasture_amd.algorithms import compute_normals_device, release_scratch
+    n = 4_000_000
+    src = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    src.resize(n)
+    src.synth_fill(42, 0)
+    curv = torch.empty(n, dtype=torch.float64, device="cuda")
+    release_scratch(hip)
+    compute_normals_device(src, 16, 0, curv.data_ptr(), 0)
+    first = curv.clone()
+    torch.cuda.synchronize()
+    held = torch.cuda.mem_get_info()[0]
+    release_scratch(hip)
+    freed = torch.cuda.mem_get_info()[0] - held
+    assert freed >= 60 * n, f"only {freed} bytes came back"
+    compute_normals_device(src, 16, 0, curv.data_ptr(), 0)
+    assert torch.equal(curv, first)
+
+
 def test_compute_normals_1e6_properties(hip):
     """Scale check (10^6 points, k = 16) through properties: every point is its own nearest neighbour, neighbour lists are
     sorted by distance, and brute-force verification of a random sample of queries against numpy."""
