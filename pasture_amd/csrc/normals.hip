@@ -1112,10 +1112,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         NCK(hipStreamSynchronize(stream));
         if (!n_un) break;
         NCK(hipMemsetAsync(unres_count, 0, 4, stream));
-        // A coarser level only while MANY queries are open (a sparse region), and two at most; a few thousand (outliers) are searched
+        // A coarser level only while MANY queries are open (a sparse region: more than ~0.1 s of all-points search), and two at most; the rest (outliers) are searched
         // exactly against all points instead (bound / filter / select above): on a grid coarse enough to reach a far outlier's neighbours
         // a cell holds millions of points and a grid search walks a cell with one lane.
-        if (level >= 3 || n_un <= 8192) {
+        if (level >= 3 || (double)n_un * (double)nf <= 2e11) {  // (the all-points search does ~2e12 pairs per second)
           NCK(fb_list.alloc((size_t)nf * 4, stream));
           hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(),
                              (uint32_t)nf, unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
