@@ -349,12 +349,12 @@ __global__ __launch_bounds__(kBlock) void split_results_kernel(const double* __r
 }
 
 // sorted positions (of the CURRENT index) of the queries flagged as unresolved by original index; the flags are cleared on the way
-__global__ __launch_bounds__(kBlock) void collect_unresolved_kernel(const uint32_t* __restrict__ sidx, uint32_t nf, uint8_t* __restrict__ flag,
+__global__ __launch_bounds__(kBlock) void collect_unresolved_kernel(const uint32_t* __restrict__ sidx, uint32_t nf, uint8_t* __restrict__ flag, uint8_t which,
                                                                     uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
   const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= nf) return;
   const uint32_t o = sidx[j];
-  if (flag[o]) { flag[o] = 0; list[atomicAdd(count, 1u)] = j; }
+  if (flag[o] == which) { flag[o] = 0; list[atomicAdd(count, 1u)] = j; }
 }
 
 // ---- grid search over global memory -------------------------------------------------------------------------------------------------
@@ -363,7 +363,7 @@ template <int K, bool DENSE, bool LIST>
 __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
                                                           const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out, int shell_cap,
-                                                          uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count) {
+                                                          uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count, uint32_t crowd) {
   const uint32_t t0 = blockIdx.x * kBlock + threadIdx.x;
   if (t0 >= nq) return;
   const uint32_t j = LIST ? qlist[t0] : t0;
@@ -377,8 +377,12 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   // candidates in pairs: both coordinate triples are requested before the first insertion (the loop was waiting on one dependent load
   // per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the pair).  The two ranges of a row are walked
   // as one sequence, so the two single end cells of an interior row share a round trip.
+  // crowd > 0 (coarser levels): a range longer than that is not walked by this one lane -- the query is flagged 2 and searched against all
+  // points by a workgroup (a coarse cell over a dense part of the cloud holds millions of points)
+  bool crowded = false;
   auto scan2 = [&](uint32_t p0, uint32_t p1, uint32_t q0, uint32_t q1) __attribute__((always_inline)) {
     const uint32_t lp = p1 - p0, total = lp + (q1 - q0);
+    if (crowd && total > crowd) { crowded = true; return; }
     for (uint32_t v = 0; v < total; v += 2) {
       const bool two = v + 1 < total;
       const uint32_t pa = v < lp ? p0 + v : q0 + (v - lp);
@@ -426,7 +430,9 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             uint32_t p = lookup_cell(table, key);
             if (p == kNoIndex) continue;
             // the cell's points two at a time: keys and coordinates of both are requested before anything is tested or inserted
+            const uint32_t p_first = p;
             for (; p < nf; p += 2) {
+              if (crowd && p - p_first > crowd) { crowded = true; break; }
               const uint32_t pb = p + 1 < nf ? p + 1 : p;
               const uint64_t ka = skeys[p], kb = skeys[pb];
               const double ax = sxyz[3 * (uint64_t)p], ay = sxyz[3 * (uint64_t)p + 1], az = sxyz[3 * (uint64_t)p + 2];
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
         }
       }
     }
+    if (crowded) { unres_flag[out.sidx[j]] = 2; atomicAdd(unres_count + 1, 1u); return; }
     if (shell_done(g, qu, qv, qw, cx, cy, cz, r, best.kth(k))) break;
     // shell_cap > 0: a query that is still open after that many shells (an outlier, a point of a region far sparser than the grid was made
     // for: shell r costs (2 r + 1)^2 rows) is handed back -- flagged by its original index -- and searched again on a coarser grid
@@ -733,6 +740,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   } else {
     // cell edge: a sphere of radius h should hold about k points  =>  (4/3 pi) h^3 * density ~ k
     GridParams frame{};  // the frame the grids live in: the cloud's own axes, or (below) its principal axes
+    const double full_mn[3] = {mn[0], mn[1], mn[2]}, full_mx[3] = {mx[0], mx[1], mx[2]};  // the bounding box (mn / mx may become a trimmed or rotated one)
     // the box the grids are laid over: the bounding box, or (below) a trimmed one when a few far points stretch it
     double ext[3], maxext = 1.0, vol = 1.0;
     int dims_used = 0;
@@ -863,6 +871,29 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // stretch the bounding box (64 outliers around 10^7 points: the cloud filled 0.001 % of it, no dense directory fitted, 42 ms instead
     // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
     // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
+    double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
+    if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
+    // GATE: is the cloud what its bounding box says?  A quick scale estimate on 2^17 points, 256 queries (normals_scale.hip; 0.3 ms) against the radius
+    // the box's volume predicts.  The 32^3 occupancy mask alone is fooled by a thin uniform halo around a dense core (1 % of the points
+    // spread over 10^5 times the core's volume fill every coarse cell: the grid was laid for the halo and every cell of the core held
+    // 400 000 points -- 32 s for 10^7 points).
+    double h_gate = 0.0, d_gate = 3.0;
+    bool concentrated = false;
+    if (n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+      const uint64_t S = (n + (1u << 17) - 1) >> 17, n_g = n / S;
+      CacheBuf xyz_g, hist_g;
+      NCK(xyz_g.alloc(n_g * 24, stream));
+      NCK(hist_g.alloc(knn_scale_scratch_bytes(), stream));
+      hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_g, xyz_g.as<double>(), partials.as<double>());
+      if (knn_scale_estimate(xyz_g.as<double>(), (uint32_t)n_g, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_g.as<unsigned int>(), stream,
+                             h_gate, d_gate, 256)) {
+        const double h_box = edge_for(m_target / 4.18879020478639);
+        concentrated = h_gate < h_box / 1.5;
+        if (debug) fprintf(stderr, "[pst knn gate] %.1f points within h=%g (dimension %.2f); the box's volume says %g%s\n", m_target, h_gate, d_gate, h_box,
+                           concentrated ? ": concentrated" : "");
+      }
+      mark("gate");
+    }
     double occupancy = 0.0;
     auto measure_box = [&]() -> bool {
 #define MCK(x) do { if ((x) != hipSuccess) return false; } while (0)
@@ -888,21 +919,36 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       for (int c = 0; c < 3; ++c) bins *= sc[c] > 0 ? (double)kOccBins : 1.0;
       occupancy = (double)set / bins;
       if (debug) fprintf(stderr, "[pst knn] occupancy of the box at 32^3: %.3f\n", occupancy);
-      double tmn[3], tmx[3], shrink = 1.0;
-      for (int c = 0; c < 3; ++c) {
-        tmn[c] = mn[c]; tmx[c] = mx[c];
-        if (!(ax[c] > 0)) continue;
-        const uint32_t* hc = hb.data() + kOccWords + c * kAxisBins;
-        uint64_t total = 0;
-        for (uint32_t i = 0; i < kAxisBins; ++i) total += hc[i];
-        const uint64_t cut = total / 2000;  // 0.05 %
-        uint32_t lo = 0, hi = kAxisBins - 1;
-        for (uint64_t acc = 0; lo < hi && acc + hc[lo] <= cut; ++lo) acc += hc[lo];
-        for (uint64_t acc = 0; hi > lo && acc + hc[hi] <= cut; --hi) acc += hc[hi];
-        lo = lo > 0 ? lo - 1 : 0; hi = hi + 1 < kAxisBins ? hi + 1 : kAxisBins - 1;
-        tmn[c] = std::fmax(mn[c], mn[c] + (double)lo / ax[c]);
-        tmx[c] = std::fmin(mx[c], mn[c] + (double)(hi + 1) / ax[c]);
-        shrink *= (tmx[c] - tmn[c]) / ext[c];
+      // The trimmed box for a tail mass `cut` (a fraction of the points at either end of every axis).  0.05 % always; for a cloud the gate
+      // found concentrated also 0.5 % and 5 % -- a tenfold cut is taken when it buys at least an eightfold smaller box (a halo).
+      auto trimmed = [&](double cut_frac, double (&tmn)[3], double (&tmx)[3]) {
+        double shrink = 1.0;
+        for (int c = 0; c < 3; ++c) {
+          tmn[c] = mn[c]; tmx[c] = mx[c];
+          if (!(ax[c] > 0)) continue;
+          const uint32_t* hc = hb.data() + kOccWords + c * kAxisBins;
+          uint64_t total = 0;
+          for (uint32_t i = 0; i < kAxisBins; ++i) total += hc[i];
+          const uint64_t cut = (uint64_t)((double)total * cut_frac);
+          uint32_t lo = 0, hi = kAxisBins - 1;
+          for (uint64_t acc = 0; lo < hi && acc + hc[lo] <= cut; ++lo) acc += hc[lo];
+          for (uint64_t acc = 0; hi > lo && acc + hc[hi] <= cut; --hi) acc += hc[hi];
+          lo = lo > 0 ? lo - 1 : 0; hi = hi + 1 < kAxisBins ? hi + 1 : kAxisBins - 1;
+          tmn[c] = std::fmax(mn[c], mn[c] + (double)lo / ax[c]);
+          tmx[c] = std::fmin(mx[c], mn[c] + (double)(hi + 1) / ax[c]);
+          shrink *= (tmx[c] - tmn[c]) / ext[c];
+        }
+        return shrink;
+      };
+      double tmn[3], tmx[3];
+      double shrink = trimmed(0.0005, tmn, tmx);
+      if (concentrated) {
+        for (double cut_frac : {0.005, 0.05}) {
+          double umn[3], umx[3];
+          const double sh = trimmed(cut_frac, umn, umx);
+          if (sh <= shrink / 8.0) { shrink = sh; for (int c = 0; c < 3; ++c) { tmn[c] = umn[c]; tmx[c] = umx[c]; } }
+          else break;
+        }
       }
       // (once a box has been trimmed, the slices are finer and a second and third look may tighten it further: any gain above 40 % is taken)
       if (pass < 3 && shrink <= (pass == 0 ? 0.125 : 0.6) && !std::getenv("PST_KNN_NO_TRIM")) {
@@ -986,13 +1032,13 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     axes_done:;
     CacheBuf xyz_s;  // a subsample of the cloud (packed xyz; may hold non-finite points): the scale estimate and the bounds of the all-points search
     uint64_t n_sub = 0;
-    double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
-    if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
     // The bounding box's volume gives the right h only for clouds that fill it.  For the others (a surface: the first guess is several
     // times too large; separate clusters: orders of magnitude) the scale is MEASURED first, without an index (normals_scale.hip): distance
     // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
     // around a typical point, and its local dimension.
-    if (occupancy < 0.9 && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+    const double h_box_now = edge_for(m_target / 4.18879020478639);
+    const bool fills = occupancy >= 0.9 && !(h_gate > 0.0 && std::fabs(h_gate / h_box_now - 1.0) > 0.3);  // the cloud is what its (trimmed) box says
+    if (!fills && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
       // the subsample: a sixteenth of the cloud, at least 2^18 and at most 2^22 points (the further the thinning, the longer the extrapolation
       // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
       const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 18, n / 16));
@@ -1092,57 +1138,73 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           if (n_fb) {
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
             KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
+                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
           }
         } else {
           const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
           KNN_DISPATCH_GRID(true, false, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
+                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
         }
       } else {
         const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
         KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count);
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
       }
-      // Queries the capped search handed back (outliers; regions far sparser than the grid was made for): again on a grid with six times the
-      // cell edge -- its first shell covers what six shells of the last one did -- until none is left; the last level is uncapped.
+      // Queries a capped search handed back (flag 1: outliers; regions far sparser than the grid was made for): again on a grid with six
+      // times the cell edge, laid over the FULL bounding box (the trimmed or rotated box of the first level clamps exactly the points these
+      // queries are made of) -- its first shell covers what six shells of the last one did.  On such a grid a cell over a dense part of
+      // the cloud holds millions of points and a grid search walks a cell with ONE lane: a query that meets a range of more than kCrowd
+      // points gives up (flag 2) and is searched exactly against all points by a workgroup (bound / filter / select above), as are the
+      // last few open ones, whose all-points search costs less than another index.
+      auto all_points = [&](uint8_t which, uint32_t n_q) -> bool {
+#define ACK(x) do { if ((x) != hipSuccess) return false; } while (0)
+        ACK(fb_list.alloc((size_t)nf * 4, stream));
+        ACK(hipMemsetAsync(unres_count + 2, 0, 4, stream));
+        hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(), (uint32_t)nf,
+                           unres.as<uint8_t>(), which, fb_list.as<uint32_t>(), unres_count + 2);
+        if (debug) fprintf(stderr, "[pst knn] %u open queries against all %llu points\n", n_q, (unsigned long long)nf);
+        if (!n_sub) {  // (clouds that fill their box had no scale estimate: take the subsample now)
+          const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
+          const uint64_t S = (n + cap_s - 1) / cap_s;
+          n_sub = n / S;
+          ACK(xyz_s.alloc(n_sub * 24, stream));
+          hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_sub, xyz_s.as<double>(),
+                             partials.as<double>());
+        }
+        const uint32_t cand_cap = 4096;
+        CacheBuf bound, cand_count, cand;
+        ACK(bound.alloc((size_t)n_q * 8, stream));
+        ACK(cand_count.alloc((size_t)n_q * 4, stream));
+        ACK(cand.alloc((size_t)n_q * cand_cap * 4, stream));
+        ACK(hipMemsetAsync(cand_count.p, 0, (size_t)n_q * 4, stream));
+        KNN_DISPATCH(knn_bound_kernel, n_q, sorted_xyz.as<double>(), (const uint32_t*)fb_list.as<uint32_t>(), n_q, (const double*)xyz_s.as<double>(), (uint32_t)n_sub, k,
+                     bound.as<double>());
+        hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
+                           (const double*)sorted_xyz.as<double>(), (uint32_t)nf, (const uint32_t*)fb_list.as<uint32_t>(), n_q, (const double*)bound.as<double>(), cand_cap,
+                           cand_count.as<uint32_t>(), cand.as<uint32_t>());
+        KNN_DISPATCH(knn_select_kernel, n_q, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_q,
+                     (const uint32_t*)cand_count.as<uint32_t>(), (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);
+        mark("all-points");
+        return true;
+#undef ACK
+      };
+      constexpr uint32_t kCrowd = 4096;
       for (int level = 1; nf; ++level) {
-        uint32_t n_un = 0;
-        NCK(hipMemcpyAsync(&n_un, unres_count, 4, hipMemcpyDeviceToHost, stream));
+        uint32_t n_open[2] = {0, 0};  // handed back by the shell cap / by the crowd guard
+        NCK(hipMemcpyAsync(n_open, unres_count, 8, hipMemcpyDeviceToHost, stream));
         NCK(hipStreamSynchronize(stream));
+        NCK(hipMemsetAsync(unres_count, 0, 8, stream));
+        if (n_open[1] && !all_points(2, n_open[1])) return -1;
+        const uint32_t n_un = n_open[0];
         if (!n_un) break;
-        NCK(hipMemsetAsync(unres_count, 0, 4, stream));
-        // A coarser level only while MANY queries are open (a sparse region: more than ~0.1 s of all-points search), and two at most; the rest (outliers) are searched
-        // exactly against all points instead (bound / filter / select above): on a grid coarse enough to reach a far outlier's neighbours
-        // a cell holds millions of points and a grid search walks a cell with one lane.
-        if (level >= 3 || (double)n_un * (double)nf <= 2e11) {  // (the all-points search does ~2e12 pairs per second)
-          NCK(fb_list.alloc((size_t)nf * 4, stream));
-          hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(),
-                             (uint32_t)nf, unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
-          if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries against all %llu points\n", level, n_un, (unsigned long long)nf);
-          if (!n_sub) {  // (clouds that fill their box had no scale estimate: take the subsample now)
-            const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
-            const uint64_t S = (n + cap_s - 1) / cap_s;
-            n_sub = n / S;
-            NCK(xyz_s.alloc(n_sub * 24, stream));
-            hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_sub, xyz_s.as<double>(),
-                               partials.as<double>());
-          }
-          const uint32_t cand_cap = 4096;
-          CacheBuf bound, cand_count, cand;
-          NCK(bound.alloc((size_t)n_un * 8, stream));
-          NCK(cand_count.alloc((size_t)n_un * 4, stream));
-          NCK(cand.alloc((size_t)n_un * cand_cap * 4, stream));
-          NCK(hipMemsetAsync(cand_count.p, 0, (size_t)n_un * 4, stream));
-          KNN_DISPATCH(knn_bound_kernel, n_un, sorted_xyz.as<double>(), (const uint32_t*)fb_list.as<uint32_t>(), n_un, (const double*)xyz_s.as<double>(), (uint32_t)n_sub, k,
-                       bound.as<double>());
-          hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
-                             (const double*)sorted_xyz.as<double>(), (uint32_t)nf, (const uint32_t*)fb_list.as<uint32_t>(), n_un, (const double*)bound.as<double>(), cand_cap,
-                             cand_count.as<uint32_t>(), cand.as<uint32_t>());
-          KNN_DISPATCH(knn_select_kernel, n_un, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_un,
-                       (const uint32_t*)cand_count.as<uint32_t>(), (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);
-          mark("all-points");
+        if (level > 8 || (double)n_un * (double)nf <= 2e11) {  // (the all-points search does ~2e12 pairs per second)
+          if (!all_points(1, n_un)) return -1;
           break;
+        }
+        if (level == 1) {  // from here on: the cloud's own axes and its full bounding box
+          frame = GridParams{};
+          for (int c = 0; c < 3; ++c) { mn[c] = full_mn[c]; mx[c] = full_mx[c]; }
+          set_box();
         }
         const double h_up = g.h * (double)kShellCap;
         GridParams trial{};
@@ -1153,17 +1215,17 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         if (!build_index(h_up, 1, up_dense)) return -1;
         dense = up_dense;
         NCK(fb_list.alloc((size_t)nf * 4, stream));
+        NCK(hipMemsetAsync(unres_count + 2, 0, 4, stream));
         hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(), (uint32_t)nf,
-                           unres.as<uint8_t>(), fb_list.as<uint32_t>(), unres_count);
-        NCK(hipMemsetAsync(unres_count, 0, 4, stream));  // (the list length is n_un; the counter now counts what this level hands back)
+                           unres.as<uint8_t>(), (uint8_t)1, fb_list.as<uint32_t>(), unres_count + 2);
         const unsigned grid = (unsigned)((n_un + kBlock - 1) / kBlock);
         const int cap = last ? 0 : kShellCap;
         if (up_dense) {
           KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, (const uint32_t*)directory.as<uint32_t>(),
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd);
         } else {
           KNN_DISPATCH_GRID(false, true, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table, (const uint32_t*)nullptr,
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd);
         }
         mark("coarser");
       }

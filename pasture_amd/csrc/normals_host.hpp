@@ -19,7 +19,7 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
 // distance histograms of 512 sampled points against the subsample `cand` (n_c packed points = every `thinning`-th point of the cloud).
 size_t knn_scale_scratch_bytes();
 bool knn_scale_estimate(const double* cand, uint32_t n_c, double thinning, double diag2, double m_target, unsigned int* scratch, hipStream_t stream,
-                        double& h_m, double& dim);
+                        double& h_m, double& dim, uint32_t max_queries = 512);
 // Searches every query whose 5x5x5-cell neighbourhood fits the box kernel; the others are appended to fb_list / *fb_count
 // (sorted indices) for knn_grid_kernel.  *fb_count must be zero on entry; fb_list must hold nf entries.
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,

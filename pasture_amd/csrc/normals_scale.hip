@@ -77,9 +77,9 @@ size_t knn_scale_scratch_bytes() { return (size_t)512 * kBins * sizeof(unsigned 
 // Returns false when nothing could be measured (HIP failure, fewer than 64 usable points).  h_m: median radius at which the full cloud holds
 // m_target points; dim: median local dimension in [1, 3].
 bool knn_scale_estimate(const double* cand, uint32_t n_c, double thinning, double diag2, double m_target, unsigned int* scratch, hipStream_t stream,
-                        double& h_m, double& dim) {
+                        double& h_m, double& dim, uint32_t max_queries) {
   if (n_c < 64 || !(diag2 > 0.0)) return false;
-  const uint32_t n_q = std::min<uint32_t>(512, n_c), q_stride = n_c / n_q;  // (2048 queries: 2.4 ms for 2^20 candidates, the same median)
+  const uint32_t n_q = std::min<uint32_t>(std::min<uint32_t>(512, max_queries), n_c), q_stride = n_c / n_q;  // (2048 queries: 2.4 ms for 2^20 candidates, the same median)
   const float top = (float)diag2;
   uint32_t top_bits;
   std::memcpy(&top_bits, &top, 4);

@@ -522,6 +522,11 @@ def _large_sparse_cloud(name, n):
         far = (r(200, 3) - 0.5) * 40000.0
         pts[torch.randint(0, n, (200,), device="cuda", generator=g)] = far
         return pts.contiguous()
+    if name == "core_with_halo":   # 1 % of the points spread thinly over 10^4 times the core's volume: every coarse cell of the box is occupied
+        pts = r(n, 3) * torch.tensor([1000.0, 1000.0, 100.0], device="cuda", dtype=torch.float64)
+        m = n // 100
+        pts[torch.randint(0, n, (m,), device="cuda", generator=g)] = (r(m, 3) - 0.5) * 20000.0
+        return pts.contiguous()
     if name == "sheet_with_outliers":   # the LiDAR case with stray returns far above and below
         xy = r(n, 2) * 1000.0
         z = 10.0 * torch.sin(xy[:, 0] / 50.0) * torch.cos(xy[:, 1] / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
@@ -543,7 +548,7 @@ def _large_sparse_cloud(name, n):
 
 
 @pytest.mark.parametrize("name,n", [("sheet", 4_000_000), ("two_clusters", 2_100_000), ("tilted_plane", 2_100_000), ("helix", 1_100_000), ("lattice_sheet", 1_500_000),
-                                    ("volume_with_outliers", 3_000_000), ("sheet_with_outliers", 3_000_000), ("diagonal_strip", 3_000_000)])
+                                    ("volume_with_outliers", 3_000_000), ("sheet_with_outliers", 3_000_000), ("diagonal_strip", 3_000_000), ("core_with_halo", 3_000_000)])
 def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
     """Clouds that leave most of their bounding box empty are gridded by their MEASURED scale (normals_scale.hip: nearest-neighbour distance
     histograms of 512 sampled points against a subsample), not by the box's volume; the large ones take the box search with the sparse
