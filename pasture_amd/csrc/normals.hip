@@ -1171,19 +1171,23 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_sub, xyz_s.as<double>(),
                              partials.as<double>());
         }
-        const uint32_t cand_cap = 4096;
+        const uint32_t cand_cap = 4096, batch = 16384;  // (16 KB of candidate list per open query: 256 MB per batch)
         CacheBuf bound, cand_count, cand;
-        ACK(bound.alloc((size_t)n_q * 8, stream));
-        ACK(cand_count.alloc((size_t)n_q * 4, stream));
-        ACK(cand.alloc((size_t)n_q * cand_cap * 4, stream));
-        ACK(hipMemsetAsync(cand_count.p, 0, (size_t)n_q * 4, stream));
-        KNN_DISPATCH(knn_bound_kernel, n_q, sorted_xyz.as<double>(), (const uint32_t*)fb_list.as<uint32_t>(), n_q, (const double*)xyz_s.as<double>(), (uint32_t)n_sub, k,
-                     bound.as<double>());
-        hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
-                           (const double*)sorted_xyz.as<double>(), (uint32_t)nf, (const uint32_t*)fb_list.as<uint32_t>(), n_q, (const double*)bound.as<double>(), cand_cap,
-                           cand_count.as<uint32_t>(), cand.as<uint32_t>());
-        KNN_DISPATCH(knn_select_kernel, n_q, sorted_xyz.as<double>(), (uint32_t)nf, k, (const uint32_t*)fb_list.as<uint32_t>(), n_q,
-                     (const uint32_t*)cand_count.as<uint32_t>(), (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);
+        const uint32_t n_b = std::min(n_q, batch);
+        ACK(bound.alloc((size_t)n_b * 8, stream));
+        ACK(cand_count.alloc((size_t)n_b * 4, stream));
+        ACK(cand.alloc((size_t)n_b * cand_cap * 4, stream));
+        for (uint32_t off = 0; off < n_q; off += batch) {
+          const uint32_t cnt = std::min(batch, n_q - off);
+          const uint32_t* ql = (const uint32_t*)fb_list.as<uint32_t>() + off;
+          ACK(hipMemsetAsync(cand_count.p, 0, (size_t)cnt * 4, stream));
+          KNN_DISPATCH(knn_bound_kernel, cnt, sorted_xyz.as<double>(), ql, cnt, (const double*)xyz_s.as<double>(), (uint32_t)n_sub, k, bound.as<double>());
+          hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
+                             (const double*)sorted_xyz.as<double>(), (uint32_t)nf, ql, cnt, (const double*)bound.as<double>(), cand_cap, cand_count.as<uint32_t>(),
+                             cand.as<uint32_t>());
+          KNN_DISPATCH(knn_select_kernel, cnt, sorted_xyz.as<double>(), (uint32_t)nf, k, ql, cnt, (const uint32_t*)cand_count.as<uint32_t>(),
+                       (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);
+        }
         mark("all-points");
         return true;
 #undef ACK
