@@ -853,24 +853,20 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
 #undef BCK
     };
 
-    // 1. LDS box search (normals_tile.hip): cell edge h = R0, the radius of the ball expected to hold M = 1.75 k points, so that the 3 x 3
-    //    rows around a query's row always cover its k-th distance when k points are found inside R0; along x the cells are rx times finer
-    //    (the points of a row are then sorted by x at that granularity and every row is trimmed to the ball).  R0 starts from the density
-    //    of the bounding box and is CORRECTED by a probe of the built index (knn_probe: mean number of points within h / 2 and h of a
-    //    sampled point, power law through the two): a surface in a 3-D box holds several times M points in the first guess.
-    // 2. otherwise the dense directory with ~k/12 points per cubic cell and two shells, when the grid is not much larger than the cloud
-    //    (volume-like data) -- 3. else Morton keys + hash table with ~k/3 points per cell.
+    // What is decided here, in this order: is the cloud what its bounding box says (a quick scale estimate against the box's volume)?  The
+    // box the grids are laid over (the bounding box; a trimmed one when far points stretch it; the box along the principal axes when the
+    // cloud is thin in a direction that is no coordinate axis).  The cell edge h = the radius of the ball that holds M = 1.75 k points --
+    // from the box's volume for clouds that fill it, else measured (normals_scale.hip), and checked by a probe of the built index.  Then
+    // 1. the LDS box search (normals_tile.hip) over a dense directory with x cells rx times finer than h, when the directory fits its
+    //    budget; what it cannot finish goes to 2 as a list;
+    // 2. otherwise the global-memory search over the dense directory with ~k/12 points per cubic cell, when the grid is not much larger
+    //    than the cloud -- 3. else over Morton keys + a hash table with ~k/3 points per cell;
+    // 4. queries 2 / 3 hand back after kShellCap shells: coarser grids over the full bounding box, then an exact search against all points.
     constexpr int kShellCap = 6;  // shells a global-memory search walks before it hands a query to a coarser grid
     TileShape shape;
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
-    // fraction of the 32^3 coarse cells of the box that hold a point (flat axes count as one layer), and -- from point counts per slice of
-    // every axis, taken in the same pass -- a TRIMMED box: the smallest slice ranges that hold all but 0.05 % of the points at either end,
-    // one slice added on each side.  It replaces the bounding box only when it is at least 8 times smaller, i.e. when a few far points
-    // stretch the bounding box (64 outliers around 10^7 points: the cloud filled 0.001 % of it, no dense directory fitted, 42 ms instead
-    // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
-    // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
     if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
     // GATE: is the cloud what its bounding box says?  A quick scale estimate on 2^17 points, 256 queries (normals_scale.hip; 0.3 ms) against the radius
@@ -894,6 +890,12 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       mark("gate");
     }
+    // fraction of the 32^3 coarse cells of the box that hold a point (flat axes count as one layer), and -- from point counts per slice of
+    // every axis, taken in the same pass -- a TRIMMED box: the smallest slice ranges that hold all but 0.05 % of the points at either end,
+    // one slice added on each side.  It replaces the bounding box only when it is at least 8 times smaller, i.e. when a few far points
+    // stretch the bounding box (64 outliers around 10^7 points: the cloud filled 0.001 % of it, no dense directory fitted, 42 ms instead
+    // of 5).  Points outside it are clamped into the boundary cells like the box's own last points; the searches stay exact (a clamped
+    // point lies beyond its cell, never nearer), the box kernel hands queries outside the box to the global-memory search.
     double occupancy = 0.0;
     auto measure_box = [&]() -> bool {
 #define MCK(x) do { if ((x) != hipSuccess) return false; } while (0)
