@@ -578,6 +578,57 @@ def test_large_sparse_clouds_knn_normals_properties(hip, oracle, name, n):
         assert time.perf_counter() - t0 < 0.5, "the search degenerated on a clustered cloud"
 
 
+def _mid_sparse_cloud(name, n):
+    rng = np.random.default_rng(17)
+    if name == "tilted_slab":      # a thin noisy slab at an angle to all three axes: gridded along its principal axes (n >= 65536)
+        uv = rng.random((n, 2)) * np.array([900.0, 300.0])
+        w = rng.normal(0, 0.05, n)
+        e0, e1 = np.array([0.6, 0.64, 0.48]), np.array([-0.8, 0.48, 0.36])
+        e2 = np.cross(e0, e1)
+        return uv[:, :1] * e0 + uv[:, 1:] * e1 + w[:, None] * e2 + np.array([5.0e5, 5.4e6, 300.0])
+    if name == "diagonal_strip":   # a flight strip at 40 degrees, UTM-sized coordinates
+        a, b = rng.random(n) * 3000.0, rng.random(n) * 120.0
+        z = 6.0 * np.sin(a / 40.0) * np.cos(b / 30.0) + 50.0 + rng.normal(0, 0.02, n)
+        c, s_ = np.cos(np.radians(40.0)), np.sin(np.radians(40.0))
+        return np.column_stack([c * a - s_ * b + 5.0e5, s_ * a + c * b + 5.4e6, z])
+    if name == "core_with_halo":   # 1 % of the points thinly over 10^4 times the core's volume
+        pts = rng.random((n, 3)) * np.array([300.0, 300.0, 30.0])
+        m = n // 100
+        pts[rng.integers(0, n, m)] = (rng.random((m, 3)) - 0.5) * 8000.0
+        return pts
+    if name == "sheet_with_strays":  # the LiDAR case with stray returns far above and below
+        xy = rng.random((n, 2)) * 400.0
+        z = 8.0 * np.sin(xy[:, 0] / 40.0) * np.cos(xy[:, 1] / 55.0) + rng.normal(0, 0.03, n)
+        pts = np.column_stack([xy, z])
+        idx = rng.integers(0, n, 150)
+        pts[idx, 2] = (rng.random(150) - 0.5) * 4000.0
+        return pts
+    if name == "two_scans":        # two scans of different density a long way apart
+        a = rng.random((n // 2, 3)) * np.array([60.0, 60.0, 10.0])
+        b = rng.random((n - n // 2, 3)) * np.array([300.0, 300.0, 20.0]) + np.array([40000.0, -25000.0, 500.0])
+        return np.concatenate([a, b])[rng.permutation(n)]
+    raise ValueError(name)
+
+
+@pytest.mark.parametrize("name", ["tilted_slab", "diagonal_strip", "core_with_halo", "sheet_with_strays", "two_scans"])
+def test_sparse_clouds_120k_every_query_vs_oracle(hip, oracle, name):
+    """The paths clouds take that are not a filled box -- measured scale, trimmed box, principal axes, coarser levels, the all-points search --
+    with EVERY neighbour list and every fit compared with the oracle (the multi-million-point tests check samples)."""
+    from pasture_amd.algorithms import compute_normals
+    n, k = 120_000, 16
+    pts = _mid_sparse_cloud(name, n)
+
+    def run(api):
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    assert np.array_equal(hk, ok), f"{(hk != ok).any(axis=1).sum()} neighbour lists differ from the oracle"
+    bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
+    assert bad.sum() == 0 and cbad.sum() == 0, f"{bad.sum()} normals / {cbad.sum()} curvatures beyond 1e-9 relative"
+
+
 def _degenerate_cloud(name):
     rng = np.random.default_rng(3)
     if name == "flat_plane":   # one grid layer: every halo row above and below is outside the grid
