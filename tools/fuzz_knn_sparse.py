@@ -1,0 +1,68 @@
+"""Differential fuzz of the kNN search on clouds that are not a filled box (run on the GPU box): random planes / strips / clusters / halos /
+outliers at random orientations, sizes and k, every neighbour list compared with the CPU oracle.  python tools/fuzz_knn_sparse.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import tests.conftest as tc
+from pasture_amd._capi import product_api
+from pasture_amd.buffers import HashMapBuffer
+from pasture_amd.layout import PointLayout, attributes as A
+from pasture_amd.algorithms import compute_normals
+
+hip, orc = product_api(), tc._load_oracle()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def rot(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    return q
+
+
+def cloud(rng):
+    n = int(rng.integers(66_000, 220_000))
+    kind = rng.choice(["slab", "strip", "clusters", "halo", "outliers", "line"])
+    R, off = rot(rng), rng.choice([0.0, 1e3, 5e5, 5e6]) * rng.normal(size=3)
+    if kind == "slab":
+        p = np.column_stack([rng.random(n) * 800, rng.random(n) * 400, rng.normal(0, rng.choice([0.0, 0.05, 2.0]), n)])
+    elif kind == "strip":
+        a = rng.random(n) * 4000; b = rng.random(n) * 100
+        p = np.column_stack([a, b, 5 * np.sin(a / 37) + rng.normal(0, 0.02, n)])
+    elif kind == "clusters":
+        m = int(rng.integers(2, 6)); parts = []
+        for i in range(m):
+            parts.append(rng.random((n // m, 3)) * rng.uniform(1, 50) + rng.normal(size=3) * rng.uniform(100, 50000))
+        p = np.concatenate(parts)
+    elif kind == "halo":
+        p = rng.random((n, 3)) * np.array([300, 300, 40.0]); m = int(n * rng.uniform(0.002, 0.03))
+        p[rng.integers(0, n, m)] = (rng.random((m, 3)) - 0.5) * rng.uniform(3000, 40000)
+    elif kind == "outliers":
+        p = rng.random((n, 3)) * np.array([500, 500, 50.0]); m = int(rng.integers(1, 400))
+        p[rng.integers(0, n, m)] = (rng.random((m, 3)) - 0.5) * rng.uniform(2000, 1e6)
+    else:
+        t = rng.random(n) * 3000
+        p = np.column_stack([t, rng.normal(0, 0.3, n), rng.normal(0, 0.3, n)])
+    p = p[rng.permutation(len(p))]
+    return kind, p @ R.T + off
+
+
+bad = 0
+for c in range(cases):
+    kind, pts = cloud(rng)
+    n, k = len(pts), int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
+    out = []
+    for api in (hip, orc):
+        b = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api)); b.resize(n)
+        b.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        t0 = time.time(); out.append(compute_normals(b, k, return_knn=True) + (time.time() - t0,))
+    (hn, hc, hk, th), (on, oc, ok, to) = out
+    diff = (hk != ok).any(axis=1)
+    if diff.any():
+        # equal distances may be listed in either order: compare the distances of the differing lists
+        d_h = ((pts[hk[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1); d_o = ((pts[ok[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1)
+        real = (d_h != d_o).any(axis=1).sum()
+    else:
+        real = 0
+    bad += int(real > 0)
+    print(f"case {c:3d} {kind:9s} n={n:6d} k={k:2d}: lists differing {int(diff.sum()):5d} (not by ties: {int(real)})  hip {th*1e3:7.1f} ms  oracle {to:5.1f} s", flush=True)
+print("FAILED" if bad else "all identical", flush=True)
