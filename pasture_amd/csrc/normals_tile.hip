@@ -306,10 +306,12 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
     grid_frame(g, qx, qy, qz, qu, qv, qw);
     const int cx = (int)cell_coord(qu, g.org[0], g.inv_hx, g.dim[0]), cy = Y0 + qr % nqy, cz = Z0 + qr / nqy;
     const int B = hr * NC1 + (active ? cx - X0 + XH : XH);  // directory entry of the query's own cell (idle lanes: any valid one)
-    // A query OUTSIDE the grid's box (the box may be a trimmed one: normals.hip) was clamped into a boundary cell; the trims below take the
-    // query to lie in its cell.  It goes to the global-memory search, which is exact for it.  (On the box's upper faces the unclamped cell
-    // number equals dim: those are the box's own last points, inside.)
-    auto beyond = [](double v, double org, double inv, uint32_t dim) { const double u = __builtin_floor((v - org) * inv); return u < 0.0 || u > (double)dim; };
+    // A query OUTSIDE the grid's box (the box may be a trimmed one: normals.hip) was clamped into a boundary cell.  The trims below bound the
+    // distance to a row of cells by the distance to its slab -- true for the points of the row, and for points clamped INTO it as seen from
+    // inside the box (they lie beyond their cell, never nearer), but not as seen from outside: a query half a cell beyond a face may have a
+    // neighbour right next to it that was clamped into the same boundary row, and the slab is half a cell away.  Such a query goes to the
+    // global-memory search, which uses no slab bound.  (Exactly ON an upper face -- the box's own last points -- is inside: slab distance 0.)
+    auto beyond = [](double v, double org, double inv, uint32_t dim) { const double t = (v - org) * inv; return t < 0.0 || t > (double)dim; };
     const bool outside = beyond(qu, g.org[0], g.inv_hx, g.dim[0]) || beyond(qv, g.org[1], g.inv_h, g.dim[1]) || beyond(qw, g.org[2], g.inv_h, g.dim[2]);
 
     KBestPacked<K> best;

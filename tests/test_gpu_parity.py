@@ -603,6 +603,15 @@ def _mid_sparse_cloud(name, n):
         idx = rng.integers(0, n, 150)
         pts[idx, 2] = (rng.random(150) - 0.5) * 4000.0
         return pts
+    if name == "fringe":           # a rotated slab, far outliers that get the box trimmed, and a fringe of points just outside the trimmed box:
+        # queries half a cell beyond a face whose neighbours are clamped into the same boundary row (a fuzz find: the box search's slab
+        # bound does not hold for them; they must go to the global-memory search)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        core = rng.random((n - 3300, 3)) * np.array([500.0, 500.0, 50.0])
+        far = (rng.random((300, 3)) - 0.5) * 60000.0
+        shell = (rng.random((3000, 3)) * np.array([560.0, 560.0, 110.0])) - np.array([30.0, 30.0, 30.0])
+        pts = np.concatenate([core, far, shell])[rng.permutation(n)]
+        return pts @ q.T + np.array([3.0e5, -2.0e5, 800.0])
     if name == "two_scans":        # two scans of different density a long way apart
         a = rng.random((n // 2, 3)) * np.array([60.0, 60.0, 10.0])
         b = rng.random((n - n // 2, 3)) * np.array([300.0, 300.0, 20.0]) + np.array([40000.0, -25000.0, 500.0])
@@ -610,7 +619,7 @@ def _mid_sparse_cloud(name, n):
     raise ValueError(name)
 
 
-@pytest.mark.parametrize("name", ["tilted_slab", "diagonal_strip", "core_with_halo", "sheet_with_strays", "two_scans"])
+@pytest.mark.parametrize("name", ["tilted_slab", "diagonal_strip", "core_with_halo", "sheet_with_strays", "two_scans", "fringe"])
 def test_sparse_clouds_120k_every_query_vs_oracle(hip, oracle, name):
     """The paths clouds take that are not a filled box -- measured scale, trimmed box, principal axes, coarser levels, the all-points search --
     with EVERY neighbour list and every fit compared with the oracle (the multi-million-point tests check samples)."""
@@ -627,6 +636,32 @@ def test_sparse_clouds_120k_every_query_vs_oracle(hip, oracle, name):
     assert np.array_equal(hk, ok), f"{(hk != ok).any(axis=1).sum()} neighbour lists differ from the oracle"
     bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
     assert bad.sum() == 0 and cbad.sum() == 0, f"{bad.sum()} normals / {cbad.sum()} curvatures beyond 1e-9 relative"
+
+
+def test_knn_fuzz_finds_stay_fixed(hip, oracle):
+    """Cases of tools/fuzz_knn_sparse.py (seed 99) that once differed from the oracle.  198 and 245: queries half a cell beyond a face of a
+    trimmed, rotated box whose neighbours were clamped into the same boundary row -- the box search's slab bound does not hold for them."""
+    import importlib.util
+    from pasture_amd.algorithms import compute_normals
+    spec = importlib.util.spec_from_file_location("fuzz_knn_sparse", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "fuzz_knn_sparse.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    for c, kind, pts, k in fuzz.cases(99, 246):
+        if c not in (198, 245):
+            continue
+        n = len(pts)
+
+        def run(api):
+            buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+            buf.resize(n)
+            buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+            return compute_normals(buf, k, return_knn=True)
+        (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+        diff = (hk != ok).any(axis=1)
+        if diff.any():  # equal distances may be listed in either order
+            q = diff.nonzero()[0]
+            d_h, d_o = ((pts[hk[q]] - pts[q, None, :]) ** 2).sum(-1), ((pts[ok[q]] - pts[q, None, :]) ** 2).sum(-1)
+            assert np.array_equal(d_h, d_o), f"case {c} ({kind}, n = {n}, k = {k}): {(d_h != d_o).any(axis=1).sum()} neighbour lists differ from the oracle"
 
 
 def _degenerate_cloud(name):

@@ -3,15 +3,6 @@ outliers at random orientations, sizes and k, every neighbour list compared with
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import tests.conftest as tc
-from pasture_amd._capi import product_api
-from pasture_amd.buffers import HashMapBuffer
-from pasture_amd.layout import PointLayout, attributes as A
-from pasture_amd.algorithms import compute_normals
-
-hip, orc = product_api(), tc._load_oracle()
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
 def rot(rng):
@@ -46,23 +37,50 @@ def cloud(rng):
     return kind, p @ R.T + off
 
 
-bad = 0
-for c in range(cases):
-    kind, pts = cloud(rng)
-    n, k = len(pts), int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
-    out = []
-    for api in (hip, orc):
-        b = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api)); b.resize(n)
-        b.set_attribute_range(A.POSITION_3D, range(0, n), pts)
-        t0 = time.time(); out.append(compute_normals(b, k, return_knn=True) + (time.time() - t0,))
-    (hn, hc, hk, th), (on, oc, ok, to) = out
-    diff = (hk != ok).any(axis=1)
-    if diff.any():
-        # equal distances may be listed in either order: compare the distances of the differing lists
-        d_h = ((pts[hk[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1); d_o = ((pts[ok[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1)
-        real = (d_h != d_o).any(axis=1).sum()
-    else:
+def cases(seed, count):
+    """(index, kind, points, k) of the first `count` cases of a seed -- a fixed sequence (PCG64), so a failing case can be named."""
+    rng = np.random.default_rng(seed)
+    for c in range(count):
+        kind, pts = cloud(rng)
+        yield c, kind, pts, int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
+
+
+def main():
+    import tests.conftest as tc
+    from pasture_amd._capi import product_api
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.layout import PointLayout, attributes as A
+    from pasture_amd.algorithms import compute_normals
+    hip, orc = product_api(), tc._load_oracle()
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = {int(v) for v in sys.argv[3].split(",")} if len(sys.argv) > 3 else None  # evaluate only these cases (the others are generated and skipped)
+    bad = 0
+    for c, kind, pts, k in cases(seed, count):
+        if only is not None and c not in only:
+            continue
+        n = len(pts)
+        out = []
+        for api in (hip, orc):
+            b = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api)); b.resize(n)
+            b.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+            t0 = time.time(); out.append(compute_normals(b, k, return_knn=True) + (time.time() - t0,))
+        (hn, hc, hk, th), (on, oc, ok, to) = out
+        diff = (hk != ok).any(axis=1)
         real = 0
-    bad += int(real > 0)
-    print(f"case {c:3d} {kind:9s} n={n:6d} k={k:2d}: lists differing {int(diff.sum()):5d} (not by ties: {int(real)})  hip {th*1e3:7.1f} ms  oracle {to:5.1f} s", flush=True)
-print("FAILED" if bad else "all identical", flush=True)
+        if diff.any():
+            # equal distances may be listed in either order: compare the distances of the differing lists
+            d_h = ((pts[hk[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1); d_o = ((pts[ok[diff]] - pts[diff.nonzero()[0], None, :]) ** 2).sum(-1)
+            real = int((d_h != d_o).any(axis=1).sum())
+        bad += int(real > 0)
+        if real and only is not None:
+            qs = diff.nonzero()[0][(d_h != d_o).any(axis=1)]
+            for q in qs[:6]:
+                dh = np.sqrt(((pts[hk[q]] - pts[q]) ** 2).sum(-1)); do = np.sqrt(((pts[ok[q]] - pts[q]) ** 2).sum(-1))
+                print(f"  query {q} at {pts[q].tolist()}\n    hip    idx {hk[q].tolist()}\n           d   {np.round(dh, 4).tolist()}\n    oracle idx {ok[q].tolist()}\n           d   {np.round(do, 4).tolist()}", flush=True)
+        print(f"case {c:3d} {kind:9s} n={n:6d} k={k:2d}: lists differing {int(diff.sum()):5d} (not by ties: {real})  hip {th*1e3:7.1f} ms  oracle {to:5.1f} s", flush=True)
+    print("FAILED" if bad else "all identical", flush=True)
+
+
+if __name__ == "__main__":
+    main()
