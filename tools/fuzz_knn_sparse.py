@@ -1,5 +1,6 @@
 """Differential fuzz of the kNN search on clouds that are not a filled box (run on the GPU box): random planes / strips / clusters / halos /
-outliers at random orientations, sizes and k, every neighbour list compared with the CPU oracle.  python tools/fuzz_knn_sparse.py [cases] [seed]"""
+outliers at random orientations, sizes and k, every neighbour list compared with the CPU oracle.  python tools/fuzz_knn_sparse.py [cases] [seed] [only,these,cases]   (FUZZ_KINDS=1: also filled boxes, sheets, lattices,
+density contrasts; FUZZ_BIG=1: 1.05 - 1.6 million points)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,9 +11,9 @@ def rot(rng):
     return q
 
 
-def cloud(rng):
-    n = int(rng.integers(66_000, 220_000))
-    kind = rng.choice(["slab", "strip", "clusters", "halo", "outliers", "line"])
+def cloud(rng, big=False, more_kinds=False):
+    n = int(rng.integers(1_050_000, 1_600_000)) if big else int(rng.integers(66_000, 220_000))
+    kind = rng.choice(["slab", "strip", "clusters", "halo", "outliers", "line"] + (["volume", "sheet", "lattice", "dense_core"] if more_kinds else []))
     R, off = rot(rng), rng.choice([0.0, 1e3, 5e5, 5e6]) * rng.normal(size=3)
     if kind == "slab":
         p = np.column_stack([rng.random(n) * 800, rng.random(n) * 400, rng.normal(0, rng.choice([0.0, 0.05, 2.0]), n)])
@@ -30,6 +31,16 @@ def cloud(rng):
     elif kind == "outliers":
         p = rng.random((n, 3)) * np.array([500, 500, 50.0]); m = int(rng.integers(1, 400))
         p[rng.integers(0, n, m)] = (rng.random((m, 3)) - 0.5) * rng.uniform(2000, 1e6)
+    elif kind == "volume":      # a filled box of random aspect
+        p = rng.random((n, 3)) * rng.uniform(5, 2000, 3)
+    elif kind == "sheet":       # an undulating surface with noise
+        xy = rng.random((n, 2)) * rng.uniform(100, 3000, 2)
+        p = np.column_stack([xy, rng.uniform(1, 30) * np.sin(xy[:, 0] / rng.uniform(20, 200)) * np.cos(xy[:, 1] / rng.uniform(20, 200)) + rng.normal(0, rng.choice([0.0, 0.02, 0.5]), n)])
+    elif kind == "lattice":     # coordinates on a coarse lattice: exact distance ties and coincident points
+        p = np.round(rng.random((n, 3)) * np.array([300, 300, rng.choice([0.0, 4.0, 60.0])])) * rng.choice([0.25, 0.5, 1.0])
+    elif kind == "dense_core":  # a density contrast of a few hundred inside one box
+        p = rng.random((n, 3)) * np.array([800, 800, 80.0]); m = n // 2
+        p[:m] = rng.random((m, 3)) * np.array([60, 60, 20.0]) + np.array([300, 500, 30.0])
     else:
         t = rng.random(n) * 3000
         p = np.column_stack([t, rng.normal(0, 0.3, n), rng.normal(0, 0.3, n)])
@@ -37,11 +48,12 @@ def cloud(rng):
     return kind, p @ R.T + off
 
 
-def cases(seed, count):
-    """(index, kind, points, k) of the first `count` cases of a seed -- a fixed sequence (PCG64), so a failing case can be named."""
+def cases(seed, count, big=False, more_kinds=False):
+    """(index, kind, points, k) of the first `count` cases of a seed -- a fixed sequence (PCG64), so a failing case can be named.
+    (big / more_kinds change the sequence: tests name cases of the default one.)"""
     rng = np.random.default_rng(seed)
     for c in range(count):
-        kind, pts = cloud(rng)
+        kind, pts = cloud(rng, big, more_kinds)
         yield c, kind, pts, int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
 
 
@@ -56,7 +68,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     only = {int(v) for v in sys.argv[3].split(",")} if len(sys.argv) > 3 else None  # evaluate only these cases (the others are generated and skipped)
     bad = 0
-    for c, kind, pts, k in cases(seed, count):
+    for c, kind, pts, k in cases(seed, count, big=bool(os.environ.get("FUZZ_BIG")), more_kinds=bool(os.environ.get("FUZZ_KINDS"))):
         if only is not None and c not in only:
             continue
         n = len(pts)
