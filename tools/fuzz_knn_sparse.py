@@ -1,6 +1,6 @@
 """Differential fuzz of the kNN search on clouds that are not a filled box (run on the GPU box): random planes / strips / clusters / halos /
 outliers at random orientations, sizes and k, every neighbour list compared with the CPU oracle.  python tools/fuzz_knn_sparse.py [cases] [seed] [only,these,cases]   (FUZZ_KINDS=1: also filled boxes, sheets, lattices,
-density contrasts; FUZZ_BIG=1: 1.05 - 1.6 million points)"""
+density contrasts; FUZZ_ONLY=kind,kind: only those; FUZZ_BIG=1: 1.05 - 1.6 million points)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,10 @@ def rot(rng):
 
 def cloud(rng, big=False, more_kinds=False):
     n = int(rng.integers(1_050_000, 1_600_000)) if big else int(rng.integers(66_000, 220_000))
-    kind = rng.choice(["slab", "strip", "clusters", "halo", "outliers", "line"] + (["volume", "sheet", "lattice", "dense_core"] if more_kinds else []))
+    kinds = ["slab", "strip", "clusters", "halo", "outliers", "line"] + (["volume", "sheet", "lattice", "dense_core"] if more_kinds else [])
+    if os.environ.get("FUZZ_ONLY"):
+        kinds = os.environ["FUZZ_ONLY"].split(",")
+    kind = rng.choice(kinds)
     R, off = rot(rng), rng.choice([0.0, 1e3, 5e5, 5e6]) * rng.normal(size=3)
     if kind == "slab":
         p = np.column_stack([rng.random(n) * 800, rng.random(n) * 400, rng.normal(0, rng.choice([0.0, 0.05, 2.0]), n)])
