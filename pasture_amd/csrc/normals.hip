@@ -1203,10 +1203,6 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         if (n_open[1] && !all_points(2, n_open[1])) return -1;
         const uint32_t n_un = n_open[0];
         if (!n_un) break;
-        if (level > 8 || (double)n_un * (double)nf <= 2e11) {  // (the all-points search does ~2e12 pairs per second)
-          if (!all_points(1, n_un)) return -1;
-          break;
-        }
         if (level == 1) {  // from here on: the cloud's own axes and its full bounding box
           frame = GridParams{};
           for (int c = 0; c < 3; ++c) { mn[c] = full_mn[c]; mx[c] = full_mx[c]; }
@@ -1217,6 +1213,13 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const uint64_t up_cells = grid_for(h_up, 1, trial);
         const bool last = std::max(trial.dim[0], std::max(trial.dim[1], trial.dim[2])) <= (uint32_t)kShellCap + 1u;
         const bool up_dense = is_dense(up_cells);
+        // all points or another level?  The all-points search does ~2e12 pairs per second; an index costs ~2 ns per point with a dense
+        // directory and ~4.5 ns with the hash table (64-bit Morton keys, eight radix passes, the table), and may leave queries open.
+        const double cost_all = (double)n_un * (double)nf / 2e12, cost_level = (double)nf * (up_dense ? 2e-9 : 4.5e-9);
+        if (level > 8 || cost_all <= 2.0 * cost_level) {
+          if (!all_points(1, n_un)) return -1;
+          break;
+        }
         if (debug) fprintf(stderr, "[pst knn] level %d: %u open queries, cell edge %g (%s)%s\n", level, n_un, h_up, up_dense ? "dense" : "hash", last ? ", uncapped" : "");
         if (!build_index(h_up, 1, up_dense)) return -1;
         dense = up_dense;
