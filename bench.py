@@ -62,6 +62,8 @@ WORKLOADS = {
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
+    "normals_knn16_sheet": (44, "the same on a LiDAR-like sheet (a noisy 2-D manifold z = f(x, y) in a 3-D box, 23 % of the box occupied) with 0.001 % "
+                                "stray points far above and below it: measured scale, trimmed box, box search, exact search of the strays"),
 }
 
 
@@ -327,6 +329,23 @@ def main():
 
         def step():
             pa.compute_normals_into(src, 16, dst)
+    elif args.workload == "normals_knn16_sheet":
+        from pasture_amd.layout import PointAttributeDefinition
+        g = torch.Generator(device="cuda")
+        g.manual_seed(SEED + first_index)
+        xy = torch.rand(n, 2, device="cuda", dtype=torch.float64, generator=g) * 1000.0
+        z = 10.0 * torch.sin(xy[:, 0] / 50.0) * torch.cos(xy[:, 1] / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+        sheet = torch.cat([xy, z[:, None]], dim=1).contiguous()
+        n_stray = max(1, n // 100000)
+        sheet[torch.randint(0, n, (n_stray,), device="cuda", generator=g), 2] = (torch.rand(n_stray, device="cuda", dtype=torch.float64, generator=g) - 0.5) * 6000.0
+        del xy, z
+        src = pa.ExternalColumnsBuffer([sheet], pa.PointLayout.from_attributes([A.POSITION_3D]), n)
+        dst = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.NORMAL, PointAttributeDefinition("Curvature", T.F64)]))
+        dst.resize(n)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+
+        def step():
+            pa.compute_normals_into(src, 16, dst)
     elif args.workload == "las0_encode":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)
@@ -557,7 +576,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "points_per_gpu": n, "global_points": global_points,
-                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16") else "LAS format 0",
+                       "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16", "normals_knn16_sheet") else "LAS format 0",
                        "parallelism": (f"index-range shard x{world} of one {global_points}-point cloud (configs[3]), one all-reduce of the 6-f64 AABB" if args.global_points
                                        else f"index-range shard x{world}, one all-reduce of the 6-f64 AABB") if distributed else "1 GPU",
                        "seed": SEED, "bounds": result},

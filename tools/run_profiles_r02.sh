@@ -20,7 +20,7 @@ for spec in "convert_affine_bounds vec3f64_stream_kernel" "normals_knn16 knn_til
   rm -rf gpurun_out/prof/$1
 done
 rm -f gpurun_out/r02/r02_workloads.jsonl
-for w in convert_affine_bounds bounds las0_to_columns las0_to_columns_bounds rawlas_to_columns rawlas_to_columns_bounds rawlas_to_records columns_to_las0 columns_to_custom41 las1_records_to_custom27 benchlayout_records_to_columns benchlayout_columns_to_records benchlayout_records_to_records las0_encode filter_big_columnar filter_big_interleaved voxelgrid_xyz narrow_f64_f32 normals_knn16; do
+for w in convert_affine_bounds bounds las0_to_columns las0_to_columns_bounds rawlas_to_columns rawlas_to_columns_bounds rawlas_to_records columns_to_las0 columns_to_custom41 las1_records_to_custom27 benchlayout_records_to_columns benchlayout_columns_to_records benchlayout_records_to_records las0_encode filter_big_columnar filter_big_interleaved voxelgrid_xyz narrow_f64_f32 normals_knn16 normals_knn16_sheet; do
   python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/r02/r02_workloads.jsonl
 done
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r02/r02_bench_line.json
