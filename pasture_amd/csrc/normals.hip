@@ -1059,7 +1059,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // around a typical point, and its local dimension.
     const double h_box_now = edge_for(m_target / 4.18879020478639);
     const bool fills = occupancy >= 0.9 && !(h_gate > 0.0 && std::fabs(h_gate / h_box_now - 1.0) > 0.3);  // the cloud is what its (trimmed) box says
-    if (!fills && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+    // (up to 4 million points the gate's subsample is thinned by at most 32 -- as good as the full estimate: taken as it is)
+    const bool gate_is_enough = h_gate > 0.0 && n <= (32ull << 17);
+    if (!fills && gate_is_enough) { h_est = h_gate; d_est = d_gate; }
+    if (!fills && !gate_is_enough && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
       // the subsample: a sixteenth of the cloud, at least 2^18 and at most 2^22 points (the further the thinning, the longer the extrapolation
       // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
       const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 18, n / 16));
