@@ -638,15 +638,43 @@ def test_sparse_clouds_120k_every_query_vs_oracle(hip, oracle, name):
     assert bad.sum() == 0 and cbad.sum() == 0, f"{bad.sum()} normals / {cbad.sum()} curvatures beyond 1e-9 relative"
 
 
-def test_knn_fuzz_finds_stay_fixed(hip, oracle):
-    """Cases of tools/fuzz_knn_sparse.py (seed 99) that once differed from the oracle.  198 and 245: queries half a cell beyond a face of a
-    trimmed, rotated box whose neighbours were clamped into the same boundary row -- the box search's slab bound does not hold for them."""
+def _fuzz_module():
     import importlib.util
-    from pasture_amd.algorithms import compute_normals
     spec = importlib.util.spec_from_file_location("fuzz_knn_sparse", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools", "fuzz_knn_sparse.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    for c, kind, pts, k in fuzz.cases(99, 246):
+    return fuzz
+
+
+@pytest.mark.parametrize("seed", range(8 * FUZZ))
+def test_random_sparse_clouds_knn_vs_oracle(hip, oracle, seed):
+    """A few cases of tools/fuzz_knn_sparse.py per run (all ten kinds of cloud, random orientation, 66 000 - 220 000 points, random k): every
+    neighbour list against the oracle.  PST_FUZZ_SCALE multiplies the number."""
+    from pasture_amd.algorithms import compute_normals
+    (c, kind, pts, k), = _fuzz_module().cases(50_000 + seed, 1, more_kinds=True)
+    n = len(pts)
+
+    def run(api):
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    diff = (hk != ok).any(axis=1)
+    if diff.any():  # equal distances may be listed in either order
+        q = diff.nonzero()[0]
+        d_h, d_o = ((pts[hk[q]] - pts[q, None, :]) ** 2).sum(-1), ((pts[ok[q]] - pts[q, None, :]) ** 2).sum(-1)
+        assert np.array_equal(d_h, d_o), f"{kind}, n = {n}, k = {k}: {(d_h != d_o).any(axis=1).sum()} neighbour lists differ from the oracle"
+    same = ~diff
+    bad, cbad = _compare_normals(hn[same], hc[same], on[same], oc[same], scales=_cov_scales(pts, ok)[same])
+    assert bad.sum() == 0 and cbad.sum() == 0, f"{kind}: {bad.sum()} normals / {cbad.sum()} curvatures beyond 1e-9 relative"
+
+
+def test_knn_fuzz_finds_stay_fixed(hip, oracle):
+    """Cases of tools/fuzz_knn_sparse.py (seed 99) that once differed from the oracle.  198 and 245: queries half a cell beyond a face of a
+    trimmed, rotated box whose neighbours were clamped into the same boundary row -- the box search's slab bound does not hold for them."""
+    from pasture_amd.algorithms import compute_normals
+    for c, kind, pts, k in _fuzz_module().cases(99, 246):
         if c not in (198, 245):
             continue
         n = len(pts)
