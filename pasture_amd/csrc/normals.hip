@@ -1082,7 +1082,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       mark("scale");
     }
-    if (k <= 32 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
+    if (k <= 64 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
       // fine x cells per h: 4 for clouds that fill their box; 2 for the others (a surface: the same box holds fewer points, the 31-cell limit of a
       // box row then makes boxes too short at rx = 4: 6.3 against 3.9 ms per 10^7 points of the sheet in tools/exp_normals_surface.py)
       uint32_t rx = (h_est > 0.0 ? d_est < 2.5 : occupancy < 0.5) ? 2 : 4;  // (the measured dimension where there is one: a sheet that fills a thin box is still a sheet)

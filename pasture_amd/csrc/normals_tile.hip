@@ -585,7 +585,7 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
 // its points into a few boxes.  bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
 bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, const uint32_t* cell_start, unsigned long long* scratch3,
                     hipStream_t stream, TileShape& t) {
-  if (k > 32 || cells == 0 || nf == 0) return false;
+  if (k > 64 || cells == 0 || nf == 0) return false;
   t.threads = 256;
   t.cap = 1536;
   if (const char* e = std::getenv("PST_KNN_TILE")) {  // "bx,by,bz"
@@ -661,7 +661,8 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
     if (k <= 8) PST_TILE_LAUNCH(8, TT, CC);                                                                                  \
     else if (k <= 16) PST_TILE_LAUNCH(16, TT, CC);                                                                           \
     else if (k <= 24) PST_TILE_LAUNCH(24, TT, CC);                                                                           \
-    else PST_TILE_LAUNCH(32, TT, CC);                                                                                        \
+    else if (k <= 32) PST_TILE_LAUNCH(32, TT, CC);                                                                           \
+    else PST_TILE_LAUNCH(64, TT, CC);                                                                                        \
   } while (0)
   PST_TILE_K(256, 1536);
 #undef PST_TILE_K

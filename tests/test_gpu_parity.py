@@ -301,7 +301,7 @@ def _compare_normals(hn, hc, on, oc, rel=1e-9, scales=None):
     return bad, cerr
 
 
-@pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5),
+@pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5), ("volume", 20_000, 40), ("surface", 25_000, 64),
                                        ("clustered", 40_000, 16), ("clustered", 30_000, 24)])
 @pytest.mark.parametrize("kind", ["V", "H"])
 def test_compute_normals_vs_oracle(hip, oracle, shape, n, k, kind):

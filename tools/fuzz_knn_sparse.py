@@ -1,6 +1,6 @@
 """Differential fuzz of the kNN search on clouds that are not a filled box (run on the GPU box): random planes / strips / clusters / halos /
 outliers at random orientations, sizes and k, every neighbour list compared with the CPU oracle.  python tools/fuzz_knn_sparse.py [cases] [seed] [only,these,cases]   (FUZZ_KINDS=1: also filled boxes, sheets, lattices,
-density contrasts; FUZZ_ONLY=kind,kind: only those; FUZZ_BIG=1: 1.05 - 1.6 million points)"""
+density contrasts; FUZZ_ONLY=kind,kind: only those; FUZZ_KS=40,64: these k in turn; FUZZ_BIG=1: 1.05 - 1.6 million points)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -57,7 +57,11 @@ def cases(seed, count, big=False, more_kinds=False):
     rng = np.random.default_rng(seed)
     for c in range(count):
         kind, pts = cloud(rng, big, more_kinds)
-        yield c, kind, pts, int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
+        k = int(rng.choice([5, 8, 12, 16, 16, 16, 24, 30]))
+        if os.environ.get("FUZZ_KS"):  # (other k: does not change the sequence of clouds)
+            ks = [int(v) for v in os.environ["FUZZ_KS"].split(",")]
+            k = ks[c % len(ks)]
+        yield c, kind, pts, k
 
 
 def main():
