@@ -1528,6 +1528,57 @@ def test_two_threads_two_streams(hip):
     assert got[1] == want[1] and got[2] == want[2]
 
 
+def test_two_threads_compute_normals(hip):
+    """compute_normals from two threads at once, each on its own stream: the search's device scratch, its counters and its per-call decisions
+    (scale estimate, trimmed box, levels) are per thread / per call.  A filled box and a sheet with stray points, three rounds each."""
+    import ctypes
+    import threading
+    import torch
+    from pasture_amd.algorithms import compute_normals_device
+    from pasture_amd.buffers import ExternalColumnsBuffer
+    n, k = 600_000, 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    box = (torch.rand(n, 3, device="cuda", dtype=torch.float64, generator=g) * torch.tensor([300.0, 300.0, 40.0], device="cuda", dtype=torch.float64)).contiguous()
+    xy = torch.rand(n, 2, device="cuda", dtype=torch.float64, generator=g) * 400.0
+    sheet = torch.cat([xy, (6.0 * torch.sin(xy[:, :1] / 40.0) + 0.02 * torch.randn(n, 1, device="cuda", dtype=torch.float64, generator=g))], dim=1)
+    sheet[torch.randint(0, n, (40,), device="cuda", generator=g), 2] = 3000.0
+    sheet = sheet.contiguous()
+    clouds = {1: box, 2: sheet}
+
+    def work(which):
+        pts = clouds[which]
+        src = ExternalColumnsBuffer([pts], PointLayout.from_attributes([A.POSITION_3D], api=hip), n)
+        normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+        curv = torch.empty(n, dtype=torch.float64, device="cuda")
+        knn = torch.empty((n, k), dtype=torch.int32, device="cuda")
+        compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
+        return normals, curv, knn
+    hip.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    want = {w: work(w) for w in (1, 2)}
+    torch.cuda.synchronize()
+    got, errors = {}, []
+
+    def runner(which):
+        try:
+            stream = torch.cuda.Stream()
+            hip.set_stream(ctypes.c_void_p(stream.cuda_stream))  # thread-local
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    got[which] = work(which)
+            stream.synchronize()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+    threads = [threading.Thread(target=runner, args=(w,)) for w in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for w in (1, 2):
+        assert all(torch.equal(a, b) for a, b in zip(got[w], want[w])), f"cloud {w}: the concurrent result differs from the single-threaded one"
+
+
 def test_two_threads_share_one_converter(hip):
     """ONE BufferLayoutConverter used from two threads at once, each with its own stream and its own buffers (the reference's converter is
     only read by convert_into_range: buffer_conversion.rs:292 takes &self).  The plan-recognition caches inside the converter are atomics;
