@@ -12,7 +12,7 @@ cp gpurun_out/r02/pmc_calibration.json $out/pmc_calibration.json
 for spec in "convert_affine_bounds vec3f64_stream_kernel" "normals_knn16 knn_tile_kernel" "voxelgrid_xyz voxel_reduce_kernel" "las0_to_columns las_records_to_columns_kernel" \
             "filter_big_interleaved filter_big_records_kernel" "filter_big_columnar filter_scatter_kernel" "columns_to_custom41 convert_tile_static_kernel" \
             "las1_records_to_custom27 convert_tile_static_kernel" "benchlayout_records_to_records convert_tile_static_kernel" "las0_encode las_encode_kernel" \
-            "rawlas_to_columns las_decode_kernel"; do
+            "rawlas_to_columns las_decode_kernel" "normals_knn16_sheet knn_tile_kernel"; do
   set -- $spec
   tools/profile_round.sh $1 > /dev/null 2>&1
   python tools/rocprof_summary.py --round r02 --workload $1 --kernel "$2" --out $out --kt gpurun_out/prof/$1/kt/bench_results.db \
