@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--cmd", default="python bench.py --no-cpu-baseline")
     ap.add_argument("--out", default="profiles")
+    ap.add_argument("--key", default=None, help="key in hbm_traffic.json and file-name stem (default: the workload)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     lines = []
@@ -84,14 +85,15 @@ def main():
                            "correction": f"FETCH_SIZE x{ff:g}, WRITE_SIZE x1, KiB x1024", "round": a.round}
                 if gather:
                     traffic["bytes_per_launch_upper"] = round(2.0 * f[1] * 1024 + w[1] * 1024)
-    txt = os.path.join(a.out, f"{a.round}_{a.workload}_rocprof.txt")
+    key = a.key or a.workload
+    txt = os.path.join(a.out, f"{a.round}_{key}_rocprof.txt")
     with open(txt, "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))
     if traffic:
         tpath = os.path.join(a.out, "hbm_traffic.json")
         allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        allt[a.workload] = traffic
+        allt[key] = traffic
         json.dump(allt, open(tpath, "w"), indent=1)
 
 
