@@ -78,6 +78,11 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --launch-dry-run (CPU test of the launcher)")
     p.add_argument("--launch-dry-run", action="store_true",
                    help="start the ranks, count them with one all-reduce, print the census and exit: no GPU work (CPU test of the N>1 launcher)")
+    p.add_argument("--collective", default="capi", choices=["capi", "torch"],
+                   help="N > 1: the AABB exchange per step. capi (default) = the boundary's own pst_bounds_allreduce (pst_comm_init_rank bootstrapped from "
+                        "the launcher's rendezvous); torch = torch.distributed.all_reduce")
+    p.add_argument("--no-configs3", action="store_true", help="N > 1: skip the configs[3] leg (ONE 10^9-point cloud sharded over the ranks) appended to the weak-scaling line")
+    p.add_argument("--configs3-points", type=int, default=1_000_000_000)
     p.add_argument("--no-north-star", action="store_true", help="skip the 10^9-point single-GPU leg (north_star size) appended at N=1")
     p.add_argument("--north-star-points", type=int, default=1_000_000_000)
     p.add_argument("--workload", default="convert_affine_bounds", choices=sorted(WORKLOADS))
@@ -281,8 +286,21 @@ def main():
         global_points, scaling = n * world, "weak"
     bytes_per_point, desc = WORKLOADS[args.workload]
     # ring of AABB records: step i writes ring[i % 4]; with N > 1 its all-reduce runs asynchronously behind the next steps
-    from pasture_amd.distributed import PipelinedBoundsReduce
-    ring = PipelinedBoundsReduce(lambda: torch.empty(6, dtype=torch.float64, device="cuda"), depth=4)
+    from pasture_amd.distributed import BoundsExchange, CapiTransport, PipelinedBoundsReduce
+
+    def make_rec():
+        return torch.empty(6, dtype=torch.float64, device="cuda")
+
+    transport = None
+    if distributed and args.collective == "capi":
+        # the product's own collective: pst_comm_init_rank over the launcher's rendezvous, pst_bounds_allreduce per step
+        transport = CapiTransport(None, api)
+        if transport.size() != world:
+            sys.stderr.write(f"bench.py: pst_comm_size = {transport.size()}, expected {world}\n")
+            sys.exit(2)
+        ring = BoundsExchange(make_rec, transport, depth=4)
+    else:
+        ring = PipelinedBoundsReduce(make_rec, depth=4)
     rec = ring.recs[0]
 
     def rec_ptr():
@@ -522,6 +540,51 @@ def main():
     elif has_reduction and ring.i:
         rec = ring.recs[(ring.i - 1) % len(ring.recs)]
     result = bounds_from_record(rec.cpu())
+    # BASELINE.json configs[3] made driver-visible: a driver that passes only `--gpus N` gets the weak-scaling line above AND this leg --
+    # ONE 10^9-point cloud sharded by index range over the N ranks (strong scaling), the same fused step, the same exchange per step,
+    # timed like the main region (barrier + synchronize on both sides, max over ranks); never folded into `value`
+    configs3 = None
+    if (distributed and world > 1 and args.workload == "convert_affine_bounds" and not args.global_points and not args.no_configs3):
+        from pasture_amd.distributed import shard_range
+        g3 = args.configs3_points
+        sh = shard_range(g3, rank, world)
+        del src, dst
+        s_src = pa.HashMapBuffer.new_from_layout(layout)
+        s_src.resize(len(sh))
+        s_src.synth_fill(SEED, sh.start)
+        s_dst = pa.HashMapBuffer.new_from_layout(layout)
+        s_dst.resize(len(sh))
+        ring3 = BoundsExchange(make_rec, transport, depth=4) if transport is not None else PipelinedBoundsReduce(make_rec, depth=4)
+        c3_steps = 10
+
+        def c3_step():
+            conv.convert_into_with_bounds_async(s_src, s_dst, ring3.current().data_ptr())
+            ring3.submit()
+        for _ in range(2):
+            c3_step()
+        ring3.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(c3_steps):
+            c3_step()
+        rec3 = ring3.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c3_elapsed = float(t.item())
+        configs3 = {"global_points": g3, "n_gpus": n_ranks_seen, "scaling": "strong", "steps": c3_steps,
+                    "ms_per_step": round(c3_elapsed / c3_steps * 1e3, 4), "value": round(g3 * c3_steps / c3_elapsed / 1e6, 2), "unit": "Mpoints/s",
+                    "aggregate_GBps": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9, 1),
+                    "frac_of_aggregate_peak": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
+                    "points_rank0": len(sh), "bounds": bounds_from_record(rec3.cpu()),
+                    "note": "BASELINE.json configs[3]: ONE cloud sharded by index range, rank r owns [r*ceil(G/N), min(G,(r+1)*ceil(G/N))); "
+                            "one AABB all-reduce per step; wall time between barriers, max over ranks"}
+        del s_src, s_dst
+
     # north_star size made driver-visible: the same fused convert + AABB over 10^9 points (24 GB in, 24 GB out) on ONE GPU, measured in this
     # run after the timed region (N = 1, default workload only); reported beside the headline, never folded into `value`
     north_star = None
@@ -597,6 +660,10 @@ def main():
                          "kernel_ms_min": round(min(kernel_ms), 4),
                          "note": "HIP events around one step's launches on the launch stream (conversion kernel + the AABB fold kernels where fused)"},
         }
+        if distributed:
+            line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
+        if configs3 is not None:
+            line["configs3_1e9"] = configs3
         if north_star is not None:
             line["north_star_1e9"] = north_star
         if world == 1 and not args.no_cpu_baseline and args.workload == "convert_affine_bounds":
@@ -606,6 +673,8 @@ def main():
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
+        if transport is not None:
+            transport.close()
         dist.destroy_process_group()
 
 

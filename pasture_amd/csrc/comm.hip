@@ -6,6 +6,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1): a process that already holds an RCCL instance -- torch.distributed's -- keeps using
 // that one (same SONAME), and the library stays loadable where RCCL is absent; the entry points then fail with PST_ERR_UNSUPPORTED.
 #include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only (ncclComm_t, ncclUniqueId, ncclFloat64, ncclMin): the functions are bound with dlsym below
 
 #include <mutex>
 #include <vector>
@@ -17,24 +18,17 @@ using namespace pst;
 
 namespace {
 
-// the slice of rccl.h this file needs (ABI of RCCL 2.x / ROCm 7: ncclResult_t and the enums are ints, ncclUniqueId is 128 opaque bytes
-// passed by value)
-typedef struct ncclComm* ncclComm_t;
-struct ncclUniqueId { char internal[128]; };
-enum { ncclSuccess = 0 };
-enum { ncclFloat64 = 8 };
-enum { ncclMin = 3 };
-
 struct Rccl {
   void* lib = nullptr;
-  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  // pointer types taken from the header's own declarations: a signature change in RCCL is a compile error here, not a silent ABI mismatch
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
 const Rccl& rccl() {
@@ -61,12 +55,23 @@ const Rccl& rccl() {
   return r;
 }
 
-void check(int rc, const char* what) {
+void check(ncclResult_t rc, const char* what) {
   if (rc != ncclSuccess) {
     const Rccl& r = rccl();
-    throw Error(PST_ERR_HIP, std::string(what) + " failed: " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error ") + " (" + std::to_string(rc) + ")");
+    throw Error(PST_ERR_HIP, std::string(what) + " failed: " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error ") + " (" + std::to_string((int)rc) + ")");
   }
 }
+
+// restores the caller's device and closes an open RCCL group when a multi-device call unwinds
+struct MultiGuard {
+  int prev = 0;
+  bool group_open = false;
+  MultiGuard() { PST_HIP_CHECK(hipGetDevice(&prev)); }
+  ~MultiGuard() {
+    if (group_open) (void)rccl().GroupEnd();
+    (void)hipSetDevice(prev);
+  }
+};
 
 // {min xyz, max xyz} <-> {min xyz, -max xyz}: ONE ncclMin all-reduce of 6 doubles then folds minima and maxima together
 __global__ void negate_max_kernel(double* rec6) {
@@ -154,6 +159,11 @@ int pst_bounds_allreduce(pst_comm* comm, double* device_rec6) {
   not_null(device_rec6, "device_rec6");
   if (comm->comms.size() != 1)
     throw Error(PST_ERR_INVALID_ARGUMENT, "pst_bounds_allreduce: this handle drives several devices; use pst_bounds_allreduce_multi");
+  int dev = -1;
+  PST_HIP_CHECK(hipGetDevice(&dev));
+  if (dev != comm->devices[0])
+    throw Error(PST_ERR_INVALID_ARGUMENT, "pst_bounds_allreduce: the communicator was created on device " + std::to_string(comm->devices[0]) +
+                                              ", the calling thread's current device is " + std::to_string(dev));
   hipStream_t s = current_stream();
   hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, s, device_rec6);
   check(rccl().AllReduce(device_rec6, device_rec6, 6, ncclFloat64, ncclMin, comm->comms[0], s), "ncclAllReduce");
@@ -167,22 +177,31 @@ int pst_bounds_allreduce_multi(pst_comm* comm, double* const* device_recs, void*
   PST_API_BEGIN
   not_null(comm, "comm");
   not_null(device_recs, "device_recs");
-  int prev = 0;
-  PST_HIP_CHECK(hipGetDevice(&prev));
   const size_t n = comm->comms.size();
+  const Rccl& r = rccl();
+  // every pointer is validated (null, and which device owns it) BEFORE the first hipSetDevice / ncclGroupStart
   for (size_t d = 0; d < n; ++d) {
-    PST_HIP_CHECK(hipSetDevice(comm->devices[d]));
-    hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, not_null(device_recs[d], "device_recs[d]"));
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, not_null(device_recs[d], "device_recs[d]")) != hipSuccess || at.device != comm->devices[d]) {
+      (void)hipGetLastError();
+      throw Error(PST_ERR_INVALID_ARGUMENT, "pst_bounds_allreduce_multi: device_recs[" + std::to_string(d) + "] is not memory of device " + std::to_string(comm->devices[d]));
+    }
   }
-  check(rccl().GroupStart(), "ncclGroupStart");
-  for (size_t d = 0; d < n; ++d)
-    check(rccl().AllReduce(device_recs[d], device_recs[d], 6, ncclFloat64, ncclMin, comm->comms[d], streams ? (hipStream_t)streams[d] : nullptr), "ncclAllReduce");
-  check(rccl().GroupEnd(), "ncclGroupEnd");
+  MultiGuard guard;
   for (size_t d = 0; d < n; ++d) {
     PST_HIP_CHECK(hipSetDevice(comm->devices[d]));
     hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
   }
-  PST_HIP_CHECK(hipSetDevice(prev));
+  check(r.GroupStart(), "ncclGroupStart");
+  guard.group_open = true;
+  for (size_t d = 0; d < n; ++d)
+    check(r.AllReduce(device_recs[d], device_recs[d], 6, ncclFloat64, ncclMin, comm->comms[d], streams ? (hipStream_t)streams[d] : nullptr), "ncclAllReduce");
+  guard.group_open = false;
+  check(r.GroupEnd(), "ncclGroupEnd");
+  for (size_t d = 0; d < n; ++d) {
+    PST_HIP_CHECK(hipSetDevice(comm->devices[d]));
+    hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
+  }
   PST_HIP_CHECK(hipGetLastError());
   PST_API_END
 }

@@ -73,6 +73,101 @@ class PipelinedBoundsReduce:
         return last
 
 
+class CapiTransport:
+    """The boundary's own collective as the transport of BoundsExchange: `pst_comm_init_rank` bootstrapped from the launcher's
+    rendezvous (rank 0's 128-byte id broadcast over the torch group), then `pst_bounds_allreduce` per record -- ONE
+    ncclAllReduce(6 x f64, ncclMin) over {min, -max}, in place, ordered on the stream it is given."""
+    name = "pst_bounds_allreduce (C ABI: one ncclAllReduce of 6 x f64 with ncclMin over {min, -max}, RCCL)"
+
+    def __init__(self, group=None, api=None):
+        from ._capi import product_api
+        self.api = api or product_api()
+        self.comm = Communicator.from_torch_group(group, self.api)
+
+    def size(self) -> int:
+        return self.comm.size()
+
+    def allreduce(self, rec, stream_handle=None, restore_handle=None) -> None:
+        import ctypes as C
+        if stream_handle is not None:  # the library launches on the calling thread's stream: point it at the exchange stream for this call
+            self.api.set_stream(C.c_void_p(stream_handle))
+        try:
+            self.comm.allreduce_bounds(rec.data_ptr())
+        finally:
+            if stream_handle is not None:
+                self.api.set_stream(C.c_void_p(restore_handle))
+
+    def close(self) -> None:
+        self.comm.destroy()
+
+
+class TorchTransport:
+    """The same exchange through torch.distributed (RCCL when the backend is "nccl", gloo on CPU): the seam the CPU tests swap in."""
+    name = "torch.distributed.all_reduce (MIN over {min, -max})"
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def size(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group)
+
+    def allreduce(self, rec, stream_handle=None, restore_handle=None) -> None:
+        allreduce_bounds_record(rec, self.group)
+
+    def close(self) -> None:
+        pass
+
+
+class BoundsExchange:
+    """The per-step exchange of the sharded path (SURVEY.md 8(e)) for a stream of steps: step i writes its local {min xyz, max xyz}
+    into `current()`; `submit()` reduces that record in place over the ranks through `transport.allreduce`.  On a GPU the reduction
+    is ordered behind the step's kernels by an event and runs on its own high-priority stream, so the next step's kernels are
+    launched without waiting for it; a ring of `depth` records keeps a record alive until its reduction has finished, and before a
+    record is written again the compute stream waits for that reduction.  `finish()` returns the last global record.
+    The transport is the only thing that differs between bench.py on RCCL (CapiTransport) and the gloo tests (TorchTransport)."""
+
+    def __init__(self, make_record, transport, depth: int = 4):
+        self.recs = [make_record() for _ in range(depth)]
+        self.transport = transport
+        self.i = 0
+        self._cuda = bool(self.recs[0].is_cuda)
+        self._done = [None] * depth
+        if self._cuda:
+            import torch
+            self._main = torch.cuda.current_stream()
+            self._side = torch.cuda.Stream(priority=-1)
+
+    def current(self):
+        b = self.i % len(self.recs)
+        if self._cuda and self._done[b] is not None:
+            self._main.wait_event(self._done[b])  # the record's previous reduction (depth steps ago) before it is overwritten
+            self._done[b] = None
+        return self.recs[b]
+
+    def submit(self) -> None:
+        b = self.i % len(self.recs)
+        rec = self.recs[b]
+        if self._cuda:
+            import torch
+            ready = torch.cuda.Event()
+            ready.record(self._main)
+            self._side.wait_event(ready)
+            self.transport.allreduce(rec, self._side.cuda_stream, self._main.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self._side)
+            self._done[b] = done
+        else:
+            self.transport.allreduce(rec)
+        self.i += 1
+
+    def finish(self):
+        if self._cuda:
+            self._side.synchronize()
+            self._done = [None] * len(self.recs)
+        return self.recs[(self.i - 1) % len(self.recs)] if self.i else None
+
+
 def shard_output_offsets(local_count: int, group=None):
     """Compaction (`filter`) over index-range shards: rank r keeps its matches in order, so its slice of the global result
     starts at the sum of the match counts of ranks < r.  One all-gather of one int64 per rank.  Returns (offset, total)."""
@@ -150,12 +245,13 @@ class Communicator:
         """Bootstraps over an existing torch.distributed group (any backend): rank 0's id is broadcast as 128 bytes."""
         import torch
         import torch.distributed as dist
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        rank, world = dist.get_rank(group), dist.get_world_size(group)  # group-local rank: the rank of the new communicator
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"  # "cuda" = torch's CURRENT device: the caller has set the rank's GPU
         t = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             t = torch.tensor(list(cls.unique_id(api)), dtype=torch.uint8, device=dev)
-        dist.broadcast(t, src=0, group=group)
+        # broadcast's `src` is a GLOBAL rank: the group's rank 0 is not global rank 0 for a sub-group
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         return cls.from_unique_id(world, rank, bytes(t.cpu().tolist()), api)
 
     @classmethod
