@@ -27,29 +27,41 @@ void ensure_device() {
 
 void stream_sync(hipStream_t s) { PST_HIP_CHECK(hipStreamSynchronize(s)); }
 
-// One workspace per (thread, stream): the asynchronous entry points of one thread may run on several streams at once (a compute and
-// a copy stream, the pipelined LAS reader / writer), and their per-block partial records and result records must not alias.
+// One workspace per (thread, device, stream): the asynchronous entry points of one thread may run on several streams at once (a compute
+// and a copy stream, the pipelined LAS reader / writer), and their per-block partial records and result records must not alias; and the
+// null stream is the same key on every GPU, so after pst_set_device(d) a thread must not be handed scratch that lives on another device.
 Workspace& workspace() {
-  static thread_local std::unordered_map<hipStream_t, Workspace> by_stream;
-  const hipStream_t cur = current_stream();
-  auto it = by_stream.find(cur);
-  if (it == by_stream.end()) {
+  struct Key {
+    int dev;
+    hipStream_t stream;
+    bool operator==(const Key& o) const { return dev == o.dev && stream == o.stream; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const { return std::hash<const void*>()((const void*)k.stream) ^ ((size_t)(unsigned)k.dev * 0x9E3779B97F4A7C15ull); }
+  };
+  static thread_local std::unordered_map<Key, Workspace, KeyHash> by_key;
+  ensure_device();
+  Key cur{0, current_stream()};
+  PST_HIP_CHECK(hipGetDevice(&cur.dev));
+  auto it = by_key.find(cur);
+  if (it == by_key.end()) {
     // a thread that keeps creating streams (one per request, say) must not keep a workspace for each of them for ever: beyond eight
-    // the idle ones are released (after a device synchronisation: their last launches may still be reading them)
-    if (by_stream.size() >= 8) {
-      (void)hipDeviceSynchronize();
-      for (auto& kv : by_stream) {
+    // the idle ones are released (after synchronising every device that owns one: their last launches may still be reading them)
+    if (by_key.size() >= 8) {
+      for (auto& kv : by_key) {
+        (void)hipSetDevice(kv.first.dev);
+        (void)hipDeviceSynchronize();
         if (kv.second.dev) (void)hipFree(kv.second.dev);
         if (kv.second.pinned) (void)hipHostFree(kv.second.pinned);
         if (kv.second.partials_buf) (void)hipFree(kv.second.partials_buf);
       }
-      by_stream.clear();
+      (void)hipSetDevice(cur.dev);
+      by_key.clear();
     }
-    it = by_stream.emplace(cur, Workspace{}).first;
+    it = by_key.emplace(cur, Workspace{}).first;
   }
   Workspace& ws = it->second;
   if (!ws.dev) {
-    ensure_device();
     PST_HIP_CHECK(hipMalloc((void**)&ws.dev, Workspace::kWorkspaceBytes));
     PST_HIP_CHECK(hipHostMalloc((void**)&ws.pinned, Workspace::kPinnedBytes, hipHostMallocDefault));
   }
@@ -72,19 +84,23 @@ uint8_t* Workspace::partials(size_t bytes) {
 // ~100 ms each on this platform, which would dominate `convert()` (allocate + convert + return).  The pool keeps freed
 // blocks (release threshold = never), so steady-state allocations are sub-microsecond and stream-ordered.
 static bool pool_ready() {
-  static int state = [] {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    int supported = 0;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) != hipSuccess || !supported) return 0;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) return 0;
-    uint64_t keep = ~0ull;
-    if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) return 0;
-    return 1;
-  }();
+  // per device: every GPU has its own default pool, and each needs its release threshold raised once
+  static std::mutex mu;
+  static int state[64] = {};  // 0 = not asked yet, 1 = ready, 2 = no pool support
   if (std::getenv("PST_NO_POOL")) return false;
-  return state == 1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    state[dev] = 2;
+    int supported = 0;
+    hipMemPool_t pool;
+    uint64_t keep = ~0ull;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess && supported &&
+        hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess)
+      state[dev] = 1;
+  }
+  return state[dev] == 1;
 }
 
 // Pool blocks remember the stream they were allocated on.  hipFreeAsync orders the release behind THAT stream's work only, so a
@@ -112,8 +128,14 @@ void dev_free_stream(void* p, hipStream_t s) {
     auto it = g_alloc_stream.find(p);
     if (it != g_alloc_stream.end()) { owner = it->second; g_alloc_stream.erase(it); }
   }
+  // Freed on the stream it was allocated on when that is the current one.  Otherwise the whole device is synchronised first (work the
+  // asynchronous entry points enqueued on the owner may still use the block) and after that ANY live stream is a safe place for the
+  // release: the current one is used, never the remembered handle -- the caller may have destroyed that stream since.
   if (owner != s) (void)hipDeviceSynchronize();
-  (void)hipFreeAsync(p, owner);
+  if (hipFreeAsync(p, s) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+  }
 }
 
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind) {

@@ -682,14 +682,21 @@ struct ScratchCache {
     }
   }
   void release_all() {  // (no call of this thread is in flight: every call synchronises its stream before it returns)
-    for (Block& b : blocks) (void)hipFree(b.p);
+    for (Block& b : blocks) (void)hipFree(b.p);  // (hipFree of another device's pointer is valid from any current device)
     blocks.clear();
   }
+  ScratchCache() = default;
+  ScratchCache(ScratchCache&& o) noexcept : blocks(std::move(o.blocks)) { o.blocks.clear(); }
+  ScratchCache(const ScratchCache&) = delete;
   ~ScratchCache() { release_all(); }
 };
+// one cache per (thread, device): after pst_set_device(d) a thread must get blocks that live on GPU d
 ScratchCache& scratch_cache() {
-  static thread_local ScratchCache c;
-  return c;
+  static thread_local std::vector<ScratchCache> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if ((size_t)dev >= per_device.size()) per_device.resize((size_t)dev + 1);
+  return per_device[(size_t)dev];
 }
 struct CacheBuf {  // same surface as DevBuf
   void* p = nullptr;
@@ -703,7 +710,7 @@ struct CallGuard {
 }  // namespace
 
 // Frees the device blocks the calling thread's kNN calls keep between calls (about 100 bytes per point of the largest recent cloud).
-void release_normals_scratch() { scratch_cache().release_all(); }
+void release_normals_scratch() { scratch_cache().release_all(); }  // (the current device's cache)
 
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,
 // or the number of degenerate neighbourhoods (> 0).

@@ -121,6 +121,61 @@ def test_pipelined_bounds_allreduce_gloo(steps):
     assert got[0] == got[1] == want
 
 
+def _exchange_records(rank, step):
+    """Local {min xyz, max xyz} of (rank, step): every slot differs between the ranks, and which rank holds the smaller minimum / the
+    larger maximum alternates from slot to slot -- a SUM, a MAX, a PROD or a no-op in place of MIN over {min, -max} gives another record."""
+    lo = [(-1.0) ** (rank + c) * (3.0 + c) + step * 0.25 - 7.0 * c for c in range(3)]
+    hi = [lo[c] + 10.0 + (-1.0) ** (rank + c + 1) * (2.0 + c) for c in range(3)]
+    return lo + hi
+
+
+def _exchange_worker(rank, world, port, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pasture_amd.distributed import BoundsExchange, TorchTransport
+    # the path bench.py's default N > 1 mode runs (BoundsExchange); the transport is the one seam: CapiTransport (pst_bounds_allreduce
+    # over RCCL) on the GPU box, TorchTransport over gloo here
+    ring = BoundsExchange(lambda: torch.empty(6, dtype=torch.float64), TorchTransport(), depth=3)
+    out = []
+    for i in range(steps):
+        rec = ring.current()
+        rec.copy_(torch.tensor(_exchange_records(rank, i), dtype=torch.float64))
+        ring.submit()
+        out.append(rec.tolist())  # CPU records are reduced synchronously
+    last = ring.finish()
+    q.put((rank, out, None if last is None else last.tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 5])
+def test_bounds_exchange_matches_aabb_union_gloo(steps):
+    """World size 2, records that differ in every slot: every step's global record equals AABB.union (bounds.rs:109-122) of the two
+    local boxes -- through the same BoundsExchange path bench.py's `--collective capi` mode uses, with the RCCL call swapped for gloo."""
+    from pasture_amd.algorithms import AABB
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, (o, l)) for r, o, l in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(steps):
+        a, b = _exchange_records(0, i), _exchange_records(1, i)
+        for c in range(3):  # the inputs really differ in every slot, and neither rank dominates
+            assert a[c] != b[c] and a[3 + c] != b[3 + c]
+        assert {a[c] < b[c] for c in range(3)} == {True, False}
+        u = AABB.union(AABB(tuple(a[:3]), tuple(a[3:])), AABB(tuple(b[:3]), tuple(b[3:])))
+        want = list(u.min()) + list(u.max())
+        assert got[0][0][i] == want and got[1][0][i] == want
+    assert got[0][1] == got[1][1] == got[0][0][-1]
+
+
 def _sharded_ops_worker(rank, world, port, n, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -275,3 +330,56 @@ def test_capi_bounds_allreduce_world_size_1_rccl(hip):
 
 
 F64 = 1.7976931348623157e308
+
+
+def _capi_rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    import ctypes
+    import pasture_amd as pa
+    from pasture_amd.distributed import BoundsExchange, CapiTransport
+    api = pa.product_api()
+    api.set_device(rank)
+    api.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    tr = CapiTransport(None, api)
+    ring = BoundsExchange(lambda: torch.empty(6, dtype=torch.float64, device="cuda"), tr, depth=3)
+    out = []
+    for i in range(5):
+        rec = ring.current()
+        rec.copy_(torch.tensor(_exchange_records(rank, i), dtype=torch.float64))
+        ring.submit()
+    last = ring.finish()
+    torch.cuda.synchronize()
+    for r in ring.recs:
+        out.append(r.cpu().tolist())
+    q.put((rank, tr.size(), out, last.cpu().tolist()))
+    tr.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_capi_bounds_allreduce_two_ranks_rccl():
+    """pst_bounds_allreduce between TWO ranks (needs two GPUs; skipped on the 1-GPU boxes): the result is AABB.union of records that
+    differ in every slot, so ncclMin over {min, -max} is told apart from every other reduction and from a no-op."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    from pasture_amd.algorithms import AABB
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capi_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, (n, o, l)) for r, n, o, l in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = _exchange_records(0, 4), _exchange_records(1, 4)
+    u = AABB.union(AABB(tuple(a[:3]), tuple(a[3:])), AABB(tuple(b[:3]), tuple(b[3:])))
+    for r in (0, 1):
+        assert got[r][0] == 2 and got[r][2] == list(u.min()) + list(u.max())

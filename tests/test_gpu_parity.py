@@ -225,27 +225,154 @@ def _affine_bounds_properties(n, first_index, windows):
 
 
 def test_full_size_shard_1p25e8_first_index(hip):
-    """ONE shard of BASELINE.json configs[3] (10^9 points over 8 GPUs = 1.25e8 per GPU) exactly as rank 3 of 8 runs it:
-    shard_range gives first_index = 3.75e8 != 0.  Also: the union of this shard's AABB with its neighbours' equals what the
-    all-reduce would produce (checked against a second shard, rank 4, through AABB.union = MIN/MAX)."""
+    """TWO neighbouring shards of BASELINE.json configs[3] (10^9 points over 8 GPUs = 1.25e8 per GPU) exactly as ranks 3 and 4 of 8 run
+    them: shard_range gives first_index = 3.75e8 and 5e8.  What the all-reduce would produce from the two local records --
+    AABB.union = MIN of the minima, MAX of the maxima (bounds.rs:109-122) -- equals the fused bounds of the concatenated index range
+    [3.75e8, 6.25e8) computed in ONE call, for the source and for the transformed result."""
     from pasture_amd.algorithms import AABB
     from pasture_amd.distributed import shard_range
-    shard = shard_range(1_000_000_000, 3, 8)
-    assert (shard.start, len(shard)) == (375_000_000, 125_000_000)
-    n = len(shard)
-    b3, f3 = _affine_bounds_properties(n, shard.start, (0, 62_499_999, n - 4096))
-    nxt = shard_range(1_000_000_000, 4, 8)
-    # the next shard starts where this one ends: the last point of rank 3 and the first of rank 4 are consecutive global indices
-    layout = PointLayout.from_attributes([A.POSITION_3D])
-    seam = HashMapBuffer.new_from_layout(layout)
-    seam.resize(2)
-    seam.synth_fill(42, nxt.start - 1)
-    tail = HashMapBuffer.new_from_layout(layout)
-    tail.resize(1)
-    tail.synth_fill(42, shard.start + n - 1)
-    assert seam.get_attribute_range(A.POSITION_3D, range(0, 1)).tobytes() == tail.get_attribute_range(A.POSITION_3D, range(0, 1)).tobytes()
-    u = AABB.union(f3, f3)
-    assert u == f3
+    s3, s4 = shard_range(1_000_000_000, 3, 8), shard_range(1_000_000_000, 4, 8)
+    assert (s3.start, len(s3)) == (375_000_000, 125_000_000) and (s4.start, len(s4)) == (500_000_000, 125_000_000) and s3.stop == s4.start
+    n = len(s3)
+    b3, f3 = _affine_bounds_properties(n, s3.start, (0, 62_499_999, n - 4096))
+    b4, f4 = _affine_bounds_properties(n, s4.start, (0, n - 4096))
+    assert b3 != b4 and f3 != f4  # two different boxes: a union with itself would prove nothing
+    b34, f34 = _affine_bounds_properties(2 * n, s3.start, (n - 2048,))  # the window straddles the seam between the shards
+    assert AABB.union(b3, b4) == b34
+    assert AABB.union(f3, f4) == f34
+
+
+# ---- interleaved buffers beyond 4 GiB: every byte offset in the record kernels must be 64-bit (buffer_conversion.rs:546-604) ----------
+
+def _needs_free_hbm(gib):
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < gib * (1 << 30):
+        pytest.skip(f"needs {gib} GiB of free HBM")
+
+
+def test_interleaved_over_4gib_las0_round_trip(hip):
+    """1.3e8 typed LAS-0 records = 4.55 GB > 2^32 bytes: interleaved -> 10 columns -> interleaved is the identity and every column equals
+    the strided field of the source -- over the WHOLE buffer, i.e. including the 6 % of the records that lie beyond the 4 GiB offset."""
+    import torch
+    _needs_free_hbm(20)
+    n = 130_000_000
+    layout = las.point_layout_from_las_point_format(las.Format(0), False)
+    assert n * layout.size_of_point_entry() > 1 << 32
+    src = VectorBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(43, 0)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    cols = conv.convert(src, HashMapBuffer)
+    src_bytes = _torch_view(src.points_ptr(), n * 35).view(n, 35)
+    for a in layout.attributes():
+        col = _torch_view(cols.column_ptr(a.attribute_definition()), n * a.size()).view(n, a.size())
+        assert torch.equal(col, src_bytes[:, a.offset():a.offset() + a.size()]), a.name()
+    back = conv.convert(cols, VectorBuffer)
+    assert torch.equal(_torch_view(back.points_ptr(), n * 35), _torch_view(src.points_ptr(), n * 35))
+    # the records past the 4 GiB mark are not all alike (a wrapped 32-bit offset would have copied the buffer's first records there)
+    first_beyond = (1 << 32) // 35 + 1
+    assert not torch.equal(src_bytes[first_beyond:first_beyond + 4096], src_bytes[:4096])
+    # interleaved -> interleaved (both tiles in LDS) over the same buffer: typed LAS-0 -> {Position3D, Intensity, Classification}
+    small = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], 1)
+    out = BufferLayoutConverter.for_layouts(layout, small).convert(src, VectorBuffer)
+    o = _torch_view(out.points_ptr(), n * 27).view(n, 27)
+    for name, lo, hi in (("Position3D", 0, 24), ("Intensity", 24, 26), ("Classification", 26, 27)):
+        a = layout.get_attribute_by_name(name)
+        assert torch.equal(o[:, lo:hi], src_bytes[:, a.offset():a.offset() + a.size()]), name
+
+
+def test_raw_las_decode_over_4gib_vs_oracle_windows(hip, oracle):
+    """2.2e8 raw LAS-0 records = 4.4 GB > 2^32 bytes through the format-specialised decoder (columnar and interleaved targets): windows at
+    the start, across the 4 GiB offset and at the very end are byte-identical to the oracle decoding the same records (the synthetic
+    generator is index-addressable), the fused AABB equals a separate pass, and an encode of the decoded columns reproduces the
+    raw records over the whole buffer."""
+    import torch
+    _needs_free_hbm(40)
+    n = 220_000_000
+    raw_h = las.point_layout_from_las_point_format(las.Format(0), True, api=hip)
+    typed_h = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    assert raw_h.size_of_point_entry() == 20 and n * 20 > 1 << 32
+    src = VectorBuffer.new_from_layout(raw_h)
+    src.resize(n)
+    src.synth_fill(7, 0)
+    conv = las.get_default_las_converter(raw_h, typed_h, SCALE, OFFSET)
+    cols = HashMapBuffer.new_from_layout(typed_h)
+    cols.resize(n)
+    fused = conv.convert_into_with_bounds(src, cols)
+    assert fused == calculate_bounds(cols)
+    recs = VectorBuffer.new_from_layout(typed_h)
+    recs.resize(n)
+    conv.convert_into(src, recs)
+    w = 8192
+    seam = (1 << 32) // 20 - w // 2
+    raw_o = las.point_layout_from_las_point_format(las.Format(0), True, api=oracle)
+    typed_o = las.point_layout_from_las_point_format(las.Format(0), False, api=oracle)
+    conv_o = las.get_default_las_converter(raw_o, typed_o, SCALE, OFFSET)
+    for first in (0, seam, n - w):
+        piece = VectorBuffer.new_from_layout(raw_o)
+        piece.resize(w)
+        piece.synth_fill(7, first)
+        assert piece.get_point_range(range(0, w)).tobytes() == src.get_point_range(range(first, first + w)).tobytes()
+        want_cols = conv_o.convert(piece, HashMapBuffer)
+        want_recs = conv_o.convert(piece, VectorBuffer)
+        assert cols.get_point_range(range(first, first + w)).tobytes() == want_cols.get_point_range(range(0, w)).tobytes(), first
+        assert recs.get_point_range(range(first, first + w)).tobytes() == want_recs.get_point_range(range(0, w)).tobytes(), first
+    # whole-buffer check: the two targets agree field by field (both passes read all 4.4 GB of records)
+    rb = _torch_view(recs.points_ptr(), n * 35).view(n, 35)
+    for a in typed_h.attributes():
+        col = _torch_view(cols.column_ptr(a.attribute_definition()), n * a.size()).view(n, a.size())
+        assert torch.equal(col, rb[:, a.offset():a.offset() + a.size()]), a.name()
+    del rb, recs
+    # and the writer reproduces the raw records from the decoded columns: X = ((x*s+o) - o)/s exactly for this generator's coordinates?  Not
+    # guaranteed bit for bit (two roundings each way), so compare every field but the position, and the position within one step
+    enc = VectorBuffer.new_from_layout(raw_h)
+    enc.resize(n)
+    las.encode_points(cols, 0, SCALE, OFFSET, enc)
+    a_b, b_b = _torch_view(src.points_ptr(), n * 20).view(n, 20), _torch_view(enc.points_ptr(), n * 20).view(n, 20)
+    assert torch.equal(a_b[:, 12:], b_b[:, 12:])
+    # three int32 at byte offsets 0, 4, 8 of every 20-byte record: a strided int32 view of the record buffer
+    a_i = torch.as_strided(_torch_view(src.points_ptr(), n * 20).view(torch.int32), (n, 3), (5, 1))
+    b_i = torch.as_strided(_torch_view(enc.points_ptr(), n * 20).view(torch.int32), (n, 3), (5, 1))
+    assert int((a_i - b_i).abs().max().item()) <= 1
+
+
+def test_compaction_into_vector_buffer_over_4gib(hip):
+    """filter_into with an interleaved target beyond 4 GiB (point_buffer.rs:1082-1136): 2.2e8 CustomPointTypeBig points (41 B), density
+    0.5 -> 1.1e8 records = 4.5 GB.  Every field of every output record equals torch's boolean indexing of the source column."""
+    import torch
+    _needs_free_hbm(40)
+    n = 220_000_000
+    big = PointLayout.from_attributes_packed([A.GPS_TIME, A.COLOR_RGB, A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY.with_custom_datatype(T.I16)], 1)
+    assert big.size_of_point_entry() == 41
+    src = HashMapBuffer.new_from_layout(big)
+    src.resize(n)
+    src.synth_fill(19, 0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    mask = torch.rand(n, device="cuda", generator=g) < 0.5
+    m8 = mask.to(torch.uint8)
+    k = int(mask.sum().item())
+    assert k * 41 > 1 << 32
+    dst = VectorBuffer.new_from_layout(big)
+    dst.resize(k)
+    assert src.filter_into(dst, (m8.data_ptr(), "device"), k) == k
+    recs = _torch_view(dst.points_ptr(), k * 41).view(k, 41)
+    for a in big.attributes():
+        x = _torch_view(src.column_ptr(a.attribute_definition()), n * a.size()).view(n, a.size())
+        assert torch.equal(x[mask], recs[:, a.offset():a.offset() + a.size()]), a.name()
+    # the generic (interpreted) compaction over the same sizes: a layout the compile-time plans do not know
+    other = PointLayout.from_attributes_packed([A.POSITION_3D, A.GPS_TIME, A.COLOR_RGB, A.INTENSITY, A.CLASSIFICATION], 1)
+    conv = BufferLayoutConverter.for_layouts(big, other)
+    src2 = conv.convert(src, HashMapBuffer)
+    del src, dst, recs
+    dst2 = VectorBuffer.new_from_layout(other)
+    dst2.resize(k)
+    assert src2.filter_into(dst2, (m8.data_ptr(), "device"), k) == k
+    recs2 = _torch_view(dst2.points_ptr(), k * 41).view(k, 41)
+    for a in other.attributes():
+        x = _torch_view(src2.column_ptr(a.attribute_definition()), n * a.size()).view(n, a.size())
+        assert torch.equal(x[mask], recs2[:, a.offset():a.offset() + a.size()]), a.name()
 
 
 def test_full_size_1e9_single_gpu_convert_bounds(hip):
