@@ -820,7 +820,6 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     CacheBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, tkeys, tstarts, fb_list;
     NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
     NCK(sorted_xyz.alloc(n * 24, stream));
-    NCK(rec.alloc(n * 32, stream));
     GridParams g{};
     uint64_t cells = 0, nf = 0;
     CellTable table{nullptr, nullptr, 0};
@@ -892,7 +891,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     TileShape shape;
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
-    unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 40);
+    unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 88);  // four counters of the probe / census kernels (88 .. 120)
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
     if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
     // GATE: is the cloud what its bounding box says?  A quick scale estimate on 2^17 points, 256 queries (normals_scale.hip; 0.3 ms) against the radius
@@ -1116,7 +1115,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const double h_new = g.h * std::pow(m_target / std::fmax(m_full, 1.0), 1.0 / D);
         if (debug) fprintf(stderr, "[pst knn probe] h=%g: %.1f points within h/2, %.1f within h (target %.1f), dimension %.2f -> h=%g\n", g.h, m_half, m_full, m_target, D, h_new);
         if (round == 2 || std::fabs(h_new / g.h - 1.0) <= 0.10 || per_cell_env > 0 || std::getenv("PST_KNN_CELL")) {
-          tiled = knn_tile_shape(g, nf, cells, k, directory.as<uint32_t>(), scratch3, stream, shape);
+          tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape);
           mark("census");
           break;
         }
@@ -1148,7 +1147,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     NCK(unres.alloc(n, stream));
     NCK(hipMemsetAsync(unres.p, 0, n, stream));
     uint32_t* unres_count = (uint32_t*)((uint8_t*)counters.p + 64);
-    RecOut sorted{rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count};
+    // results: straight into the caller's outputs (default), or as 32-byte records + split_results_kernel (PST_KNN_DIRECT=0: the A/B switch)
+    static const bool direct_out = !(std::getenv("PST_KNN_DIRECT") && std::atoi(std::getenv("PST_KNN_DIRECT")) == 0);
+    if (!direct_out) NCK(rec.alloc(n * 32, stream));
+    RecOut sorted{direct_out ? nullptr : rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count,
+                  out.normals_f64, out.curvature_f64, out.normal_attr, out.normal_stride, out.curv_attr, out.curv_stride};
     if (nf) {
       if (dense) {
         const uint32_t* cell_start = directory.as<uint32_t>();
@@ -1157,14 +1160,27 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           // the global-memory search as a list
           NCK(fb_list.alloc(nf * 4, stream));
           NCK(hipMemsetAsync(fb_count, 0, 4, stream));
-          launch_knn_tile(shape, sorted_xyz.as<double>(), cell_start, g, k, (uint32_t)nf, sorted, fb_list.as<uint32_t>(), fb_count, stream);
+          // clouds that do not fill their box launch one workgroup per box that holds a query (a sheet leaves two thirds of them empty)
+          CacheBuf box_list;
+          uint32_t n_list = 0;
+          const uint32_t* list_ptr = nullptr;
+          static const bool list_on = !(std::getenv("PST_KNN_BOX_LIST") && std::atoi(std::getenv("PST_KNN_BOX_LIST")) == 0);
+          if (!fills && list_on) {
+            NCK(box_list.alloc((size_t)knn_box_count(shape, g) * 4, stream));
+            n_list = knn_box_list(shape, cell_start, g, box_list.as<uint32_t>(), unres_count + 3, stream);
+            if (n_list == 0xFFFFFFFFu) return -1;
+            list_ptr = box_list.as<uint32_t>();
+            if (debug) fprintf(stderr, "[pst knn] %u of %u boxes hold a query\n", n_list, knn_box_count(shape, g));
+            mark("box-list");
+          }
+          launch_knn_tile(shape, sorted_xyz.as<double>(), cell_start, g, k, (uint32_t)nf, sorted, fb_list.as<uint32_t>(), fb_count, list_ptr, n_list, stream);
           uint32_t n_fb = 0;
           NCK(hipMemcpyAsync(&n_fb, fb_count, 4, hipMemcpyDeviceToHost, stream));
           NCK(hipStreamSynchronize(stream));
           mark("box-search");
           if (debug)
-            fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
-                    (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.threads,
+            fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u kernel=%c threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
+                    (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.tag, shape.threads,
                     shape.cap, n_fb);
           if (n_fb) {
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
@@ -1279,8 +1295,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
                          sorted);
     }
     mark("fallback");
-    hipLaunchKernelGGL(split_results_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const double*)rec.as<double>(), n, out);
-    mark("split");
+    if (!direct_out) {
+      hipLaunchKernelGGL(split_results_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const double*)rec.as<double>(), n, out);
+      mark("split");
+    }
     if (trace) fprintf(stderr, "[pst knn trace]%s\n", trace_line.c_str());
     NCK(hipGetLastError());
   }

@@ -205,24 +205,47 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   return f;
 }
 
-// Results leave the search kernels as ONE aligned 32-byte record {normal xyz, curvature} per point, written at the point's ORIGINAL
-// index: a full-sector store (no read-modify-write of partial sectors, which is what separate 12-byte and 8-byte stores into the
-// caller's columns cost), hidden behind the compute-bound search.  split_results_kernel (normals.hip) then streams the records into the
-// caller's outputs (f64 arrays / NORMAL Vec3f32 attribute with the Rust `as` narrowing / Curvature attribute), fully coalesced.
+// Where the results of a search kernel go.  Two forms:
+//   * rec != null: ONE aligned 32-byte record {normal xyz, curvature} per point at the point's ORIGINAL index (a full-sector store);
+//     split_results_kernel (normals.hip) then streams the records into the caller's outputs;
+//   * rec == null (direct): the kernel writes the caller's outputs itself -- f64 arrays and / or the NORMAL (Vec3f32, Rust `as`
+//     narrowing) and Curvature (F64) attributes at their strides.  12- and 8-byte random stores cost 40 + 32 bytes of HBM writes per
+//     point against 32 for the record, but there is no second pass over 32 n bytes and no 32 n-byte scratch array; behind the
+//     instruction-bound box search the extra write traffic is hidden.
 struct RecOut {
-  double* rec;              // [n][4] f64: nx, ny, nz, curvature, indexed by ORIGINAL point index
+  double* rec;              // [n][4] f64: nx, ny, nz, curvature, indexed by ORIGINAL point index; null = direct
   const uint32_t* sidx;     // sorted position -> original index
   long long* knn;           // [n][k] int64 (-1 = none), original indices, or null
   uint32_t* knn_u32;        // [n][k] uint32 (0xFFFFFFFF = none) or null
   int* error_count;         // neighbourhoods with fewer than 3 usable points
+  // direct form (used when rec == null; any of them may be null / 0)
+  double* normals_f64;      // [n][3]
+  double* curvature_f64;    // [n]
+  uint64_t normal_attr;     // device address of the NORMAL (Vec3f32) attribute of point 0
+  uint64_t normal_stride;
+  uint64_t curv_attr;       // device address of the Curvature (F64) attribute of point 0
+  uint64_t curv_stride;
 };
 
 __device__ __forceinline__ void write_record(const RecOut& o, uint64_t orig, const Fit& f) {
   if (!f.ok) { atomicAdd(o.error_count, 1); return; }
-  double* r = o.rec + 4 * orig;
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  *reinterpret_cast<d2*>(r) = d2{f.nx, f.ny};
-  *reinterpret_cast<d2*>(r + 2) = d2{f.nz, f.curvature};
+  if (o.rec) {
+    double* r = o.rec + 4 * orig;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<d2*>(r) = d2{f.nx, f.ny};
+    *reinterpret_cast<d2*>(r + 2) = d2{f.nz, f.curvature};
+    return;
+  }
+  // whole values in as few store instructions as possible: a scattered store costs the memory pipeline one pass per lane whatever its width
+  struct __attribute__((packed, aligned(1))) F3 { float x, y, z; };
+  struct __attribute__((packed, aligned(8))) D3 { double x, y, z; };
+  if (o.normals_f64) *reinterpret_cast<D3*>(o.normals_f64 + 3 * orig) = D3{f.nx, f.ny, f.nz};
+  if (o.curvature_f64) o.curvature_f64[orig] = f.curvature;
+  if (o.normal_attr) {  // f64 -> f32 narrowing of the normal = Rust `as` (RNE, overflow -> inf)
+    const F3 v{(float)f.nx, (float)f.ny, (float)f.nz};
+    __builtin_memcpy(as_global(o.normal_attr) + orig * o.normal_stride, &v, sizeof(F3));  // one 12-byte store (global_store_dwordx3)
+  }
+  if (o.curv_attr) store_un<double>(as_global(o.curv_attr) + orig * o.curv_stride, f.curvature);
 }
 __device__ __forceinline__ void write_knn(const RecOut& o, uint64_t orig, uint32_t k, uint32_t t, uint32_t neighbour_orig) {  // kNoIndex = none
   if (o.knn) o.knn[orig * k + t] = neighbour_orig == kNoIndex ? -1ll : (long long)neighbour_orig;

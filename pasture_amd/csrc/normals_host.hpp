@@ -7,11 +7,11 @@
 
 namespace pstk {
 
-struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; };
+struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; char tag = '1'; };  // tag: which instance of the box kernel (normals_tile.hip)
 // false: no box fits (k > 32, or even a single query row with its halo exceeds the LDS budget at this density)
-// (measured: census kernels over the dense directory; scratch3 = 24 bytes of device memory; synchronises the stream)
-bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, const uint32_t* cell_start, unsigned long long* scratch3,
-                    hipStream_t stream, TileShape& t);
+// (measured: census kernels over the dense directory; scratch3 = 32 bytes of device memory; synchronises the stream)
+bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
+                    unsigned long long* scratch3, hipStream_t stream, TileShape& t);
 // mean number of points within h / 2 and within h of a sampled point of the sorted cloud (synchronises the stream); false on failure
 bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t nf, unsigned long long* scratch3, hipStream_t stream,
                double& mean_half, double& mean_full);
@@ -22,7 +22,10 @@ bool knn_scale_estimate(const double* cand, uint32_t n_c, double thinning, doubl
                         double& h_m, double& dim, uint32_t max_queries = 512);
 // Searches every query whose 5x5x5-cell neighbourhood fits the box kernel; the others are appended to fb_list / *fb_count
 // (sorted indices) for knn_grid_kernel.  *fb_count must be zero on entry; fb_list must hold nf entries.
+// box_list / n_list: the boxes to search (knn_box_list: those that hold a query), or null: every box of the grid.
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,
-                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, hipStream_t stream);
+                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, const uint32_t* box_list, uint32_t n_list, hipStream_t stream);
+uint32_t knn_box_count(const TileShape& t, const pstn::GridParams& g);
+uint32_t knn_box_list(const TileShape& t, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t* list, uint32_t* count_dev, hipStream_t stream);
 
 }  // namespace pstk

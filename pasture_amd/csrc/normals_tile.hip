@@ -70,6 +70,7 @@ struct TileArgs {
   double tau0;                 // a-priori bound on the squared k-th distance (+inf = none), see launch_knn_tile
   unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
   double tau0_below;           // the largest double below tau0
+  const uint32_t* box_list;    // the boxes to search (null: all n_boxes of them, box = workgroup id); n_boxes = its length then
   uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 48
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan, 8 = nothing queued, 16 = no copy, 32 = no records, 64 = empty kernel
 };
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
   __shared__ uint32_t s_next;
   constexpr int NW = THREADS / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t box = xcd_block_id();
-  if (box >= a.n_boxes) return;
+  const uint32_t wg = xcd_block_id();
+  if (wg >= a.n_boxes) return;
   if (a.ablate & 64u) return;
+  const uint32_t box = a.box_list ? a.box_list[wg] : wg;
   const GridParams& g = a.g;
   const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2];
   const int bxi = (int)(box % a.nbx), byi = (int)((box / a.nbx) % a.nby), bzi = (int)(box / (a.nbx * a.nby));
@@ -469,6 +471,499 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
   }
 }
 
+// =====================================================================================================================================
+// Box search, second form (round 3): the SCAN and the k-best list run in f32 on box-relative coordinates; f64 only proves the result.
+//
+// The first form above spends ~24 vector instructions per candidate: f64 differences and products for every one of the ~97 candidates of
+// a query, and two f64 operations per list entry for every one of the ~27 that enter the list.  Here
+//   * every staged point also gets a BOX-RELATIVE f32 copy r = (float)((x - c) * s): c = the box's centre, s chosen so that the a-priori
+//     bound tau0 on the squared k-th distance maps to 2^21 (coordinates in units of h / 1448).  The scan tests candidates in PACKED f32
+//     (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two candidates per instruction) against a limit with upward slack;
+//   * list keys are 32-bit: the squared f32 distance truncated to a 21-bit integer (v_cvt_u32_f32) above the 11-bit LDS slot.  Sorted
+//     insertion is ONE v_med3_u32 per entry -- new[t] = med3(old[t-1], old[t], x) is the clamp of x into [old[t-1], old[t]] -- instead of
+//     v_max_f64 + v_min_f64, and the list takes K + 1 registers instead of 2 (K + 1);
+//   * candidates past the end of a row segment (a step tests four) are real staged points: they are tested like the others instead of
+//     being masked out (the slots behind the last staged point hold a far-away sentinel);
+//   * the EXACT f64 squared distances (the same sequence of operations as the reference) of the k best are computed once, at the end:
+//       - they must ascend strictly in list order, ties by slot (the order the first form produces); a candidate that was tested twice
+//         (an overrun into another segment of the same query) shows up as two equal neighbours and fails this test;
+//       - completeness: every candidate that is NOT among the first k entries has a key >= key[k], so its f32 distance is at least
+//         fix(key[k]) and its exact distance at least fix(key[k]) - eps (eps bounds |f32 - exact| for points of the box, see
+//         launch_knn_tile2); the k-th exact distance must lie below that, and below tau0 (3 x 3 rows cover that radius);
+//     a query that fails either test joins the fallback list like the sparse ones (measured: ~0.1 % of a uniform cloud).
+// The result is therefore the same neighbour list in the same order as the first form's, or the query is searched by the exact kernel.
+// P3LDS = false: the f64 coordinates are not staged at all; the end phase reads them from the sorted array in global memory (L2: the box
+// was just copied from there) through a slot -> sorted-index map, which leaves 16 instead of 36 bytes of LDS per staged point.
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int K>
+struct KBestU32 {
+  uint32_t key[K + 1];  // ascending; 0xFFFFFFFF = empty
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t <= K; ++t) key[t] = 0xFFFFFFFFu;
+  }
+  __device__ __forceinline__ void insert(uint32_t x) {  // x = 0xFFFFFFFF is a no-op; from the top down: in place
+#pragma unroll
+    for (int t = K; t >= 1; --t) asm("v_med3_u32 %0, %1, %0, %2" : "+v"(key[t]) : "v"(key[t - 1]), "v"(x));
+    asm("v_min_u32 %0, %0, %1" : "+v"(key[0]) : "v"(x));
+  }
+  __device__ __forceinline__ uint32_t at(uint32_t i) const {  // key[i] without dynamic register indexing
+    uint32_t v = key[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) v = (uint32_t)t == i ? key[t] : v;
+    return v;
+  }
+};
+
+struct Tile2Args {
+  TileArgs t;
+  double s;        // f32 coordinates are (x - c) * s
+  double s2;       // s * s: exact squared distance -> key units
+  double eps;      // bound on |f32 squared distance - exact squared distance * s2| for two points of a box (key units)
+  float lim0;      // scan limit before the first insertion round: tau0 * s2 + eps, rounded up
+  float kx, kyz;   // f32 coordinate -> fine x cells / rows: inv_hx / s, inv_h / s
+  uint32_t gap;    // bins (F = key >> slot bits) two list entries must be apart for their exact order to be certain
+  uint32_t f_max;  // the k-th entry's bin must lie below this one: upper edge + eps < tau0 * s2
+};
+
+template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN>
+__global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args aa) {
+  const TileArgs& a = aa.t;
+  constexpr int CS = CAP + BATCH;
+  constexpr uint32_t SLOT_BITS = CAP <= 2048 ? 11u : 12u, SLOT_MASK = (1u << SLOT_BITS) - 1u;
+  static_assert(CAP + BATCH <= (1 << SLOT_BITS), "slots must fit the key");
+  constexpr int kQ = 16;  // queue entries per lane
+  // staged points: f32 box-relative copy (scan) + f64 originals (proof and plane fit), or + the map to the sorted array; one region,
+  // which holds the raw 32-bit directory entries ([NR][32]) until the points arrive
+  constexpr int PT_BYTES = P3LDS ? 36 * CS : 16 * CS;
+  static_assert(PT_BYTES >= kMaxRows * 32 * 4, "raw directory does not fit the point region");
+  __shared__ __attribute__((aligned(16))) uint8_t pts[PT_BYTES];
+  double* P3s = reinterpret_cast<double*>(pts);                                   // [3][CS] (P3LDS)
+  float* R3 = reinterpret_cast<float*>(pts + (P3LDS ? 24 * CS : 0));              // [3][CS]
+  uint32_t* Jmap = reinterpret_cast<uint32_t*>(pts + 12 * CS);                    // [CS]    (!P3LDS)
+  uint32_t* raw = reinterpret_cast<uint32_t*>(pts);
+  __shared__ uint16_t ldir[kMaxDir];
+  __shared__ uint32_t g0[kMaxRows];
+  __shared__ uint32_t rbase[kMaxRows + 1];
+  __shared__ uint32_t qpre[kMaxQRows + 1];
+  __shared__ uint16_t qbuf[kQ * THREADS];
+  __shared__ uint32_t s_next;
+  constexpr int NW = THREADS / 64;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wg = xcd_block_id();
+  if (wg >= a.n_boxes) return;
+  if (a.ablate & 64u) return;
+  const uint32_t box = a.box_list ? a.box_list[wg] : wg;
+  PST_KNN_STAT(const long long t_start = clock64(); long long t_flush = 0;)
+  const GridParams& g = a.g;
+  const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2];
+  const int bxi = (int)(box % a.nbx), byi = (int)((box / a.nbx) % a.nby), bzi = (int)(box / (a.nbx * a.nby));
+  const int X0 = bxi * (int)a.bx, Y0 = byi * (int)a.by, Z0 = bzi * (int)a.bz;
+  const int XH = (int)g.rx + 1;
+  const int HX = (int)a.bx + 2 * XH, HY = (int)a.by + 2 * kHalo, HZ = (int)a.bz + 2 * kHalo;
+  const int NC1 = HX + 1, NR = HY * HZ, nqy = (int)a.by, nqr = (int)(a.by * a.bz);
+  auto row_in_grid = [&](int r, uint64_t& cell0) {
+    const int y = Y0 - kHalo + r % HY, z = Z0 - kHalo + r / HY;
+    cell0 = ((uint64_t)z * (uint64_t)dim1 + (uint64_t)y) * (uint64_t)dim0;
+    return y >= 0 && y < dim1 && z >= 0 && z < dim2;
+  };
+  auto clamp_x = [&](int x) { return (uint32_t)(x < 0 ? 0 : (x > dim0 ? dim0 : x)); };
+  // the box's centre in the cloud's own coordinates: every f32 coordinate is relative to it
+  double ctr[3];
+  {
+    const double cu = g.org[0] + ((double)X0 + 0.5 * (double)a.bx) * g.hx, cv = g.org[1] + ((double)Y0 + 0.5 * (double)a.by) * g.h,
+                 cw = g.org[2] + ((double)Z0 + 0.5 * (double)a.bz) * g.h;
+    if (g.rotated) {  // (u, v, w) = rot (x - rot_c)  =>  x = rot_c + rot^T (u, v, w)
+      ctr[0] = g.rot_c[0] + g.rot[0] * cu + g.rot[3] * cv + g.rot[6] * cw;
+      ctr[1] = g.rot_c[1] + g.rot[1] * cu + g.rot[4] * cv + g.rot[7] * cw;
+      ctr[2] = g.rot_c[2] + g.rot[2] * cu + g.rot[5] * cv + g.rot[8] * cw;
+    } else { ctr[0] = cu; ctr[1] = cv; ctr[2] = cw; }
+  }
+
+  // ---- A: raw directory entries of every halo row --------------------------------------------------------------------------------
+  for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
+    const int c = (int)(tid & 31u);
+    if (c < NC1) {
+      uint64_t c0;
+      raw[r * 32 + c] = row_in_grid(r, c0) ? a.cell_start[c0 + clamp_x(X0 - XH + c)] : 0u;
+    }
+  }
+  if (tid == 0) s_next = 0;
+#pragma unroll
+  for (int i = 0; i < kQ; ++i) qbuf[i * THREADS + tid] = 0;
+  __syncthreads();  // (1)
+  auto qrow_halo = [&](int qr) { return (kHalo + qr / nqy) * HY + kHalo + qr % nqy; };
+  uint32_t total;
+  {
+    uint32_t v[3], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; v[u] = r < NR ? raw[r * 32 + HX] - raw[r * 32] : 0u; sum += v[u]; }
+    uint32_t run = wave_excl_scan(sum, lane, total);
+    if (wave == 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { const int r = 3 * (int)lane + u; if (r < NR) { rbase[r] = run; g0[r] = raw[r * 32]; } run += v[u]; }
+      if (lane == 0) rbase[NR] = total;
+      uint32_t cnt = 0;
+      if ((int)lane < nqr) { const int r = qrow_halo((int)lane); cnt = raw[r * 32 + XH + (int)a.bx] - raw[r * 32 + XH]; }
+      uint32_t tot;
+      const uint32_t ex = wave_excl_scan(cnt, lane, tot);
+      if ((int)lane < nqr) qpre[lane] = ex;
+      if (lane == 0) qpre[nqr] = tot;
+    }
+  }
+  if (total == 0) return;
+  if (total > (uint32_t)CAP) {
+    for (int qr = (int)wave; qr < nqr; qr += NW) {
+      const int r = qrow_halo(qr);
+      const uint32_t s0 = raw[r * 32 + XH], s1 = raw[r * 32 + XH + (int)a.bx];
+      for (uint32_t j = s0 + lane; j < s1; j += 64) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
+    }
+    return;
+  }
+  // ---- C: coalesced copy of the row segments; the loads of the first pass are requested HERE, off the raw directory, and land while the
+  //         local directory is written -------------------------------------------------------------------------------------------
+  constexpr int kRows = THREADS >= 1024 ? 4 : (THREADS >= 512 ? 4 : 8), kChunks = 4;
+  double cv[kRows][kChunks];
+  uint32_t len3[kRows];
+  const bool copy_on = !(a.ablate & 16u);
+#pragma unroll
+  for (int u = 0; u < kRows; ++u) {
+    const int r = (int)wave * kRows + u;
+    const uint32_t first = r < NR ? raw[r * 32] : 0u;
+    len3[u] = r < NR && copy_on ? 3u * (raw[r * 32 + HX] - first) : 0u;
+    const double* src = a.sxyz + 3ull * first;
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) cv[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
+  }
+  __syncthreads();  // (2) row sums published
+  // ---- B: local 16-bit directory --------------------------------------------------------------------------------------------------
+  for (int r = (int)(tid >> 5); r < NR; r += THREADS / 32) {
+    const int c = (int)(tid & 31u);
+    if (c < NC1) ldir[r * NC1 + c] = (uint16_t)(raw[r * 32 + c] - g0[r] + rbase[r]);
+  }
+  __syncthreads();  // (3) the raw directory is dead: the point region can be filled
+  {
+    auto put = [&](uint32_t base, uint32_t gfirst, uint32_t e, double v) __attribute__((always_inline)) {
+      const uint32_t pt = e / 3u, c = e - 3u * pt;
+      const double cc = c == 0 ? ctr[0] : (c == 1 ? ctr[1] : ctr[2]);
+      R3[c * CS + base + pt] = (float)((v - cc) * aa.s);
+      if constexpr (P3LDS) P3s[c * CS + base + pt] = v;
+      else if (c == 0) Jmap[base + pt] = gfirst + pt;
+    };
+    auto store_rows = [&](int r0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = r0 + u;
+        if (r >= NR) continue;
+        const uint32_t base = rbase[r], gf = g0[r];
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) if (lane + 64u * c < len3[u]) put(base, gf, lane + 64u * c, cv[u][c]);
+        if (len3[u] > 64u * kChunks) {
+          const double* src = a.sxyz + 3ull * gf;
+          for (uint32_t e = lane + 64u * kChunks; e < len3[u]; e += 64) put(base, gf, e, src[e]);
+        }
+      }
+    };
+    store_rows((int)wave * kRows);
+    for (int r0 = (NW + (int)wave) * kRows; r0 < NR && copy_on; r0 += NW * kRows) {  // boxes with more than NW * kRows rows
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const int r = r0 + u;
+        len3[u] = r < NR ? 3u * (rbase[r + 1] - rbase[r]) : 0u;
+        const double* src = a.sxyz + 3ull * (r < NR ? g0[r] : 0u);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) cv[u][c] = lane + 64u * c < len3[u] ? src[lane + 64u * c] : 0.0;
+      }
+      store_rows(r0);
+    }
+    // the slots behind the last staged point: a step may read them; far away in f32 (their squared distance overflows to +inf)
+    if (tid < (uint32_t)BATCH) {
+      R3[total + tid] = 3.0e38f; R3[CS + total + tid] = 3.0e38f; R3[2 * CS + total + tid] = 3.0e38f;
+      if constexpr (!P3LDS) Jmap[total + tid] = 0u;
+    }
+  }
+  __syncthreads();  // (4) points staged
+  PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 8, (unsigned long long)(clock64() - t_start));)
+  const float* Rx = R3;
+  const float* Ry = R3 + CS;
+  const float* Rz = R3 + 2 * CS;
+  const uint32_t Q = qpre[nqr];
+  const uint32_t m = a.nf < a.k ? a.nf : a.k;
+  auto exact_xyz = [&](uint32_t sl, double& x, double& y, double& z) __attribute__((always_inline)) {
+    if constexpr (P3LDS) { x = P3s[sl]; y = P3s[CS + sl]; z = P3s[2 * CS + sl]; }
+    else { const double* pp = a.sxyz + 3ull * Jmap[sl]; x = pp[0]; y = pp[1]; z = pp[2]; }
+  };
+
+  for (;;) {
+    uint32_t c0 = 0;
+    if (lane == 0) c0 = atomicAdd(&s_next, 64u);
+    c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+    if (c0 >= Q) break;
+    const uint32_t q = c0 + lane;
+    const bool active = q < Q;
+    PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 2, 1ull);)
+    PST_KNN_STAT(const long long t_chunk = clock64(); t_flush = 0;)
+    int qr = 0;
+    {
+      int lo = 0, hi = nqr;
+      const uint32_t qq = active ? q : 0u;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qpre[mid] <= qq) lo = mid; else hi = mid; }
+      qr = lo;
+    }
+    const int hr = qrow_halo(qr);
+    const uint32_t slot = active ? (uint32_t)ldir[hr * NC1 + XH] + (q - qpre[qr]) : 0u;
+    const float rqx = Rx[slot], rqy = Ry[slot], rqz = Rz[slot];
+    const uint32_t j = g0[hr] + (slot - rbase[hr]);
+    // The query's position in the halo's cell coordinates, from its f32 copy: (u, v, w) = rot (x - c) + (centre of the box in the frame),
+    // exact to ~2e-6 cells -- far inside the slack of the trims below.  Only the SUM cell + fraction enters the trims, so a query that
+    // sits on a cell border may be booked into either cell.  A query outside the grid's box (clamped into a boundary cell) must go to the
+    // exact search (see the first form); "outside" is decided with 1e-4 cells of margin towards the inside.
+    int B;
+    bool outside;
+    float fx, fy, fz;
+    {
+      float ru = rqx, rv = rqy, rw = rqz;
+      if (g.rotated) {
+        ru = (float)g.rot[0] * rqx + (float)g.rot[1] * rqy + (float)g.rot[2] * rqz;
+        rv = (float)g.rot[3] * rqx + (float)g.rot[4] * rqy + (float)g.rot[5] * rqz;
+        rw = (float)g.rot[6] * rqx + (float)g.rot[7] * rqy + (float)g.rot[8] * rqz;
+      }
+      const float px = ru * aa.kx + (0.5f * (float)a.bx + (float)XH);        // halo cells along x
+      const float py = rv * aa.kyz + 0.5f * (float)a.by, pz = rw * aa.kyz + 0.5f * (float)a.bz;  // query rows along y, z (0 = the box's first row)
+      const float cxf = fminf(fmaxf(floorf(px), (float)XH), (float)(XH + (int)a.bx - 1));
+      const int qy_l = qr % nqy, qz_l = qr / nqy;
+      fx = fminf(fmaxf(px - cxf, 0.0f), 1.0f);
+      fy = fminf(fmaxf(py - (float)qy_l, 0.0f), 1.0f);
+      fz = fminf(fmaxf(pz - (float)qz_l, 0.0f), 1.0f);
+      B = hr * NC1 + (active ? (int)cxf : XH);
+      const float m_in = 1e-4f;
+      outside = (X0 == 0 && px - (float)XH < m_in) || (X0 + (int)a.bx >= dim0 && px - (float)(XH + dim0 - X0) > -m_in) ||
+                (Y0 == 0 && py < m_in) || (Y0 + (int)a.by >= dim1 && py - (float)(dim1 - Y0) > -m_in) ||
+                (Z0 == 0 && pz < m_in) || (Z0 + (int)a.bz >= dim2 && pz - (float)(dim2 - Z0) > -m_in) || !(px == px && py == py && pz == pz);
+    }
+
+    KBestU32<K> best;
+    best.init();
+    // per-lane queue of candidate slots: entry i of lane tid at qbuf[i * THREADS + tid]; qaddr = LDS byte address of the next free entry
+    constexpr uint32_t QSTRIDE = 2u * THREADS;
+    const uint32_t qbase = (uint32_t)(uintptr_t)(&qbuf[tid]);
+    uint32_t qaddr = qbase;
+    const uint32_t qroom = qbase + (uint32_t)(kQ - BATCH) * QSTRIDE;  // a lane scans only while BATCH more entries fit
+    float lim = aa.lim0;
+    auto flush = [&]() __attribute__((always_inline)) {
+      // nothing here is predicated per lane: a lane without an entry reads a stale (valid) slot and inserts 0xFFFFFFFF, which changes nothing
+      const uint32_t qn = (qaddr - qbase) / QSTRIDE;
+      // the longest queue of the wave (scalar: five ballots), so that the loop below is a counted one with scalar control
+      uint32_t qmax = 0;
+#pragma unroll
+      for (int bit = 4; bit >= 0; --bit)
+        qmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(qn >= (qmax | (1u << bit))) ? qmax | (1u << bit) : qmax));
+      uint32_t p0 = qbuf[tid];
+      uint32_t p1 = qbuf[THREADS + tid];
+      float x0 = Rx[p0], y0 = Ry[p0], z0 = Rz[p0];
+      for (uint32_t i = 0; i < qmax; ++i) {
+        const bool has = i < qn;
+        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 1, 1ull);)
+        const uint32_t p2 = qbuf[(i + 2 < (uint32_t)kQ ? i + 2 : (uint32_t)kQ - 1u) * THREADS + tid];
+        const float x1 = Rx[p1], y1 = Ry[p1], z1 = Rz[p1];
+        // the same three operations, in the same order, as the scan's packed ones: the same value
+        const float dx = x0 - rqx, dy = y0 - rqy, dz = z0 - rqz;
+        float d2 = dx * dx;
+        d2 = __builtin_fmaf(dy, dy, d2);
+        d2 = __builtin_fmaf(dz, dz, d2);
+        uint32_t fix = (uint32_t)d2;  // v_cvt_u32_f32: toward zero, monotone
+        fix = fix < 0x1FFFFEu ? fix : 0x1FFFFEu;
+        uint32_t key = SLOT_BITS == 12u ? (((fix >> 1) << SLOT_BITS) | p0) : ((fix << SLOT_BITS) | p0);
+        key = has ? key : 0xFFFFFFFFu;
+        best.insert(key);
+        p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
+      }
+      qaddr = qbase;
+      // every later candidate that could still enter the list has an f32 distance below the upper edge of the last key's bin
+      const uint32_t kl = best.key[K];
+      const float edge = SLOT_BITS == 12u ? (float)(((kl >> SLOT_BITS) + 1u) << 1) : (float)((kl >> SLOT_BITS) + 1u);
+      lim = kl != 0xFFFFFFFFu ? __builtin_fminf(lim, edge) : lim;
+    };
+    uint32_t ent[kSegs];
+    {
+      const float bound = (float)a.tau0 * ((float)(g.inv_h * g.inv_h) * 1.00002f) + 2e-5f, rxf = (float)g.rx * 1.00001f, xh = (float)XH;
+      const bool on = active && !outside;
+#pragma unroll
+      for (int sg = 0; sg < kSegs; ++sg) {
+        constexpr int kDy[kSegs] = {0, -1, 1, 0, 0, -1, 1, -1, 1}, kDz[kSegs] = {0, 0, 0, -1, 1, -1, -1, 1, 1};
+        const int dy = kDy[sg], dz = kDz[sg];
+        const float ty = (float)dy - fy, tz = (float)dz - fz;
+        const float gy = fmaxf(0.0f, fmaxf(ty, -ty - 1.0f)), gz = fmaxf(0.0f, fmaxf(tz, -tz - 1.0f));
+        const float r2 = bound - (gy * gy + gz * gz);
+        const float ext = __builtin_amdgcn_sqrtf(fmaxf(r2, 0.0f)) * rxf + 8e-6f;  // (+ the f32 position's own error)
+        const float lo_f = fmaxf(floorf(fx - ext), -xh), hi_f = fminf(floorf(fx + ext), xh);
+        const int Bd = B + (dz * HY + dy) * NC1;
+        const uint32_t s0 = ldir[Bd + (int)lo_f], s1 = ldir[Bd + (int)hi_f + 1];
+        ent[sg] = (on && r2 > 0.0f) ? (s0 | (s1 << 16)) : 0u;
+      }
+    }
+    const f2v qx2 = {rqx, rqx}, qy2 = {rqy, rqy}, qz2 = {rqz, rqz};
+    PST_KNN_STAT(const long long t_scan = clock64(); if (lane == 0) atomicAdd(a.dbg + 9, (unsigned long long)(t_scan - t_chunk));)
+    uint32_t left = kSegs;
+    uint32_t p = 0, pe = 0;
+    for (;;) {
+      // ONE shift of the segment table per step, written as selects (a branch made the compiler copy the table at the loop's latch):
+      // a lane that drew an empty range idles this step and draws again in the next
+      {
+        const bool take = p >= pe && left != 0u;
+        const uint32_t e = ent[0];
+#pragma unroll
+        for (int sg = 0; sg + 1 < kSegs; ++sg) ent[sg] = take ? ent[sg + 1] : ent[sg];
+        p = take ? (e & 0xFFFFu) : p;
+        pe = take ? (e >> 16) : pe;
+        left = take ? left - 1u : left;
+      }
+      // A lane whose queue could overflow WAITS; the queues are emptied when at most flush_at lanes can go on scanning
+      const bool room = qaddr <= qroom;
+      const bool scan = p < pe && room;
+      const uint64_t can = __builtin_amdgcn_ballot_w64(scan || (p >= pe && left != 0u)), waiting = __builtin_amdgcn_ballot_w64(p < pe && !room);
+      if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
+        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(scan ? BATCH : 0));)
+        if (scan) {  // ONE predicate per step; inside, nothing branches and the execution mask stays put
+          f2v cxs[BATCH / 2], cys[BATCH / 2], czs[BATCH / 2];
+#pragma unroll
+          for (int u = 0; u < BATCH / 2; ++u) {
+            cxs[u] = f2v{Rx[p + 2 * u], Rx[p + 2 * u + 1]};
+            cys[u] = f2v{Ry[p + 2 * u], Ry[p + 2 * u + 1]};
+            czs[u] = f2v{Rz[p + 2 * u], Rz[p + 2 * u + 1]};
+          }
+#pragma unroll
+          for (int u = 0; u < BATCH / 2; ++u) {
+            const f2v dx = cxs[u] - qx2, dy = cys[u] - qy2, dz = czs[u] - qz2;
+            f2v d2 = dx * dx;
+            d2 = __builtin_elementwise_fma(dy, dy, d2);
+            d2 = __builtin_elementwise_fma(dz, dz, d2);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              // the slot is written in any case (a scanning lane has room for BATCH entries) and kept if the candidate passes; candidates
+              // behind the end of the segment are staged points like any other
+              *reinterpret_cast<uint16_t __attribute__((address_space(3)))*>(qaddr) = (uint16_t)(p + (uint32_t)(2 * u + hh));
+              const bool pass = d2[hh] <= lim;
+              PST_KNN_STAT(if (pass) atomicAdd(a.dbg + 4, 1ull);)
+              qaddr += pass ? QSTRIDE : 0u;
+            }
+          }
+          const uint32_t pn = p + (uint32_t)BATCH;
+          p = pn < pe ? pn : pe;
+        }
+      } else {
+        PST_KNN_STAT(const long long t_f0 = clock64();)
+        if (__builtin_amdgcn_ballot_w64(qaddr != qbase)) flush();  // ONE inlined copy of the insertion code
+        PST_KNN_STAT(t_flush += clock64() - t_f0;)
+        if (!__builtin_amdgcn_ballot_w64(p < pe || left != 0u)) break;
+      }
+    }
+    PST_KNN_STAT(const long long t_proof = clock64(); if (lane == 0) { atomicAdd(a.dbg + 10, (unsigned long long)(t_proof - t_scan - t_flush)); atomicAdd(a.dbg + 11, (unsigned long long)t_flush); })
+    // ---- the proof ------------------------------------------------------------------------------------------------------------
+    // Keys ascend.  F = key >> SLOT_BITS is the candidate's f32 squared distance in bins of `unit` key units, and the exact squared
+    // distance (times s2) lies within eps of the f32 one.  Two entries whose bins are at least `gap` = floor(1 + 2 eps / unit) + 1
+    // apart are therefore in their exact order, strictly; and everything that is NOT among the first k entries has a key >= key[k].
+    //   * all k adjacent pairs (0,1) .. (k-1,k) at least `gap` apart: the first k entries ARE the k nearest, in ascending exact order;
+    //   * a closer pair INSIDE the list (about 2e-4 of the pairs) is settled with the exact f64 distances of its two points (ties by
+    //     slot, as the first form does) -- unless the next pair is close too (three entries in one window: exact search);
+    //   * a close pair at the k / k+1 boundary cannot be settled here (unseen candidates may sit in the same window): exact search.
+    // The k-th exact distance must also lie below tau0 (the 3 x 3 rows cover that radius): its bin's upper edge + eps < tau0 * s2.
+    bool ok;
+    uint32_t nb[K];
+    {
+      const uint32_t kk = a.k;
+      uint32_t amb = 0;  // bit t: the pair (t, t + 1) is closer than `gap`
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        if ((uint32_t)t < kk) {
+          const uint32_t d = (best.key[t + 1] >> SLOT_BITS) - (best.key[t] >> SLOT_BITS);  // (an empty entry: F = all ones, never close)
+          amb |= d < aa.gap ? 1u << t : 0u;
+        }
+      }
+      const uint32_t k_last = best.at(kk - 1u);
+      ok = k_last != 0xFFFFFFFFu && (k_last >> SLOT_BITS) < aa.f_max;   // k entries, the k-th inside tau0
+      ok = ok && !(amb & (amb >> 1)) && !((amb >> (kk - 1u)) & 1u);      // no chain of close pairs, none at the boundary
+      amb = ok ? amb : 0u;
+      // the neighbours' LDS slots, in list order (a separate array: the key registers are not written outside the insertion rounds)
+#pragma unroll
+      for (int t = 0; t < K; ++t) nb[t] = best.key[t] & SLOT_MASK;
+      if (__builtin_amdgcn_ballot_w64(amb != 0u)) {  // rare: about one wave in five settles one pair
+        double qx, qy, qz;
+        exact_xyz(slot, qx, qy, qz);
+#pragma unroll
+        for (int t = 0; t + 1 < K; ++t) {
+          if (__builtin_amdgcn_ballot_w64((amb >> t) & 1u)) {
+            const bool mine = (amb >> t) & 1u;
+            const uint32_t s0 = mine ? nb[t] : 0u, s1 = mine ? nb[t + 1] : 0u;
+            double x0, y0, z0, x1, y1, z1;
+            exact_xyz(s0, x0, y0, z0);
+            exact_xyz(s1, x1, y1, z1);
+            const double ax = x0 - qx, ay = y0 - qy, az = z0 - qz, bx = x1 - qx, by = y1 - qy, bz = z1 - qz;
+            const double e0 = ax * ax + ay * ay + az * az, e1 = bx * bx + by * by + bz * bz;
+            const bool swap = mine && (e1 < e0 || (e1 == e0 && s1 < s0));
+            nb[t] = swap ? s1 : nb[t];
+            nb[t + 1] = swap ? s0 : nb[t + 1];
+            if (mine && e1 == e0 && s1 == s0) ok = false;  // the same point twice: a step ran over the end of a segment into another one of this query
+          }
+        }
+      }
+    }
+    const bool done = a.ablate ? true : !outside && ok;
+    PST_KNN_STAT(if (active && !outside && !ok) atomicAdd(a.dbg + 5, 1ull);)
+    if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
+    // (the original index is requested here, together with the neighbours' coordinates: a load left in flight across the scan loop is
+    //  waited for at the loop's head, and this one comes from HBM)
+    const uint32_t orig = active && done ? a.out.sidx[j] : 0u;
+    PST_KNN_STAT(const long long t_fit = clock64(); if (lane == 0) atomicAdd(a.dbg + 12, (unsigned long long)(t_fit - t_proof));)
+    if (active && done && !(a.ablate & 32u)) {
+      if constexpr (WITH_KNN) {
+        for (uint32_t t = 0; t < a.k; ++t) {
+          uint32_t v = kNoIndex;
+          uint32_t pl = 0;
+#pragma unroll
+          for (int u = 0; u < K; ++u) pl = (uint32_t)u == t ? nb[u] : pl;
+          if (t < m) {
+            if constexpr (P3LDS) {
+              int lo = 0, hi = NR;
+              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rbase[mid] <= pl) lo = mid; else hi = mid; }
+              v = a.out.sidx[g0[lo] + (pl - rbase[lo])];
+            } else {
+              v = a.out.sidx[Jmap[pl]];
+            }
+          }
+          write_knn(a.out, orig, a.k, t, v);
+        }
+      }
+      Fit f{0, 0, 0, 0, 1};
+      if constexpr (!P3LDS && K <= 16) {
+        // f64 coordinates from global memory: every neighbour is fetched ONCE (the plane fit walks the neighbours twice, and a gather of
+        // 64 scattered 24-byte points keeps the texture path busy for ~64 cycles whether it hits the cache or not)
+        double nx[K], ny[K], nz[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          nx[u] = 0; ny[u] = 0; nz[u] = 0;
+          if ((uint32_t)u < m) exact_xyz(nb[u], nx[u], ny[u], nz[u]);
+        }
+        if (!(a.ablate & 2u)) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+#pragma unroll
+          for (int u = 0; u < K; ++u) if ((uint32_t)u == t) { x = nx[u]; y = ny[u]; z = nz[u]; }
+        });
+      } else {
+        if (!(a.ablate & 2u)) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+          uint32_t pl = 0;
+#pragma unroll
+          for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = nb[u];
+          exact_xyz(pl, x, y, z);
+        });
+      }
+      write_record(a.out, orig, f);
+    }
+    PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
+  }
+  PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 14, (unsigned long long)(clock64() - t_start));)
+}
+
 // ---- density probe: how many points does a ball of radius h (and h / 2) around a typical point hold? ---------------------------------
 // The grid's cell edge h should be the radius R0 of the ball expected to hold M points.  The volume of the bounding box gives that only
 // for clouds that fill their box: a surface in a 3-D box (the LiDAR case) has far more points inside R0 than n * ball / box.  The probe
@@ -510,11 +1005,11 @@ __global__ __launch_bounds__(kBlock) void knn_probe_kernel(const double* __restr
 }
 
 // ---- box census: what would a box shape stage?  One thread per box: staged points (halo) and queries, from the directory alone.
-// sums: [0] queries, [1] staged points over non-empty boxes, [2] queries of boxes whose halo exceeds the capacity
+// sums: [0] queries, [1] staged points over non-empty boxes, [2] queries of boxes whose halo exceeds the capacity, [3] non-empty boxes
 __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __restrict__ cell_start, GridParams g, uint32_t bx, uint32_t by, uint32_t bz,
                                                             uint32_t nbx, uint32_t nby, uint32_t n_boxes, uint32_t cap, unsigned long long* __restrict__ sums) {
   const uint32_t box = blockIdx.x * kBlock + threadIdx.x;
-  unsigned long long q = 0, staged = 0, lost = 0;
+  unsigned long long q = 0, staged = 0, lost = 0, occupied = 0;
   if (box < n_boxes) {
     const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2], XH = (int)g.rx + 1;
     const int X0 = (int)(box % nbx) * (int)bx, Y0 = (int)((box / nbx) % nby) * (int)by, Z0 = (int)(box / (nbx * nby)) * (int)bz;
@@ -528,10 +1023,38 @@ __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __re
       }
     if (q == 0) staged = 0;
     if (staged > cap) lost = q;
+    occupied = q != 0;
   }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) { q += shfl_xor_any(q, off); staged += shfl_xor_any(staged, off); lost += shfl_xor_any(lost, off); }
-  if ((threadIdx.x & 63u) == 0 && q) { atomicAdd(sums, q); atomicAdd(sums + 1, staged); atomicAdd(sums + 2, lost); }
+  for (int off = 32; off >= 1; off >>= 1) {
+    q += shfl_xor_any(q, off); staged += shfl_xor_any(staged, off); lost += shfl_xor_any(lost, off); occupied += shfl_xor_any(occupied, off);
+  }
+  if ((threadIdx.x & 63u) == 0 && q) { atomicAdd(sums, q); atomicAdd(sums + 1, staged); atomicAdd(sums + 2, lost); atomicAdd(sums + 3, occupied); }
+}
+
+// ---- the boxes that hold a query, in box order (one thread per box; a wave appends its boxes with ONE atomic): clouds that are not a
+// filled box (a surface in a 3-D grid: two thirds of the boxes are empty) launch a workgroup per listed box, not per box
+__global__ __launch_bounds__(kBlock) void knn_box_list_kernel(const uint32_t* __restrict__ cell_start, GridParams g, uint32_t bx, uint32_t by, uint32_t bz, uint32_t nbx,
+                                                              uint32_t nby, uint32_t n_boxes, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t box = blockIdx.x * kBlock + threadIdx.x;
+  bool has = false;
+  if (box < n_boxes) {
+    const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2];
+    const int X0 = (int)(box % nbx) * (int)bx, Y0 = (int)((box / nbx) % nby) * (int)by, Z0 = (int)(box / (nbx * nby)) * (int)bz;
+    const uint32_t x0 = (uint32_t)X0, x1 = (uint32_t)(X0 + (int)bx > dim0 ? dim0 : X0 + (int)bx);
+    for (int z = Z0; z < Z0 + (int)bz && z < dim2 && !has; ++z)
+      for (int y = Y0; y < Y0 + (int)by && y < dim1; ++y) {
+        const uint64_t row = ((uint64_t)z * dim1 + (uint64_t)y) * dim0;
+        if (cell_start[row + x1] != cell_start[row + x0]) { has = true; break; }
+      }
+  }
+  const uint64_t m = __builtin_amdgcn_ballot_w64(has);
+  if (m == 0) return;
+  const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == first) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+  base = (uint32_t)__shfl((int)base, (int)first, 64);
+  if (has) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = box;
 }
 
 }  // namespace
@@ -539,6 +1062,26 @@ __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __re
 namespace pstk {
 
 namespace {
+// Which box kernel runs (PST_KNN_VAR, read once): "1" = the first form (f64 scan, packed f64 keys); letters = instances of the second form
+// (f32 scan, 32-bit keys): threads per workgroup, staged-point capacity, f64 coordinates in LDS or read from global memory, candidates
+// per scan step.  The default is the measured optimum.
+struct TileVariant { int version; uint32_t threads, cap; bool p3lds; int batch; char tag; };
+// volume_like: the cloud fills its (trimmed) box -- boxes are full and large ones pay (512 threads, 3000 staged points, two workgroups per
+// CU); otherwise (surfaces, strips: most of a box's cells are empty and the 31-cell / 64-row limits of a box bind before its capacity)
+// 256 threads and 1536 points, four workgroups per CU.  Same-box A/B at 10^8 points: uniform cloud 35.4 (D) / 37.0 (G) / 36.8 (B) ms per
+// call, LiDAR-like sheet 96 (D) / 80.7 (G) / 86.4 (B); the first form: 41.5 / 88.9.
+const TileVariant& tile_variant(bool volume_like) {
+  static const TileVariant v1{1, 256, 1536, true, 4, '1'}, vB{2, 256, 2044, false, 4, 'B'}, vD{2, 512, 3000, false, 4, 'D'}, vG{2, 256, 1536, false, 4, 'G'};
+  static const char forced = [] { const char* e = std::getenv("PST_KNN_VAR"); return e && *e ? *e : '\0'; }();
+  switch (forced) {
+    case '1': return v1;
+    case 'B': return vB;
+    case 'D': return vD;
+    case 'G': return vG;
+    default: return volume_like ? vD : vG;
+  }
+}
+
 bool tile_fits(const pstn::GridParams& g, uint32_t bx, uint32_t by, uint32_t bz) {
   const uint32_t hx = bx + 2 * (g.rx + 1), hy = by + 2 * kHalo, hz = bz + 2 * kHalo;
   return bx <= g.dim[0] && by <= g.dim[1] && bz <= g.dim[2] && hx <= (uint32_t)kMaxRowCells && by * bz <= (uint32_t)kMaxQRows &&
@@ -569,7 +1112,7 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
   const uint32_t samples = 1u << 16;
   const uint32_t stride = std::max<uint32_t>(1u, nf / samples);
   const uint32_t n_s = (nf + stride - 1) / stride;
-  if (hipMemsetAsync(scratch3, 0, 24, stream) != hipSuccess) return false;
+  if (hipMemsetAsync(scratch3, 0, 32, stream) != hipSuccess) return false;
   hipLaunchKernelGGL(knn_probe_kernel, dim3((n_s + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sxyz, cell_start, g, nf, stride, scratch3);
   unsigned long long h[3] = {};
   if (hipMemcpyAsync(h, scratch3, 24, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
@@ -583,11 +1126,14 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
 // whose census (knn_census_kernel: staged points and queries of every box, read off the directory) loses at most 2 % of the queries to boxes
 // that exceed the LDS capacity wins.  Average density would do for a cloud that fills its bounding box; a surface in a 3-D box puts all
 // its points into a few boxes.  bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
-bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, const uint32_t* cell_start, unsigned long long* scratch3,
-                    hipStream_t stream, TileShape& t) {
+bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
+                    unsigned long long* scratch3, hipStream_t stream, TileShape& t) {
   if (k > 64 || cells == 0 || nf == 0) return false;
-  t.threads = 256;
-  t.cap = 1536;
+  const TileVariant& var = tile_variant(volume_like);
+  const bool v2 = var.version == 2 && k <= 16;  // (the second form is instantiated for k <= 16; larger k: the first form)
+  t.threads = v2 ? var.threads : 256;
+  t.cap = v2 ? var.cap : 1536;
+  t.tag = v2 ? var.tag : '1';
   if (const char* e = std::getenv("PST_KNN_TILE")) {  // "bx,by,bz"
     unsigned x = 0, y = 0, z = 0;
     if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z && tile_fits(g, x, y, z)) { t.bx = x; t.by = y; t.bz = z; return true; }
@@ -596,38 +1142,85 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
   double budget = 0.90 * (double)t.cap / rho;
   TileShape last{};
   double shrink = 1.0;
+  static const bool debug = std::getenv("PST_KNN_DEBUG") != nullptr;
+  // census of one shape: h[0] queries, h[1] staged points, h[2] queries lost to boxes over capacity, h[3] non-empty boxes
+  auto census = [&](const TileShape& c, unsigned long long (&h)[4]) -> int {
+    const uint32_t nbx = (g.dim[0] + c.bx - 1) / c.bx, nby = (g.dim[1] + c.by - 1) / c.by, nbz = (g.dim[2] + c.bz - 1) / c.bz;
+    const uint64_t n_boxes = (uint64_t)nbx * nby * nbz;
+    if (n_boxes >= 0x7FFFFFFFull) return 1;
+    if (hipMemsetAsync(scratch3, 0, 32, stream) != hipSuccess) return -1;
+    hipLaunchKernelGGL(knn_census_kernel, dim3((unsigned)((n_boxes + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cell_start, g, c.bx, c.by, c.bz, nbx, nby,
+                       (uint32_t)n_boxes, t.cap, scratch3);
+    if (hipMemcpyAsync(h, scratch3, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1;
+    if (debug)
+      fprintf(stderr, "[pst knn census] box %ux%ux%u: halo amplification %.2f, %.2f %% of the queries in boxes over capacity, %.0f queries per occupied box\n", c.bx, c.by,
+              c.bz, h[0] ? (double)h[1] / (double)h[0] : 0.0, h[0] ? 100.0 * (double)h[2] / (double)h[0] : 0.0, h[3] ? (double)h[0] / (double)h[3] : 0.0);
+    return 0;
+  };
   for (int attempt = 0; attempt < 14; ++attempt) {
     budget *= shrink;
     TileShape c = t;
     if (!best_box(g, budget, c)) break;
     if (c.bx == last.bx && c.by == last.by && c.bz == last.bz) continue;
     last = c;
-    const uint32_t nbx = (g.dim[0] + c.bx - 1) / c.bx, nby = (g.dim[1] + c.by - 1) / c.by, nbz = (g.dim[2] + c.bz - 1) / c.bz;
-    const uint64_t n_boxes = (uint64_t)nbx * nby * nbz;
-    if (n_boxes >= 0x7FFFFFFFull) break;
-    if (hipMemsetAsync(scratch3, 0, 24, stream) != hipSuccess) return false;
-    hipLaunchKernelGGL(knn_census_kernel, dim3((unsigned)((n_boxes + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cell_start, g, c.bx, c.by, c.bz, nbx, nby,
-                       (uint32_t)n_boxes, t.cap, scratch3);
-    unsigned long long h[3] = {};
-    if (hipMemcpyAsync(h, scratch3, 24, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
-    if (std::getenv("PST_KNN_DEBUG"))
-      fprintf(stderr, "[pst knn census] box %ux%ux%u: halo amplification %.2f, %.2f %% of the queries in boxes over capacity\n", c.bx, c.by, c.bz,
-              h[0] ? (double)h[1] / (double)h[0] : 0.0, h[0] ? 100.0 * (double)h[2] / (double)h[0] : 0.0);
-    if (h[0] && (double)h[2] <= 0.02 * (double)h[0]) { t.bx = c.bx; t.by = c.by; t.bz = c.bz; return true; }
+    unsigned long long h[4] = {};
+    const int rc = census(c, h);
+    if (rc < 0) return false;
+    if (rc > 0) break;
+    if (h[0] && (double)h[2] <= 0.02 * (double)h[0]) {
+      t.bx = c.bx; t.by = c.by; t.bz = c.bz;
+      // ROUNDS.  The queries of a box are handed to the workgroup's waves in chunks of 64, so a box of Q queries keeps its LDS for
+      // ceil(Q / threads) rounds, and in the last round most waves have left: 560 queries on 256 threads use 8.75 of 12 wave slots, and
+      // no other workgroup can take the idle ones while the box holds its LDS.  If the typical box (mean + two standard deviations of
+      // a Poisson count) needs r rounds and fills less than 85 % of them, the box is shortened along x to what r - 1 rounds hold --
+      // unless that costs more than a quarter of its length (more halo per query, more workgroups).
+      static const bool rounds_on = !(std::getenv("PST_KNN_ROUNDS") && std::atoi(std::getenv("PST_KNN_ROUNDS")) == 0);
+      if (rounds_on && h[3]) {
+        const double qbar = (double)h[0] / (double)h[3], nt = (double)t.threads;
+        const double rounds = std::ceil((qbar + 2.0 * std::sqrt(qbar)) / nt);
+        if (rounds >= 2.0 && qbar / (rounds * nt) < 0.85) {
+          const double target = (rounds - 1.0) * nt - 2.0 * std::sqrt((rounds - 1.0) * nt);
+          const uint32_t bx2 = (uint32_t)std::floor((double)t.bx * target / qbar);
+          if (bx2 >= 1 && 4 * bx2 >= 3 * t.bx && bx2 < t.bx) {
+            TileShape c2 = t;
+            c2.bx = bx2;
+            unsigned long long h2[4] = {};
+            if (tile_fits(g, c2.bx, c2.by, c2.bz) && census(c2, h2) == 0 && h2[0] && (double)h2[2] <= 0.02 * (double)h2[0]) t.bx = bx2;
+          }
+        }
+      }
+      return true;
+    }
     // most queries lost: the cloud is locally several times denser than its grid average (a surface): big steps down; otherwise fine ones
     shrink = h[0] && (double)h[2] > 0.5 * (double)h[0] ? 0.6 : 0.85;
   }
   return false;
 }
 
+// The boxes of shape `t` that hold at least one query, ascending, into list[0 .. return value); count_dev = one device word.  Returns
+// 0xFFFFFFFF on a HIP failure.  (synchronises the stream)
+uint32_t knn_box_list(const TileShape& t, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t* list, uint32_t* count_dev, hipStream_t stream) {
+  const uint32_t nbx = (g.dim[0] + t.bx - 1) / t.bx, nby = (g.dim[1] + t.by - 1) / t.by, nbz = (g.dim[2] + t.bz - 1) / t.bz;
+  const uint32_t n_boxes = nbx * nby * nbz;
+  if (hipMemsetAsync(count_dev, 0, 4, stream) != hipSuccess) return 0xFFFFFFFFu;
+  hipLaunchKernelGGL(knn_box_list_kernel, dim3((n_boxes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cell_start, g, t.bx, t.by, t.bz, nbx, nby, n_boxes, list, count_dev);
+  uint32_t n = 0;
+  if (hipMemcpyAsync(&n, count_dev, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
+  return n;
+}
+uint32_t knn_box_count(const TileShape& t, const pstn::GridParams& g) {
+  return ((g.dim[0] + t.bx - 1) / t.bx) * ((g.dim[1] + t.by - 1) / t.by) * ((g.dim[2] + t.bz - 1) / t.bz);
+}
+
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,
-                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, hipStream_t stream) {
+                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, const uint32_t* box_list, uint32_t n_list, hipStream_t stream) {
   TileArgs a{};
   a.sxyz = sxyz; a.cell_start = cell_start; a.g = g;
   a.bx = t.bx; a.by = t.by; a.bz = t.bz;
   a.nbx = (g.dim[0] + t.bx - 1) / t.bx; a.nby = (g.dim[1] + t.by - 1) / t.by;
   const uint32_t nbz = (g.dim[2] + t.bz - 1) / t.bz;
-  a.n_boxes = a.nbx * a.nby * nbz;
+  a.n_boxes = box_list ? n_list : a.nbx * a.nby * nbz;
+  a.box_list = box_list;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
   if (const char* e = std::getenv("PST_KNN_ABLATE")) a.ablate = (uint32_t)std::atoi(e);
   a.flush_at = 48;
@@ -644,13 +1237,76 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
 #ifdef PST_KNN_STATS
   static unsigned long long* dbg_dev = nullptr;
   {
-    if (!dbg_dev) (void)hipMalloc((void**)&dbg_dev, 64);
-    (void)hipMemsetAsync(dbg_dev, 0, 64, stream);
+    if (!dbg_dev) (void)hipMalloc((void**)&dbg_dev, 128);
+    (void)hipMemsetAsync(dbg_dev, 0, 128, stream);
     a.dbg = dbg_dev;
   }
 #endif
   const unsigned grid = (a.n_boxes + 7u) & ~7u;
   const bool knn = out.knn != nullptr || out.knn_u32 != nullptr;
+  if (t.tag != '1') {
+    // Second form.  Key units: f32 coordinates are (x - c) s with s^2 tau0 + eps = 2^21 - 3, so that every squared distance that passes the
+    // scan's first limit converts to a 21-bit integer.  eps bounds |f32 squared distance - exact squared distance * s^2| for two points
+    // of one box: coordinates are at most L sqrt(U) in magnitude (L = half diagonal of the halo box in units of h, plus one; U = s^2 h^2 ~
+    // 2^21), so their f32 rounding error is at most half an ulp there, a coordinate difference (<= sqrt(U) for anything inside tau0) adds
+    // half an ulp of its own, and the three products / fused adds of the squared distance 4 * 2^-24 relative.  Times 1.5 for safety.
+    Tile2Args b{};
+    const double hxh = (double)(t.bx + 2 * (g.rx + 1)) / (2.0 * (double)g.rx), hyh = 0.5 * (double)(t.by + 2 * kHalo), hzh = 0.5 * (double)(t.bz + 2 * kHalo);
+    const double L = std::sqrt(hxh * hxh + hyh * hyh + hzh * hzh) + 1.0;
+    const double U0 = 2097152.0, sU = std::sqrt(U0);
+    auto ulp32 = [](double v) { const float f = (float)v; return (double)(std::nextafter(f, 3.0e38f) - f); };
+    const double d_r = 0.5 * ulp32(L * sU * 1.01), d_dx = 2.0 * d_r + 0.5 * ulp32(sU * 1.01);
+    const double eps = 1.5 * (2.0 * std::sqrt(3.0) * sU * 1.01 * d_dx + 3.0 * d_dx * d_dx + 4.0 * U0 / 16777216.0);
+    const double T = a.tau0;                       // squared length in the cloud's units
+    b.s2 = (2097149.0 - eps) / T;                  // tau0 * s2 + eps = 2^21 - 3
+    b.s = std::sqrt(b.s2);
+    b.s2 = b.s * b.s;
+    b.eps = eps;
+    b.lim0 = std::nextafter((float)(T * b.s2 + eps), 3.0e38f);
+    b.kx = (float)(g.inv_hx / b.s);
+    b.kyz = (float)(g.inv_h / b.s);
+    {
+      const double unit = t.cap > 2048 ? 2.0 : 1.0;  // 12 slot bits leave 20 for the distance: bins of two key units
+      b.gap = (uint32_t)std::floor(1.0 + 2.0 * eps / unit) + 1u;
+      const double fm = std::floor((T * b.s2 - eps) / unit) - 1.0;  // (F + 1) unit + eps < tau0 s2
+      b.f_max = fm > 0.0 ? (uint32_t)fm : 0u;
+    }
+    b.t = a;
+#define PST_TILE2_LAUNCH(KK, TT, CC, P3, BB, WW)                                                                               \
+    do {                                                                                                                       \
+      if (knn) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true>), dim3(grid), dim3(TT), 0, stream, b);      \
+      else hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false>), dim3(grid), dim3(TT), 0, stream, b);         \
+    } while (0)
+#define PST_TILE2_K(TT, CC, P3, BB, WW)                                                                                        \
+    do {                                                                                                                       \
+      if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW);                                                                     \
+      else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW);                                                                           \
+    } while (0)
+    switch (t.tag) {
+      case 'D': PST_TILE2_K(512, 3000, false, 4, 4); break;
+      case 'G': PST_TILE2_K(256, 1536, false, 4, 4); break;
+      default: PST_TILE2_K(256, 2044, false, 4, 3); break;
+    }
+#undef PST_TILE2_K
+#undef PST_TILE2_LAUNCH
+#ifdef PST_KNN_STATS
+    {
+      unsigned long long h[16] = {};
+      (void)hipMemcpyAsync(h, a.dbg, 128, hipMemcpyDeviceToHost, stream);
+      (void)hipStreamSynchronize(stream);
+      {
+        const double tot = (double)(h[14] ? h[14] : 1);
+        fprintf(stderr, "[pst knn tile2 %c] wave time (clock samples drain the LDS queue: indicative only): staging %.1f %%, chunk set-up %.1f %%, scan %.1f %%, insertion rounds %.1f %%, proof %.1f %%, fit + results %.1f %%, (other: chunk hand-out, exit) %.1f %%; %.0f kcycles per query wave\n",
+                t.tag, 100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot, 100.0 * h[13] / tot,
+                100.0 * (tot - (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13])) / tot, tot / 1000.0 / (double)(h[2] ? h[2] : 1));
+      }
+      fprintf(stderr, "[pst knn tile2 %c] query waves %llu: scan steps %.1f, insertion steps %.1f per wave; slots tested %.1f, queued %.1f per query; %.4f %% failed the proof; eps %.2f\n",
+              t.tag, h[2], (double)h[0] / (double)(h[2] ? h[2] : 1), (double)h[1] / (double)(h[2] ? h[2] : 1), (double)h[3] / (double)nf, (double)h[4] / (double)nf,
+              100.0 * (double)h[5] / (double)nf, eps);
+    }
+#endif
+    return;
+  }
 #define PST_TILE_LAUNCH(KK, TT, CC)                                                                                          \
   do {                                                                                                                       \
     if (knn) hipLaunchKernelGGL((knn_tile_kernel<KK, TT, CC, true>), dim3(grid), dim3(TT), 0, stream, a);                   \
