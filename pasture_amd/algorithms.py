@@ -95,8 +95,8 @@ def compute_normals_device(point_cloud: _Buffer, k_nn: int, normals_ptr: int = 0
 
 
 def release_scratch(api=None) -> None:
-    """Frees the device scratch the calling thread's compute_normals* calls keep between calls (about 100 bytes per point of the largest
-    recent cloud).  Never needed for correctness."""
+    """Frees the device scratch the calling thread's compute_normals* calls keep between calls (about 55 bytes per point of the largest
+    recent cloud, never more than PST_SCRATCH_MAX_BYTES = 8 GiB by default).  Never needed for correctness."""
     from ._capi import product_api
     (api or product_api()).release_scratch()
 

@@ -1,4 +1,5 @@
 // rocPRIM calls of the spatial-index builders, isolated in one translation unit (the headers are heavy).
+#include <cstdlib>
 #include <cstring>
 #include <iterator>
 
@@ -8,9 +9,11 @@
 
 namespace pstk {
 
-hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+hipError_t sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
                           size_t n, unsigned end_bit, hipStream_t stream) {
-  return rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+  static const bool lib_only = [] { const char* e = std::getenv("PST_SORT"); return e && std::strcmp(e, "rocprim") == 0; }();
+  if (!lib_only && radix_sort_pairs_supported(n, end_bit)) return radix_sort_pairs_u32(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, end_bit, stream);
+  return rocprim::radix_sort_pairs(tmp, bytes, (const uint32_t*)keys_in, keys_out, (const uint32_t*)vals_in, vals_out, n, 0u, end_bit, stream);
 }
 hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                           size_t n, unsigned end_bit, hipStream_t stream) {

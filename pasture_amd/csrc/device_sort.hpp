@@ -8,9 +8,15 @@
 
 namespace pstk {
 
-// stable LSD radix sort of (key, value) pairs on key bits [0, end_bit); n < 2^32
-hipError_t sort_pairs_u32(void* tmp, size_t& bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+// stable LSD radix sort of (key, value) pairs on key bits [0, end_bit); n < 2^32.  BOTH pairs of buffers are scratch (the passes
+// alternate between them); the result is in (keys_out, vals_out).  Up to 27 key bits: the library's own three-pass sort (radix_sort.hip);
+// beyond that, or with PST_SORT=rocprim (the A/B switch): rocPRIM.
+hipError_t sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
                           size_t n, unsigned end_bit, hipStream_t stream);
+// radix_sort.hip
+bool radix_sort_pairs_supported(size_t n, unsigned end_bit);
+hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned end_bit,
+                                hipStream_t stream);
 hipError_t sort_pairs_u64(void* tmp, size_t& bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
                           size_t n, unsigned end_bit, hipStream_t stream);
 // exclusive prefix sum of u32 counts into u64 offsets (out[0] = 0)

@@ -676,11 +676,27 @@ struct ScratchCache {
     for (Block& b : blocks) { held += b.bytes; if (b.busy) used += b.bytes; else b.idle_calls += 1; b.busy = false; }
     if (held > 2 * used) {
       for (size_t i = 0; i < blocks.size();) {
-        if (blocks[i].idle_calls >= 2) { (void)hipFree(blocks[i].p); blocks[i] = blocks.back(); blocks.pop_back(); }
+        if (blocks[i].idle_calls >= 2) { held -= blocks[i].bytes; (void)hipFree(blocks[i].p); blocks[i] = blocks.back(); blocks.pop_back(); }
         else ++i;
       }
     }
+    // CAP: a thread never keeps more than PST_SCRATCH_MAX_BYTES (default 8 GiB: the scratch of a 1.5 * 10^8-point call) between calls.
+    // Beyond it the largest blocks go back to the driver first -- a larger cloud then pays the allocations on every call.
+    static const size_t cap = [] {
+      const char* e = std::getenv("PST_SCRATCH_MAX_BYTES");
+      const long long v = e ? std::atoll(e) : -1;
+      return v >= 0 ? (size_t)v : (size_t)8 << 30;
+    }();
+    while (held > cap && !blocks.empty()) {
+      size_t big = 0;
+      for (size_t i = 1; i < blocks.size(); ++i) if (blocks[i].bytes > blocks[big].bytes) big = i;
+      held -= blocks[big].bytes;
+      (void)hipFree(blocks[big].p);
+      blocks[big] = blocks.back();
+      blocks.pop_back();
+    }
   }
+  size_t held_bytes() const { size_t h = 0; for (const Block& b : blocks) h += b.bytes; return h; }
   void release_all() {  // (no call of this thread is in flight: every call synchronises its stream before it returns)
     for (Block& b : blocks) (void)hipFree(b.p);  // (hipFree of another device's pointer is valid from any current device)
     blocks.clear();
@@ -709,7 +725,7 @@ struct CallGuard {
 };
 }  // namespace
 
-// Frees the device blocks the calling thread's kNN calls keep between calls (about 100 bytes per point of the largest recent cloud).
+// Frees the device blocks the calling thread's kNN calls keep between calls (about 55 bytes per point of the largest recent cloud, capped at PST_SCRATCH_MAX_BYTES, default 8 GiB).
 void release_normals_scratch() { scratch_cache().release_all(); }  // (the current device's cache)
 
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,

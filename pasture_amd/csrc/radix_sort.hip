@@ -1,0 +1,244 @@
+// Stable LSD radix sort of (u32 key, u32 value) pairs for the spatial-index builders, written for gfx950 (wave64, 160 KB LDS per CU).
+//
+// What it sorts: voxel keys of voxelgrid_filter (27 bits for the bench cloud; pasture-algorithms/src/voxel_grid.rs:109-166 groups points by
+// voxel -- the sequential per-voxel centroid sums :124-166 need the points of a voxel in their ORIGINAL order, hence stable) and the row-major
+// cell numbers of the kNN grid (normal_estimation.rs:103-120 is a kd-tree there; here ~26 bits).  The library sort (rocPRIM) takes four
+// 7-bit passes for such keys at ~2.3 TB/s of moved bytes per pass; this one takes THREE passes of ceil(bits / 3) <= 9 bits.
+//
+// One pass = three kernels, no spinning on other workgroups (no decoupled look-back: every kernel boundary is a device-wide barrier):
+//   1. radix_hist_kernel     per tile of 8192 keys a 2^d-bin digit histogram (LDS atomics), stored digit-major: counts[digit][tile];
+//   2. radix_scan_kernel     one workgroup per digit turns its row into exclusive prefix sums and leaves the row's total; then one
+//                            workgroup scans the 2^d totals: dbase[digit] = first output position of the digit;
+//   3. radix_scatter_kernel  per tile: keys are loaded WAVE-STRIPED (item i of lane l of wave w = element w * 1024 + i * 64 + l of the tile), so
+//                            the order (wave, item, lane) is memory order.  Rank of a key among the tile's keys of the same digit =
+//                            (same-digit keys of earlier waves) + (of earlier items of its wave) + (of lower lanes in its item): the last by
+//                            MATCHING the digit across the wave -- d ballots, each lane keeps the lanes that agree with it in every bit --
+//                            the middle one from a per-wave counter array in LDS that the lowest matching lane advances, the first by a scan
+//                            over the waves' counters.  Keys and values are then placed in LDS in digit order and leave in runs: consecutive
+//                            lanes write consecutive addresses of a digit's output range (16 pairs per digit and tile on average: 64-byte runs).
+// Traffic per pass: 4 (histogram) + 8 + 8 bytes per pair.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_sort.hpp"
+
+namespace pstk {
+
+namespace {
+
+constexpr int kThreads = 512, kWaves = kThreads / 64, kItems = 16, kTile = kThreads * kItems;  // 8192 pairs per tile
+constexpr int kMaxRadix = 512;
+
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, uint32_t shift, uint32_t mask) { return (key >> shift) & mask; }
+// Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2.  A tile's run for a digit (64 bytes on average) is
+// followed in the output by the NEXT tile's run for that digit: with tile = workgroup id the two halves of a 128-byte line are written
+// through different L2s; numbering the tiles so that every XCD owns a contiguous eighth lets neighbouring runs meet in one L2.
+__device__ __forceinline__ uint32_t logical_tile() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
+__global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint32_t shift, uint32_t mask, uint32_t tiles,
+                                                              uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[kMaxRadix];
+  const uint32_t tile = logical_tile(), tid = threadIdx.x;
+  if (tile >= tiles) return;
+  for (uint32_t d = tid; d <= mask; d += kThreads) hist[d] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)tile * kTile;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const uint64_t e = base + (uint64_t)i * kThreads + tid;  // (any order will do for counting: lane-contiguous loads)
+    if (e < n) atomicAdd(&hist[digit_of(keys[e], shift, mask)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t d = tid; d <= mask; d += kThreads) counts[(uint64_t)d * tiles + tile] = hist[d];
+}
+
+// one workgroup per digit: counts[d][0 .. tiles) -> exclusive prefix sums in place, totals[d] = the row's sum
+__global__ __launch_bounds__(kThreads) void radix_scan_rows_kernel(uint32_t* __restrict__ counts, uint32_t tiles, uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[kWaves];
+  __shared__ uint32_t carry;
+  uint32_t* row = counts + (uint64_t)blockIdx.x * tiles;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < tiles; t0 += kThreads) {
+    const uint32_t t = t0 + tid;
+    const uint32_t v = t < tiles ? row[t] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+      if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = carry;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) before += (uint32_t)w < wave ? wsum[w] : 0u;
+    if (t < tiles) row[t] = before + inc - v;
+    __syncthreads();
+    if (tid == kThreads - 1) carry = before + inc;
+    __syncthreads();
+  }
+  if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+// one workgroup: dbase[d] = sum of totals[0 .. d)
+__global__ __launch_bounds__(kThreads) void radix_scan_totals_kernel(const uint32_t* __restrict__ totals, uint32_t radix, uint32_t* __restrict__ dbase) {
+  __shared__ uint32_t wsum[kWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t v = tid < radix ? totals[tid] : 0u;
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) before += (uint32_t)w < wave ? wsum[w] : 0u;
+  if (tid < radix) dbase[tid] = before + inc - v;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kThreads, 4) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t n, uint32_t shift,
+                                                                    uint32_t tiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ dbase,
+                                                                    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  constexpr uint32_t RADIX = 1u << BITS, MASK = RADIX - 1u;
+  __shared__ uint32_t stage_k[kTile];
+  __shared__ uint32_t stage_v[kTile];
+  __shared__ uint16_t wcount[kWaves][RADIX];  // per wave and digit: keys seen so far; afterwards: keys of earlier waves
+  __shared__ uint32_t dstart[RADIX];          // first LDS position of the digit's keys in this tile
+  __shared__ uint32_t gbase[RADIX];           // global position of the digit's first key of this tile, minus dstart
+  __shared__ uint32_t wsum[kWaves];
+  const uint32_t tile = logical_tile(), tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tile >= tiles) return;
+  const uint64_t base = (uint64_t)tile * kTile;
+  const uint32_t tile_n = (uint32_t)((n - base) < (uint64_t)kTile ? (n - base) : (uint64_t)kTile);
+  for (uint32_t d = lane; d < RADIX; d += 64) wcount[wave][d] = 0;
+  uint32_t key[kItems], val[kItems];
+  const uint32_t e0 = wave * (kItems * 64u) + lane;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const uint32_t e = e0 + (uint32_t)i * 64u;
+    key[i] = e < tile_n ? keys_in[base + e] : 0xFFFFFFFFu;
+    val[i] = e < tile_n ? vals_in[base + e] : 0u;
+  }
+  // ---- rank within the wave, item by item (memory order) -----------------------------------------------------------------------------
+  uint16_t rank[kItems];
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64u - lane));  // lanes below this one
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const bool valid = e0 + (uint32_t)i * 64u < tile_n;
+    const uint32_t d = digit_of(key[i], shift, MASK);
+    uint64_t peers = __builtin_amdgcn_ballot_w64(valid);  // lanes whose item exists ...
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {                       // ... and whose digit agrees with this lane's in every bit
+      const uint64_t m = __builtin_amdgcn_ballot_w64((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t below = (uint32_t)__builtin_popcountll(peers & lt);
+    const uint32_t seen = wcount[wave][d];  // (every peer reads the counter before its lowest lane advances it: one wave, program order)
+    if (valid && below == 0) wcount[wave][d] = (uint16_t)(seen + (uint32_t)__builtin_popcountll(peers));
+    rank[i] = (uint16_t)(seen + below);
+  }
+  __syncthreads();
+  // ---- per digit: keys of earlier waves, the tile's count; then the digit's first position in the tile and in the output ----------
+  uint32_t mine = 0;  // the tile's number of keys with digit `tid` (RADIX <= kThreads: one digit per thread)
+  if (tid < RADIX) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { const uint32_t c = wcount[w][tid]; wcount[w][tid] = (uint16_t)run; run += c; }
+    mine = run;
+  }
+  uint32_t inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+    if (lane >= (uint32_t)off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (tid < RADIX) {
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) before += (uint32_t)w < wave ? wsum[w] : 0u;
+    const uint32_t start = before + inc - mine;
+    dstart[tid] = start;
+    gbase[tid] = dbase[tid] + counts[(uint64_t)tid * tiles + tile] - start;
+  }
+  __syncthreads();
+  // ---- place pairs in LDS in digit order (stable), then write runs -------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    if (e0 + (uint32_t)i * 64u < tile_n) {
+      const uint32_t d = digit_of(key[i], shift, MASK);
+      const uint32_t pos = dstart[d] + wcount[wave][d] + rank[i];
+      stage_k[pos] = key[i];
+      stage_v[pos] = val[i];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const uint32_t p = (uint32_t)i * kThreads + tid;
+    if (p < tile_n) {
+      const uint32_t k = stage_k[p];
+      const uint64_t g = (uint64_t)gbase[digit_of(k, shift, MASK)] + p;
+      keys_out[g] = k;
+      vals_out[g] = stage_v[p];
+    }
+  }
+}
+
+struct Plan { unsigned passes, bits[3]; uint32_t tiles; size_t counts_bytes, total_bytes; };
+Plan plan_for(size_t n, unsigned end_bit) {
+  Plan p{};
+  p.passes = end_bit <= 9 ? 1u : 3u;  // an odd number of passes: the result lands in the second pair of buffers
+  unsigned left = end_bit ? end_bit : 1u;
+  for (unsigned i = 0; i < p.passes; ++i) { p.bits[i] = (left + (p.passes - i) - 1) / (p.passes - i); left -= p.bits[i]; }
+  p.tiles = (uint32_t)((n + kTile - 1) / kTile);
+  p.counts_bytes = ((size_t)kMaxRadix * (p.tiles ? p.tiles : 1u) * 4 + 255) & ~(size_t)255;
+  p.total_bytes = p.counts_bytes + 2 * kMaxRadix * 4;
+  return p;
+}
+
+}  // namespace
+
+bool radix_sort_pairs_supported(size_t n, unsigned end_bit) { return end_bit <= 27 && n < 0xFFFFFFF0ull; }
+
+// Sorts (keys_a, vals_a) by key bits [0, end_bit); BOTH pairs of buffers are scratch, the result is in (keys_b, vals_b).
+hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned end_bit,
+                                hipStream_t stream) {
+  const Plan p = plan_for(n, end_bit);
+  if (!tmp) { bytes = p.total_bytes; return hipSuccess; }
+  if (bytes < p.total_bytes) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  uint32_t* counts = (uint32_t*)tmp;
+  uint32_t* totals = (uint32_t*)((uint8_t*)tmp + p.counts_bytes);
+  uint32_t* dbase = totals + kMaxRadix;
+  uint32_t *ki = keys_a, *ko = keys_b, *vi = vals_a, *vo = vals_b;
+  const unsigned grid = (p.tiles + 7u) & ~7u;  // (logical_tile: a multiple of 8 workgroups)
+  unsigned shift = 0;
+  for (unsigned pass = 0; pass < p.passes; ++pass) {
+    const unsigned b = p.bits[pass];
+    const uint32_t radix = 1u << b, mask = radix - 1u;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(grid), dim3(kThreads), 0, stream, ki, (uint64_t)n, shift, mask, p.tiles, counts);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(radix), dim3(kThreads), 0, stream, counts, p.tiles, totals);
+    hipLaunchKernelGGL(radix_scan_totals_kernel, dim3(1), dim3(kThreads), 0, stream, totals, radix, dbase);
+#define PST_SCATTER(B)                                                                                                                            \
+  case B: hipLaunchKernelGGL(radix_scatter_kernel<B>, dim3(grid), dim3(kThreads), 0, stream, ki, vi, (uint64_t)n, shift, p.tiles, counts, dbase, ko, vo); break;
+    switch (b) {
+      PST_SCATTER(1) PST_SCATTER(2) PST_SCATTER(3) PST_SCATTER(4) PST_SCATTER(5) PST_SCATTER(6) PST_SCATTER(7) PST_SCATTER(8) PST_SCATTER(9)
+      default: return hipErrorInvalidValue;
+    }
+#undef PST_SCATTER
+    shift += b;
+    uint32_t* t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace pstk

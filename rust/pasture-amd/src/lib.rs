@@ -3,11 +3,14 @@
 //! `pasture_amd/*.py`, which drives the same C entry points and is covered by the parity tests.
 //!
 //! Drop-in surface (same names / argument meaning / panics as pasture-core 0.5):
-//!   DeviceVectorBuffer, DeviceHashMapBuffer         ~ VectorBuffer, HashMapBuffer      (containers/point_buffer.rs)
+//!   DeviceVectorBuffer, DeviceHashMapBuffer         ~ VectorBuffer, HashMapBuffer      (containers/point_buffer.rs), storage in HBM
+//!   PinnedVectorBuffer, PinnedHashMapBuffer         ~ the same with `&[u8]` views: pinned host memory both pasture's CPU code and the kernels address
 //!   DeviceBufferLayoutConverter                     ~ BufferLayoutConverter            (layout/conversion/buffer_conversion.rs)
 //!   calculate_bounds, minmax_attribute, compute_normals, transform_attribute           (pasture-algorithms)
 use pasture_amd_sys::*;
-use pasture_core::containers::{BorrowedBuffer, BorrowedMutBuffer, MakeBufferFromLayout, OwningBuffer};
+use pasture_core::containers::{
+    BorrowedBuffer, BorrowedMutBuffer, ColumnarBuffer, ColumnarBufferMut, InterleavedBuffer, InterleavedBufferMut, MakeBufferFromLayout, OwningBuffer,
+};
 use pasture_core::layout::{PointAttributeDataType, PointAttributeDefinition, PointAttributeMember, PointLayout, PrimitiveType};
 use pasture_core::math::AABB;
 use pasture_core::nalgebra::{Point3, Vector3};
@@ -96,8 +99,9 @@ macro_rules! device_buffer {
             unsafe fn get_attribute_unchecked(&self, member: &PointAttributeMember, index: usize, data: &mut [u8]) {
                 self.get_attribute_range(member.attribute_definition(), index..index + 1, data)  // one D2H per call: debugging only
             }
-            // as_interleaved()/as_columnar() stay `None`: `&[u8]` views of HBM cannot be handed to the CPU loops.  Bulk work
-            // goes through DeviceBufferLayoutConverter and the functions below.
+            // as_interleaved()/as_columnar() stay `None` HERE: `&[u8]` views of HBM cannot be handed to the CPU loops.  Bulk work goes
+            // through DeviceBufferLayoutConverter and the functions below; PinnedVectorBuffer / PinnedHashMapBuffer (end of this file)
+            // are the kinds that answer with real slices.
         }
         impl<'a> BorrowedMutBuffer<'a> for $name {
             unsafe fn set_point(&mut self, index: usize, point_data: &[u8]) { self.set_point_range(index..index + 1, point_data) }
@@ -218,4 +222,196 @@ pub fn las_encode_points(points: &impl DeviceBuffer, point_format: u8, scale: [f
                          first_record: usize, bounds: &mut [f64; 6], points_by_return: &mut [u64; 15], large_file: bool) {
     check(unsafe { pst_las_encode_points(points.handle(), point_format as u32, scale.as_ptr(), offset.as_ptr(), records.raw(), first_record,
                                          bounds.as_mut_ptr(), points_by_return.as_mut_ptr(), if large_file { 15 } else { 5 }) })
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pinned-host buffers: ONE allocation that pasture's unmodified CPU code and the kernels both address.
+//
+// `pst_buffer_create(.., PST_MEM_PINNED_HOST)` allocates the storage with hipHostMalloc: host memory that the GPU reads and writes in place
+// over the host link (zero-copy).  Its pointers (`pst_buffer_points_ptr` / `pst_buffer_column_ptr`) are ordinary host addresses, so these
+// types CAN answer `as_interleaved()` / `as_columnar()` with real `&[u8]` slices (containers/point_buffer.rs:504-654) -- pasture's own
+// dispatch (`buffer_conversion.rs:326-356`, `.expect("Source buffer must either be an interleaved or columnar buffer")`), its views,
+// iterators, readers and writers work on them unchanged -- while DeviceBufferLayoutConverter / calculate_bounds / compute_normals take the
+// same handle.  The price is the link: a kernel streams such a buffer at ~55 GB/s instead of ~6 TB/s.  Use them where the CPU side
+// touches the points anyway (a reader that fills a chunk, a writer that drains one: pasture-io's 1 MiB chunk loops) and keep
+// DeviceVectorBuffer / DeviceHashMapBuffer for everything that stays on the GPU between kernels.
+//
+// Synchronisation: the kernels are stream-ordered; a `&[u8]` view must not be read while a launch that writes the buffer is in flight.
+// The synchronous entry points (everything in this file) return after the stream has drained; after an `*_async` call the caller runs
+// `pst_stream_synchronize()` before touching the slices.
+macro_rules! pinned_common {
+    ($name:ident, $storage:expr) => {
+        pub struct $name { handle: *mut pst_buffer, layout: PointLayout }
+        impl $name {
+            pub fn raw(&self) -> *mut pst_buffer { self.handle }
+            fn len_(&self) -> usize { let mut n = 0usize; check(unsafe { pst_buffer_len(self.handle, &mut n) }); n }
+        }
+        impl Drop for $name { fn drop(&mut self) { unsafe { pst_buffer_destroy(self.handle) }; } }
+        impl DeviceBuffer for $name { fn handle(&self) -> *mut pst_buffer { self.raw() } }
+        impl<'a> MakeBufferFromLayout<'a> for $name {
+            fn new_from_layout(point_layout: PointLayout) -> Self {
+                let l = LayoutHandle::new(&point_layout);
+                let mut h = std::ptr::null_mut();
+                check(unsafe { pst_buffer_create(l.0, $storage, PST_MEM_PINNED_HOST, &mut h) });
+                Self { handle: h, layout: point_layout }
+            }
+        }
+        impl<'a> OwningBuffer<'a> for $name {
+            unsafe fn push_points(&mut self, point_bytes: &[u8]) {
+                let stride = self.layout.size_of_point_entry() as usize;
+                let (old, add) = (self.len_(), point_bytes.len() / stride);
+                self.resize(old + add);
+                self.set_point_range(old..old + add, point_bytes);
+            }
+            /// zero-fills new points like `Vec::resize(_, 0)` (point_buffer.rs:777-781, 1308-1320); may move the storage: slices taken
+            /// before are invalidated by the borrow checker (`&mut self`)
+            fn resize(&mut self, count: usize) { check(unsafe { pst_buffer_resize(self.handle, count) }) }
+            fn clear(&mut self) { self.resize(0) }
+        }
+    };
+}
+
+pinned_common!(PinnedVectorBuffer, PST_STORAGE_INTERLEAVED);
+impl PinnedVectorBuffer {
+    fn bytes(&self) -> &[u8] {
+        let mut p: *mut std::os::raw::c_void = std::ptr::null_mut();
+        check(unsafe { pst_buffer_points_ptr(self.handle, &mut p) });
+        let n = self.len_() * self.layout.size_of_point_entry() as usize;
+        if n == 0 { &[] } else { unsafe { std::slice::from_raw_parts(p as *const u8, n) } }
+    }
+    fn bytes_mut(&mut self) -> &mut [u8] {
+        let mut p: *mut std::os::raw::c_void = std::ptr::null_mut();
+        check(unsafe { pst_buffer_points_ptr(self.handle, &mut p) });
+        let n = self.len_() * self.layout.size_of_point_entry() as usize;
+        if n == 0 { &mut [] } else { unsafe { std::slice::from_raw_parts_mut(p as *mut u8, n) } }
+    }
+}
+impl<'a> BorrowedBuffer<'a> for PinnedVectorBuffer {
+    fn len(&self) -> usize { self.len_() }
+    fn point_layout(&self) -> &PointLayout { &self.layout }
+    // the same copies VectorBuffer makes (point_buffer.rs:706-739), from the shared allocation
+    fn get_point(&self, index: usize, data: &mut [u8]) { data.copy_from_slice(self.get_point_ref(index)) }
+    fn get_point_range(&self, range: Range<usize>, data: &mut [u8]) { data.copy_from_slice(self.get_point_range_ref(range)) }
+    unsafe fn get_attribute_unchecked(&self, member: &PointAttributeMember, index: usize, data: &mut [u8]) {
+        let stride = self.layout.size_of_point_entry() as usize;
+        let start = index * stride + member.offset() as usize;
+        data.copy_from_slice(&self.bytes()[start..start + member.size() as usize])
+    }
+    fn as_interleaved(&self) -> Option<&dyn InterleavedBuffer<'a>> { Some(self) }   // pasture's dispatch takes the interleaved branch
+}
+impl<'a> InterleavedBuffer<'a> for PinnedVectorBuffer {
+    fn get_point_ref<'b>(&'b self, index: usize) -> &'b [u8] where 'a: 'b { self.get_point_range_ref(index..index + 1) }
+    fn get_point_range_ref<'b>(&'b self, range: Range<usize>) -> &'b [u8] where 'a: 'b {
+        let stride = self.layout.size_of_point_entry() as usize;
+        &self.bytes()[range.start * stride..range.end * stride]   // point_buffer.rs:856-866
+    }
+}
+impl<'a> BorrowedMutBuffer<'a> for PinnedVectorBuffer {
+    unsafe fn set_point(&mut self, index: usize, point_data: &[u8]) { self.get_point_mut(index).copy_from_slice(point_data) }
+    unsafe fn set_point_range(&mut self, point_range: Range<usize>, point_data: &[u8]) { self.get_point_range_mut(point_range).copy_from_slice(point_data) }
+    unsafe fn set_attribute(&mut self, attribute: &PointAttributeDefinition, index: usize, attribute_data: &[u8]) {
+        self.set_attribute_range(attribute, index..index + 1, attribute_data)
+    }
+    unsafe fn set_attribute_range(&mut self, attribute: &PointAttributeDefinition, point_range: Range<usize>, attribute_data: &[u8]) {
+        let m = self.layout.get_attribute(attribute).expect("Attribute not found in PointLayout of buffer").clone();
+        let (stride, off, size) = (self.layout.size_of_point_entry() as usize, m.offset() as usize, m.size() as usize);
+        let first = point_range.start;
+        let bytes = self.bytes_mut();
+        for (i, chunk) in attribute_data.chunks_exact(size).enumerate() {
+            let start = (first + i) * stride + off;
+            bytes[start..start + size].copy_from_slice(chunk);
+        }
+    }
+    fn swap(&mut self, from_index: usize, to_index: usize) {
+        let stride = self.layout.size_of_point_entry() as usize;
+        if from_index == to_index { return; }
+        let (lo, hi) = (from_index.min(to_index), from_index.max(to_index));
+        let (a, b) = self.bytes_mut().split_at_mut(hi * stride);
+        a[lo * stride..(lo + 1) * stride].swap_with_slice(&mut b[..stride]);
+    }
+    fn as_interleaved_mut(&mut self) -> Option<&mut dyn InterleavedBufferMut<'a>> { Some(self) }
+}
+impl<'a> InterleavedBufferMut<'a> for PinnedVectorBuffer {
+    fn get_point_mut<'b>(&'b mut self, index: usize) -> &'b mut [u8] where 'a: 'b { self.get_point_range_mut(index..index + 1) }
+    fn get_point_range_mut<'b>(&'b mut self, range: Range<usize>) -> &'b mut [u8] where 'a: 'b {
+        let stride = self.layout.size_of_point_entry() as usize;
+        &mut self.bytes_mut()[range.start * stride..range.end * stride]
+    }
+}
+
+pinned_common!(PinnedHashMapBuffer, PST_STORAGE_COLUMNAR);
+impl PinnedHashMapBuffer {
+    fn column(&self, attribute: &PointAttributeDefinition) -> (*mut u8, usize) {
+        let name = CString::new(attribute.name()).unwrap();
+        let dt = datatype_to_c(attribute.datatype());
+        let mut p: *mut std::os::raw::c_void = std::ptr::null_mut();
+        // PST_ERR_MISSING_ATTRIBUTE -> the panic of HashMapBuffer::get_attribute_ref (point_buffer.rs:1374-1387)
+        check(unsafe { pst_buffer_column_ptr(self.handle, name.as_ptr(), &dt, &mut p) });
+        (p as *mut u8, attribute.size() as usize)
+    }
+}
+impl<'a> BorrowedBuffer<'a> for PinnedHashMapBuffer {
+    fn len(&self) -> usize { self.len_() }
+    fn point_layout(&self) -> &PointLayout { &self.layout }
+    fn get_point(&self, index: usize, data: &mut [u8]) {   // gathers the attributes like HashMapBuffer::get_point (:1131-1147)
+        for a in self.layout.attributes() {
+            let (off, size) = (a.offset() as usize, a.size() as usize);
+            data[off..off + size].copy_from_slice(self.get_attribute_ref(a.attribute_definition(), index));
+        }
+    }
+    fn get_point_range(&self, range: Range<usize>, data: &mut [u8]) {
+        let stride = self.layout.size_of_point_entry() as usize;
+        for (k, i) in range.enumerate() { self.get_point(i, &mut data[k * stride..(k + 1) * stride]) }
+    }
+    unsafe fn get_attribute_unchecked(&self, member: &PointAttributeMember, index: usize, data: &mut [u8]) {
+        data.copy_from_slice(self.get_attribute_ref(member.attribute_definition(), index))
+    }
+    fn as_columnar(&self) -> Option<&dyn ColumnarBuffer<'a>> { Some(self) }   // pasture's dispatch takes the columnar branch
+}
+impl<'a> ColumnarBuffer<'a> for PinnedHashMapBuffer {
+    fn get_attribute_ref<'b>(&'b self, attribute: &PointAttributeDefinition, index: usize) -> &'b [u8] where 'a: 'b {
+        self.get_attribute_range_ref(attribute, index..index + 1)
+    }
+    fn get_attribute_range_ref<'b>(&'b self, attribute: &PointAttributeDefinition, range: Range<usize>) -> &'b [u8] where 'a: 'b {
+        let (p, size) = self.column(attribute);
+        assert!(range.end <= self.len_());
+        if range.is_empty() { &[] } else { unsafe { std::slice::from_raw_parts(p.add(range.start * size), range.len() * size) } }   // :1389-1402
+    }
+}
+impl<'a> BorrowedMutBuffer<'a> for PinnedHashMapBuffer {
+    unsafe fn set_point(&mut self, index: usize, point_data: &[u8]) {
+        let members: Vec<PointAttributeMember> = self.layout.attributes().cloned().collect();
+        for a in &members {
+            let (off, size) = (a.offset() as usize, a.size() as usize);
+            self.get_attribute_mut(a.attribute_definition(), index).copy_from_slice(&point_data[off..off + size]);
+        }
+    }
+    unsafe fn set_point_range(&mut self, point_range: Range<usize>, point_data: &[u8]) {
+        let stride = self.layout.size_of_point_entry() as usize;
+        for (k, i) in point_range.enumerate() { self.set_point(i, &point_data[k * stride..(k + 1) * stride]) }
+    }
+    unsafe fn set_attribute(&mut self, attribute: &PointAttributeDefinition, index: usize, attribute_data: &[u8]) {
+        self.get_attribute_mut(attribute, index).copy_from_slice(attribute_data)
+    }
+    unsafe fn set_attribute_range(&mut self, attribute: &PointAttributeDefinition, point_range: Range<usize>, attribute_data: &[u8]) {
+        self.get_attribute_range_mut(attribute, point_range).copy_from_slice(attribute_data)
+    }
+    fn swap(&mut self, from_index: usize, to_index: usize) {
+        let members: Vec<PointAttributeMember> = self.layout.attributes().cloned().collect();
+        for a in &members {
+            let (p, size) = self.column(a.attribute_definition());
+            if from_index != to_index { unsafe { std::ptr::swap_nonoverlapping(p.add(from_index * size), p.add(to_index * size), size) } }
+        }
+    }
+    fn as_columnar_mut(&mut self) -> Option<&mut dyn ColumnarBufferMut<'a>> { Some(self) }
+}
+impl<'a> ColumnarBufferMut<'a> for PinnedHashMapBuffer {
+    fn get_attribute_mut<'b>(&'b mut self, attribute: &PointAttributeDefinition, index: usize) -> &'b mut [u8] where 'a: 'b {
+        self.get_attribute_range_mut(attribute, index..index + 1)
+    }
+    fn get_attribute_range_mut<'b>(&'b mut self, attribute: &PointAttributeDefinition, range: Range<usize>) -> &'b mut [u8] where 'a: 'b {
+        let (p, size) = self.column(attribute);
+        assert!(range.end <= self.len_());
+        if range.is_empty() { &mut [] } else { unsafe { std::slice::from_raw_parts_mut(p.add(range.start * size), range.len() * size) } }   // :1425-1438
+    }
 }

@@ -82,3 +82,34 @@ def test_plain_c_program_runs_on_the_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("OK: 100000 points")
+
+
+def test_rust_repr_c_layouts_match_the_header(tmp_path):
+    """No rustc in the image: the layouts rust/pasture-amd-sys declares (#[repr(C)]) are pinned mechanically instead.  tools/gen_rust_sys.py
+    writes the Rust structs AND tests/abi/rust_layout_asserts.c (_Static_assert of sizeof / alignof / offsetof per field) from one model;
+    the C file must compile against include/pasture_amd.h, the committed generated files must be what the generator produces now, and every
+    struct the header defines must be in the model."""
+    import shutil
+    import subprocess
+    gen = os.path.join(ROOT, "tools", "gen_rust_sys.py")
+    rs = os.path.join(ROOT, "rust", "pasture-amd-sys", "src", "lib.rs")
+    cf = os.path.join(ROOT, "tests", "abi", "rust_layout_asserts.c")
+    before = (open(rs).read(), open(cf).read())
+    try:
+        subprocess.check_call(["python3", gen], stdout=subprocess.DEVNULL)
+        after = (open(rs).read(), open(cf).read())
+    finally:
+        open(rs, "w").write(before[0])
+        open(cf, "w").write(before[1])
+    assert after == before, "rust/pasture-amd-sys/src/lib.rs or tests/abi/rust_layout_asserts.c is stale: run tools/gen_rust_sys.py"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-c", "-I", os.path.join(ROOT, "include"), cf, "-o", str(tmp_path / "asserts.o")])
+    # a wrong number must actually fail (the check is not vacuous)
+    bad = tmp_path / "bad.c"
+    bad.write_text(before[1].replace("sizeof(pst_datatype) == 40", "sizeof(pst_datatype) == 48"))
+    assert "sizeof(pst_datatype) == 48" in bad.read_text()
+    r = subprocess.run(["gcc", "-std=c11", "-c", "-I", os.path.join(ROOT, "include"), str(bad), "-o", str(tmp_path / "bad.o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "sizeof(pst_datatype)" in r.stderr
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pasture_amd.h")).read(), flags=re.S)
+    defined = set(re.findall(r"typedef struct(?:\s+\w+)?\s*\{[^}]*\}\s*(pst_\w+)\s*;", hdr))
+    assert defined and all(f"sizeof({s})" in before[1] for s in defined), defined
+    assert shutil.which("gcc")

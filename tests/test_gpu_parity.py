@@ -468,8 +468,8 @@ def test_compute_normals_into_device_columns(hip, oracle):
 
 
 def test_release_scratch_returns_the_knn_cache(hip):
-    """pst_release_scratch: the kNN search keeps ~100 bytes of device scratch per point between calls (per thread); releasing it gives the
-    memory back and the next call simply allocates again."""
+    """pst_release_scratch: the kNN search keeps ~55 bytes of device scratch per point between calls (per thread and device; never more than
+    PST_SCRATCH_MAX_BYTES, default 8 GiB); releasing it gives the memory back and the next call simply allocates again."""
     import torch
     from pasture_amd.algorithms import compute_normals_device, release_scratch
     n = 4_000_000
@@ -484,7 +484,7 @@ def test_release_scratch_returns_the_knn_cache(hip):
     held = torch.cuda.mem_get_info()[0]
     release_scratch(hip)
     freed = torch.cuda.mem_get_info()[0] - held
-    assert freed >= 60 * n, f"only {freed} bytes came back"
+    assert freed >= 40 * n, f"only {freed} bytes came back"
     compute_normals_device(src, 16, 0, curv.data_ptr(), 0)
     assert torch.equal(curv, first)
 

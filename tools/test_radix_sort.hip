@@ -1,0 +1,65 @@
+// Standalone check of pasture_amd/csrc/radix_sort.hip against std::stable_sort (built and run on the GPU box):
+//   hipcc -O2 --offload-arch=gfx950 -Ipasture_amd/csrc tools/test_radix_sort.hip pasture_amd/csrc/radix_sort.hip -o /tmp/test_radix && /tmp/test_radix
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <numeric>
+#include <random>
+#include <vector>
+
+#include "device_sort.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main() {
+  std::mt19937_64 rng(7);
+  const size_t sizes[] = {0, 1, 2, 63, 64, 65, 1000, 8191, 8192, 8193, 100003, 1 << 20, 3000001, 100000000};
+  const unsigned bitsv[] = {1, 5, 9, 10, 17, 18, 25, 26, 27};
+  int fails = 0;
+  for (size_t n : sizes) {
+    for (unsigned bits : bitsv) {
+      if (n == 100000000 && bits != 27 && bits != 26) continue;
+      std::vector<uint32_t> k(n), v(n);
+      const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+      // a mix: uniform keys, and (every third case) keys confined to few values so that equal keys abound
+      const bool few = (n + bits) % 3 == 0;
+      for (size_t i = 0; i < n; ++i) { k[i] = (uint32_t)rng() & mask; if (few) k[i] &= 0x1Fu; v[i] = (uint32_t)i; }
+      uint32_t *ka, *kb, *va, *vb;
+      CK(hipMalloc(&ka, n * 4 + 16)); CK(hipMalloc(&kb, n * 4 + 16)); CK(hipMalloc(&va, n * 4 + 16)); CK(hipMalloc(&vb, n * 4 + 16));
+      CK(hipMemcpy(ka, k.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, v.data(), n * 4, hipMemcpyHostToDevice));
+      size_t bytes = 0;
+      CK(pstk::radix_sort_pairs_u32(nullptr, bytes, ka, kb, va, vb, n, bits, nullptr));
+      void* tmp;
+      CK(hipMalloc(&tmp, bytes));
+      CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr));
+      CK(hipDeviceSynchronize());
+      double ms = 0;
+      if (n >= (1 << 20)) {
+        // timing: re-upload and sort three times
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipMemcpy(ka, k.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, v.data(), n * 4, hipMemcpyHostToDevice));
+          CK(hipEventRecord(e0)); CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr)); CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float t; CK(hipEventElapsedTime(&t, e0, e1)); best = std::min(best, t);
+        }
+        ms = best;
+      }
+      std::vector<uint32_t> gk(n), gv(n);
+      CK(hipMemcpy(gk.data(), kb, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gv.data(), vb, n * 4, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> order(n);
+      std::iota(order.begin(), order.end(), 0u);
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k[a] < k[b]; });
+      bool ok = true;
+      for (size_t i = 0; i < n && ok; ++i) ok = gv[i] == order[i] && gk[i] == k[order[i]];
+      if (!ok) { ++fails; printf("MISMATCH n=%zu bits=%u few=%d\n", n, bits, (int)few); }
+      else if (ms > 0) printf("ok n=%zu bits=%u %s: %.3f ms (%.2f TB/s of 16 B per pair and pass x3)\n", n, bits, few ? "few" : "uniform", ms, 3.0 * 16.0 * n / ms / 1e9);
+      CK(hipFree(ka)); CK(hipFree(kb)); CK(hipFree(va)); CK(hipFree(vb)); CK(hipFree(tmp));
+    }
+  }
+  printf("radix sort check: %d failures\n", fails);
+  return fails != 0;
+}
