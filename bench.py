@@ -660,6 +660,26 @@ def main():
                          "kernel_ms_min": round(min(kernel_ms), 4),
                          "note": "HIP events around one step's launches on the launch stream (conversion kernel + the AABB fold kernels where fused)"},
         }
+        if args.workload.startswith("normals_knn"):
+            # The kNN call is bound by its vector-instruction count, not by HBM: beside the HBM lower bound above, the
+            # bound that binds -- vector (wave64) instructions of the dominant kernel per launch, from the committed SQ_INSTS_VALU pass,
+            # over the chip's issue rate (256 CUs x 4 SIMDs, one wave instruction per 4 cycles at 2.4 GHz).
+            try:
+                v = json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get(args.workload)
+            except Exception:
+                v = None
+            if v and v.get("points") == n:
+                issue_rate = 256 * 4 * 2.4e9 / 4.0
+                bound_ms = v["valu_wave_instructions_per_launch"] / issue_rate * 1e3
+                line["roofline"]["bound_valu"] = {
+                    "kernel": v["kernel"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"],
+                    "valu_wave_instructions_per_point": round(v["valu_wave_instructions_per_launch"] / n, 2),
+                    "issue_rate_wave_instructions_per_s": issue_rate, "bound_ms": round(bound_ms, 3),
+                    "kernel_ms": v.get("kernel_ms"), "frac_of_kernel": round(bound_ms / v["kernel_ms"], 4) if v.get("kernel_ms") else None,
+                    "frac_of_step": round(bound_ms / (kernel_ms_avg), 4),
+                    "source": f"profiles/knn_valu.json (round {v.get('round')}: rocprofv3 --pmc SQ_INSTS_VALU and --kernel-trace passes of this workload); NOT measured in this run",
+                    "note": "frac_of_kernel = time the dominant kernel's vector instructions need at full issue rate / its measured duration; "
+                            "frac_of_step = the same against the whole call (index build, sort, fallback searches included)"}
         if distributed:
             line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
         if configs3 is not None:
