@@ -140,6 +140,7 @@ _PRODUCT_SIGNATURES = {
     "compute_normals_into": [_P, _SZ, _P],
     "compute_normals_device": [_P, _SZ, _P, _P, _P],
     "release_scratch": [],
+    "reload_tuning": [],
     "comm_unique_id": [_P],
     "comm_init_rank": [C.c_int, C.c_int, _P, _PP],
     "comm_init": [C.c_int, _PP],

@@ -94,6 +94,15 @@ def compute_normals_device(point_cloud: _Buffer, k_nn: int, normals_ptr: int = 0
                                            C.c_void_p(knn_ptr or None))
 
 
+def reload_tuning(api=None) -> None:
+    """The PST_KNN_* switches are read from the environment once per process; this reads them again (tests and A/B harnesses that change
+    them inside one process).  The oracle has no such switches: a no-op there."""
+    from ._capi import product_api
+    api = api or product_api()
+    if hasattr(api, "reload_tuning"):
+        api.reload_tuning()
+
+
 def release_scratch(api=None) -> None:
     """Frees the device scratch the calling thread's compute_normals* calls keep between calls (about 55 bytes per point of the largest
     recent cloud, never more than PST_SCRATCH_MAX_BYTES = 8 GiB by default).  Never needed for correctness."""

@@ -31,6 +31,7 @@
 #include "kernels.hpp"
 #include "normals_device.hpp"
 #include "normals_host.hpp"
+#include "normals_plan.hpp"
 
 using namespace pstn;
 
@@ -246,14 +247,32 @@ __global__ __launch_bounds__(kBlock) void build_directory_kernel(const uint32_t*
   }
 }
 
-// The same directory for clouds that leave most cells empty (a surface in a 3-D box: whole grid rows without a point): the kernel above
-// fills the cells of a gap from ONE thread.  Here the run heads are scattered into a 0xFFFFFFFF-filled array and a suffix minimum
-// (device_sort.hip) carries each head back over the empty cells in front of it: 8.4 -> 0.6 ms for 5 * 10^7 cells and 10^7 points.
-__global__ __launch_bounds__(kBlock) void scatter_heads_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells, uint32_t* __restrict__ cell_start) {
+// The same directory for clouds that leave most cells empty (a surface in a 3-D box: whole grid rows without a point; 1.9 * 10^9 cells for 10^8
+// points of the LiDAR-like sheet).  Round 2 scattered the run heads into a 0xFFFFFFFF-filled array and took a suffix minimum over ALL cells
+// (a 7.5 GB fill plus a 15 GB scan: 7 ms).  Now the directory is written exactly once, in blocks of kDirBlock cells:
+//   dir_block_heads_kernel   first sorted point of every block that holds a run head (atomicMin into one word per block);
+//   (suffix minimum over the BLOCK words: 1/1024 of the cells)  -> block_first[b] = first sorted point with key >= b * kDirBlock;
+//   dir_fill_kernel          a workgroup per block: the block's points are the sorted range [block_first[b], block_first[b + 1]); an empty
+//                            block writes that one value 1024 times, the others find every cell's first point by binary search in the range.
+constexpr uint32_t kDirBlock = 1024;
+__global__ __launch_bounds__(kBlock) void dir_block_heads_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells, uint32_t* __restrict__ block_first) {
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j <= nf; j += step) {
-    const uint64_t k = j < nf ? keys[j] : cells;
-    if (j == 0 || keys[j - 1] != k) cell_start[k] = (uint32_t)j;
+    const uint64_t k = j < nf ? keys[j] : cells;  // (the end sentinel: cell_start[cells] = nf)
+    if (j == 0 || keys[j - 1] != k) atomicMin(&block_first[k / kDirBlock], (uint32_t)j);
+  }
+}
+__global__ __launch_bounds__(kBlock) void dir_fill_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells, const uint32_t* __restrict__ block_first,
+                                                          uint64_t n_blocks, uint32_t* __restrict__ cell_start) {
+  const uint64_t b = blockIdx.x;
+  const uint32_t j0 = block_first[b], j1 = b + 1 < n_blocks ? block_first[b + 1] : (uint32_t)nf;
+#pragma unroll
+  for (uint32_t u = 0; u < kDirBlock / kBlock; ++u) {
+    const uint64_t c = b * kDirBlock + u * kBlock + threadIdx.x;
+    if (c > cells) break;
+    uint32_t lo = j0, hi = j1;  // first j in [j0, j1] with key[j] >= c (j1 when there is none)
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < c) lo = mid + 1; else hi = mid; }
+    cell_start[c] = lo;
   }
 }
 
@@ -682,11 +701,7 @@ struct ScratchCache {
     }
     // CAP: a thread never keeps more than PST_SCRATCH_MAX_BYTES (default 8 GiB: the scratch of a 1.5 * 10^8-point call) between calls.
     // Beyond it the largest blocks go back to the driver first -- a larger cloud then pays the allocations on every call.
-    static const size_t cap = [] {
-      const char* e = std::getenv("PST_SCRATCH_MAX_BYTES");
-      const long long v = e ? std::atoll(e) : -1;
-      return v >= 0 ? (size_t)v : (size_t)8 << 30;
-    }();
+    const size_t cap = (size_t)knn_tuning().scratch_max;
     while (held > cap && !blocks.empty()) {
       size_t big = 0;
       for (size_t i = 1; i < blocks.size(); ++i) if (blocks[i].bytes > blocks[big].bytes) big = i;
@@ -784,23 +799,18 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     GridParams frame{};  // the frame the grids live in: the cloud's own axes, or (below) its principal axes
     const double full_mn[3] = {mn[0], mn[1], mn[2]}, full_mx[3] = {mx[0], mx[1], mx[2]};  // the bounding box (mn / mx may become a trimmed or rotated one)
     // the box the grids are laid over: the bounding box, or (below) a trimmed one when a few far points stretch it
-    double ext[3], maxext = 1.0, vol = 1.0;
-    int dims_used = 0;
-    auto set_box = [&]() {
-      for (int c = 0; c < 3; ++c) ext[c] = mx[c] - mn[c];
-      maxext = std::fmax(ext[0], std::fmax(ext[1], ext[2]));
-      if (!(maxext > 0.0)) maxext = 1.0;
-      // treat flat axes (extent < 1e-6 of the largest) as thickness-free: density is per area / per length then
-      vol = 1.0; dims_used = 0;
-      for (int c = 0; c < 3; ++c) if (ext[c] > maxext * 1e-9) { vol *= ext[c]; dims_used += 1; }
-    };
+    const KnnTuning& tune = knn_tuning();
+    BoxStats bs{};
+    double (&ext)[3] = bs.ext;
+    double& maxext = bs.maxext;
+    auto set_box = [&]() { bs = BoxStats::of(mn, mx); };
     set_box();
     // Points per cell.  With the hash table every cell costs a probe, so few fat cells win: ~k/3 points per cell (the first
     // shell of 27 cells almost always suffices).  With the dense directory a whole row of cells is one range, and small cells win
     // because the searched cube approximates the k-sphere better: ~k/12 points per cell, two shells
     // (global-memory search at k = 16, 10^8 points: 5.33 -> 126 ms, 2.2 -> 116, 1.3 -> 100, 0.8 -> 107, 0.4 -> 145).
     auto grid_for = [&](double h, uint32_t rx, GridParams& g) -> uint64_t {
-      if (const char* e = std::getenv("PST_KNN_CELL")) { const double v = std::atof(e); if (v > 0) h = v; }
+      if (tune.cell > 0) h = tune.cell;
       const double min_h = maxext * (double)rx / 2000000.0;  // <= 2^21 cells per axis
       if (!(h > min_h)) h = min_h;
       g.h = h; g.inv_h = 1.0 / h; g.rx = rx; g.hx = h / (double)rx; g.inv_hx = (double)rx / h;
@@ -815,12 +825,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       }
       return (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];
     };
-    auto edge_for = [&](double per_cell) { return dims_used ? std::pow(vol * per_cell / (double)n, 1.0 / dims_used) : maxext; };
-    auto is_dense = [&](uint64_t cells) { return cells <= std::max<uint64_t>(4 * n, 1u << 20) && cells < 0xFFFFFFF0ull; };
-    double per_cell_env = 0.0;
-    if (const char* e = std::getenv("PST_KNN_PER_CELL")) per_cell_env = std::atof(e);
-    const bool debug = std::getenv("PST_KNN_DEBUG") != nullptr;
-    const bool trace = std::getenv("PST_KNN_TRACE") != nullptr;  // host wall time of every phase (each mark synchronises the stream)
+    auto edge_for = [&](double per_cell) { return bs.edge_for(per_cell, n); };
+    auto is_dense = [&](uint64_t cells) { return dense_directory_ok(cells, n); };
+    const double per_cell_env = tune.per_cell;
+    const bool debug = tune.debug;
+    const bool trace = tune.trace;  // host wall time of every phase (each mark synchronises the stream)
     auto t_prev = std::chrono::steady_clock::now();
     std::string trace_line;
     auto mark = [&](const char* what) {
@@ -833,7 +842,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       t_prev = now;
     };
 
-    CacheBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, tkeys, tstarts, fb_list;
+    CacheBuf keys, keys2, idx, idx2, sorted_xyz, tmp, rec, directory, dir_blocks, tkeys, tstarts, fb_list;
     NCK(keys.alloc(n * 8, stream)); NCK(keys2.alloc(n * 8, stream)); NCK(idx.alloc(n * 4, stream)); NCK(idx2.alloc(n * 4, stream));
     NCK(sorted_xyz.alloc(n * 24, stream));
     GridParams g{};
@@ -870,12 +879,16 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (dense) {
         BCK(directory.alloc((cells + 2) * 4, stream));
         if (cells > 3 * nf) {
-          BCK(hipMemsetAsync(directory.p, 0xFF, (cells + 1) * 4, stream));
-          hipLaunchKernelGGL(scatter_heads_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
+          const uint64_t n_dblocks = (cells + 1 + kDirBlock - 1) / kDirBlock;
+          BCK(dir_blocks.alloc(n_dblocks * 4, stream));
+          BCK(hipMemsetAsync(dir_blocks.p, 0xFF, n_dblocks * 4, stream));
+          hipLaunchKernelGGL(dir_block_heads_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, dir_blocks.as<uint32_t>());
           size_t sb = 0;
-          BCK(suffix_min_u32(nullptr, sb, directory.as<uint32_t>(), cells + 1, stream));
+          BCK(suffix_min_u32(nullptr, sb, dir_blocks.as<uint32_t>(), n_dblocks, stream));
           BCK(tmp.alloc(sb, stream));
-          BCK(suffix_min_u32(tmp.p, sb, directory.as<uint32_t>(), cells + 1, stream));
+          BCK(suffix_min_u32(tmp.p, sb, dir_blocks.as<uint32_t>(), n_dblocks, stream));
+          hipLaunchKernelGGL(dir_fill_kernel, dim3((unsigned)n_dblocks), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, (const uint32_t*)dir_blocks.as<uint32_t>(),
+                             n_dblocks, directory.as<uint32_t>());
         } else {
           hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
         }
@@ -903,20 +916,19 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // 2. otherwise the global-memory search over the dense directory with ~k/12 points per cubic cell, when the grid is not much larger
     //    than the cloud -- 3. else over Morton keys + a hash table with ~k/3 points per cell;
     // 4. queries 2 / 3 hand back after kShellCap shells: coarser grids over the full bounding box, then an exact search against all points.
-    constexpr int kShellCap = 6;  // shells a global-memory search walks before it hands a query to a coarser grid
     TileShape shape;
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 88);  // four counters of the probe / census kernels (88 .. 120)
     double m_target = 1.75 * (double)k;  // points the ball of radius h should hold
-    if (const char* e = std::getenv("PST_KNN_TAU_M")) { const double v = std::atof(e); if (v > 0) m_target = v; }
+    if (tune.tau_m > 0) m_target = tune.tau_m;
     // GATE: is the cloud what its bounding box says?  A quick scale estimate on 2^17 points, 256 queries (normals_scale.hip; 0.3 ms) against the radius
     // the box's volume predicts.  The 32^3 occupancy mask alone is fooled by a thin uniform halo around a dense core (1 % of the points
     // spread over 10^5 times the core's volume fill every coarse cell: the grid was laid for the halo and every cell of the core held
     // 400 000 points -- 32 s for 10^7 points).
     double h_gate = 0.0, d_gate = 3.0;
     bool concentrated = false;
-    if (n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+    if (n >= 4096 && !tune.forced_scale() && !tune.no_scale) {
       const uint64_t S = (n + (1u << 17) - 1) >> 17, n_g = n / S;
       CacheBuf xyz_g, hist_g;
       NCK(xyz_g.alloc(n_g * 24, stream));
@@ -924,8 +936,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, (const uint8_t*)xyz.as<double>(), 24 * S, n_g, xyz_g.as<double>(), partials.as<double>());
       if (knn_scale_estimate(xyz_g.as<double>(), (uint32_t)n_g, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_g.as<unsigned int>(), stream,
                              h_gate, d_gate, 256)) {
-        const double h_box = edge_for(m_target / 4.18879020478639);
-        concentrated = h_gate < h_box / 1.5;
+        const double h_box = edge_for(m_target / kBallVolume);
+        concentrated = cloud_is_concentrated(h_gate, h_box);
         if (debug) fprintf(stderr, "[pst knn gate] %.1f points within h=%g (dimension %.2f); the box's volume says %g%s\n", m_target, h_gate, d_gate, h_box,
                            concentrated ? ": concentrated" : "");
       }
@@ -964,25 +976,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (debug) fprintf(stderr, "[pst knn] occupancy of the box at 32^3: %.3f\n", occupancy);
       // The trimmed box for a tail mass `cut` (a fraction of the points at either end of every axis).  0.05 % always; for a cloud the gate
       // found concentrated also 0.5 % and 5 % -- a tenfold cut is taken when it buys at least an eightfold smaller box (a halo).
-      auto trimmed = [&](double cut_frac, double (&tmn)[3], double (&tmx)[3]) {
-        double shrink = 1.0;
-        for (int c = 0; c < 3; ++c) {
-          tmn[c] = mn[c]; tmx[c] = mx[c];
-          if (!(ax[c] > 0)) continue;
-          const uint32_t* hc = hb.data() + kOccWords + c * kAxisBins;
-          uint64_t total = 0;
-          for (uint32_t i = 0; i < kAxisBins; ++i) total += hc[i];
-          const uint64_t cut = (uint64_t)((double)total * cut_frac);
-          uint32_t lo = 0, hi = kAxisBins - 1;
-          for (uint64_t acc = 0; lo < hi && acc + hc[lo] <= cut; ++lo) acc += hc[lo];
-          for (uint64_t acc = 0; hi > lo && acc + hc[hi] <= cut; --hi) acc += hc[hi];
-          lo = lo > 0 ? lo - 1 : 0; hi = hi + 1 < kAxisBins ? hi + 1 : kAxisBins - 1;
-          tmn[c] = std::fmax(mn[c], mn[c] + (double)lo / ax[c]);
-          tmx[c] = std::fmin(mx[c], mn[c] + (double)(hi + 1) / ax[c]);
-          shrink *= (tmx[c] - tmn[c]) / ext[c];
-        }
-        return shrink;
-      };
+      auto trimmed = [&](double cut_frac, double (&tmn)[3], double (&tmx)[3]) { return trimmed_box<kAxisBins>(hb.data() + kOccWords, mn, mx, ax, cut_frac, tmn, tmx); };
       double tmn[3], tmx[3];
       double shrink = trimmed(0.0005, tmn, tmx);
       if (concentrated) {
@@ -994,7 +988,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         }
       }
       // (once a box has been trimmed, the slices are finer and a second and third look may tighten it further: any gain above 40 % is taken)
-      if (pass < 3 && shrink <= (pass == 0 ? 0.125 : 0.6) && !std::getenv("PST_KNN_NO_TRIM")) {
+      if (take_trimmed_box(pass, shrink) && !tune.no_trim) {
         if (debug) fprintf(stderr, "[pst knn] trimmed box: %.3g of the volume: [%g, %g] x [%g, %g] x [%g, %g]\n", shrink, tmn[0], tmx[0], tmn[1], tmx[1], tmn[2], tmx[2]);
         for (int c = 0; c < 3; ++c) { mn[c] = tmn[c]; mx[c] = tmx[c]; }
         set_box();
@@ -1012,7 +1006,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // the hash directory.  The covariance of a subsample (inside the trimmed box) gives the principal axes; if the box in THAT frame is
     // at most a third of the volume, the grid is laid in it: cells, rows and trims use rotated coordinates (grid_frame), distances the
     // original ones.
-    if (occupancy < 0.5 && n >= (1u << 16) && !std::getenv("PST_KNN_NO_ROTATE")) {
+    if (consider_rotation(occupancy, n, tune)) {
       const uint64_t S_m = std::max<uint64_t>(1, n >> 20), n_m = n / S_m;
       CacheBuf sums;
       NCK(sums.alloc(80, stream));
@@ -1050,7 +1044,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           for (int cc = 0; cc < 3; ++cc) cand.rot[3 * r + cc] = V[cc][order[r]];
         double align = 1.0;  // the smallest of the rows' largest components: 1 = the principal axes ARE the coordinate axes (in some order)
         for (int r = 0; r < 3; ++r) align = std::fmin(align, std::fmax(std::fabs(cand.rot[3 * r]), std::fmax(std::fabs(cand.rot[3 * r + 1]), std::fabs(cand.rot[3 * r + 2]))));
-        if (align >= 0.995) { mark("axes"); goto axes_done; }  // within 6 degrees: nothing to gain, no pass over the points
+        if (axes_are_coordinate_axes(align)) { mark("axes"); goto axes_done; }  // within 6 degrees: nothing to gain, no pass over the points
         hipLaunchKernelGGL(framed_bounds_kernel, dim3(sgrid), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], cand, partials.as<double>());
         NCK(hipMemcpyAsync(hp.data(), partials.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
         NCK(hipStreamSynchronize(stream));
@@ -1062,7 +1056,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           double rext = std::fmax(rmx[0] - rmn[0], std::fmax(rmx[1] - rmn[1], rmx[2] - rmn[2]));
           for (int cc = 0; cc < 3; ++cc) { v_now *= std::fmax(ext[cc], 1e-6 * maxext); v_rot *= std::fmax(rmx[cc] - rmn[cc], 1e-6 * rext); }
           if (debug) fprintf(stderr, "[pst knn] principal axes: box %.3g of the axis-aligned one (%g x %g x %g)\n", v_rot / v_now, rmx[0] - rmn[0], rmx[1] - rmn[1], rmx[2] - rmn[2]);
-          if (v_rot <= 0.35 * v_now) {
+          if (take_rotated_box(v_rot, v_now)) {
             frame = cand;
             for (int cc = 0; cc < 3; ++cc) { mn[cc] = rmn[cc]; mx[cc] = rmx[cc]; }
             set_box();
@@ -1079,12 +1073,12 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // times too large; separate clusters: orders of magnitude) the scale is MEASURED first, without an index (normals_scale.hip): distance
     // histograms of 512 sampled points against a subsample of 2^20 to 2^22 points give the radius at which the cloud holds M points
     // around a typical point, and its local dimension.
-    const double h_box_now = edge_for(m_target / 4.18879020478639);
-    const bool fills = occupancy >= 0.9 && !(h_gate > 0.0 && std::fabs(h_gate / h_box_now - 1.0) > 0.3);  // the cloud is what its (trimmed) box says
+    const double h_box_now = edge_for(m_target / kBallVolume);
+    const bool fills = cloud_fills_box(occupancy, h_gate, h_box_now);  // the cloud is what its (trimmed) box says
     // (up to 4 million points the gate's subsample is thinned by at most 32 -- as good as the full estimate: taken as it is)
-    const bool gate_is_enough = h_gate > 0.0 && n <= (32ull << 17);
-    if (!fills && gate_is_enough) { h_est = h_gate; d_est = d_gate; }
-    if (!fills && !gate_is_enough && n >= 4096 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL") && !std::getenv("PST_KNN_NO_SCALE")) {
+    const bool gate_enough = gate_is_enough(h_gate, n);
+    if (!fills && gate_enough) { h_est = h_gate; d_est = d_gate; }
+    if (!fills && !gate_enough && n >= 4096 && !tune.forced_scale() && !tune.no_scale) {
       // the subsample: a sixteenth of the cloud, at least 2^18 and at most 2^22 points (the further the thinning, the longer the extrapolation
       // down to the radius of M points: at 1 in 96 the sheet's h came out 8 % low)
       const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 18, n / 16));
@@ -1099,27 +1093,25 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (knn_scale_estimate(xyz_s.as<double>(), (uint32_t)n_s, (double)S, ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2], m_target, hist_s.as<unsigned int>(), stream,
                              h_m, dim_m)) {
         if (debug) fprintf(stderr, "[pst knn scale] %llu of %llu points: %.1f points within h=%g, dimension %.2f (by the box's volume: %g)\n", (unsigned long long)n_s,
-                           (unsigned long long)n, m_target, h_m, dim_m, edge_for(m_target / 4.18879020478639));
+                           (unsigned long long)n, m_target, h_m, dim_m, edge_for(m_target / kBallVolume));
         h_est = h_m; d_est = dim_m;
       }
       mark("scale");
     }
-    if (k <= 64 && !std::getenv("PST_KNN_NO_TILE") && (occupancy >= 0.5 || n >= (1u << 20) || std::getenv("PST_KNN_FORCE_TILE"))) {
+    if (try_box_search(k, occupancy, n, tune)) {
       // fine x cells per h: 4 for clouds that fill their box; 2 for the others (a surface: the same box holds fewer points, the 31-cell limit of a
       // box row then makes boxes too short at rx = 4: 6.3 against 3.9 ms per 10^7 points of the sheet in tools/exp_normals_surface.py)
-      uint32_t rx = (h_est > 0.0 ? d_est < 2.5 : occupancy < 0.5) ? 2 : 4;  // (the measured dimension where there is one: a sheet that fills a thin box is still a sheet)
-      if (const char* e = std::getenv("PST_KNN_RX")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) rx = (uint32_t)v; }
+      uint32_t rx = fine_cells_per_h(h_est, d_est, occupancy, tune);
       // points per (cubic) cell of edge R0: M = (4/3 pi) R0^3 * density  =>  R0^3 * density = M / (4/3 pi)
-      double h = h_est > 0.0 ? h_est : edge_for(per_cell_env > 0 ? per_cell_env : m_target / 4.18879020478639);
+      double h = h_est > 0.0 ? h_est : edge_for(per_cell_env > 0 ? per_cell_env : m_target / kBallVolume);
       for (int round = 0; round < 3; ++round) {
         GridParams trial{};
         // (clustered clouds and surfaces leave cells empty: 4 bytes each, up to 20 per point are accepted here)
         uint64_t trial_cells = grid_for(h, rx, trial);
-        const char* budget_env = std::getenv("PST_KNN_CELL_BUDGET");  // cells per point the dense directory may take (default 20: 80 bytes per point; 12 left the 10^8-point sheet at rx = 1: 84 against 71 ms)
-        const uint64_t budget_mult = budget_env && std::atol(budget_env) > 0 ? (uint64_t)std::atol(budget_env) : 20;
-        const uint64_t cell_budget = std::max<uint64_t>(budget_mult * n, 1u << 20);
-        while (rx > 1 && !(trial_cells <= cell_budget && trial_cells < 0xFFFFFFF0ull)) { rx >>= 1; trial_cells = grid_for(h, rx, trial); }  // coarser x cells before giving up
-        if (!(trial_cells <= cell_budget && trial_cells < 0xFFFFFFF0ull)) break;
+        // (default 20 cells per point: 80 bytes per point; 12 left the 10^8-point sheet at rx = 1: 84 against 71 ms)
+        const uint64_t cell_budget = directory_budget(n, tune);
+        while (rx > 1 && !directory_fits(trial_cells, cell_budget)) { rx >>= 1; trial_cells = grid_for(h, rx, trial); }  // coarser x cells before giving up
+        if (!directory_fits(trial_cells, cell_budget)) break;
         if (!build_index(h, rx, true)) return -1;
         mark("index");
         if (!nf) break;
@@ -1127,10 +1119,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         if (!knn_probe(sorted_xyz.as<double>(), directory.as<uint32_t>(), g, (uint32_t)nf, scratch3, stream, m_half, m_full)) return -1;
         // N(r) ~ r^D through (h/2, m_half) and (h, m_full); the radius that holds M points
         mark("probe");
-        const double D = std::fmin(3.0, std::fmax(1.0, std::log2(std::fmax(m_full, 1.0) / std::fmax(m_half, 1.0))));
-        const double h_new = g.h * std::pow(m_target / std::fmax(m_full, 1.0), 1.0 / D);
+        const ProbeFit pf = probe_fit(g.h, m_half, m_full, m_target);
+        const double D = pf.dim, h_new = pf.h_new;
         if (debug) fprintf(stderr, "[pst knn probe] h=%g: %.1f points within h/2, %.1f within h (target %.1f), dimension %.2f -> h=%g\n", g.h, m_half, m_full, m_target, D, h_new);
-        if (round == 2 || std::fabs(h_new / g.h - 1.0) <= 0.10 || per_cell_env > 0 || std::getenv("PST_KNN_CELL")) {
+        if (probe_accepts(round, g.h, h_new, tune)) {
           tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape);
           mark("census");
           break;
@@ -1145,18 +1137,13 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       // radius h_est holds M points and N(r) ~ r^D; a cubic cell of edge h holds about what a ball of radius c_D h does (c = 0.62 in 3-D,
       // 0.56 in 2-D, 0.5 in 1-D).  A cloud of dimension D occupies 3^D of the 27 cells of the first shell, so the cell's share is scaled by
       // 3^(3-D): the first shell then holds the same number of candidates whatever the dimension.
-      double h_dense = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(0.5, (double)k / 12.0));
-      double h_hash = edge_for(per_cell_env > 0 ? per_cell_env : std::fmax(1.0, (double)k / 3.0));
-      if (h_est > 0.0 && per_cell_env <= 0 && !std::getenv("PST_KNN_CELL")) {
-        const double c_d = 0.44 + 0.06 * d_est, shells = std::pow(3.0, 3.0 - d_est), m_ball = m_target;
-        const double hd = h_est / c_d * std::pow(std::fmax(0.5, (double)k / 12.0) * shells / m_ball, 1.0 / d_est);
-        const double hh = h_est / c_d * std::pow(std::fmax(1.0, (double)k / 3.0) * shells / m_ball, 1.0 / d_est);
-        if (debug) fprintf(stderr, "[pst knn] measured scale: cell edge %g (dense) / %g (hash) instead of %g / %g from the bounding box\n", hd, hh, h_dense, h_hash);
-        h_dense = hd; h_hash = hh;
-      }
+      const FallbackEdges fe = fallback_edges(bs, n, k, h_est, d_est, m_target, tune);
+      const double h_dense = fe.dense, h_hash = fe.hash;
+      if (debug && h_est > 0.0 && !tune.forced_scale())
+        fprintf(stderr, "[pst knn] measured scale: cell edge %g (dense) / %g (hash) instead of the bounding box's\n", h_dense, h_hash);
       GridParams trial{};
       dense = is_dense(grid_for(h_dense, 1, trial));
-      if (const char* e = std::getenv("PST_KNN_DENSE")) dense = dense && *e != '0';
+      if (tune.dense == 0) dense = false;
       if (!build_index(dense ? h_dense : h_hash, 1, dense)) return -1;
     }
     CacheBuf unres;  // one byte per point, by ORIGINAL index: the query was handed back by a capped search
@@ -1164,7 +1151,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     NCK(hipMemsetAsync(unres.p, 0, n, stream));
     uint32_t* unres_count = (uint32_t*)((uint8_t*)counters.p + 64);
     // results: straight into the caller's outputs (default), or as 32-byte records + split_results_kernel (PST_KNN_DIRECT=0: the A/B switch)
-    static const bool direct_out = !(std::getenv("PST_KNN_DIRECT") && std::atoi(std::getenv("PST_KNN_DIRECT")) == 0);
+    const bool direct_out = tune.direct_out;
     if (!direct_out) NCK(rec.alloc(n * 32, stream));
     RecOut sorted{direct_out ? nullptr : rec.as<double>(), idx2.as<uint32_t>(), out.knn, out.knn_u32, out.error_count,
                   out.normals_f64, out.curvature_f64, out.normal_attr, out.normal_stride, out.curv_attr, out.curv_stride};
@@ -1180,8 +1167,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           CacheBuf box_list;
           uint32_t n_list = 0;
           const uint32_t* list_ptr = nullptr;
-          static const bool list_on = !(std::getenv("PST_KNN_BOX_LIST") && std::atoi(std::getenv("PST_KNN_BOX_LIST")) == 0);
-          if (!fills && list_on) {
+          if (!fills && tune.box_list) {
             NCK(box_list.alloc((size_t)knn_box_count(shape, g) * 4, stream));
             n_list = knn_box_list(shape, cell_start, g, box_list.as<uint32_t>(), unres_count + 3, stream);
             if (n_list == 0xFFFFFFFFu) return -1;
@@ -1258,7 +1244,6 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         return true;
 #undef ACK
       };
-      constexpr uint32_t kCrowd = 4096;
       for (int level = 1; nf; ++level) {
         uint32_t n_open[2] = {0, 0};  // handed back by the shell cap / by the crowd guard
         NCK(hipMemcpyAsync(n_open, unres_count, 8, hipMemcpyDeviceToHost, stream));
@@ -1279,8 +1264,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const bool up_dense = is_dense(up_cells);
         // all points or another level?  The all-points search does ~2e12 pairs per second; an index costs ~2 ns per point with a dense
         // directory and ~4.5 ns with the hash table (64-bit Morton keys, eight radix passes, the table), and may leave queries open.
-        const double cost_all = (double)n_un * (double)nf / 2e12, cost_level = (double)nf * (up_dense ? 2e-9 : 4.5e-9);
-        if (level > 8 || cost_all <= 2.0 * cost_level) {
+        if (search_all_points(level, n_un, nf, up_dense)) {
           if (!all_points(1, n_un)) return -1;
           break;
         }

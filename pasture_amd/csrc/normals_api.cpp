@@ -1,5 +1,6 @@
 // compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130) — argument checks + host/device plumbing; the
 // neighbour search and the plane fit run in normals.hip.
+#include "normals_plan.hpp"
 #include "runtime.hpp"
 
 using namespace pst;
@@ -111,6 +112,12 @@ int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals,
 int pst_release_scratch(void) {
   PST_API_BEGIN
   pstk::release_normals_scratch();
+  PST_API_END
+}
+
+int pst_reload_tuning(void) {
+  PST_API_BEGIN
+  pstk::knn_reload_tuning();
   PST_API_END
 }
 

@@ -36,6 +36,7 @@
 #include "kernels.hpp"
 #include "normals_device.hpp"
 #include "normals_host.hpp"
+#include "normals_plan.hpp"
 
 using namespace pstn;
 
@@ -1070,15 +1071,13 @@ struct TileVariant { int version; uint32_t threads, cap; bool p3lds; int batch; 
 // CU); otherwise (surfaces, strips: most of a box's cells are empty and the 31-cell / 64-row limits of a box bind before its capacity)
 // 256 threads and 1536 points, four workgroups per CU.  Same-box A/B at 10^8 points: uniform cloud 35.4 (D) / 37.0 (G) / 36.8 (B) ms per
 // call, LiDAR-like sheet 96 (D) / 80.7 (G) / 86.4 (B); the first form: 41.5 / 88.9.
-const TileVariant& tile_variant(bool volume_like) {
+const TileVariant& tile_variant(uint32_t k, bool volume_like) {
   static const TileVariant v1{1, 256, 1536, true, 4, '1'}, vB{2, 256, 2044, false, 4, 'B'}, vD{2, 512, 3000, false, 4, 'D'}, vG{2, 256, 1536, false, 4, 'G'};
-  static const char forced = [] { const char* e = std::getenv("PST_KNN_VAR"); return e && *e ? *e : '\0'; }();
-  switch (forced) {
-    case '1': return v1;
+  switch (box_kernel_for(k, volume_like, knn_tuning())) {
     case 'B': return vB;
     case 'D': return vD;
     case 'G': return vG;
-    default: return volume_like ? vD : vG;
+    default: return v1;
   }
 }
 
@@ -1129,20 +1128,17 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
 bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
                     unsigned long long* scratch3, hipStream_t stream, TileShape& t) {
   if (k > 64 || cells == 0 || nf == 0) return false;
-  const TileVariant& var = tile_variant(volume_like);
-  const bool v2 = var.version == 2 && k <= 16;  // (the second form is instantiated for k <= 16; larger k: the first form)
-  t.threads = v2 ? var.threads : 256;
-  t.cap = v2 ? var.cap : 1536;
-  t.tag = v2 ? var.tag : '1';
-  if (const char* e = std::getenv("PST_KNN_TILE")) {  // "bx,by,bz"
-    unsigned x = 0, y = 0, z = 0;
-    if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z && tile_fits(g, x, y, z)) { t.bx = x; t.by = y; t.bz = z; return true; }
-  }
+  const TileVariant& var = tile_variant(k, volume_like);  // (the second form is instantiated for k <= 16; larger k: the first form)
+  const KnnTuning& tune = knn_tuning();
+  t.threads = var.threads;
+  t.cap = var.cap;
+  t.tag = var.tag;
+  if (tune.tile[0] && tile_fits(g, tune.tile[0], tune.tile[1], tune.tile[2])) { t.bx = tune.tile[0]; t.by = tune.tile[1]; t.bz = tune.tile[2]; return true; }  // PST_KNN_TILE
   const double rho = (double)nf / (double)cells;  // points per fine cell, averaged over the whole grid: the first guess
   double budget = 0.90 * (double)t.cap / rho;
   TileShape last{};
   double shrink = 1.0;
-  static const bool debug = std::getenv("PST_KNN_DEBUG") != nullptr;
+  const bool debug = tune.debug;
   // census of one shape: h[0] queries, h[1] staged points, h[2] queries lost to boxes over capacity, h[3] non-empty boxes
   auto census = [&](const TileShape& c, unsigned long long (&h)[4]) -> int {
     const uint32_t nbx = (g.dim[0] + c.bx - 1) / c.bx, nby = (g.dim[1] + c.by - 1) / c.by, nbz = (g.dim[2] + c.bz - 1) / c.bz;
@@ -1174,19 +1170,13 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
       // no other workgroup can take the idle ones while the box holds its LDS.  If the typical box (mean + two standard deviations of
       // a Poisson count) needs r rounds and fills less than 85 % of them, the box is shortened along x to what r - 1 rounds hold --
       // unless that costs more than a quarter of its length (more halo per query, more workgroups).
-      static const bool rounds_on = !(std::getenv("PST_KNN_ROUNDS") && std::atoi(std::getenv("PST_KNN_ROUNDS")) == 0);
-      if (rounds_on && h[3]) {
-        const double qbar = (double)h[0] / (double)h[3], nt = (double)t.threads;
-        const double rounds = std::ceil((qbar + 2.0 * std::sqrt(qbar)) / nt);
-        if (rounds >= 2.0 && qbar / (rounds * nt) < 0.85) {
-          const double target = (rounds - 1.0) * nt - 2.0 * std::sqrt((rounds - 1.0) * nt);
-          const uint32_t bx2 = (uint32_t)std::floor((double)t.bx * target / qbar);
-          if (bx2 >= 1 && 4 * bx2 >= 3 * t.bx && bx2 < t.bx) {
-            TileShape c2 = t;
-            c2.bx = bx2;
-            unsigned long long h2[4] = {};
-            if (tile_fits(g, c2.bx, c2.by, c2.bz) && census(c2, h2) == 0 && h2[0] && (double)h2[2] <= 0.02 * (double)h2[0]) t.bx = bx2;
-          }
+      if (tune.rounds && h[3]) {
+        const uint32_t bx2 = box_length_for_whole_rounds(t.bx, (double)h[0] / (double)h[3], t.threads);  // (normals_plan.hpp: ROUNDS)
+        if (bx2 != t.bx) {
+          TileShape c2 = t;
+          c2.bx = bx2;
+          unsigned long long h2[4] = {};
+          if (tile_fits(g, c2.bx, c2.by, c2.bz) && census(c2, h2) == 0 && h2[0] && (double)h2[2] <= 0.02 * (double)h2[0]) t.bx = bx2;
         }
       }
       return true;
@@ -1222,9 +1212,8 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   a.n_boxes = box_list ? n_list : a.nbx * a.nby * nbz;
   a.box_list = box_list;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
-  if (const char* e = std::getenv("PST_KNN_ABLATE")) a.ablate = (uint32_t)std::atoi(e);
-  a.flush_at = 48;
-  if (const char* e = std::getenv("PST_KNN_FLUSH_AT")) a.flush_at = (uint32_t)std::atoi(e);
+  a.ablate = knn_tuning().ablate;
+  a.flush_at = knn_tuning().flush_at;
   // A-priori bound on the squared k-th distance: the grid's cell edge h was chosen as the radius of the sphere expected to hold about
   // 1.75 k points (normals.hip), and candidates beyond tau0 = h^2 (less a few ulps for the packed keys) are not even queued.  Without
   // it every candidate passes the "closer than the current k-th" test until a lane's list is full, and about k (1 + ln(N / k)) of N

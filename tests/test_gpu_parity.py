@@ -860,16 +860,22 @@ def test_box_search_forced_on_sparse_clouds_vs_oracle(hip, oracle, monkeypatch, 
     from pasture_amd.algorithms import compute_normals
     pts = _degenerate_cloud(shape) if shape == "two_planes" else _normals_inputs(n, 5, shape)
     n, k = len(pts), 16
+    from pasture_amd.algorithms import reload_tuning
     monkeypatch.setenv("PST_KNN_FORCE_TILE", "1")
     if budget:
         monkeypatch.setenv("PST_KNN_CELL_BUDGET", budget)
+    reload_tuning(hip)  # the switches are read once per process
 
     def run(api):
         buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
         buf.resize(n)
         buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
         return compute_normals(buf, k, return_knn=True)
-    (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    try:
+        (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    finally:
+        monkeypatch.undo()
+        reload_tuning(hip)
     assert np.array_equal(hk, ok)
     bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
     assert bad.sum() == 0 and cbad.sum() == 0
