@@ -105,7 +105,7 @@ def reload_tuning(api=None) -> None:
 
 def release_scratch(api=None) -> None:
     """Frees the device scratch the calling thread's compute_normals* calls keep between calls (about 55 bytes per point of the largest
-    recent cloud, never more than PST_SCRATCH_MAX_BYTES = 8 GiB by default).  Never needed for correctness."""
+    recent cloud, never more than PST_SCRATCH_MAX_BYTES = 16 GiB by default).  Never needed for correctness."""
     from ._capi import product_api
     (api or product_api()).release_scratch()
 

@@ -259,20 +259,56 @@ __global__ __launch_bounds__(kBlock) void dir_block_heads_kernel(const uint32_t*
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j <= nf; j += step) {
     const uint64_t k = j < nf ? keys[j] : cells;  // (the end sentinel: cell_start[cells] = nf)
-    if (j == 0 || keys[j - 1] != k) atomicMin(&block_first[k / kDirBlock], (uint32_t)j);
+    // the FIRST point of a block: exactly one writer per block word, no atomics
+    if (j == 0 || keys[j - 1] / kDirBlock != k / kDirBlock) block_first[k / kDirBlock] = (uint32_t)j;
   }
 }
 __global__ __launch_bounds__(kBlock) void dir_fill_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells, const uint32_t* __restrict__ block_first,
                                                           uint64_t n_blocks, uint32_t* __restrict__ cell_start) {
-  const uint64_t b = blockIdx.x;
+  static_assert(kDirBlock == 4 * kBlock, "four cells per thread");
+  __shared__ uint32_t cs[kDirBlock];
+  __shared__ uint32_t wmin[kBlock / 64];
+  const uint64_t b = blockIdx.x, c0 = b * kDirBlock;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t j0 = block_first[b], j1 = b + 1 < n_blocks ? block_first[b + 1] : (uint32_t)nf;
+  uint32_t v[4];
+  if (j0 == j1) {  // no point in this block: every cell starts at the next block's first point
+    v[0] = v[1] = v[2] = v[3] = j0;
+  } else {
+    // the block's run heads land on their cells in LDS; a suffix minimum carries each head back over the empty cells in front of it
+    for (uint32_t t = tid; t < kDirBlock; t += kBlock) cs[t] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t j = j0 + tid; j < j1; j += kBlock) {
+      const uint32_t k = keys[j];
+      if (j == j0 || keys[j - 1] != k) cs[k - (uint32_t)c0] = j;
+    }
+    __syncthreads();
+    uint32_t run = 0xFFFFFFFFu;
 #pragma unroll
-  for (uint32_t u = 0; u < kDirBlock / kBlock; ++u) {
-    const uint64_t c = b * kDirBlock + u * kBlock + threadIdx.x;
-    if (c > cells) break;
-    uint32_t lo = j0, hi = j1;  // first j in [j0, j1] with key[j] >= c (j1 when there is none)
-    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < c) lo = mid + 1; else hi = mid; }
-    cell_start[c] = lo;
+    for (int u = 3; u >= 0; --u) { run = min(run, cs[4 * tid + (uint32_t)u]); v[u] = run; }
+    uint32_t suf = run;  // minimum over this thread's cells and those of the higher lanes of its wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_down((int)suf, off, 64);
+      if (lane + (uint32_t)off < 64u) suf = min(suf, o);
+    }
+    if (lane == 0) wmin[wave] = suf;
+    __syncthreads();
+    uint32_t right = j1;  // everything to the right of this thread's cells: higher lanes, higher waves, then the next block
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) if (w > wave) right = min(right, wmin[w]);
+    const uint32_t hi = (uint32_t)__shfl_down((int)suf, 1, 64);
+    if (lane < 63u) right = min(right, hi);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = min(v[u], right);
+  }
+  const uint64_t c = c0 + 4ull * tid;
+  if (c + 3 <= cells) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<u4*>(cell_start + c) = u4{v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (c + (uint64_t)u <= cells) cell_start[c + u] = v[u];
   }
 }
 
@@ -699,7 +735,7 @@ struct ScratchCache {
         else ++i;
       }
     }
-    // CAP: a thread never keeps more than PST_SCRATCH_MAX_BYTES (default 8 GiB: the scratch of a 1.5 * 10^8-point call) between calls.
+    // CAP: a thread never keeps more than PST_SCRATCH_MAX_BYTES (default 16 GiB: a 10^8-point surface with its 7.5 GB directory keeps 13.6) between calls.
     // Beyond it the largest blocks go back to the driver first -- a larger cloud then pays the allocations on every call.
     const size_t cap = (size_t)knn_tuning().scratch_max;
     while (held > cap && !blocks.empty()) {
@@ -740,7 +776,7 @@ struct CallGuard {
 };
 }  // namespace
 
-// Frees the device blocks the calling thread's kNN calls keep between calls (about 55 bytes per point of the largest recent cloud, capped at PST_SCRATCH_MAX_BYTES, default 8 GiB).
+// Frees the device blocks the calling thread's kNN calls keep between calls (about 55 bytes per point of the largest recent cloud, capped at PST_SCRATCH_MAX_BYTES, default 16 GiB).
 void release_normals_scratch() { scratch_cache().release_all(); }  // (the current device's cache)
 
 // Returns 0 on success, -1 on a HIP failure (hipGetLastError has it), -2 for inputs beyond the 32-bit point indices of the spatial index,

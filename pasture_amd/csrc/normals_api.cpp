@@ -107,7 +107,7 @@ int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals,
   PST_API_END
 }
 
-// The kNN search keeps its device scratch (sorted copy of the positions, keys, directory, directory: ~55 bytes per point, at most PST_SCRATCH_MAX_BYTES = 8 GiB by default) in a
+// The kNN search keeps its device scratch (sorted copy of the positions, keys, directory, directory: ~55 bytes per point, at most PST_SCRATCH_MAX_BYTES = 16 GiB by default) in a
 // per-thread cache between calls -- allocating it per call stalled every few calls for seconds at 10^8 points.  This hands it back.
 int pst_release_scratch(void) {
   PST_API_BEGIN

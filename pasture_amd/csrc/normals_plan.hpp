@@ -29,7 +29,7 @@ struct KnnTuning {
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
   unsigned ablate = 0;         // PST_KNN_ABLATE (tuning only)
   unsigned flush_at = 48;      // PST_KNN_FLUSH_AT
-  long long scratch_max = (long long)8 << 30;  // PST_SCRATCH_MAX_BYTES
+  long long scratch_max = (long long)16 << 30;  // PST_SCRATCH_MAX_BYTES (default 16 GiB: a 10^8-point surface keeps 13.6 GB, 7.5 of them its directory)
 
   static KnnTuning from_env() {
     KnnTuning t;

@@ -30,7 +30,7 @@ struct Cloud {
 int main() {
   // no PST_KNN_* variable set: the defaults
   const KnnTuning t = KnnTuning{};
-  CHECK(t.cell_budget == 20 && t.flush_at == 48 && t.direct_out && t.box_list && t.rounds && !t.forced_scale() && t.scratch_max == ((long long)8 << 30));
+  CHECK(t.cell_budget == 20 && t.flush_at == 48 && t.direct_out && t.box_list && t.rounds && !t.forced_scale() && t.scratch_max == ((long long)16 << 30));
 
   const Cloud clouds[] = {
       // 10^8 uniform points in 1000 x 1000 x 100 (bench normals_knn16): full box, gate agrees with the volume

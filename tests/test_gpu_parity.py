@@ -469,7 +469,7 @@ def test_compute_normals_into_device_columns(hip, oracle):
 
 def test_release_scratch_returns_the_knn_cache(hip):
     """pst_release_scratch: the kNN search keeps ~55 bytes of device scratch per point between calls (per thread and device; never more than
-    PST_SCRATCH_MAX_BYTES, default 8 GiB); releasing it gives the memory back and the next call simply allocates again."""
+    PST_SCRATCH_MAX_BYTES, default 16 GiB); releasing it gives the memory back and the next call simply allocates again."""
     import torch
     from pasture_amd.algorithms import compute_normals_device, release_scratch
     n = 4_000_000

@@ -37,7 +37,7 @@ def test_knn_tuning_is_read_from_the_environment_once(tmp_path):
     exe = str(tmp_path / "t")
     subprocess.check_call([gxx, "-std=c++17", "-I", os.path.join(ROOT, "pasture_amd", "csrc"), str(src), "-o", exe])
     env = {k: v for k, v in os.environ.items() if not k.startswith("PST_")}
-    assert subprocess.run([exe], capture_output=True, text=True, env=env).stdout.split() == ["0", "0", "0", "0", "20", "0000000", "-1", "111", "0", "0,0,0", "48", str(8 << 30)]
+    assert subprocess.run([exe], capture_output=True, text=True, env=env).stdout.split() == ["0", "0", "0", "0", "20", "0000000", "-1", "111", "0", "0,0,0", "48", str(16 << 30)]
     env.update({"PST_KNN_CELL": "2.5", "PST_KNN_PER_CELL": "3", "PST_KNN_TAU_M": "30", "PST_KNN_RX": "2", "PST_KNN_CELL_BUDGET": "7", "PST_KNN_DEBUG": "1",
                 "PST_KNN_NO_TRIM": "1", "PST_KNN_FORCE_TILE": "1", "PST_KNN_DENSE": "0", "PST_KNN_DIRECT": "0", "PST_KNN_ROUNDS": "0", "PST_KNN_VAR": "G",
                 "PST_KNN_TILE": "12,4,3", "PST_KNN_FLUSH_AT": "32", "PST_SCRATCH_MAX_BYTES": "1024"})

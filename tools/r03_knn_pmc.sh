@@ -12,8 +12,10 @@ for v in ${VARS:-1 B D}; do
 import sqlite3, glob
 db = glob.glob("$d/*_results.db")
 cur = sqlite3.connect(db[0]).cursor()
+import re
 for r in list(cur.execute("select name, total_calls, average, percentage from top_kernels"))[:${TOPN:-8}]:
-    print(f"  {r[0].split('(')[0][-70:]:70s} calls {r[1]:3d} avg_us {r[2]:10.1f} pct {r[3]:5.1f}")
+    nm = re.sub(r"\(anonymous namespace\)::|pstk::|pstn::|void |rocprim::ROCPRIM_\d+_NS::detail::", "", r[0])
+    print(f"  {nm[:60]:60s} calls {r[1]:3d} avg_us {r[2]:10.1f} pct {r[3]:5.1f}")
 PY
   if [ -z "$NO_PMC" ]; then
   for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F64"; do
