@@ -1,4 +1,13 @@
 cd /root/repo
-python -m pytest tests -x -q -m gpu -k "normals or knn or sparse" 2>&1 | tail -3
-for w in normals_knn16_sheet normals_knn16; do python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', d['ms_per_step'])"; done
-python tools/fuzz_knn_sparse.py 40 11 2>&1 | tail -2
+export TMPDIR=/tmp
+d=/tmp/kt_vox; rm -rf $d; mkdir -p $d
+timeout 600 rocprofv3 --kernel-trace --stats -d $d -o p -- python bench.py --no-cpu-baseline --workload voxelgrid_xyz --steps 5 --warmup 1 > $d/log.txt 2>&1
+python - <<PY
+import sqlite3, glob, re
+db = glob.glob("$d/*_results.db")
+cur = sqlite3.connect(db[0]).cursor()
+for r in list(cur.execute("select name, total_calls, average, percentage from top_kernels"))[:18]:
+    nm = re.sub(r"\(anonymous namespace\)::|pstk::|pstn::|void |rocprim::ROCPRIM_\d+_NS::detail::", "", r[0])
+    print(f"  {nm[:70]:70s} calls {r[1]:3d} avg_us {r[2]/1000:10.1f} pct {r[3]:5.1f}")
+PY
+tail -1 $d/log.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('voxel ms/step', d['ms_per_step'], d['roofline']['kernel_ms_min'])"

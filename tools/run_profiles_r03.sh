@@ -25,11 +25,11 @@ w, kern, pmc_db, kt_db, path = sys.argv[1:6]
 cur = sqlite3.connect(pmc_db).cursor()
 rows = list(cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by kernel_name, counter_name", (f"%{kern}%",)))
 kt = sqlite3.connect(kt_db).cursor()
-ms = {r[0]: r[1] / 1e6 for r in kt.execute("select name, average from top_kernels where name like ?", (f"%{kern}%",))}
+ms = {r[0]: r[1] / 1e3 for r in kt.execute("select name, average from top_kernels where name like ?", (f"%{kern}%",))}  # (average is in microseconds)
 allv = json.load(open(path)) if os.path.exists(path) else {}
 for name, counter, val, cnt in rows:
     if counter == "SQ_INSTS_VALU":
-        allv[w] = {"kernel": name.split("(")[0], "valu_wave_instructions_per_launch": round(val), "launches": cnt, "points": 100000000,
+        allv[w] = {"kernel": name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], "valu_wave_instructions_per_launch": round(val), "launches": cnt, "points": 100000000,
                    "kernel_ms": round(ms.get(name, 0.0), 4) or None, "round": "r03"}
         for n2, c2, v2, _ in rows:
             if n2 == name and c2 != "SQ_INSTS_VALU": allv[w][c2.lower()] = round(v2)
@@ -39,13 +39,13 @@ PY
   fi
   rm -rf gpurun_out/prof/$1
 done
+cp $out/knn_valu.json profiles/knn_valu.json 2>/dev/null
+cp $out/hbm_traffic.json profiles/hbm_traffic.json 2>/dev/null
 if [ -z "${NO_LINES:-}" ]; then
 rm -f gpurun_out/r03/r03_workloads.jsonl
 for w in convert_affine_bounds bounds las0_to_columns las0_to_columns_bounds rawlas_to_columns rawlas_to_columns_bounds rawlas_to_records columns_to_las0 columns_to_custom41 las1_records_to_custom27 benchlayout_records_to_columns benchlayout_columns_to_records benchlayout_records_to_records las0_encode filter_big_columnar filter_big_interleaved voxelgrid_xyz narrow_f64_f32 normals_knn16 normals_knn16_sheet; do
   python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/r03/r03_workloads.jsonl
 done
-cp $out/knn_valu.json profiles/knn_valu.json 2>/dev/null
-cp $out/hbm_traffic.json profiles/hbm_traffic.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/r03/r03_bench_line.json
 wc -l gpurun_out/r03/r03_workloads.jsonl
 fi
