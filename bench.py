@@ -291,13 +291,30 @@ def main():
     def make_rec():
         return torch.empty(6, dtype=torch.float64, device="cuda")
 
-    transport = None
+    transport, collective_note = None, None
     if distributed and args.collective == "capi":
-        # the product's own collective: pst_comm_init_rank over the launcher's rendezvous, pst_bounds_allreduce per step
-        transport = CapiTransport(None, api)
-        if transport.size() != world:
-            sys.stderr.write(f"bench.py: pst_comm_size = {transport.size()}, expected {world}\n")
-            sys.exit(2)
+        # the product's own collective: pst_comm_init_rank over the launcher's rendezvous, pst_bounds_allreduce per step.  If ANY rank cannot
+        # set it up (RCCL not loadable through dlopen, say) every rank falls back to torch.distributed together -- and the line says so.
+        err = None
+        try:
+            transport = CapiTransport(None, api)
+            if transport.size() != world:
+                err = f"pst_comm_size = {transport.size()}, expected {world}"
+        except Exception as e:  # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        bad = torch.tensor([1 if err else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(bad)
+        if int(bad.item()):
+            if transport is not None:
+                try:
+                    transport.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            transport = None
+            collective_note = f"--collective capi could not be set up on {int(bad.item())} of {world} ranks ({err or 'another rank failed'}): torch.distributed.all_reduce instead"
+            if rank == 0:
+                sys.stderr.write("bench.py: " + collective_note + "\n")
+    if transport is not None:
         ring = BoundsExchange(make_rec, transport, depth=4)
     else:
         ring = PipelinedBoundsReduce(make_rec, depth=4)
@@ -544,7 +561,9 @@ def main():
     # ONE 10^9-point cloud sharded by index range over the N ranks (strong scaling), the same fused step, the same exchange per step,
     # timed like the main region (barrier + synchronize on both sides, max over ranks); never folded into `value`
     configs3 = None
-    if (distributed and world > 1 and args.workload == "convert_affine_bounds" and not args.global_points and not args.no_configs3):
+    # (a single rank started under torchrun with PASTURE_FORCE_DIST=1 runs this leg too: the way the N > 1 code path is exercised on a 1-GPU box)
+    if (distributed and (world > 1 or os.environ.get("PASTURE_FORCE_DIST") == "1") and args.workload == "convert_affine_bounds"
+            and not args.global_points and not args.no_configs3):
         from pasture_amd.distributed import shard_range
         g3 = args.configs3_points
         sh = shard_range(g3, rank, world)
@@ -682,6 +701,8 @@ def main():
                             "frac_of_step = the same against the whole call (index build, sort, fallback searches included)"}
         if distributed:
             line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
+            if collective_note:
+                line["config"]["collective_note"] = collective_note
         if configs3 is not None:
             line["configs3_1e9"] = configs3
         if north_star is not None:

@@ -383,3 +383,29 @@ def test_capi_bounds_allreduce_two_ranks_rccl():
     u = AABB.union(AABB(tuple(a[:3]), tuple(a[3:])), AABB(tuple(b[:3]), tuple(b[3:])))
     for r in (0, 1):
         assert got[r][0] == 2 and got[r][2] == list(u.min()) + list(u.max())
+
+
+@pytest.mark.gpu
+def test_bench_n_gt_1_code_path_with_one_forced_rank():
+    """The N > 1 path of bench.py on a 1-GPU box: one rank under torch.distributed.run with PASTURE_FORCE_DIST=1 runs what the driver's
+    `--gpus N` run runs -- pst_comm_init_rank bootstrapped from the rendezvous, pst_bounds_allreduce per step on the exchange stream, the
+    configs[3] leg -- and must report the bounds a plain run reports."""
+    import json
+    import subprocess
+    common = ["--steps", "5", "--warmup", "4", "--no-cpu-baseline", "--no-north-star", "--points", "10000000"]
+    plain = _run_bench(*common)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    want = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"PASTURE_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--configs3-points", "30000001", *common]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["config"]["collective"].startswith("pst_bounds_allreduce") and "collective_note" not in got["config"]
+    assert got["config"]["bounds"] == want["config"]["bounds"] and got["n_gpus"] == 1
+    c3 = got["configs3_1e9"]
+    assert c3["global_points"] == 30000001 and c3["points_rank0"] == 30000001 and c3["scaling"] == "strong" and c3["value"] > 0
+    # the exchange must not dominate the step (a cold record buffer once cost 40 ms inside the timed region)
+    assert got["ms_per_step"] < 3.0 * want["ms_per_step"] + 0.2

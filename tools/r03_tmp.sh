@@ -1,13 +1,7 @@
 cd /root/repo
-export TMPDIR=/tmp
-d=/tmp/kt_vox; rm -rf $d; mkdir -p $d
-timeout 600 rocprofv3 --kernel-trace --stats -d $d -o p -- python bench.py --no-cpu-baseline --workload voxelgrid_xyz --steps 5 --warmup 1 > $d/log.txt 2>&1
-python - <<PY
-import sqlite3, glob, re
-db = glob.glob("$d/*_results.db")
-cur = sqlite3.connect(db[0]).cursor()
-for r in list(cur.execute("select name, total_calls, average, percentage from top_kernels"))[:18]:
-    nm = re.sub(r"\(anonymous namespace\)::|pstk::|pstn::|void |rocprim::ROCPRIM_\d+_NS::detail::", "", r[0])
-    print(f"  {nm[:70]:70s} calls {r[1]:3d} avg_us {r[2]/1000:10.1f} pct {r[3]:5.1f}")
-PY
-tail -1 $d/log.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('voxel ms/step', d['ms_per_step'], d['roofline']['kernel_ms_min'])"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for st in 20 200; do
+PASTURE_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps $st --warmup 3 --no-cpu-baseline --no-north-star --no-configs3 --collective capi 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('capi steps $st', d['ms_per_step'], d['roofline']['frac'])"
+done
