@@ -1,7 +1,5 @@
 cd /root/repo
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-for st in 20 200; do
-PASTURE_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps $st --warmup 3 --no-cpu-baseline --no-north-star --no-configs3 --collective capi 2>&1 | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print('capi steps $st', d['ms_per_step'], d['roofline']['frac'])"
-done
+timeout 900 python -m pytest tests -x -q -m gpu -k "filter or compaction or append" 2>&1 | tail -4
+for rep in 1 2 3; do for lb in 0 1; do for w in filter_big_columnar filter_big_interleaved; do
+  PST_FILTER_LOOKBACK=$lb timeout 300 python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w lookback=$lb', d['roofline']['frac'], d['roofline']['kernel_ms_avg'], d['roofline']['kernel_ms_min'])"
+done; done; done
