@@ -7,6 +7,9 @@
 
 namespace pstk {
 
+// A run-time plan takes a compile-time plan's kernel only if it equals it FIELD BY FIELD.  Not compared, on purpose: the tile (the static
+// plan brings its own: plan_equals<P<.., T>> is the same predicate for every T), and scale / offset / mask / shift / xf_on_source -- they are
+// read by the kernels only for entries with a transformation, and an entry with xf_kind != 0 never matches (below).
 template <typename SP>
 static bool plan_equals(const ConvertPlan& p) {
   const ConvertHeader& h = p.h;
