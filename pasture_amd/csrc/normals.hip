@@ -174,17 +174,27 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
   if (local) atomicAdd(n_finite, local);  // the compiler folds this to one atomic per wave
 }
 
+template <int UNROLL>
 __global__ __launch_bounds__(kBlock) void reorder_kernel(const double* __restrict__ xyz, const uint32_t* __restrict__ idx, uint64_t n,
                                                          double* __restrict__ sorted_xyz) {
-  // one random 24-byte read per point (8-byte aligned): a 16-byte + an 8-byte load, the store side is lane-contiguous
+  // one random 24-byte read per point (8-byte aligned): a 16-byte + an 8-byte load, the store side is lane-contiguous.  UNROLL points per
+  // thread and step: their indices are read first, then all their gathers are in flight together (the kernel runs at the memory system's
+  // random-request rate; PST_REORDER_UNROLL is the A/B switch)
   typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-  const uint64_t step = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += step) {
-    const uint64_t i = idx[j];
-    const d2u xy = *reinterpret_cast<const d2u*>(xyz + 3 * i);
-    const double z = xyz[3 * i + 2];
-    *reinterpret_cast<d2u*>(sorted_xyz + 3 * j) = xy;
-    sorted_xyz[3 * j + 2] = z;
+  const uint64_t step = (uint64_t)gridDim.x * kBlock * UNROLL;
+  for (uint64_t j0 = (uint64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; j0 < n; j0 += step) {
+    uint64_t i[UNROLL];
+    d2u xy[UNROLL];
+    double z[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { const uint64_t j = j0 + (uint64_t)u * kBlock; i[u] = j < n ? idx[j] : 0; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { xy[u] = *reinterpret_cast<const d2u*>(xyz + 3 * i[u]); z[u] = xyz[3 * i[u] + 2]; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t j = j0 + (uint64_t)u * kBlock;
+      if (j < n) { *reinterpret_cast<d2u*>(sorted_xyz + 3 * j) = xy[u]; sorted_xyz[3 * j + 2] = z[u]; }
+    }
   }
 }
 
@@ -906,7 +916,12 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         BCK(tmp.alloc(tmp_bytes, stream));
         BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
       }
-      hipLaunchKernelGGL(reorder_kernel, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+      {
+        static const int unroll = [] { const char* e = std::getenv("PST_REORDER_UNROLL"); return e && *e ? std::atoi(e) : 2; }();  // (same box, whole kNN call at 10^8 points: 32.6 / 32.3 / 32.4 ms for 1 / 2 / 4)
+        if (unroll >= 4) hipLaunchKernelGGL(reorder_kernel<4>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else if (unroll == 2) hipLaunchKernelGGL(reorder_kernel<2>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else hipLaunchKernelGGL(reorder_kernel<1>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+      }
       unsigned long long h_counts[2] = {0, 0};
       BCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
       BCK(hipStreamSynchronize(stream));

@@ -528,7 +528,7 @@ struct Tile2Args {
   uint32_t f_max;  // the k-th entry's bin must lie below this one: upper edge + eps < tau0 * s2
 };
 
-template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN>
+template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN, bool ROT>
 __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args aa) {
   const TileArgs& a = aa.t;
   constexpr int CS = CAP + BATCH;
@@ -575,7 +575,8 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
   {
     const double cu = g.org[0] + ((double)X0 + 0.5 * (double)a.bx) * g.hx, cv = g.org[1] + ((double)Y0 + 0.5 * (double)a.by) * g.h,
                  cw = g.org[2] + ((double)Z0 + 0.5 * (double)a.bz) * g.h;
-    if (g.rotated) {  // (u, v, w) = rot (x - rot_c)  =>  x = rot_c + rot^T (u, v, w)
+    if constexpr (ROT) {  // (u, v, w) = rot (x - rot_c)  =>  x = rot_c + rot^T (u, v, w)   (ROT: a separate instance -- the nine matrix entries and the
+                          //  centre are 24 scalar registers the kernel does not have to spare, see launch_knn_tile)
       ctr[0] = g.rot_c[0] + g.rot[0] * cu + g.rot[3] * cv + g.rot[6] * cw;
       ctr[1] = g.rot_c[1] + g.rot[1] * cu + g.rot[4] * cv + g.rot[7] * cw;
       ctr[2] = g.rot_c[2] + g.rot[2] * cu + g.rot[5] * cv + g.rot[8] * cw;
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     float fx, fy, fz;
     {
       float ru = rqx, rv = rqy, rw = rqz;
-      if (g.rotated) {
+      if constexpr (ROT) {
         ru = (float)g.rot[0] * rqx + (float)g.rot[1] * rqy + (float)g.rot[2] * rqz;
         rv = (float)g.rot[3] * rqx + (float)g.rot[4] * rqy + (float)g.rot[5] * rqz;
         rw = (float)g.rot[6] * rqx + (float)g.rot[7] * rqy + (float)g.rot[8] * rqz;
@@ -1263,8 +1264,10 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
     b.t = a;
 #define PST_TILE2_LAUNCH(KK, TT, CC, P3, BB, WW)                                                                               \
     do {                                                                                                                       \
-      if (knn) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true>), dim3(grid), dim3(TT), 0, stream, b);      \
-      else hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false>), dim3(grid), dim3(TT), 0, stream, b);         \
+      if (knn && g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, true>), dim3(grid), dim3(TT), 0, stream, b);        \
+      else if (knn) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, false>), dim3(grid), dim3(TT), 0, stream, b);              \
+      else if (g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, true>), dim3(grid), dim3(TT), 0, stream, b);        \
+      else hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, false>), dim3(grid), dim3(TT), 0, stream, b);                      \
     } while (0)
 #define PST_TILE2_K(TT, CC, P3, BB, WW)                                                                                        \
     do {                                                                                                                       \
