@@ -55,10 +55,23 @@ __device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __res
   if (n == 0) return 0;
   const double t = (p - origin) * inv_leaf;
   uint32_t index = t >= 1.0 ? (t < (double)(n - 1) ? (uint32_t)t : n - 1) : 0u;  // NaN -> 0
-  // first index with !(markers[i] < p); the reference's scan never passes the last marker (it is >= max >= p); NaN -> 0
-  while (index + 1 < n && markers[index] < p) index += 1;
-  while (index > 0 && !(markers[index - 1] < p)) index -= 1;
-  if (index > 0 && p - markers[index - 1] < markers[index] - p) index -= 1;  // "clamp values to the better fitting marker"
+  // The guess is off by at most one in all but freak cases (the markers are accumulated sums), so the three markers around it are read
+  // TOGETHER -- one LDS round trip instead of a dependent load per step -- and decide: lb = first index with !(markers[i] < p), never past
+  // the last marker (it is >= max >= p); NaN -> 0.  Anything the three cannot decide walks the array as before.
+  const double a = index > 0 ? markers[index - 1] : 0.0, b = markers[index], c = index + 1 < n ? markers[index + 1] : 0.0;
+  double lo, hi;  // markers[lb - 1], markers[lb]
+  bool have = false;
+  if (index == 0 || a < p) {
+    if (!(b < p) || index + 1 == n) { lo = a; hi = b; have = true; }                                     // lb = index
+    else if (index + 2 == n || !(c < p)) { index += 1; lo = b; hi = c; have = true; }                    // lb = index + 1
+  }
+  if (!have) {
+    while (index + 1 < n && markers[index] < p) index += 1;
+    while (index > 0 && !(markers[index - 1] < p)) index -= 1;
+    hi = markers[index];
+    lo = index > 0 ? markers[index - 1] : 0.0;
+  }
+  if (index > 0 && p - lo < hi - p) index -= 1;  // "clamp values to the better fitting marker"
   return index;
 }
 

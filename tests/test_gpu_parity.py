@@ -881,6 +881,33 @@ def test_box_search_forced_on_sparse_clouds_vs_oracle(hip, oracle, monkeypatch, 
     assert bad.sum() == 0 and cbad.sum() == 0
 
 
+@pytest.mark.parametrize("var", ["1", "B", "D", "G"])
+@pytest.mark.parametrize("shape,n,k", [("volume", 200_000, 16), ("surface", 1_200_000, 16), ("volume", 150_000, 7)])
+def test_every_instance_of_the_box_kernel_vs_oracle(hip, oracle, monkeypatch, var, shape, n, k):
+    """The box search ships in four instances (normals_tile.hip): the first form ('1': f64 scan, packed f64 keys; k > 16 by default) and
+    three of the second form ('D': 512 threads / 3000 staged points, volume-like clouds; 'G': 256 / 1536, the others; 'B': 256 / 2044).
+    The default picks one per cloud; PST_KNN_VAR forces each of them through a volume-like and a surface-like cloud (the surface is large
+    enough for the box search and launches one workgroup per box that holds a query): identical neighbour lists, normals within 1e-9."""
+    from pasture_amd.algorithms import compute_normals, reload_tuning
+    pts = _normals_inputs(n, 11, shape)
+    monkeypatch.setenv("PST_KNN_VAR", var)
+    reload_tuning(hip)
+
+    def run(api):
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=api))
+        buf.resize(n)
+        buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        return compute_normals(buf, k, return_knn=True)
+    try:
+        (hn, hc, hk), (on, oc, ok) = both(run, hip, oracle)
+    finally:
+        monkeypatch.undo()
+        reload_tuning(hip)
+    assert np.array_equal(hk, ok)
+    bad, cbad = _compare_normals(hn, hc, on, oc, scales=_cov_scales(pts, ok))
+    assert bad.sum() == 0 and cbad.sum() == 0
+
+
 @pytest.mark.parametrize("n_side,k", [(48, 16), (40, 8), (36, 27)])
 def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
     """LAS coordinates are integers times a scale: equal distances are the rule, not the exception.  On a jittered-then-quantised lattice
