@@ -9,8 +9,8 @@
 namespace pstk {
 
 // stable LSD radix sort of (key, value) pairs on key bits [0, end_bit); n < 2^32.  BOTH pairs of buffers are scratch (the passes
-// alternate between them); the result is in (keys_out, vals_out).  Up to 27 key bits: the library's own three-pass sort (radix_sort.hip);
-// beyond that, or with PST_SORT=rocprim (the A/B switch): rocPRIM.
+// alternate between them); the result is in (keys_out, vals_out).  The library's own sort (radix_sort.hip: one, three or four passes);
+// with PST_SORT=rocprim (the A/B switch): rocPRIM.
 hipError_t sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in, uint32_t* vals_out,
                           size_t n, unsigned end_bit, hipStream_t stream);
 // radix_sort.hip

@@ -422,13 +422,20 @@ __global__ __launch_bounds__(kBlock) void collect_unresolved_kernel(const uint32
   if (flag[o] == which) { flag[o] = 0; list[atomicAdd(count, 1u)] = j; }
 }
 
+// the flags of listed open queries (sorted positions), cleared once the all-points search has taken them from the list
+__global__ __launch_bounds__(kBlock) void clear_flags_kernel(const uint32_t* __restrict__ list, uint32_t n_q, const uint32_t* __restrict__ sidx, uint8_t* __restrict__ flag) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < n_q) flag[sidx[list[t]]] = 0;
+}
+
 // ---- grid search over global memory -------------------------------------------------------------------------------------------------
 // LIST: the queries are the sorted indices qlist[0 .. nq) (what the box kernel could not finish); otherwise all nf sorted points.
 template <int K, bool DENSE, bool LIST>
 __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
                                                           const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out, int shell_cap,
-                                                          uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count, uint32_t crowd) {
+                                                          uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count, uint32_t crowd,
+                                                          uint32_t* __restrict__ open_lists, uint32_t open_cap) {
   const uint32_t t0 = blockIdx.x * kBlock + threadIdx.x;
   if (t0 >= nq) return;
   const uint32_t j = LIST ? qlist[t0] : t0;
@@ -515,13 +522,16 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
         }
       }
     }
-    if (crowded) { unres_flag[out.sidx[j]] = 2; atomicAdd(unres_count + 1, 1u); return; }
+    // (an open query is flagged by its ORIGINAL index -- a coarser level re-sorts the points -- and, for the all-points search of THIS index,
+    //  listed by its sorted position: open_lists[0 .. cap) hand-backs, [cap .. 2 cap) crowded ones)
+    if (crowded) { unres_flag[out.sidx[j]] = 2; const uint32_t at = atomicAdd(unres_count + 1, 1u); if (at < open_cap) open_lists[open_cap + at] = j; return; }
     if (shell_done(g, qu, qv, qw, cx, cy, cz, r, best.kth(k))) break;
     // shell_cap > 0: a query that is still open after that many shells (an outlier, a point of a region far sparser than the grid was made
     // for: shell r costs (2 r + 1)^2 rows) is handed back -- flagged by its original index -- and searched again on a coarser grid
     if (shell_cap > 0 && r == shell_cap && r < max_r) {
       unres_flag[out.sidx[j]] = 1;
-      atomicAdd(unres_count, 1u);
+      const uint32_t at = atomicAdd(unres_count, 1u);
+      if (at < open_cap) open_lists[at] = j;
       return;
     }
   }
@@ -1197,7 +1207,9 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (tune.dense == 0) dense = false;
       if (!build_index(dense ? h_dense : h_hash, 1, dense)) return -1;
     }
-    CacheBuf unres;  // one byte per point, by ORIGINAL index: the query was handed back by a capped search
+    CacheBuf unres, open_lists;  // one byte per point, by ORIGINAL index: the query was handed back by a capped search; and their sorted positions
+    constexpr uint32_t kOpenCap = 1u << 22;  // listed open queries per kind (beyond that the flags are collected in a pass over all points)
+    NCK(open_lists.alloc((size_t)2 * kOpenCap * 4, stream));
     NCK(unres.alloc(n, stream));
     NCK(hipMemsetAsync(unres.p, 0, n, stream));
     uint32_t* unres_count = (uint32_t*)((uint8_t*)counters.p + 64);
@@ -1238,17 +1250,17 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           if (n_fb) {
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
             KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
+                              (const uint32_t*)fb_list.as<uint32_t>(), n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
           }
         } else {
           const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
           KNN_DISPATCH_GRID(true, false, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
+                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
         }
       } else {
         const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
         KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u);
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
       }
       // Queries a capped search handed back (flag 1: outliers; regions far sparser than the grid was made for): again on a grid with six
       // times the cell edge, laid over the FULL bounding box (the trimmed or rotated box of the first level clamps exactly the points these
@@ -1258,10 +1270,18 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       // last few open ones, whose all-points search costs less than another index.
       auto all_points = [&](uint8_t which, uint32_t n_q) -> bool {
 #define ACK(x) do { if ((x) != hipSuccess) return false; } while (0)
-        ACK(fb_list.alloc((size_t)nf * 4, stream));
-        ACK(hipMemsetAsync(unres_count + 2, 0, 4, stream));
-        hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(), (uint32_t)nf,
-                           unres.as<uint8_t>(), which, fb_list.as<uint32_t>(), unres_count + 2);
+        const uint32_t* open_q = nullptr;
+        if (n_q <= kOpenCap) {
+          // the search that flagged them listed their sorted positions (same index: nothing was re-sorted in between): no pass over all points
+          open_q = open_lists.as<uint32_t>() + (which == 2 ? kOpenCap : 0u);
+          hipLaunchKernelGGL(clear_flags_kernel, dim3((n_q + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, open_q, n_q, (const uint32_t*)idx2.as<uint32_t>(), unres.as<uint8_t>());
+        } else {
+          ACK(fb_list.alloc((size_t)nf * 4, stream));
+          ACK(hipMemsetAsync(unres_count + 2, 0, 4, stream));
+          hipLaunchKernelGGL(collect_unresolved_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const uint32_t*)idx2.as<uint32_t>(), (uint32_t)nf,
+                             unres.as<uint8_t>(), which, fb_list.as<uint32_t>(), unres_count + 2);
+          open_q = fb_list.as<uint32_t>();
+        }
         if (debug) fprintf(stderr, "[pst knn] %u open queries against all %llu points\n", n_q, (unsigned long long)nf);
         if (!n_sub) {  // (clouds that fill their box had no scale estimate: take the subsample now)
           const uint64_t cap_s = std::min<uint64_t>(1u << 22, std::max<uint64_t>(1u << 20, n / 16));
@@ -1279,7 +1299,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         ACK(cand.alloc((size_t)n_b * cand_cap * 4, stream));
         for (uint32_t off = 0; off < n_q; off += batch) {
           const uint32_t cnt = std::min(batch, n_q - off);
-          const uint32_t* ql = (const uint32_t*)fb_list.as<uint32_t>() + off;
+          const uint32_t* ql = open_q + off;
           ACK(hipMemsetAsync(cand_count.p, 0, (size_t)cnt * 4, stream));
           // (the first quarter of the subsample -- itself a uniform thinning, in input order -- is enough for the bound: four times the
           // candidates per query, which the culled filter and the select kernel barely notice, for a quarter of the scan)
@@ -1330,10 +1350,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const int cap = last ? 0 : kShellCap;
         if (up_dense) {
           KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, (const uint32_t*)directory.as<uint32_t>(),
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap);
         } else {
           KNN_DISPATCH_GRID(false, true, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table, (const uint32_t*)nullptr,
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap);
         }
         mark("coarser");
       }

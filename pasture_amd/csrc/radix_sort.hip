@@ -3,7 +3,8 @@
 // What it sorts: voxel keys of voxelgrid_filter (27 bits for the bench cloud; pasture-algorithms/src/voxel_grid.rs:109-166 groups points by
 // voxel -- the sequential per-voxel centroid sums :124-166 need the points of a voxel in their ORIGINAL order, hence stable) and the row-major
 // cell numbers of the kNN grid (normal_estimation.rs:103-120 is a kd-tree there; here ~26 bits).  The library sort (rocPRIM) takes four
-// 7-bit passes for such keys at ~2.3 TB/s of moved bytes per pass; this one takes THREE passes of ceil(bits / 3) <= 9 bits.
+// 7-bit passes for such keys at ~2.3 TB/s of moved bytes per pass; this one takes THREE passes of ceil(bits / 3) <= 9 bits (four of <= 8 bits
+// for 28 .. 32 key bits: the kNN grid of a surface in a 3-D box has ~2 * 10^9 cells).
 //
 // One pass = three kernels, no spinning on other workgroups (no decoupled look-back: every kernel boundary is a device-wide barrier):
 //   1. radix_hist_kernel     per tile of 8192 keys a 2^d-bin digit histogram (LDS atomics), stored digit-major: counts[digit][tile];
@@ -192,10 +193,12 @@ __global__ __launch_bounds__(kThreads, 4) void radix_scatter_kernel(const uint32
   }
 }
 
-struct Plan { unsigned passes, bits[3]; uint32_t tiles; size_t counts_bytes, total_bytes; };
+struct Plan { unsigned passes, bits[4]; uint32_t tiles; size_t counts_bytes, total_bytes; };
 Plan plan_for(size_t n, unsigned end_bit) {
   Plan p{};
-  p.passes = end_bit <= 9 ? 1u : 3u;  // an odd number of passes: the result lands in the second pair of buffers
+  // up to 9 bits one pass, up to 27 three (an odd number: the result lands in the second pair of buffers); 28 .. 32 bits four passes of
+  // <= 8 bits and one copy of the result into the second pair (two 4 n-byte copies: 0.15 ms per 10^8 pairs, less than a fifth pass)
+  p.passes = end_bit <= 9 ? 1u : (end_bit <= 27 ? 3u : 4u);
   unsigned left = end_bit ? end_bit : 1u;
   for (unsigned i = 0; i < p.passes; ++i) { p.bits[i] = (left + (p.passes - i) - 1) / (p.passes - i); left -= p.bits[i]; }
   p.tiles = (uint32_t)((n + kTile - 1) / kTile);
@@ -206,7 +209,7 @@ Plan plan_for(size_t n, unsigned end_bit) {
 
 }  // namespace
 
-bool radix_sort_pairs_supported(size_t n, unsigned end_bit) { return end_bit <= 27 && n < 0xFFFFFFF0ull; }
+bool radix_sort_pairs_supported(size_t n, unsigned end_bit) { return end_bit <= 32 && n < 0xFFFFFFF0ull; }
 
 // Sorts (keys_a, vals_a) by key bits [0, end_bit); BOTH pairs of buffers are scratch, the result is in (keys_b, vals_b).
 hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned end_bit,
@@ -237,6 +240,11 @@ hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint
     shift += b;
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
+  }
+  if (p.passes % 2 == 0) {  // an even number of passes leaves the result in the first pair (now `ki` / `vi`): copy it over
+    hipError_t e = hipMemcpyAsync(keys_b, keys_a, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(vals_b, vals_a, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }
