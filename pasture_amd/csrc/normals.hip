@@ -978,6 +978,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     //    than the cloud -- 3. else over Morton keys + a hash table with ~k/3 points per cell;
     // 4. queries 2 / 3 hand back after kShellCap shells: coarser grids over the full bounding box, then an exact search against all points.
     TileShape shape;
+    BoxListSink box_sink;
     bool tiled = false;
     double h_est = 0.0, d_est = 3.0;  // measured (clouds that do not fill their box): the radius holding M = 1.75 k points, the local dimension
     unsigned long long* scratch3 = (unsigned long long*)((uint8_t*)counters.p + 88);  // four counters of the probe / census kernels (88 .. 120)
@@ -1184,7 +1185,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const double D = pf.dim, h_new = pf.h_new;
         if (debug) fprintf(stderr, "[pst knn probe] h=%g: %.1f points within h/2, %.1f within h (target %.1f), dimension %.2f -> h=%g\n", g.h, m_half, m_full, m_target, D, h_new);
         if (probe_accepts(round, g.h, h_new, tune)) {
-          tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape);
+          // (clouds that do not fill their box: the census of the winning shape also lists the boxes that hold a query)
+          box_sink.alloc = [&](size_t bytes) -> uint32_t* { CacheBuf b; return b.alloc(bytes, stream) == hipSuccess ? b.as<uint32_t>() : nullptr; };
+          box_sink.count_dev = (uint32_t*)((uint8_t*)counters.p + 76);
+          box_sink.list = nullptr; box_sink.n = 0;
+          tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape, (!fills && tune.box_list) ? &box_sink : nullptr);
           mark("census");
           break;
         }
@@ -1230,7 +1235,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           CacheBuf box_list;
           uint32_t n_list = 0;
           const uint32_t* list_ptr = nullptr;
-          if (!fills && tune.box_list) {
+          if (!fills && tune.box_list && box_sink.list) {
+            list_ptr = box_sink.list;
+            n_list = box_sink.n;
+            if (debug) fprintf(stderr, "[pst knn] %u of %u boxes hold a query (listed by the census)\n", n_list, knn_box_count(shape, g));
+          } else if (!fills && tune.box_list) {
             NCK(box_list.alloc((size_t)knn_box_count(shape, g) * 4, stream));
             n_list = knn_box_list(shape, cell_start, g, box_list.as<uint32_t>(), unres_count + 3, stream);
             if (n_list == 0xFFFFFFFFu) return -1;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+
 #include "normals_device.hpp"
 
 namespace pstk {
@@ -10,8 +12,16 @@ namespace pstk {
 struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; char tag = '1'; };  // tag: which instance of the box kernel (normals_tile.hip)
 // false: no box fits (k > 32, or even a single query row with its halo exceeds the LDS budget at this density)
 // (measured: census kernels over the dense directory; scratch3 = 32 bytes of device memory; synchronises the stream)
+// sink (nullable): every census also lists the boxes that hold a query; on success list / n describe the winning shape (list == null: none
+// was written, e.g. a forced shape -- knn_box_list builds it then)
+struct BoxListSink {
+  std::function<uint32_t*(size_t)> alloc;  // device memory for one list (stays valid until the call ends)
+  uint32_t* count_dev = nullptr;           // one device word
+  const uint32_t* list = nullptr;
+  uint32_t n = 0;
+};
 bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
-                    unsigned long long* scratch3, hipStream_t stream, TileShape& t);
+                    unsigned long long* scratch3, hipStream_t stream, TileShape& t, BoxListSink* sink = nullptr);
 // mean number of points within h / 2 and within h of a sampled point of the sorted cloud (synchronises the stream); false on failure
 bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t nf, unsigned long long* scratch3, hipStream_t stream,
                double& mean_half, double& mean_full);

@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(kBlock) void knn_probe_kernel(const double* __restr
 // ---- box census: what would a box shape stage?  One thread per box: staged points (halo) and queries, from the directory alone.
 // sums: [0] queries, [1] staged points over non-empty boxes, [2] queries of boxes whose halo exceeds the capacity, [3] non-empty boxes
 __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __restrict__ cell_start, GridParams g, uint32_t bx, uint32_t by, uint32_t bz,
-                                                            uint32_t nbx, uint32_t nby, uint32_t n_boxes, uint32_t cap, unsigned long long* __restrict__ sums) {
+                                                            uint32_t nbx, uint32_t nby, uint32_t n_boxes, uint32_t cap, unsigned long long* __restrict__ sums,
+                                                            uint32_t* __restrict__ list, uint32_t* __restrict__ list_count) {
   const uint32_t box = blockIdx.x * kBlock + threadIdx.x;
   unsigned long long q = 0, staged = 0, lost = 0, occupied = 0;
   if (box < n_boxes) {
@@ -1026,6 +1027,16 @@ __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __re
     if (q == 0) staged = 0;
     if (staged > cap) lost = q;
     occupied = q != 0;
+  }
+  if (list) {  // the boxes that hold a query, ascending within a wave (a wave appends its boxes with ONE atomic): the launch list of the box search
+    const uint64_t m = __builtin_amdgcn_ballot_w64(occupied != 0);
+    if (m) {
+      const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == first) base = atomicAdd(list_count, (uint32_t)__builtin_popcountll(m));
+      base = (uint32_t)__shfl((int)base, (int)first, 64);
+      if (occupied) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = box;
+    }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1127,7 +1138,7 @@ bool knn_probe(const double* sxyz, const uint32_t* cell_start, const pstn::GridP
 // that exceed the LDS capacity wins.  Average density would do for a cloud that fills its bounding box; a surface in a 3-D box puts all
 // its points into a few boxes.  bx counts FINE cells along x (edge h / rx), by and bz rows (edge h).
 bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
-                    unsigned long long* scratch3, hipStream_t stream, TileShape& t) {
+                    unsigned long long* scratch3, hipStream_t stream, TileShape& t, BoxListSink* sink) {
   if (k > 64 || cells == 0 || nf == 0) return false;
   const TileVariant& var = tile_variant(k, volume_like);  // (the second form is instantiated for k <= 16; larger k: the first form)
   const KnnTuning& tune = knn_tuning();
@@ -1141,13 +1152,22 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
   double shrink = 1.0;
   const bool debug = tune.debug;
   // census of one shape: h[0] queries, h[1] staged points, h[2] queries lost to boxes over capacity, h[3] non-empty boxes
+  // (with a sink: every census also lists the boxes that hold a query, in a buffer of its own; the caller launches from the list of the
+  //  shape that wins -- h[3] is its length)
+  const uint32_t* last_list = nullptr;
   auto census = [&](const TileShape& c, unsigned long long (&h)[4]) -> int {
     const uint32_t nbx = (g.dim[0] + c.bx - 1) / c.bx, nby = (g.dim[1] + c.by - 1) / c.by, nbz = (g.dim[2] + c.bz - 1) / c.bz;
     const uint64_t n_boxes = (uint64_t)nbx * nby * nbz;
     if (n_boxes >= 0x7FFFFFFFull) return 1;
     if (hipMemsetAsync(scratch3, 0, 32, stream) != hipSuccess) return -1;
+    uint32_t* list = nullptr;
+    if (sink) {
+      list = sink->alloc((size_t)n_boxes * 4);
+      if (!list || hipMemsetAsync(sink->count_dev, 0, 4, stream) != hipSuccess) return -1;
+    }
+    last_list = list;
     hipLaunchKernelGGL(knn_census_kernel, dim3((unsigned)((n_boxes + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, cell_start, g, c.bx, c.by, c.bz, nbx, nby,
-                       (uint32_t)n_boxes, t.cap, scratch3);
+                       (uint32_t)n_boxes, t.cap, scratch3, list, sink ? sink->count_dev : nullptr);
     if (hipMemcpyAsync(h, scratch3, 32, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return -1;
     if (debug)
       fprintf(stderr, "[pst knn census] box %ux%ux%u: halo amplification %.2f, %.2f %% of the queries in boxes over capacity, %.0f queries per occupied box\n", c.bx, c.by,
@@ -1166,6 +1186,7 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
     if (rc > 0) break;
     if (h[0] && (double)h[2] <= 0.02 * (double)h[0]) {
       t.bx = c.bx; t.by = c.by; t.bz = c.bz;
+      if (sink) { sink->list = last_list; sink->n = (uint32_t)h[3]; }
       // ROUNDS.  The queries of a box are handed to the workgroup's waves in chunks of 64, so a box of Q queries keeps its LDS for
       // ceil(Q / threads) rounds, and in the last round most waves have left: 560 queries on 256 threads use 8.75 of 12 wave slots, and
       // no other workgroup can take the idle ones while the box holds its LDS.  If the typical box (mean + two standard deviations of
@@ -1177,7 +1198,10 @@ bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint
           TileShape c2 = t;
           c2.bx = bx2;
           unsigned long long h2[4] = {};
-          if (tile_fits(g, c2.bx, c2.by, c2.bz) && census(c2, h2) == 0 && h2[0] && (double)h2[2] <= 0.02 * (double)h2[0]) t.bx = bx2;
+          if (tile_fits(g, c2.bx, c2.by, c2.bz) && census(c2, h2) == 0 && h2[0] && (double)h2[2] <= 0.02 * (double)h2[0]) {
+            t.bx = bx2;
+            if (sink) { sink->list = last_list; sink->n = (uint32_t)h2[3]; }
+          }
         }
       }
       return true;
