@@ -273,19 +273,23 @@ __global__ __launch_bounds__(kBlock) void dir_block_heads_kernel(const uint32_t*
     if (j == 0 || keys[j - 1] / kDirBlock != k / kDirBlock) block_first[k / kDirBlock] = (uint32_t)j;
   }
 }
+constexpr uint32_t kDirPerGroup = 8;
 __global__ __launch_bounds__(kBlock) void dir_fill_kernel(const uint32_t* __restrict__ keys, uint64_t nf, uint64_t cells, const uint32_t* __restrict__ block_first,
                                                           uint64_t n_blocks, uint32_t* __restrict__ cell_start) {
   static_assert(kDirBlock == 4 * kBlock, "four cells per thread");
   __shared__ uint32_t cs[kDirBlock];
   __shared__ uint32_t wmin[kBlock / 64];
-  const uint64_t b = blockIdx.x, c0 = b * kDirBlock;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // kDirPerGroup consecutive blocks of cells per workgroup (1.8 * 10^6 workgroups of 4 KB each were bound by their launches: 2.2 ms for 7.5 GB)
+  for (uint64_t b = (uint64_t)blockIdx.x * kDirPerGroup; b < n_blocks && b < ((uint64_t)blockIdx.x + 1) * kDirPerGroup; ++b) {
+  const uint64_t c0 = b * kDirBlock;
   const uint32_t j0 = block_first[b], j1 = b + 1 < n_blocks ? block_first[b + 1] : (uint32_t)nf;
   uint32_t v[4];
   if (j0 == j1) {  // no point in this block: every cell starts at the next block's first point
     v[0] = v[1] = v[2] = v[3] = j0;
   } else {
     // the block's run heads land on their cells in LDS; a suffix minimum carries each head back over the empty cells in front of it
+    __syncthreads();  // (the previous block of cells is done with cs / wmin)
     for (uint32_t t = tid; t < kDirBlock; t += kBlock) cs[t] = 0xFFFFFFFFu;
     __syncthreads();
     for (uint32_t j = j0 + tid; j < j1; j += kBlock) {
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(kBlock) void dir_fill_kernel(const uint32_t* __rest
   } else {
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (c + (uint64_t)u <= cells) cell_start[c + u] = v[u];
+  }
   }
 }
 
@@ -948,7 +953,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           BCK(suffix_min_u32(nullptr, sb, dir_blocks.as<uint32_t>(), n_dblocks, stream));
           BCK(tmp.alloc(sb, stream));
           BCK(suffix_min_u32(tmp.p, sb, dir_blocks.as<uint32_t>(), n_dblocks, stream));
-          hipLaunchKernelGGL(dir_fill_kernel, dim3((unsigned)n_dblocks), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, (const uint32_t*)dir_blocks.as<uint32_t>(),
+          hipLaunchKernelGGL(dir_fill_kernel, dim3((unsigned)((n_dblocks + kDirPerGroup - 1) / kDirPerGroup)), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, (const uint32_t*)dir_blocks.as<uint32_t>(),
                              n_dblocks, directory.as<uint32_t>());
         } else {
           hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, keys2.as<uint32_t>(), nf, cells, directory.as<uint32_t>());
