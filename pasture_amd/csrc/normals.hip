@@ -150,26 +150,43 @@ __global__ __launch_bounds__(kBlock) void framed_bounds_kernel(const double* __r
   }
 }
 
+// The points are walked in the radix sort's tiles (walk.tile_size consecutive points per workgroup and step); with walk.counts the digit
+// histogram of the sort's first pass is counted on the way (radix_sort.hip: counts[digit][tile]).  idx == nullptr: the sort numbers the points.
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__ xyz, uint64_t n, GridParams g, KeyT* __restrict__ keys,
-                                                      uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite) {
+                                                      uint32_t* __restrict__ idx, unsigned long long* __restrict__ n_finite, pstk::RadixFirstPass walk) {
+  __shared__ uint32_t hist[512];
   unsigned long long local = 0;
-  const uint64_t step = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
-    const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    uint64_t key = kInvalidKey;
-    if (finite3(x, y, z)) {
-      double u, v, w;
-      grid_frame(g, x, y, z, u, v, w);
-      const uint32_t cx = cell_coord(u, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(v, g.org[1], g.inv_h, g.dim[1]),
-                     cz = cell_coord(w, g.org[2], g.inv_h, g.dim[2]);
-      key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
-      local += 1;
-    } else if (g.dense) {
-      key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
+  const uint32_t mask = walk.counts ? (1u << walk.bits) - 1u : 0u, steps = walk.tile_size / kBlock;
+  for (uint64_t tile = blockIdx.x; tile < walk.tiles; tile += gridDim.x) {
+    if (walk.counts) {
+      for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) hist[d] = 0;
+      __syncthreads();
     }
-    keys[i] = (KeyT)key;
-    idx[i] = (uint32_t)i;
+    for (uint32_t it = 0; it < steps; ++it) {
+      const uint64_t i = tile * walk.tile_size + (uint64_t)it * kBlock + threadIdx.x;
+      if (i >= n) break;
+      const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+      uint64_t key = kInvalidKey;
+      if (finite3(x, y, z)) {
+        double u, v, w;
+        grid_frame(g, x, y, z, u, v, w);
+        const uint32_t cx = cell_coord(u, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(v, g.org[1], g.inv_h, g.dim[1]),
+                       cz = cell_coord(w, g.org[2], g.inv_h, g.dim[2]);
+        key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
+        local += 1;
+      } else if (g.dense) {
+        key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
+      }
+      keys[i] = (KeyT)key;
+      if (idx) idx[i] = (uint32_t)i;
+      if (walk.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+    }
+    if (walk.counts) {
+      __syncthreads();
+      for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) walk.counts[(uint64_t)d * walk.tiles + tile] = hist[d];
+      __syncthreads();
+    }
   }
   if (local) atomicAdd(n_finite, local);  // the compiler folds this to one atomic per wave
 }
@@ -435,8 +452,9 @@ __global__ __launch_bounds__(kBlock) void clear_flags_kernel(const uint32_t* __r
 
 // ---- grid search over global memory -------------------------------------------------------------------------------------------------
 // LIST: the queries are the sorted indices qlist[0 .. nq) (what the box kernel could not finish); otherwise all nf sorted points.
+constexpr int kScanBatch = 4;
 template <int K, bool DENSE, bool LIST>
-__global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
+__global__ __launch_bounds__(kBlock, K <= 16 ? 4 : 1) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
                                                           const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out, int shell_cap,
                                                           uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count, uint32_t crowd,
@@ -451,8 +469,8 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
             cz = (int)cell_coord(qw, g.org[2], g.inv_h, g.dim[2]);
   KBest<K> best;
   best.init();
-  // candidates in pairs: both coordinate triples are requested before the first insertion (the loop was waiting on one dependent load
-  // per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the pair).  The two ranges of a row are walked
+  // candidates in batches: all coordinate triples of a batch are requested before the first insertion (the loop was waiting on one dependent
+  // load per candidate); the insertion itself stays ONE inlined copy (a not-unrolled loop over the batch).  The two ranges of a row are walked
   // as one sequence, so the two single end cells of an interior row share a round trip.
   // crowd > 0 (coarser levels): a range longer than that is not walked by this one lane -- the query is flagged 2 and searched against all
   // points by a workgroup (a coarse cell over a dense part of the cloud holds millions of points)
@@ -460,18 +478,26 @@ __global__ __launch_bounds__(kBlock) void knn_grid_kernel(const double* __restri
   auto scan2 = [&](uint32_t p0, uint32_t p1, uint32_t q0, uint32_t q1) __attribute__((always_inline)) {
     const uint32_t lp = p1 - p0, total = lp + (q1 - q0);
     if (crowd && total > crowd) { crowded = true; return; }
-    for (uint32_t v = 0; v < total; v += 2) {
-      const bool two = v + 1 < total;
-      const uint32_t pa = v < lp ? p0 + v : q0 + (v - lp);
-      const uint32_t vb = two ? v + 1 : v;
-      const uint32_t pb = vb < lp ? p0 + vb : q0 + (vb - lp);
-      const double ax = sxyz[3 * (uint64_t)pa], ay = sxyz[3 * (uint64_t)pa + 1], az = sxyz[3 * (uint64_t)pa + 2];
-      const double bx = sxyz[3 * (uint64_t)pb], by = sxyz[3 * (uint64_t)pb + 1], bz = sxyz[3 * (uint64_t)pb + 2];
-      const double adx = ax - qx, ady = ay - qy, adz = az - qz, bdx = bx - qx, bdy = by - qy, bdz = bz - qz;
-      const double da = adx * adx + ady * ady + adz * adz;
-      const double db = two ? bdx * bdx + bdy * bdy + bdz * bdz : __builtin_inf();
+    // (kScanBatch candidates per step: one lane walks ~900 candidates when its k-th neighbour lies beyond the first shell, one round trip
+    //  to L2 per step -- 1.59 ms per 0.9 * 10^6 such queries with pairs)
+    for (uint32_t v = 0; v < total; v += kScanBatch) {
+      uint32_t pp[kScanBatch];
+      double dd[kScanBatch];
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) {
+        const uint32_t vu = v + (uint32_t)u < total ? v + (uint32_t)u : v;
+        pp[u] = vu < lp ? p0 + vu : q0 + (vu - lp);
+      }
+      double cx_[kScanBatch], cy_[kScanBatch], cz_[kScanBatch];
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) { cx_[u] = sxyz[3 * (uint64_t)pp[u]]; cy_[u] = sxyz[3 * (uint64_t)pp[u] + 1]; cz_[u] = sxyz[3 * (uint64_t)pp[u] + 2]; }
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) {
+        const double dx = cx_[u] - qx, dy = cy_[u] - qy, dz = cz_[u] - qz;
+        dd[u] = v + (uint32_t)u < total ? dx * dx + dy * dy + dz * dz : __builtin_inf();
+      }
 #pragma nounroll
-      for (int u = 0; u < 2; ++u) best.insert(u ? db : da, u ? pb : pa);
+      for (int u = 0; u < kScanBatch; ++u) best.insert(dd[u], pp[u]);
     }
   };
   const int max_r = (int)max(g.dim[0], max(g.dim[1], g.dim[2]));
@@ -920,22 +946,30 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
       if (dense) { key_bits = 1; while (key_bits < 32 && (1ull << key_bits) <= cells) ++key_bits; }  // keys 0 .. cells (< 2^32)
       BCK(hipMemsetAsync(counters.p, 0, 16, stream));
       size_t tmp_bytes = 0;
+      pstk::RadixFirstPass walk{nullptr, (uint32_t)((cnt + 8191) / 8192), 0, 8192};
       if (dense) {
-        hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(sgrid), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint32_t>(), idx.as<uint32_t>(), n_finite);
+        // the library's own sort numbers the points itself and takes the histogram of its first pass from the key kernel
         BCK(sort_pairs_u32(nullptr, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
         BCK(tmp.alloc(tmp_bytes, stream));
-        BCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
+        const pstk::RadixFirstPass first = pstk::sort_first_pass(tmp.p, cnt, key_bits);
+        if (first.counts) walk = first;
+        hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(std::max(1u, walk.tiles)), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint32_t>(), (uint32_t*)nullptr, n_finite, walk);
+        BCK(sort_pairs_u32(tmp.p, tmp_bytes, keys.as<uint32_t>(), keys2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream, true, &first));
       } else {
-        hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(sgrid), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite);
+        hipLaunchKernelGGL(keys_kernel<uint64_t>, dim3(std::max(1u, walk.tiles)), dim3(kBlock), 0, stream, src, cnt, g, keys.as<uint64_t>(), idx.as<uint32_t>(), n_finite, walk);
         BCK(sort_pairs_u64(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
         BCK(tmp.alloc(tmp_bytes, stream));
         BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
       }
       {
         static const int unroll = [] { const char* e = std::getenv("PST_REORDER_UNROLL"); return e && *e ? std::atoi(e) : 2; }();  // (same box, whole kNN call at 10^8 points: 32.6 / 32.3 / 32.4 ms for 1 / 2 / 4)
-        if (unroll >= 4) hipLaunchKernelGGL(reorder_kernel<4>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
-        else if (unroll == 2) hipLaunchKernelGGL(reorder_kernel<2>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
-        else hipLaunchKernelGGL(reorder_kernel<1>, dim3(sgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        // one step per workgroup (a grid of cnt / (256 * unroll) workgroups): a plain random gather of 10^8 points measured 2.41 ms that way and
+        // 2.58 ms with 2048 workgroups looping (tools/exp_locality.hip)
+        const int u = unroll >= 4 ? 4 : (unroll == 2 ? 2 : 1);
+        const unsigned rgrid = (unsigned)std::max<uint64_t>(1, (cnt + (uint64_t)kBlock * u - 1) / ((uint64_t)kBlock * u));
+        if (u == 4) hipLaunchKernelGGL(reorder_kernel<4>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else if (u == 2) hipLaunchKernelGGL(reorder_kernel<2>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else hipLaunchKernelGGL(reorder_kernel<1>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
       }
       unsigned long long h_counts[2] = {0, 0};
       BCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));

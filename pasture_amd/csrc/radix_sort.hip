@@ -42,12 +42,28 @@ __global__ __launch_bounds__(kThreads) void radix_hist_kernel(const uint32_t* __
   const uint32_t tile = logical_tile(), tid = threadIdx.x;
   if (tile >= tiles) return;
   for (uint32_t d = tid; d <= mask; d += kThreads) hist[d] = 0;
-  __syncthreads();
   const uint64_t base = (uint64_t)tile * kTile;
+  // all of the thread's keys are requested before the first is counted (any order will do for counting: 16 bytes per lane and load; the tile
+  // starts at a multiple of 32 KiB of the key array; an array that is not 16-byte aligned takes the element loop)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 k[kItems / 4];
+  const bool whole = base + kTile <= n && ((uintptr_t)keys & 15u) == 0;
+  if (whole) {
 #pragma unroll
-  for (int i = 0; i < kItems; ++i) {
-    const uint64_t e = base + (uint64_t)i * kThreads + tid;  // (any order will do for counting: lane-contiguous loads)
-    if (e < n) atomicAdd(&hist[digit_of(keys[e], shift, mask)], 1u);
+    for (int i = 0; i < kItems / 4; ++i) k[i] = *reinterpret_cast<const u32x4*>(keys + base + ((uint64_t)i * kThreads + tid) * 4);
+  }
+  __syncthreads();
+  if (whole) {
+#pragma unroll
+    for (int i = 0; i < kItems / 4; ++i) {
+      atomicAdd(&hist[digit_of(k[i].x, shift, mask)], 1u); atomicAdd(&hist[digit_of(k[i].y, shift, mask)], 1u);
+      atomicAdd(&hist[digit_of(k[i].z, shift, mask)], 1u); atomicAdd(&hist[digit_of(k[i].w, shift, mask)], 1u);
+    }
+  } else {
+    for (int i = 0; i < kItems; ++i) {
+      const uint64_t e = base + (uint64_t)i * kThreads + tid;
+      if (e < n) atomicAdd(&hist[digit_of(keys[e], shift, mask)], 1u);
+    }
   }
   __syncthreads();
   for (uint32_t d = tid; d <= mask; d += kThreads) counts[(uint64_t)d * tiles + tile] = hist[d];
@@ -102,7 +118,8 @@ __global__ __launch_bounds__(kThreads) void radix_scan_totals_kernel(const uint3
   if (tid < radix) dbase[tid] = before + inc - v;
 }
 
-template <int BITS>
+// IOTA: the values of the first pass are the element numbers 0 .. n-1 and are not read (the key kernels of the callers do not write them)
+template <int BITS, bool IOTA>
 __global__ __launch_bounds__(kThreads, 4) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t n, uint32_t shift,
                                                                     uint32_t tiles, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ dbase,
                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
@@ -124,7 +141,8 @@ __global__ __launch_bounds__(kThreads, 4) void radix_scatter_kernel(const uint32
   for (int i = 0; i < kItems; ++i) {
     const uint32_t e = e0 + (uint32_t)i * 64u;
     key[i] = e < tile_n ? keys_in[base + e] : 0xFFFFFFFFu;
-    val[i] = e < tile_n ? vals_in[base + e] : 0u;
+    if constexpr (IOTA) val[i] = (uint32_t)(base + e);
+    else val[i] = e < tile_n ? vals_in[base + e] : 0u;
   }
   // ---- rank within the wave, item by item (memory order) -----------------------------------------------------------------------------
   uint16_t rank[kItems];
@@ -211,9 +229,17 @@ Plan plan_for(size_t n, unsigned end_bit) {
 
 bool radix_sort_pairs_supported(size_t n, unsigned end_bit) { return end_bit <= 32 && n < 0xFFFFFFF0ull; }
 
+// Where a caller's key kernel leaves the digit histogram of the FIRST pass (it has every key in a register anyway: one kernel and one read of
+// the keys less): counts[digit * tiles + tile] = number of keys of tile `tile` (tile_size consecutive keys) whose lowest `bits` bits are `digit`.
+RadixFirstPass radix_sort_first_pass(void* tmp, size_t n, unsigned end_bit) {
+  const Plan p = plan_for(n, end_bit);
+  return RadixFirstPass{(uint32_t*)tmp, p.tiles, p.bits[0], (uint32_t)kTile};
+}
+
 // Sorts (keys_a, vals_a) by key bits [0, end_bit); BOTH pairs of buffers are scratch, the result is in (keys_b, vals_b).
+// vals_a == nullptr: the values are the element numbers (nothing is read; vals_a is still needed as scratch by sorts of more than one pass).
 hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n, unsigned end_bit,
-                                hipStream_t stream) {
+                                hipStream_t stream, bool iota, bool first_hist_ready) {
   const Plan p = plan_for(n, end_bit);
   if (!tmp) { bytes = p.total_bytes; return hipSuccess; }
   if (bytes < p.total_bytes) return hipErrorInvalidValue;
@@ -227,11 +253,15 @@ hipError_t radix_sort_pairs_u32(void* tmp, size_t& bytes, uint32_t* keys_a, uint
   for (unsigned pass = 0; pass < p.passes; ++pass) {
     const unsigned b = p.bits[pass];
     const uint32_t radix = 1u << b, mask = radix - 1u;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(grid), dim3(kThreads), 0, stream, ki, (uint64_t)n, shift, mask, p.tiles, counts);
+    if (!(pass == 0 && first_hist_ready))
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(grid), dim3(kThreads), 0, stream, ki, (uint64_t)n, shift, mask, p.tiles, counts);
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(radix), dim3(kThreads), 0, stream, counts, p.tiles, totals);
     hipLaunchKernelGGL(radix_scan_totals_kernel, dim3(1), dim3(kThreads), 0, stream, totals, radix, dbase);
-#define PST_SCATTER(B)                                                                                                                            \
-  case B: hipLaunchKernelGGL(radix_scatter_kernel<B>, dim3(grid), dim3(kThreads), 0, stream, ki, vi, (uint64_t)n, shift, p.tiles, counts, dbase, ko, vo); break;
+#define PST_SCATTER(B)                                                                                                                                           \
+  case B:                                                                                                                                                      \
+    if (pass == 0 && iota) hipLaunchKernelGGL((radix_scatter_kernel<B, true>), dim3(grid), dim3(kThreads), 0, stream, ki, vi, (uint64_t)n, shift, p.tiles, counts, dbase, ko, vo); \
+    else hipLaunchKernelGGL((radix_scatter_kernel<B, false>), dim3(grid), dim3(kThreads), 0, stream, ki, vi, (uint64_t)n, shift, p.tiles, counts, dbase, ko, vo);               \
+    break;
     switch (b) {
       PST_SCATTER(1) PST_SCATTER(2) PST_SCATTER(3) PST_SCATTER(4) PST_SCATTER(5) PST_SCATTER(6) PST_SCATTER(7) PST_SCATTER(8) PST_SCATTER(9)
       default: return hipErrorInvalidValue;

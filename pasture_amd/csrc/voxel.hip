@@ -18,6 +18,7 @@
 //                                       ties -> smallest value (the reference's HashMap iteration order is random)
 // Gather-bound (points of a voxel are scattered in the source) + sort-bound: no MFMA.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "device_common.hpp"
@@ -78,12 +79,17 @@ __device__ __forceinline__ uint32_t find_leaf_axis(double p, const double* __res
 struct AxisGrid { const double* markers; uint32_t n; uint32_t shift; double origin, inv_leaf; };
 
 // LDS_MARKERS: the three marker arrays are staged in LDS first (they are walked twice per point and axis: the arithmetic guess is
-// usually off by at most one, but every step is a dependent load); grids with more markers than kLdsMarkers read them from global memory.
+// usually off by at most one, but every step is a dependent load) -- dynamic LDS of exactly their size, so that a grid of a few hundred markers
+// leaves the CU to eight workgroups; grids with more markers than kLdsMarkers read them from global memory.
+// The points are walked in the radix sort's tiles (first.tile_size consecutive points per workgroup and step) and the digit histogram of the
+// sort's first pass is counted on the way (radix_sort.hip: counts[digit][tile]) -- the sort then starts with its scatter.  idx == nullptr: the
+// sort numbers the points itself.
 constexpr uint32_t kLdsMarkers = 6144;  // 48 KiB
 template <typename KeyT, bool LDS_MARKERS>
 __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy,
-                                                            AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx) {
-  __shared__ double lds_markers[LDS_MARKERS ? kLdsMarkers : 1];
+                                                            AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx, pstk::RadixFirstPass first) {
+  extern __shared__ double lds_markers[];
+  __shared__ uint32_t hist[512];
   if constexpr (LDS_MARKERS) {
     // gx.markers, gy.markers, gz.markers are consecutive in one device array (voxel_grid_build)
     const uint32_t total = gx.n + gy.n + gz.n;
@@ -91,13 +97,29 @@ __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __res
     __syncthreads();
     gx.markers = lds_markers; gy.markers = lds_markers + gx.n; gz.markers = lds_markers + gx.n + gy.n;
   }
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
-    const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
-    const uint64_t kx = find_leaf_axis(x, gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(y, gy.markers, gy.n, gy.origin, gy.inv_leaf),
-                   kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
-    keys[i] = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
-    idx[i] = (uint32_t)i;
+  const uint32_t mask = first.counts ? (1u << first.bits) - 1u : 0u, steps = first.tile_size / kBlock;
+  for (uint64_t tile = blockIdx.x; tile < first.tiles; tile += gridDim.x) {
+    if (first.counts) {
+      for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) hist[d] = 0;
+      __syncthreads();
+    }
+    for (uint32_t it = 0; it < steps; ++it) {
+      const uint64_t i = tile * first.tile_size + (uint64_t)it * kBlock + threadIdx.x;
+      if (i >= n) break;
+      cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
+      const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
+      const uint64_t kx = find_leaf_axis(x, gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(y, gy.markers, gy.n, gy.origin, gy.inv_leaf),
+                     kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
+      const KeyT key = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
+      keys[i] = key;
+      if (idx) idx[i] = (uint32_t)i;
+      if (first.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+    }
+    if (first.counts) {
+      __syncthreads();
+      for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) first.counts[(uint64_t)d * first.tiles + tile] = hist[d];
+      __syncthreads();
+    }
   }
 }
 
@@ -259,35 +281,35 @@ __device__ __forceinline__ void reduce_voxel_by_lane(const VoxelAttr& at, const 
   } else { store_un<float>(d, (float)a0); store_un<float>(d + 4, (float)a1); store_un<float>(d + 8, (float)a2); }
 }
 
-__global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t wave0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * kBlock) >> 6;
-  const uint64_t n_groups = (a.n_voxels + 63) / 64;
-  bool any_mode = false;
-  for (uint32_t ai = 0; ai < a.n_attrs; ++ai) any_mode = any_mode || a.attrs[ai].reduce == pstk::VX_MOST_COMMON || a.attrs[ai].reduce == pstk::VX_MOST_COMMON_BOOL;
-  for (uint64_t grp = wave0; grp < n_groups; grp += n_waves) {
+// The 64 voxels of group `grp`, by the waves of one workgroup WITHOUT staging: every wave computes the voxels' sizes, wave 0 takes the small
+// voxels one per lane, and the waves share the voxels that need a whole wave (most-common attributes; everything of large voxels) round robin.
+// `skip_avg`: the averages and max-pools of this group have been reduced from LDS already (voxel_reduce_kernel below).
+__device__ __forceinline__ void reduce_group_by_waves(const VoxelArgs& a, uint64_t grp, uint32_t lane, uint32_t wave, uint32_t n_waves, bool any_mode, bool skip_avg) {
+  {
     // ---- phase 1: lane l owns voxel 64*grp + l; averages and max-pools of small voxels ----
     const uint64_t lv = grp * 64 + lane;
     uint32_t lm = 0;
     uint64_t ls = 0;
     if (lv < a.n_voxels) { ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); }
-    const bool small = lm != 0 && lm <= kSmallVoxel;
-    if (small) {
+    const bool small = lm != 0 && (lm <= kSmallVoxel || skip_avg);
+    if (small && !skip_avg && wave == 0) {
       for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
         const VoxelAttr& at = a.attrs[ai];
         if (at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM || at.reduce == pstk::VX_MAX_POOL)
           reduce_voxel_by_lane(at, a.sorted_idx + ls, lm, a.dst_first + lv);
       }
     }
-    // ---- phase 2: the wave walks the voxels that still need it: most-common attributes, and everything of large voxels ----
+    // ---- phase 2: the waves walk the voxels that still need one: most-common attributes, and everything of large voxels ----
     uint64_t todo = __ballot(lm != 0 && (any_mode || !small));
+    uint32_t turn = 0;
     while (todo) {
       const uint32_t vl = (uint32_t)__builtin_ctzll(todo);
       todo &= todo - 1;
+      if (turn++ % n_waves != wave) continue;
       const uint64_t v = grp * 64 + vl;
       const uint64_t s = a.starts[v];
       const uint32_t m = (uint32_t)(a.starts[v + 1] - s);  // n < 2^32
-      const bool by_lane_done = m <= kSmallVoxel;
+      const bool by_lane_done = m <= kSmallVoxel || skip_avg;
       const uint32_t* idx = a.sorted_idx + s;
       const uint64_t out = a.dst_first + v;
       if (m > kMidVoxel && lane == 0) a.big_list[atomicAdd(a.big_count, 1u)] = (uint32_t)v;
@@ -383,6 +405,95 @@ __global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a)
   }
 }
 
+// One workgroup per group of 64 consecutive voxels.  Averages and max-pools are reduced from LDS: the group's points (consecutive in the sorted
+// order: starts[64 grp] .. starts[64 grp + 64)) are fetched by ALL lanes of the workgroup, one point per lane and step with the index list read
+// lane-contiguously -- as many independent random reads in flight as a plain permutation of the points has -- and stored by component; then lane l
+// of wave c adds component c of voxel l's points in their sorted (= original) order, the reference's `x_sum += v.x` loop (:343-376, :400-431).
+// The one-voxel-per-lane loop over global memory that this replaces kept one dependent index -> point chain per lane (3.3 ms per 10^8 points
+// against 2.4 ms for a permutation).  Groups with more than `cap` points (dense voxels) go the unstaged way, shared by the four waves.
+__global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a, const uint32_t cap) {
+  extern __shared__ double staged[];  // [3][cap]
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t grp = blockIdx.x;
+  bool any_mode = false, any_avg = false;
+  for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+    const uint32_t r = a.attrs[ai].reduce;
+    any_mode = any_mode || r == pstk::VX_MOST_COMMON || r == pstk::VX_MOST_COMMON_BOOL;
+    any_avg = any_avg || r == pstk::VX_AVG_VEC || r == pstk::VX_AVG_NUM || r == pstk::VX_MAX_POOL;
+  }
+  const uint64_t v0 = grp * 64, v1 = v0 + 64 < a.n_voxels ? v0 + 64 : a.n_voxels;
+  const uint64_t p0 = a.starts[v0];
+  const uint64_t cnt64 = a.starts[v1] - p0;
+  const bool stage = any_avg && cnt64 <= (uint64_t)cap;
+  if (stage) {
+    const uint32_t cnt = (uint32_t)cnt64;
+    const uint64_t lv = v0 + lane;
+    uint32_t lm = 0, lo = 0;  // lane l: voxel v0 + l has lm points, the first is staged at `lo`
+    if (lv < a.n_voxels) { const uint64_t ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); lo = (uint32_t)(ls - p0); }
+    const uint32_t* __restrict__ idx = a.sorted_idx + p0;
+    for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
+      const VoxelAttr& at = a.attrs[ai];
+      if (!(at.reduce == pstk::VX_AVG_VEC || at.reduce == pstk::VX_AVG_NUM || at.reduce == pstk::VX_MAX_POOL)) continue;
+      const uint32_t nc = at.reduce == pstk::VX_AVG_VEC ? 3u : 1u, sk = scalar_of(at.kind);
+      // ---- fetch: four points per lane in flight --------------------------------------------------------------------------------------
+      constexpr int U = 4;
+      for (uint32_t j0 = tid; j0 < cnt; j0 += kBlock * U) {
+        uint32_t i[U];
+        double x0[U], x1[U], x2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint32_t j = j0 + (uint32_t)u * kBlock; i[u] = j < cnt ? idx[j] : idx[j0]; }
+        if (nc == 3 && sk == CT_F64) {
+          typedef double d2u __attribute__((ext_vector_type(2), aligned(1)));
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            cgptr_t p = (cgptr_t)as_global(at.src) + (uint64_t)i[u] * at.src_stride;
+            const d2u xy = *reinterpret_cast<const PST_AS_GLOBAL d2u*>(p);
+            x0[u] = xy.x; x1[u] = xy.y; x2[u] = load_un<double>(p + 16);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            x0[u] = load_as_f64(at, sk, i[u], 0);
+            if (nc == 3) { x1[u] = load_as_f64(at, sk, i[u], 1); x2[u] = load_as_f64(at, sk, i[u], 2); }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = j0 + (uint32_t)u * kBlock;
+          if (j < cnt) {
+            staged[j] = x0[u];
+            if (nc == 3) { staged[cap + j] = x1[u]; staged[2 * cap + j] = x2[u]; }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- reduce: wave c, lane l = component c of voxel v0 + l --------------------------------------------------------------------------
+      if (wave < nc && lm != 0) {
+        const double* __restrict__ col = staged + wave * cap + lo;
+        gptr_t d = as_global(at.dst) + (a.dst_first + lv) * at.dst_stride;
+        if (at.reduce == pstk::VX_MAX_POOL) {
+          double cur = 0.0;  // :175
+          for (uint32_t j = 0; j < lm; ++j) { const double x = col[j]; if (x > cur) cur = x; }
+          if (at.kind == 9) store_un<double>(d, cur);
+          else if (at.kind == 6) store_un<uint64_t>(d, rust_as<uint64_t, double>(cur));
+          else store_un<uint8_t>(d, rust_as<uint8_t, double>(cur));
+        } else {
+          double sum = 0.0;
+          for (uint32_t j = 0; j < lm; ++j) sum += col[j];
+          const double avg = sum / (double)lm;
+          if (at.reduce == pstk::VX_AVG_NUM) store_un<uint16_t>(d, rust_as<uint16_t, double>(avg));  // `as u16` :489, :638
+          else if (at.kind == 14) store_un<double>(d + 8 * wave, avg);
+          else if (at.kind == 11) store_un<uint16_t>(d + 2 * wave, rust_as<uint16_t, double>(avg));  // ColorRGB :626
+          else store_un<float>(d + 4 * wave, (float)avg);                                              // Normal :676
+        }
+      }
+      __syncthreads();
+    }
+    if (!any_mode) return;
+  }
+  reduce_group_by_waves(a, grp, lane, wave, kBlock / 64, any_mode, stage);
+}
+
 // One block per voxel with more than kMidVoxel points: 65536-bin histogram (ascending bins are ascending values) in the block's private global scratch.
 __global__ __launch_bounds__(kBlock) void voxel_mode_big_kernel(const VoxelArgs a, uint32_t* __restrict__ hist_all) {
   uint32_t* hist = hist_all + (size_t)blockIdx.x * 65536u;
@@ -435,18 +546,13 @@ static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_b
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
   VCK(st->keys.alloc(n * sizeof(KeyT), stream)); VCK(st->keys2.alloc(n * sizeof(KeyT), stream));
   VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)device_cus() * 16));
-  if (gx.n + gy.n + gz.n <= kLdsMarkers)
-    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, true>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
-                       st->idx.as<uint32_t>());
-  else
-    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, false>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
-                       st->idx.as<uint32_t>());
   const uint64_t tiles = (n + (uint64_t)kBlock * kHeadsPerThread - 1) / ((uint64_t)kBlock * kHeadsPerThread);
   size_t tmp_sort = 0, tmp_scan = 0;
+  constexpr bool own_keys = sizeof(KeyT) == 4;  // (32-bit keys: the library's own sort numbers the points and takes its first histogram from the key kernel)
+  RadixFirstPass first{nullptr, 0, 0, 0};
   auto sort = [&](void* tmp, size_t& bytes) {
-    if constexpr (sizeof(KeyT) == 4)
-      return sort_pairs_u32(tmp, bytes, st->keys.as<uint32_t>(), st->keys2.as<uint32_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream);
+    if constexpr (own_keys)
+      return sort_pairs_u32(tmp, bytes, st->keys.as<uint32_t>(), st->keys2.as<uint32_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream, true, &first);
     else
       return sort_pairs_u64(tmp, bytes, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream);
   };
@@ -455,6 +561,17 @@ static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_b
   VCK(st->unique.alloc((tiles + 1) * 8, stream));  // exclusive scan of the tile counts (+ the total)
   VCK(exclusive_sum_u32_u64(nullptr, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
   VCK(st->tmp.alloc(std::max(tmp_sort, tmp_scan), stream));
+  if constexpr (own_keys) first = sort_first_pass(st->tmp.p, n, end_bit);
+  RadixFirstPass walk = first;  // (no histogram wanted: the same walk, nothing counted)
+  if (!walk.counts) { walk.tile_size = 8192; walk.tiles = (uint32_t)((n + 8191) / 8192); walk.bits = 0; }
+  uint32_t* idx_out = own_keys ? nullptr : st->idx.as<uint32_t>();
+  const unsigned grid = (unsigned)std::max<uint32_t>(1, walk.tiles);
+  const uint32_t n_markers = gx.n + gy.n + gz.n;
+  if (n_markers <= kLdsMarkers)
+    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, true>), dim3(grid), dim3(kBlock), (size_t)n_markers * 8, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
+                       idx_out, walk);
+  else
+    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, false>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(), idx_out, walk);
   VCK(sort(st->tmp.p, tmp_sort));
   VCK(hipMemsetAsync(st->counts.as<uint32_t>() + tiles, 0, 4, stream));
   hipLaunchKernelGGL((voxel_heads_kernel<KeyT, false>), dim3((unsigned)tiles), dim3(kBlock), 0, stream, (const KeyT*)st->keys2.as<KeyT>(), n,
@@ -509,9 +626,18 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
     a.attrs[i] = VoxelAttr{src_addr[i], dst_addr[i], src_stride[i], dst_stride[i], reduce[i], kind[i]};
     any_mode = any_mode || reduce[i] == VX_MOST_COMMON || reduce[i] == VX_MOST_COMMON_BOOL;
   }
-  const uint64_t waves_needed = (st->n_voxels + 63) / 64;
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((waves_needed + 3) / 4, (uint64_t)device_cus() * 32));
-  hipLaunchKernelGGL(voxel_reduce_kernel, dim3(grid), dim3(kBlock), 0, stream, a);
+  // LDS for the points of 64 voxels: 1.6 x the average group (a Poisson-filled grid of 15 points per voxel: 960 +- 31 per group), between
+  // 1024 and 6144 points (24 .. 144 KiB: four .. one workgroups per CU); groups beyond it take the unstaged path
+  const uint64_t groups = (st->n_voxels + 63) / 64;
+  if (groups == 0) return hipGetLastError() == hipSuccess;
+  if (groups > 0x7FFFFFFFull) return false;
+  static const uint32_t cap_env = [] { const char* e = std::getenv("PST_VOXEL_STAGE"); return e && *e ? (uint32_t)std::strtoul(e, nullptr, 10) : ~0u; }();  // 0 = never stage (A/B)
+  uint32_t cap = (uint32_t)std::min<uint64_t>(6144, std::max<uint64_t>(1024, (st->n * 8 / 5) / groups + 63)) & ~63u;
+  if (cap_env != ~0u) cap = std::min<uint32_t>(cap_env, 6144) & ~63u;
+  const size_t lds = (size_t)std::max<uint32_t>(cap, 64) * 3 * sizeof(double);
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 3 * 8) == hipSuccess;
+  if (!lds_ok) return false;
+  hipLaunchKernelGGL(voxel_reduce_kernel, dim3((unsigned)groups), dim3(kBlock), lds, stream, a, cap);
   if (any_mode && st->n > kMidVoxel) {
     unsigned int n_big = 0;
     if (hipMemcpyAsync(&n_big, st->big_count.p, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;

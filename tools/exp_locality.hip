@@ -29,6 +29,25 @@ __global__ void __launch_bounds__(256) gather_kernel(P3* __restrict__ out, const
     out[i] = in[idx[i]];
 }
 
+// the library's reorder_kernel<UNROLL> (normals.hip): grid-stride, a 16-byte + an 8-byte load per point
+template <int UNROLL>
+__global__ __launch_bounds__(256) void reorder_like_kernel(const double* __restrict__ xyz, const uint32_t* __restrict__ idx, uint64_t n, double* __restrict__ sorted_xyz) {
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    const uint64_t step = (uint64_t)gridDim.x * 256 * UNROLL;
+    for (uint64_t j0 = (uint64_t)blockIdx.x * 256 * UNROLL + threadIdx.x; j0 < n; j0 += step) {
+        uint64_t i[UNROLL]; d2u xy[UNROLL]; double z[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { const uint64_t j = j0 + (uint64_t)u * 256; i[u] = j < n ? idx[j] : 0; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { xy[u] = *reinterpret_cast<const d2u*>(xyz + 3 * i[u]); z[u] = xyz[3 * i[u] + 2]; }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint64_t j = j0 + (uint64_t)u * 256;
+            if (j < n) { *reinterpret_cast<d2u*>(sorted_xyz + 3 * j) = xy[u]; sorted_xyz[3 * j + 2] = z[u]; }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) scatter_kernel(P3* __restrict__ out, const P3* __restrict__ in, const uint32_t* __restrict__ dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -53,6 +72,30 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
         printf("gather  window 2^%-2u points (%8.1f MB): %7.3f ms\n", lg, w * 24.0 / 1e6, best);
+        if (lg == 26) {
+            for (unsigned g : {2048u, 8192u, 32768u, 0u}) {
+                const unsigned grid = g ? g : (n + 511) / 512;
+                float b2 = 1e9f;
+                for (int r = 0; r < 4; ++r) {
+                    CK(hipEventRecord(e0));
+                    reorder_like_kernel<2><<<grid, 256>>>((const double*)a, idx, n, (double*)b);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); b2 = std::min(b2, ms);
+                }
+                printf("   reorder-like <2>, grid %8u: %7.3f ms\n", grid, b2);
+            }
+            for (unsigned g : {8192u, 0u}) {
+                const unsigned grid = g ? g : (n + 255) / 256;
+                float b2 = 1e9f;
+                for (int r = 0; r < 4; ++r) {
+                    CK(hipEventRecord(e0));
+                    reorder_like_kernel<1><<<grid, 256>>>((const double*)a, idx, n, (double*)b);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); b2 = std::min(b2, ms);
+                }
+                printf("   reorder-like <1>, grid %8u: %7.3f ms\n", grid, b2);
+            }
+        }
     }
     // stable bucket ranks on the host
     std::vector<uint32_t> dst(n);

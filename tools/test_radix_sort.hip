@@ -26,6 +26,8 @@ int main() {
       // a mix: uniform keys, and (every third case) keys confined to few values so that equal keys abound
       const bool few = (n + bits) % 3 == 0;
       for (size_t i = 0; i < n; ++i) { k[i] = (uint32_t)rng() & mask; if (few) k[i] &= 0x1Fu; v[i] = (uint32_t)i; }
+      const bool iota = (n + bits) % 2 == 1;  // the sort numbers the elements itself: the value buffer then holds garbage
+      if (iota) for (size_t i = 0; i < n; ++i) v[i] = 0xDEADBEEFu;
       uint32_t *ka, *kb, *va, *vb;
       CK(hipMalloc(&ka, n * 4 + 16)); CK(hipMalloc(&kb, n * 4 + 16)); CK(hipMalloc(&va, n * 4 + 16)); CK(hipMalloc(&vb, n * 4 + 16));
       CK(hipMemcpy(ka, k.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, v.data(), n * 4, hipMemcpyHostToDevice));
@@ -33,7 +35,7 @@ int main() {
       CK(pstk::radix_sort_pairs_u32(nullptr, bytes, ka, kb, va, vb, n, bits, nullptr));
       void* tmp;
       CK(hipMalloc(&tmp, bytes));
-      CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr));
+      CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr, iota));
       CK(hipDeviceSynchronize());
       double ms = 0;
       if (n >= (1 << 20)) {
@@ -42,7 +44,7 @@ int main() {
         float best = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
           CK(hipMemcpy(ka, k.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(va, v.data(), n * 4, hipMemcpyHostToDevice));
-          CK(hipEventRecord(e0)); CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr)); CK(hipEventRecord(e1));
+          CK(hipEventRecord(e0)); CK(pstk::radix_sort_pairs_u32(tmp, bytes, ka, kb, va, vb, n, bits, nullptr, iota)); CK(hipEventRecord(e1));
           CK(hipEventSynchronize(e1));
           float t; CK(hipEventElapsedTime(&t, e0, e1)); best = std::min(best, t);
         }
@@ -56,7 +58,7 @@ int main() {
       bool ok = true;
       for (size_t i = 0; i < n && ok; ++i) ok = gv[i] == order[i] && gk[i] == k[order[i]];
       if (!ok) { ++fails; printf("MISMATCH n=%zu bits=%u few=%d\n", n, bits, (int)few); }
-      else if (ms > 0) printf("ok n=%zu bits=%u %s: %.3f ms\n", n, bits, few ? "few" : "uniform", ms);
+      else if (ms > 0) printf("ok n=%zu bits=%u %s%s: %.3f ms\n", n, bits, few ? "few" : "uniform", iota ? " (values numbered by the sort)" : "", ms);
       CK(hipFree(ka)); CK(hipFree(kb)); CK(hipFree(va)); CK(hipFree(vb)); CK(hipFree(tmp));
     }
   }
