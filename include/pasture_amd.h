@@ -167,6 +167,12 @@ int pst_buffer_append(pst_buffer* self, const pst_buffer* other);
  * *out_matches (optional) = number of mask hits. */
 int pst_buffer_filter_into(const pst_buffer* src, pst_buffer* dst, const uint8_t* mask, uint32_t mask_memkind, int64_t num_matches_hint,
                            size_t* out_matches);
+/* stream-ordered variant for callers that know the count (`Some(num_matches)`, as the reference's bench passes it,
+ * benches/buffer_filter_bench.rs:62-74): count, scan and copies are enqueued on the current stream and the call returns; no host
+ * synchronisation, no panic mapping.  The mask is a device pointer.  At most num_matches points are written; the number of mask hits
+ * is copied to *device_count_out (device-accessible memory, optional) in stream order -- a value above num_matches is the
+ * reference's slice panic (:1103-1108) and the caller's to check.  dst->len < num_matches -> PST_ERR_RANGE (checked on the host). */
+int pst_buffer_filter_into_async(const pst_buffer* src, pst_buffer* dst, const uint8_t* device_mask, size_t num_matches, uint64_t* device_count_out);
 /* HashMapBuffer::filter::<B, _> (point_buffer.rs:1064-1076): new buffer of out_storage holding exactly the matching points */
 int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, pst_buffer** out);
 

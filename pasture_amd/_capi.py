@@ -139,6 +139,7 @@ _PRODUCT_SIGNATURES = {
     "las_encode_range_async": [_P, _SZ, _SZ, C.c_uint32, _D3, _D3, _P, _SZ, _P, _P, C.c_uint32],
     "compute_normals_into": [_P, _SZ, _P],
     "compute_normals_device": [_P, _SZ, _P, _P, _P],
+    "buffer_filter_into_async": [_P, _P, _P, C.c_size_t, _P],
     "release_scratch": [],
     "reload_tuning": [],
     "comm_unique_id": [_P],

@@ -168,6 +168,11 @@ class _Buffer:
         self.api.buffer_filter_into(self._h, buffer._h, ptr, kind, -1 if num_matches_hint is None else num_matches_hint, C.byref(n))
         return n.value
 
+    def filter_into_async(self, buffer: "_Buffer", device_mask_ptr: int, num_matches: int, device_count_ptr: int = 0) -> None:
+        """Stream-ordered filter_into for a device mask and a known count (`Some(num_matches)`): nothing waits on the host; the number
+        of mask hits lands in the 8 bytes at device_count_ptr (optional) in stream order."""
+        self.api.buffer_filter_into_async(self._h, buffer._h, C.c_void_p(int(device_mask_ptr)), num_matches, C.c_void_p(int(device_count_ptr) or None))
+
     # device-side helpers ---------------------------------------------------------------------------------
     def synth_fill(self, seed: int, first_index: int = 0) -> None:
         self.api.buffer_synth_fill(self._h, seed, first_index)

@@ -20,7 +20,8 @@ __global__ void iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
 }  // namespace
 
 RadixFirstPass sort_first_pass(void* tmp, size_t n, unsigned end_bit) {
-  if (library_sort_only() || !radix_sort_pairs_supported(n, end_bit) || !tmp || n == 0) return RadixFirstPass{nullptr, 0, 0, 0};
+  static const bool no_fuse = [] { const char* e = std::getenv("PST_SORT_FUSE"); return e && *e == '0'; }();  // A/B: the sort counts its first histogram itself
+  if (no_fuse || library_sort_only() || !radix_sort_pairs_supported(n, end_bit) || !tmp || n == 0) return RadixFirstPass{nullptr, 0, 0, 0};
   return radix_sort_first_pass(tmp, n, end_bit);
 }
 

@@ -1,6 +1,7 @@
 // pst_buffer_append / pst_buffer_filter_into / pst_buffer_filter: host plumbing for append and predicate compaction.
 // Reference: pasture-core/src/containers/point_buffer.rs:419-489 (OwningBufferExt::append), :1064-1136 (HashMapBuffer::filter,
 // filter_into); the predicate arrives as a byte mask (benches/buffer_filter_bench.rs:62-64).
+#include <cstdint>
 #include <memory>
 
 #include "runtime.hpp"
@@ -18,7 +19,10 @@ struct TempDev {
 // Compaction of src's points with mask != 0 into dst[0, matches); returns the number of matches.
 // counted: the caller has just run launch_filter_count for the same mask / length (the tile counts and offsets are still in the
 // workspace and `num_matches_hint` is the count it read): the count and scan launches are not repeated.
-size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, bool mask_on_device, int64_t num_matches_hint, bool counted = false) {
+// count_out (stream-ordered form): no host synchronisation at all -- the count is copied to `count_out` (device-accessible memory, optional)
+// in stream order and the "more matches than the hint" panic is the caller's to check; needs a device mask and a hint.
+size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, bool mask_on_device, int64_t num_matches_hint, bool counted = false,
+                   bool stream_ordered = false, unsigned long long* count_out = nullptr) {
   if (!src.columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
   if (dst.layout != src.layout) throw Error(PST_ERR_LAYOUT_MISMATCH, "PointLayouts must match");  // :1088-1090
   const size_t n = src.len;
@@ -40,7 +44,8 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   Workspace& ws = workspace();
   if (!counted) {
     pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s);
-    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (!stream_ordered) PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    else if (count_out) PST_HIP_CHECK(hipMemcpyAsync(count_out, total_dev, sizeof(unsigned long long), hipMemcpyDefault, s));
   }
   // With Some(num_matches) (the reference's bench passes it) nothing on the host depends on the count before the copies are
   // launched: count, scan and scatter run back to back and the count is read once, at the end.  Without it the target check
@@ -71,6 +76,7 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
       !pstk::launch_filter_scatter(mask_dev, n, tile, scratch, num_matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(),
                                    size.data(), (int)na, dst_aos, dst_aos ? aos_addr(dst, 0) : 0, dst_stride, covered == dst.layout.size, s))
     throw Error(PST_ERR_HIP, std::string("filter launch failed: ") + hipGetErrorString(hipGetLastError()));
+  if (stream_ordered) return num_matches;
   stream_sync(s);  // the staged mask is released on return
   if (hinted) matches = (size_t)*(const unsigned long long*)(ws.pinned + 768);
   if (matches > num_matches)  // the reference indexes dst_attribute_data[..num_matches] out of range (:1103-1108)
@@ -88,6 +94,17 @@ int pst_buffer_filter_into(const pst_buffer* src, pst_buffer* dst, const uint8_t
   if (mask_memkind > PST_MEM_PINNED_HOST) throw Error(PST_ERR_INVALID_ARGUMENT, "invalid mask memory kind");
   const size_t m = filter_into(*not_null(src, "src"), *not_null(dst, "dst"), mask, mask_memkind == PST_MEM_DEVICE, num_matches_hint);
   if (out_matches) *out_matches = m;
+  PST_API_END
+}
+
+int pst_buffer_filter_into_async(const pst_buffer* src, pst_buffer* dst, const uint8_t* device_mask, size_t num_matches, uint64_t* device_count_out) {
+  PST_API_BEGIN
+  if (num_matches > (size_t)INT64_MAX) throw Error(PST_ERR_INVALID_ARGUMENT, "num_matches out of range");
+  if (not_null(src, "src")->len == 0 && device_count_out) {
+    ensure_device();
+    PST_HIP_CHECK(hipMemsetAsync(device_count_out, 0, sizeof(unsigned long long), current_stream()));
+  }
+  filter_into(*src, *not_null(dst, "dst"), device_mask, true, (int64_t)num_matches, false, true, reinterpret_cast<unsigned long long*>(device_count_out));
   PST_API_END
 }
 

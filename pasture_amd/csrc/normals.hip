@@ -163,24 +163,36 @@ __global__ __launch_bounds__(kBlock) void keys_kernel(const double* __restrict__
       for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) hist[d] = 0;
       __syncthreads();
     }
-    for (uint32_t it = 0; it < steps; ++it) {
-      const uint64_t i = tile * walk.tile_size + (uint64_t)it * kBlock + threadIdx.x;
-      if (i >= n) break;
-      const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-      uint64_t key = kInvalidKey;
-      if (finite3(x, y, z)) {
-        double u, v, w;
-        grid_frame(g, x, y, z, u, v, w);
-        const uint32_t cx = cell_coord(u, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(v, g.org[1], g.inv_h, g.dim[1]),
-                       cz = cell_coord(w, g.org[2], g.inv_h, g.dim[2]);
-        key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
-        local += 1;
-      } else if (g.dense) {
-        key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
+    constexpr uint32_t U = 4;  // points per thread in flight (tile_size is a multiple of U * kBlock)
+    for (uint32_t it = 0; it < steps; it += U) {
+      const uint64_t i0 = tile * walk.tile_size + (uint64_t)it * kBlock + threadIdx.x;
+      if (i0 >= n) break;
+      double px[U], py[U], pz[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * kBlock < n ? i0 + (uint64_t)u * kBlock : i0;
+        px[u] = xyz[3 * i]; py[u] = xyz[3 * i + 1]; pz[u] = xyz[3 * i + 2];
       }
-      keys[i] = (KeyT)key;
-      if (idx) idx[i] = (uint32_t)i;
-      if (walk.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * kBlock;
+        if (i >= n) break;
+        const double x = px[u], y = py[u], z = pz[u];
+        uint64_t key = kInvalidKey;
+        if (finite3(x, y, z)) {
+          double uu, v, w;
+          grid_frame(g, x, y, z, uu, v, w);
+          const uint32_t cx = cell_coord(uu, g.org[0], g.inv_hx, g.dim[0]), cy = cell_coord(v, g.org[1], g.inv_h, g.dim[1]),
+                         cz = cell_coord(w, g.org[2], g.inv_h, g.dim[2]);
+          key = g.dense ? ((uint64_t)cz * g.dim[1] + cy) * g.dim[0] + cx : morton3(cx, cy, cz);
+          local += 1;
+        } else if (g.dense) {
+          key = (uint64_t)g.dim[0] * g.dim[1] * g.dim[2];  // one past the last cell: non-finite points sort to the end
+        }
+        keys[i] = (KeyT)key;
+        if (idx) idx[i] = (uint32_t)i;
+        if (walk.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+      }
     }
     if (walk.counts) {
       __syncthreads();
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void clear_flags_kernel(const uint32_t* __r
 
 // ---- grid search over global memory -------------------------------------------------------------------------------------------------
 // LIST: the queries are the sorted indices qlist[0 .. nq) (what the box kernel could not finish); otherwise all nf sorted points.
-constexpr int kScanBatch = 4;
+constexpr int kScanBatch = 4;    // candidates requested together by the one-lane-per-query search
 template <int K, bool DENSE, bool LIST>
 __global__ __launch_bounds__(kBlock, K <= 16 ? 4 : 1) void knn_grid_kernel(const double* __restrict__ sxyz, const uint64_t* __restrict__ skeys, uint32_t nf, uint32_t k,
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
@@ -478,8 +490,10 @@ __global__ __launch_bounds__(kBlock, K <= 16 ? 4 : 1) void knn_grid_kernel(const
   auto scan2 = [&](uint32_t p0, uint32_t p1, uint32_t q0, uint32_t q1) __attribute__((always_inline)) {
     const uint32_t lp = p1 - p0, total = lp + (q1 - q0);
     if (crowd && total > crowd) { crowded = true; return; }
-    // (kScanBatch candidates per step: one lane walks ~900 candidates when its k-th neighbour lies beyond the first shell, one round trip
-    //  to L2 per step -- 1.59 ms per 0.9 * 10^6 such queries with pairs)
+    // (kScanBatch candidates per step, all requested before the first is tested: 1.59 -> 1.48 ms per 0.9 * 10^6 queries of the 10^8-point
+    //  cloud against pairs.  Measured and dropped: a per-lane insertion queue in LDS, emptied when some lane's is nearly full -- an insertion
+    //  runs for the whole wave when ONE lane inserts, but the walk is bound by its dependent directory and candidate round trips, not by
+    //  instructions: 1.48 ms either way.)
     for (uint32_t v = 0; v < total; v += kScanBatch) {
       uint32_t pp[kScanBatch];
       double dd[kScanBatch];
@@ -490,7 +504,11 @@ __global__ __launch_bounds__(kBlock, K <= 16 ? 4 : 1) void knn_grid_kernel(const
       }
       double cx_[kScanBatch], cy_[kScanBatch], cz_[kScanBatch];
 #pragma unroll
-      for (int u = 0; u < kScanBatch; ++u) { cx_[u] = sxyz[3 * (uint64_t)pp[u]]; cy_[u] = sxyz[3 * (uint64_t)pp[u] + 1]; cz_[u] = sxyz[3 * (uint64_t)pp[u] + 2]; }
+      for (int u = 0; u < kScanBatch; ++u) {  // a 16-byte and an 8-byte request per point
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u xy = *reinterpret_cast<const d2u*>(sxyz + 3 * (uint64_t)pp[u]);
+        cx_[u] = xy.x; cy_[u] = xy.y; cz_[u] = sxyz[3 * (uint64_t)pp[u] + 2];
+      }
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {
         const double dx = cx_[u] - qx, dy = cy_[u] - qy, dz = cz_[u] - qz;
@@ -652,13 +670,47 @@ __global__ __launch_bounds__(kBlock) void knn_bound_kernel(const double* __restr
   if (blockIdx.x >= nq) return;
   const uint32_t j = qlist[blockIdx.x];
   const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
+  // eight points per thread and step, all requested before the first is tested (one workgroup walks the whole subsample)
+  constexpr int U = 8;
+  auto walk = [&](auto&& each) __attribute__((always_inline)) {
+    for (uint32_t p0 = threadIdx.x; p0 < n_sub; p0 += kBlock * U) {
+      double x[U], y[U], z[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * kBlock < n_sub ? p0 + (uint32_t)u * kBlock : p0;
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        const d2u xy = *reinterpret_cast<const d2u*>(sub + 3 * (uint64_t)p);
+        x[u] = xy.x; y[u] = xy.y; z[u] = sub[3 * (uint64_t)p + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double dx = x[u] - qx, dy = y[u] - qy, dz = z[u] - qz;
+        const double d = dx * dx + dy * dy + dz * dz;  // (NaN for a non-finite point of the subsample: fails every comparison below)
+        if (p0 + (uint32_t)u * kBlock < n_sub) each(d, p0 + (uint32_t)u * kBlock);
+      }
+    }
+  };
+  // Pass 1: every thread's nearest point.  The k-th smallest of these 256 minima (k <= 64 distinct points) is at least the k-th distance
+  // of the whole subsample, so pass 2 inserts only what lies within it -- a few dozen points per workgroup.  Without it every candidate of
+  // every thread walked the sorted list (an insertion runs for the whole wave when ONE lane inserts: 4096 x 110 instructions per wave, 3.2 ms
+  // for 1000 queries against 10^6 points).
+  __shared__ double mins[kBlock];
+  __shared__ double limit_s;
+  double mine = __builtin_inf();
+  walk([&](double d, uint32_t) __attribute__((always_inline)) { mine = d < mine ? d : mine; });
+  mins[threadIdx.x] = mine;
+  if (threadIdx.x == 0) limit_s = __builtin_inf();
+  __syncthreads();
+  {
+    uint32_t below = 0;  // minima ordered before this thread's (ties: lower thread first)
+    for (uint32_t t = 0; t < kBlock; ++t) { const double o = mins[t]; below += (o < mine || (o == mine && t < threadIdx.x)) ? 1u : 0u; }
+    if (below == k - 1 && k <= kBlock) limit_s = mine;  // (fewer than k finite minima: +inf, everything is inserted)
+  }
+  __syncthreads();
+  const double limit = limit_s;
   RecOut none{};
   block_select_and_fit<K>(sxyz, n_sub, k, j, none, bound + blockIdx.x, [&](auto&& take) __attribute__((always_inline)) {
-    for (uint32_t p = threadIdx.x; p < n_sub; p += kBlock) {
-      const double dx = sub[3 * (uint64_t)p] - qx, dy = sub[3 * (uint64_t)p + 1] - qy, dz = sub[3 * (uint64_t)p + 2] - qz;
-      const double d = dx * dx + dy * dy + dz * dz;
-      if (d == d) take(d, p);  // (the subsample may hold non-finite points)
-    }
+    walk([&](double d, uint32_t p) __attribute__((always_inline)) { if (d <= limit) take(d, p); });
   });
 }
 

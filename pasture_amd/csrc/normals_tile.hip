@@ -1017,14 +1017,19 @@ __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __re
     const int dim0 = (int)g.dim[0], dim1 = (int)g.dim[1], dim2 = (int)g.dim[2], XH = (int)g.rx + 1;
     const int X0 = (int)(box % nbx) * (int)bx, Y0 = (int)((box / nbx) % nby) * (int)by, Z0 = (int)(box / (nbx * nby)) * (int)bz;
     auto cl = [&](int x) { return (uint32_t)(x < 0 ? 0 : (x > dim0 ? dim0 : x)); };
-    for (int z = Z0 - kHalo; z < Z0 + (int)bz + kHalo; ++z)
-      for (int y = Y0 - kHalo; y < Y0 + (int)by + kHalo; ++y) {
-        if (y < 0 || y >= dim1 || z < 0 || z >= dim2) continue;
+    // the queries first: a box without one stages nothing, and its halo rows are not looked up (a surface in a 3-D grid: 88 % of the boxes)
+    for (int z = Z0; z < Z0 + (int)bz && z < dim2; ++z)
+      for (int y = Y0; y < Y0 + (int)by && y < dim1; ++y) {
         const uint64_t row = ((uint64_t)z * dim1 + (uint64_t)y) * dim0;
-        staged += cell_start[row + cl(X0 + (int)bx + XH)] - cell_start[row + cl(X0 - XH)];
-        if (y >= Y0 && y < Y0 + (int)by && z >= Z0 && z < Z0 + (int)bz) q += cell_start[row + cl(X0 + (int)bx)] - cell_start[row + cl(X0)];
+        q += cell_start[row + cl(X0 + (int)bx)] - cell_start[row + cl(X0)];
       }
-    if (q == 0) staged = 0;
+    if (q != 0)
+      for (int z = Z0 - kHalo; z < Z0 + (int)bz + kHalo; ++z)
+        for (int y = Y0 - kHalo; y < Y0 + (int)by + kHalo; ++y) {
+          if (y < 0 || y >= dim1 || z < 0 || z >= dim2) continue;
+          const uint64_t row = ((uint64_t)z * dim1 + (uint64_t)y) * dim0;
+          staged += cell_start[row + cl(X0 + (int)bx + XH)] - cell_start[row + cl(X0 - XH)];
+        }
     if (staged > cap) lost = q;
     occupied = q != 0;
   }

@@ -103,17 +103,28 @@ __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __res
       for (uint32_t d = threadIdx.x; d <= mask; d += kBlock) hist[d] = 0;
       __syncthreads();
     }
-    for (uint32_t it = 0; it < steps; ++it) {
-      const uint64_t i = tile * first.tile_size + (uint64_t)it * kBlock + threadIdx.x;
-      if (i >= n) break;
-      cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
-      const double x = load_un<double>(p), y = load_un<double>(p + 8), z = load_un<double>(p + 16);
-      const uint64_t kx = find_leaf_axis(x, gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(y, gy.markers, gy.n, gy.origin, gy.inv_leaf),
-                     kz = find_leaf_axis(z, gz.markers, gz.n, gz.origin, gz.inv_leaf);
-      const KeyT key = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
-      keys[i] = key;
-      if (idx) idx[i] = (uint32_t)i;
-      if (first.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+    constexpr uint32_t U = 4;  // points per thread in flight (tile_size is a multiple of U * kBlock)
+    for (uint32_t it = 0; it < steps; it += U) {
+      const uint64_t i0 = tile * first.tile_size + (uint64_t)it * kBlock + threadIdx.x;
+      if (i0 >= n) break;
+      double px[U], py[U], pz[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * kBlock < n ? i0 + (uint64_t)u * kBlock : i0;
+        cgptr_t p = (cgptr_t)((uint64_t)(uintptr_t)pos_base + i * pos_stride);
+        px[u] = load_un<double>(p); py[u] = load_un<double>(p + 8); pz[u] = load_un<double>(p + 16);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * kBlock;
+        if (i >= n) break;
+        const uint64_t kx = find_leaf_axis(px[u], gx.markers, gx.n, gx.origin, gx.inv_leaf), ky = find_leaf_axis(py[u], gy.markers, gy.n, gy.origin, gy.inv_leaf),
+                       kz = find_leaf_axis(pz[u], gz.markers, gz.n, gz.origin, gz.inv_leaf);
+        const KeyT key = (KeyT)((kx << gx.shift) | (ky << gy.shift) | kz);  // x-major: integer order == the reference's (x, y, z) tuple order
+        keys[i] = key;
+        if (idx) idx[i] = (uint32_t)i;
+        if (first.counts) atomicAdd(&hist[(uint32_t)key & mask], 1u);
+      }
     }
     if (first.counts) {
       __syncthreads();

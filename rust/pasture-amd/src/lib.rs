@@ -211,6 +211,16 @@ impl DeviceHashMapBuffer {
                                               num_matches_hint.map(|n| n as i64).unwrap_or(-1), &mut matches) });
         matches
     }
+
+    /// The stream-ordered form for `Some(num_matches)` and a mask that already lives on the device: count, scan and copies are enqueued and the
+    /// call returns.  `device_count_out` (device-accessible, may be null) receives the number of mask hits in stream order; more hits than
+    /// `num_matches` is the reference's slice panic (point_buffer.rs:1103-1108) and the caller's to check after its own synchronisation.
+    ///
+    /// # Safety
+    /// `device_mask` must point to `self.len()` bytes of device memory that stay valid until the stream has run the call.
+    pub unsafe fn filter_into_async(&self, buffer: &mut impl DeviceBuffer, device_mask: *const u8, num_matches: usize, device_count_out: *mut u64) {
+        check(pst_buffer_filter_into_async(self.raw(), buffer.handle(), device_mask, num_matches, device_count_out))
+    }
 }
 
 /// OwningBufferExt::append (point_buffer.rs:419-489)

@@ -132,3 +132,41 @@ def test_filter_into_hint_and_panics(api):
     assert src.filter_into(big, mask, n) == k
     for a in layout.attributes():
         assert np.array_equal(big.view_attribute(a.attribute_definition())[:k], rec[a.name()][mask])
+
+
+@pytest.mark.gpu
+def test_filter_into_async_matches_the_synchronous_call(hip):
+    """The stream-ordered filter_into (`Some(num_matches)`, device mask; point_buffer.rs:1082-1136): same target as the synchronous call, the
+    hit count delivered in stream order; a hint below the hit count writes only `hint` points and reports the real count (the reference's
+    slice panic :1103-1108 becomes the caller's check); a target shorter than the hint is refused on the host."""
+    import torch
+    api = hip
+    layout = custom_point_type_big(api)
+    n = 300_007
+    rec = random_records(layout, n, 9)
+    src = HashMapBuffer.from_numpy(rec, layout)
+    mask_h = np.random.default_rng(5).random(n) < 0.37
+    mask = torch.from_numpy(mask_h.astype(np.uint8)).cuda()
+    k = int(mask_h.sum())
+    hits = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    for kind in (HashMapBuffer, VectorBuffer):
+        got = kind.new_from_layout(layout)
+        got.resize(k)
+        src.filter_into_async(got, mask.data_ptr(), k, hits.data_ptr())
+        src.filter_into_async(got, mask.data_ptr(), k, hits.data_ptr())  # back to back on one stream: the scratch is reused in stream order
+        assert int(hits.item()) == k
+        assert_same(got, rec[mask_h])
+        # fewer points announced than the mask selects: only `hint` points are written, the count says what the mask holds
+        short = kind.new_from_layout(layout)
+        short.resize(k)
+        hint = k - 1000
+        src.filter_into_async(short, mask.data_ptr(), hint, hits.data_ptr())
+        assert int(hits.item()) == k
+        for a in layout.attributes():
+            col = short.get_attribute_range(a.attribute_definition(), range(0, k))
+            assert np.array_equal(col[:hint], rec[a.name()][mask_h][:hint]), a.name()
+            assert not np.ascontiguousarray(col[hint:]).view(np.uint8).any(), a.name()
+        tiny = kind.new_from_layout(layout)
+        tiny.resize(k - 1)
+        with pytest.raises(PasturePanic, match="at least as large as the number of predicate matches"):
+            src.filter_into_async(tiny, mask.data_ptr(), k)
