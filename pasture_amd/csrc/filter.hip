@@ -414,24 +414,41 @@ __global__ __launch_bounds__(kBlock) void filter_big_records_kernel(const Filter
     const uint32_t cm = (m - j0) < mc ? (m - j0) : mc;
     const uint64_t ga = a.dst_aos + (out0 + j0) * STRIDE;
     const uint32_t mis = (uint32_t)(ga & 15u);
-    for (uint32_t j = threadIdx.x; j < cm; j += kBlock) {
-      const uint64_t i = first + sel[j0 + j];
-      const uint64_t g = load_un<uint64_t>(gps + i * 8);
-      const uint32_t c0 = load_un<uint32_t>(col + i * 6);
-      const uint16_t c1 = load_un<uint16_t>(col + i * 6 + 4);
-      const u32x4 pa = load_un<u32x4>(pos + i * 24);
-      const uint64_t pz = load_un<uint64_t>(pos + i * 24 + 16);
-      const uint8_t cl = load_un<uint8_t>(cls + i);
-      const uint16_t in = load_un<uint16_t>(inten + i * 2);
-      pstlas::RecordImage<STRIDE> img;
-      img.put(0, 8, g);
-      img.put(8, 6, (uint64_t)c0 | ((uint64_t)c1 << 32));
-      img.put(14, 8, (uint64_t)pa.x | ((uint64_t)pa.y << 32));
-      img.put(22, 8, (uint64_t)pa.z | ((uint64_t)pa.w << 32));
-      img.put(30, 8, pz);
-      img.put(38, 1, cl);
-      img.put(39, 2, in);
-      img.store(lds + (mis + j * STRIDE));
+    // a chunk is up to three points per lane (24 KiB of 41-byte records, 256 lanes): the pieces of ALL of a lane's points are requested before
+    // the first record is assembled (one round trip per chunk instead of one per point)
+    constexpr int UG = 3;
+    for (uint32_t jb = threadIdx.x; jb < cm; jb += kBlock * UG) {
+      uint64_t g[UG], pz[UG];
+      uint32_t c0[UG];
+      uint16_t c1[UG], in[UG];
+      u32x4 pa[UG];
+      uint8_t cl[UG];
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const uint32_t j = jb + (uint32_t)u * kBlock < cm ? jb + (uint32_t)u * kBlock : jb;
+        const uint64_t i = first + sel[j0 + j];
+        g[u] = load_un<uint64_t>(gps + i * 8);
+        c0[u] = load_un<uint32_t>(col + i * 6);
+        c1[u] = load_un<uint16_t>(col + i * 6 + 4);
+        pa[u] = load_un<u32x4>(pos + i * 24);
+        pz[u] = load_un<uint64_t>(pos + i * 24 + 16);
+        cl[u] = load_un<uint8_t>(cls + i);
+        in[u] = load_un<uint16_t>(inten + i * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < UG; ++u) {
+        const uint32_t j = jb + (uint32_t)u * kBlock;
+        if (j >= cm) break;
+        pstlas::RecordImage<STRIDE> img;
+        img.put(0, 8, g[u]);
+        img.put(8, 6, (uint64_t)c0[u] | ((uint64_t)c1[u] << 32));
+        img.put(14, 8, (uint64_t)pa[u].x | ((uint64_t)pa[u].y << 32));
+        img.put(22, 8, (uint64_t)pa[u].z | ((uint64_t)pa[u].w << 32));
+        img.put(30, 8, pz[u]);
+        img.put(38, 1, cl[u]);
+        img.put(39, 2, in[u]);
+        img.store(lds + (mis + j * STRIDE));
+      }
     }
     __syncthreads();
     tile_store<kBlock>(lds, as_global(ga - mis), mis, cm * STRIDE);

@@ -714,11 +714,20 @@ __global__ __launch_bounds__(kBlock) void knn_bound_kernel(const double* __restr
   });
 }
 
-constexpr uint32_t kFilterPts = 4;     // points per thread of the filter
+constexpr uint32_t kFilterPts = 4;     // points per thread of the filter (per 10^8 points and 1000 queries: 2 -> 1.57 ms, 4 -> 1.56 ms, 8 -> 2.40 ms)
 constexpr uint32_t kFilterChunk = 256;  // queries staged per step
-__global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __restrict__ sxyz, uint32_t nf, const uint32_t* __restrict__ qlist, uint32_t nq,
-                                                            const double* __restrict__ bound, uint32_t cap, uint32_t* __restrict__ cand_count,
-                                                            uint32_t* __restrict__ cand) {
+// qpack[q] = {x, y, z, bound} of open query q (knn_pack_queries_kernel): every workgroup of the filter stages every query, and fetching them
+// through the query list (index -> point -> coordinates, a dependent round trip per chunk and workgroup) was most of its 1.7 ms
+__global__ __launch_bounds__(kBlock) void knn_pack_queries_kernel(const double* __restrict__ sxyz, const uint32_t* __restrict__ qlist, uint32_t nq,
+                                                                  const double* __restrict__ bound, double* __restrict__ qpack) {
+  const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t j = qlist[q];
+  qpack[4 * (uint64_t)q] = sxyz[3 * (uint64_t)j]; qpack[4 * (uint64_t)q + 1] = sxyz[3 * (uint64_t)j + 1]; qpack[4 * (uint64_t)q + 2] = sxyz[3 * (uint64_t)j + 2];
+  qpack[4 * (uint64_t)q + 3] = bound[q];
+}
+__global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __restrict__ sxyz, uint32_t nf, const double* __restrict__ qpack, uint32_t nq, uint32_t cap,
+                                                            uint32_t* __restrict__ cand_count, uint32_t* __restrict__ cand) {
   __shared__ double sq[4 * kFilterChunk];  // x, y, z, bound of the staged queries
   __shared__ double box[6];                // bounding box of the workgroup's points: consecutive SORTED points, a few grid cells
   __shared__ double scratch[(kBlock / 64) * 6];
@@ -727,10 +736,23 @@ __global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __rest
   const uint32_t p0 = (blockIdx.x * kBlock + threadIdx.x) * kFilterPts;
   double px[kFilterPts], py[kFilterPts], pz[kFilterPts];
   double mn[3] = {kF64Max, kF64Max, kF64Max}, mx[3] = {-kF64Max, -kF64Max, -kF64Max};
+  if (p0 + kFilterPts <= nf) {  // the thread's points are 24 * kFilterPts contiguous bytes (16-byte aligned: kFilterPts is even): 16-byte requests
+    static_assert(kFilterPts % 2 == 0, "whole 16-byte pieces");
+    typedef double d2a __attribute__((ext_vector_type(2)));
+    double w[3 * kFilterPts];
+#pragma unroll
+    for (uint32_t i = 0; i < 3 * kFilterPts / 2; ++i) { const d2a v = *reinterpret_cast<const d2a*>(sxyz + 3 * (uint64_t)p0 + 2 * i); w[2 * i] = v.x; w[2 * i + 1] = v.y; }
+#pragma unroll
+    for (uint32_t u = 0; u < kFilterPts; ++u) { px[u] = w[3 * u]; py[u] = w[3 * u + 1]; pz[u] = w[3 * u + 2]; }
+  } else {
+#pragma unroll
+    for (uint32_t u = 0; u < kFilterPts; ++u) {
+      const uint32_t p = p0 + u < nf ? p0 + u : nf - 1;
+      px[u] = sxyz[3 * (uint64_t)p]; py[u] = sxyz[3 * (uint64_t)p + 1]; pz[u] = sxyz[3 * (uint64_t)p + 2];
+    }
+  }
 #pragma unroll
   for (uint32_t u = 0; u < kFilterPts; ++u) {
-    const uint32_t p = p0 + u < nf ? p0 + u : nf - 1;
-    px[u] = sxyz[3 * (uint64_t)p]; py[u] = sxyz[3 * (uint64_t)p + 1]; pz[u] = sxyz[3 * (uint64_t)p + 2];
     mn[0] = __builtin_fmin(mn[0], px[u]); mx[0] = __builtin_fmax(mx[0], px[u]);
     mn[1] = __builtin_fmin(mn[1], py[u]); mx[1] = __builtin_fmax(mx[1], py[u]);
     mn[2] = __builtin_fmin(mn[2], pz[u]); mx[2] = __builtin_fmax(mx[2], pz[u]);
@@ -743,8 +765,9 @@ __global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __rest
     if (threadIdx.x == 0) n_act = 0;
     __syncthreads();
     if (threadIdx.x < cnt) {
-      const uint32_t j = qlist[q0 + threadIdx.x];
-      const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2], b = bound[q0 + threadIdx.x];
+      typedef double d2a __attribute__((ext_vector_type(2)));
+      const d2a xy = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + threadIdx.x)), zb = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + threadIdx.x) + 2);
+      const double qx = xy.x, qy = xy.y, qz = zb.x, b = zb.y;
       sq[threadIdx.x] = qx; sq[kFilterChunk + threadIdx.x] = qy; sq[2 * kFilterChunk + threadIdx.x] = qz; sq[3 * kFilterChunk + threadIdx.x] = b;
       // squared distance from the query to the box: only a query whose bound reaches the box can find a candidate here
       const double ex = __builtin_fmax(0.0, __builtin_fmax(box[0] - qx, qx - box[3])), ey = __builtin_fmax(0.0, __builtin_fmax(box[1] - qy, qy - box[4])),
@@ -1280,6 +1303,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           box_sink.alloc = [&](size_t bytes) -> uint32_t* { CacheBuf b; return b.alloc(bytes, stream) == hipSuccess ? b.as<uint32_t>() : nullptr; };
           box_sink.count_dev = (uint32_t*)((uint8_t*)counters.p + 76);
           box_sink.list = nullptr; box_sink.n = 0;
+          box_sink.sorted_cells = keys2.as<uint32_t>();  // (dense grids: 32-bit row-major cell numbers, sorted)
           tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape, (!fills && tune.box_list) ? &box_sink : nullptr);
           mark("census");
           break;
@@ -1408,9 +1432,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
                              partials.as<double>());
         }
         const uint32_t cand_cap = 4096, batch = 16384;  // (16 KB of candidate list per open query: 256 MB per batch)
-        CacheBuf bound, cand_count, cand;
+        CacheBuf bound, cand_count, cand, qpack;
         const uint32_t n_b = std::min(n_q, batch);
         ACK(bound.alloc((size_t)n_b * 8, stream));
+        ACK(qpack.alloc((size_t)n_b * 32, stream));
         ACK(cand_count.alloc((size_t)n_b * 4, stream));
         ACK(cand.alloc((size_t)n_b * cand_cap * 4, stream));
         for (uint32_t off = 0; off < n_q; off += batch) {
@@ -1421,8 +1446,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           // candidates per query, which the culled filter and the select kernel barely notice, for a quarter of the scan)
           const uint32_t n_bound = (uint32_t)std::max<uint64_t>(n_sub / 4, std::min<uint64_t>(n_sub, 1u << 18));
           KNN_DISPATCH(knn_bound_kernel, cnt, sorted_xyz.as<double>(), ql, cnt, (const double*)xyz_s.as<double>(), n_bound, k, bound.as<double>());
+          hipLaunchKernelGGL(knn_pack_queries_kernel, dim3((cnt + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, (const double*)sorted_xyz.as<double>(), ql, cnt,
+                             (const double*)bound.as<double>(), qpack.as<double>());
           hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)((nf + kBlock * kFilterPts - 1) / (kBlock * kFilterPts))), dim3(kBlock), 0, stream,
-                             (const double*)sorted_xyz.as<double>(), (uint32_t)nf, ql, cnt, (const double*)bound.as<double>(), cand_cap, cand_count.as<uint32_t>(),
+                             (const double*)sorted_xyz.as<double>(), (uint32_t)nf, (const double*)qpack.as<double>(), cnt, cand_cap, cand_count.as<uint32_t>(),
                              cand.as<uint32_t>());
           KNN_DISPATCH(knn_select_kernel, cnt, sorted_xyz.as<double>(), (uint32_t)nf, k, ql, cnt, (const uint32_t*)cand_count.as<uint32_t>(),
                        (const uint32_t*)cand.as<uint32_t>(), cand_cap, sorted);

@@ -19,6 +19,8 @@ struct BoxListSink {
   uint32_t* count_dev = nullptr;           // one device word
   const uint32_t* list = nullptr;
   uint32_t n = 0;
+  const uint32_t* sorted_cells = nullptr;  // the points' cell numbers in sorted order (the index builder's keys), or null: a census of a grid
+                                           // far larger than the cloud counts the queries of the boxes from these instead of the directory
 };
 bool knn_tile_shape(const pstn::GridParams& g, uint64_t nf, uint64_t cells, uint32_t k, bool volume_like, const uint32_t* cell_start,
                     unsigned long long* scratch3, hipStream_t stream, TileShape& t, BoxListSink* sink = nullptr);

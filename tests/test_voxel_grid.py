@@ -248,3 +248,21 @@ def test_nan_coordinates_fall_into_marker_zero(api):
     assert np.array_equal(pos[1], [5.0, 5.0, 5.0]) and inten[1] == 50
     assert np.array_equal(pos[2], [9.0, 9.0, 9.0]) and inten[2] == 30
     assert pos[3][0] == 9.1 and np.isnan(pos[3][1]) and inten[3] == 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["0", "64", "6144"])
+def test_voxel_reduction_paths_agree(stage):
+    """The centroid reduction has two paths per group of 64 voxels -- staged through LDS (the group's points fetched one per lane, sums from LDS)
+    and unstaged (one voxel per lane or per wave over global memory) -- chosen by the group's size against a capacity derived from the average
+    voxel.  PST_VOXEL_STAGE pins the capacity (0 = never stage, 64 = only groups of single-point voxels, 6144 = the maximum): this file's
+    product cases must pass with every setting (the switch is read once per process, hence the child interpreter)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PST_VOXEL_STAGE=stage)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_voxel_grid.py"), "-x", "-q", "-m", "gpu", "-k", "not test_voxel_reduction_paths_agree",
+                        "-p", "no:cacheprovider"], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
