@@ -1037,21 +1037,35 @@ __global__ __launch_bounds__(kBlock) void knn_census_kernel(const uint32_t* __re
     if (staged > cap) lost = q;
     occupied = q != 0;
   }
-  if (list) {  // the boxes that hold a query, ascending within a wave (a wave appends its boxes with ONE atomic): the launch list of the box search
-    const uint64_t m = __builtin_amdgcn_ballot_w64(occupied != 0);
-    if (m) {
-      const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__builtin_ctzll(m);
-      uint32_t base = 0;
-      if (lane == first) base = atomicAdd(list_count, (uint32_t)__builtin_popcountll(m));
-      base = (uint32_t)__shfl((int)base, (int)first, 64);
-      if (occupied) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = box;
-    }
-  }
+  // Atomics on one address are served one after the other (~10 ns each): the workgroup, not the wave, appends its boxes and adds its sums.
+  __shared__ uint32_t wave_occ[kBlock / 64];
+  __shared__ uint32_t list_base;
+  __shared__ unsigned long long wave_sums[kBlock / 64][4];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint64_t m = __builtin_amdgcn_ballot_w64(occupied != 0);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    q += shfl_xor_any(q, off); staged += shfl_xor_any(staged, off); lost += shfl_xor_any(lost, off); occupied += shfl_xor_any(occupied, off);
+    q += shfl_xor_any(q, off); staged += shfl_xor_any(staged, off); lost += shfl_xor_any(lost, off);
   }
-  if ((threadIdx.x & 63u) == 0 && q) { atomicAdd(sums, q); atomicAdd(sums + 1, staged); atomicAdd(sums + 2, lost); atomicAdd(sums + 3, occupied); }
+  if (lane == 0) {
+    wave_occ[wave] = (uint32_t)__builtin_popcountll(m);
+    wave_sums[wave][0] = q; wave_sums[wave][1] = staged; wave_sums[wave][2] = lost;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t[3] = {0, 0, 0};
+    uint32_t occ = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { t[0] += wave_sums[w][0]; t[1] += wave_sums[w][1]; t[2] += wave_sums[w][2]; occ += wave_occ[w]; }
+    if (t[0]) { atomicAdd(sums, t[0]); atomicAdd(sums + 1, t[1]); atomicAdd(sums + 2, t[2]); atomicAdd(sums + 3, (unsigned long long)occ); }
+    list_base = list && occ ? atomicAdd(list_count, occ) : 0u;
+  }
+  if (list) {  // the boxes that hold a query, ascending within a workgroup: the launch list of the box search
+    __syncthreads();
+    uint32_t before = list_base;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_occ[w];
+    if (occupied) list[before + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = box;
+  }
 }
 
 // ---- queries per box from the sorted cell numbers: one lane per point, runs of one box (the points of a row segment are consecutive) are
