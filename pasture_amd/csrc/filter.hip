@@ -60,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __res
 // (one 16-byte load), so 10^8 points (48,829 tiles) need 12 rounds of a 1024-thread scan (16 counts per thread and 3 rounds measured
 // slower: the 16 strided 8-byte stores per thread cost more than the saved rounds).
 constexpr uint32_t kScanPer = 4;
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets) {
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets,
+                                                         unsigned long long* __restrict__ total_also) {  // total_also: a caller's word that receives the total too (or null)
   __shared__ unsigned long long wave_tot[2][16];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned long long carry = 0;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
     for (uint32_t k = 0; k < kScanPer; ++k) { if (i0 + k < n_tiles) offsets[i0 + k] = before; before += c[k]; }
     carry += all;
   }
-  if (threadIdx.x == 0) offsets[n_tiles] = carry;
+  if (threadIdx.x == 0) { offsets[n_tiles] = carry; if (total_also) *total_also = carry; }
 }
 
 constexpr int kMaxFilterAttrs = 32;
@@ -494,13 +495,13 @@ static uint32_t filter_chunk(uint32_t dst_stride, long default_budget = 15L * 10
 
 // Phase 1: counts + offsets (offsets[n_tiles] = number of matches), device memory inside `workspace`.
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
-                         hipStream_t stream) {
+                         hipStream_t stream, unsigned long long* total_also) {
   const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
   unsigned long long* offsets = (unsigned long long*)workspace;
   uint32_t* counts = (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
   const uint32_t tiles_per_block = (kBlock / 64) * kCountTilesPerWave;
   hipLaunchKernelGGL(mask_count_kernel, dim3((n_tiles + tiles_per_block - 1) / tiles_per_block), dim3(kBlock), 0, stream, mask_dev, n, tile, n_tiles, counts);
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)counts, n_tiles, offsets);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)counts, n_tiles, offsets, total_also);
   *out_total_dev = offsets + n_tiles;
 }
 

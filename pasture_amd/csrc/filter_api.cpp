@@ -43,9 +43,9 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   const unsigned long long* total_dev = nullptr;
   Workspace& ws = workspace();
   if (!counted) {
-    pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s);
+    // (stream-ordered form: the scan kernel writes the total to the caller's word itself -- no copy operation between the kernels)
+    pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s, stream_ordered ? count_out : nullptr);
     if (!stream_ordered) PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    else if (count_out) PST_HIP_CHECK(hipMemcpyAsync(count_out, total_dev, sizeof(unsigned long long), hipMemcpyDefault, s));
   }
   // With Some(num_matches) (the reference's bench passes it) nothing on the host depends on the count before the copies are
   // launched: count, scan and scatter run back to back and the count is read once, at the end.  Without it the target check

@@ -84,7 +84,7 @@ bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint6
 size_t filter_workspace_bytes(uint64_t n);
 uint32_t filter_tile(bool dst_aos, uint32_t dst_stride);
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
-                         hipStream_t stream);
+                         hipStream_t stream, unsigned long long* total_also = nullptr);
 bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, uint64_t limit, const uint64_t* src_addr,
                            const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_off, const uint32_t* size, int n_attrs,
                            bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream);

@@ -550,11 +550,6 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
   __shared__ uint32_t qpre[kMaxQRows + 1];
   __shared__ uint16_t qbuf[kQ * THREADS];
   __shared__ uint32_t s_next;
-  // queries the box hands to the exact search: collected here and appended to the global list with ONE atomic per workgroup (an atomic on the list's
-  // counter is a round trip to memory for the wave that waits for it -- 0.68 * 10^6 of them per 10^8 uniform points, one per chunk with a failure)
-  constexpr uint32_t kLocalFb = 64;
-  __shared__ uint32_t fb_local[kLocalFb];
-  __shared__ uint32_t fb_n;
   constexpr int NW = THREADS / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t wg = xcd_block_id();
@@ -596,7 +591,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       raw[r * 32 + c] = row_in_grid(r, c0) ? a.cell_start[c0 + clamp_x(X0 - XH + c)] : 0u;
     }
   }
-  if (tid == 0) { s_next = 0; fb_n = 0; }
+  if (tid == 0) s_next = 0;
 #pragma unroll
   for (int i = 0; i < kQ; ++i) qbuf[i * THREADS + tid] = 0;
   __syncthreads();  // (1)
@@ -918,11 +913,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     }
     const bool done = a.ablate ? true : !outside && ok;
     PST_KNN_STAT(if (active && !outside && !ok) atomicAdd(a.dbg + 5, 1ull);)
-    if (active && !done) {
-      const uint32_t sl = atomicAdd(&fb_n, 1u);
-      if (sl < kLocalFb) fb_local[sl] = j;
-      else a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
-    }
+    if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
     // (the original index is requested here, together with the neighbours' coordinates: a load left in flight across the scan loop is
     //  waited for at the loop's head, and this one comes from HBM)
     const uint32_t orig = active && done ? a.out.sidx[j] : 0u;
@@ -971,14 +962,6 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       write_record(a.out, orig, f);
     }
     PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
-  }
-  __syncthreads();  // every wave has left the chunk loop: the box's list of handed-back queries is complete
-  if (wave == 0) {
-    const uint32_t nl = fb_n < kLocalFb ? fb_n : kLocalFb;
-    uint32_t base = 0;
-    if (lane == 0 && nl) base = atomicAdd(a.fb_count, nl);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (lane < nl) a.fb_list[base + lane] = fb_local[lane];
   }
   PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 14, (unsigned long long)(clock64() - t_start));)
 }
