@@ -908,6 +908,27 @@ struct CacheBuf {  // same surface as DevBuf
   hipError_t alloc(size_t bytes, hipStream_t) { p = scratch_cache().take(bytes); return p ? hipSuccess : hipErrorOutOfMemory; }
   template <typename T> T* as() { return (T*)p; }
 };
+// A second stream per calling thread and device: the permutation of the points (reorder_kernel: bound by random read requests) runs there while
+// the caller's stream builds the cell directory from the sorted keys (bound by streaming writes: 7.5 GB for a LiDAR sheet of 10^8 points) --
+// the two need nothing from each other.  fork / join: events that order the side stream behind, and the caller's stream after, that work.
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+SideStream& side_stream() {
+  thread_local std::vector<SideStream> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if ((size_t)dev >= per_device.size()) per_device.resize((size_t)dev + 1);
+  SideStream& ss = per_device[(size_t)dev];
+  if (!ss.s) {
+    ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+    if (!ss.ok) (void)hipGetLastError();
+  }
+  return ss;
+}
 struct CallGuard {
   hipStream_t stream;
   ~CallGuard() { (void)hipStreamSynchronize(stream); scratch_cache().end_call(); }  // blocks go back only when nothing in flight uses them
@@ -1026,6 +1047,11 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
     // (src, cnt): the points to index -- all of them, or the subsample the density estimate below works on
     auto build_index = [&](double h, uint32_t rx, bool dense, const double* src = nullptr, uint64_t cnt = 0) -> bool {
 #define BCK(x) do { if ((x) != hipSuccess) return false; } while (0)
+      struct Join {  // every way out of this function: the caller's stream waits for what was sent to the side stream
+        hipStream_t stream;
+        SideStream* ss = nullptr;
+        ~Join() { if (ss && hipStreamWaitEvent(stream, ss->join, 0) != hipSuccess) { (void)hipStreamSynchronize(ss->s); } }
+      } join{stream};
       if (!src) { src = xyz.as<double>(); cnt = n; }
       cells = grid_for(h, rx, g);
       g.dense = dense ? 1u : 0u;
@@ -1054,9 +1080,16 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         // 2.58 ms with 2048 workgroups looping (tools/exp_locality.hip)
         const int u = unroll >= 4 ? 4 : (unroll == 2 ? 2 : 1);
         const unsigned rgrid = (unsigned)std::max<uint64_t>(1, (cnt + (uint64_t)kBlock * u - 1) / ((uint64_t)kBlock * u));
-        if (u == 4) hipLaunchKernelGGL(reorder_kernel<4>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
-        else if (u == 2) hipLaunchKernelGGL(reorder_kernel<2>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
-        else hipLaunchKernelGGL(reorder_kernel<1>, dim3(rgrid), dim3(kBlock), 0, stream, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        // on the side stream, behind the sort; the caller's stream goes on to the directory and waits for the points when this function returns
+        hipStream_t rs = stream;
+        if (tune.side_stream) {
+          SideStream& ss = side_stream();
+          if (ss.ok && hipEventRecord(ss.fork, stream) == hipSuccess && hipStreamWaitEvent(ss.s, ss.fork, 0) == hipSuccess) { rs = ss.s; join.ss = &ss; }
+        }
+        if (u == 4) hipLaunchKernelGGL(reorder_kernel<4>, dim3(rgrid), dim3(kBlock), 0, rs, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else if (u == 2) hipLaunchKernelGGL(reorder_kernel<2>, dim3(rgrid), dim3(kBlock), 0, rs, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        else hipLaunchKernelGGL(reorder_kernel<1>, dim3(rgrid), dim3(kBlock), 0, rs, src, idx2.as<uint32_t>(), cnt, sorted_xyz.as<double>());
+        if (join.ss && hipEventRecord(join.ss->join, rs) != hipSuccess) { (void)hipStreamSynchronize(rs); join.ss = nullptr; return false; }
       }
       unsigned long long h_counts[2] = {0, 0};
       BCK(hipMemcpyAsync(&h_counts[0], n_finite, 8, hipMemcpyDeviceToHost, stream));
