@@ -46,9 +46,10 @@ __global__ __launch_bounds__(kQPerBlock) void knn_scale_kernel(const double* __r
     __syncthreads();
     for (uint32_t e = t; e < 3 * cnt; e += kQPerBlock) tile[e] = cand[3ull * base + e];
     __syncthreads();
+#pragma unroll 4
     for (uint32_t c = 0; c < cnt; ++c) {  // every lane reads the same candidate: LDS broadcast
       const double dx = tile[3 * c] - qx, dy = tile[3 * c + 1] - qy, dz = tile[3 * c + 2] - qz;
-      const float d2 = (float)(dx * dx + dy * dy + dz * dz);
+      const float d2 = (float)__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));  // (an estimate: fused multiply-adds are welcome here)
       // bits >> 23 = the biased exponent: bin edges at powers of two.  0 (the query itself, duplicates) and everything below the range go
       // to bin 0; NaN / inf (non-finite coordinates) come out above the range and are not counted.
       const int b = (int)(__float_as_uint(d2) >> 23) - bin_off;
