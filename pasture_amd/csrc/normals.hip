@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void knn_bound_kernel(const double* __restr
 }
 
 constexpr uint32_t kFilterPts = 4;     // points per thread of the filter (per 10^8 points and 1000 queries: 2 -> 1.57 ms, 4 -> 1.56 ms, 8 -> 2.40 ms)
-constexpr uint32_t kFilterChunk = 256;  // queries staged per step
+constexpr uint32_t kFilterQPer = 4, kFilterChunk = kFilterQPer * 256;  // queries tested per lane and per step
 // qpack[q] = {x, y, z, bound} of open query q (knn_pack_queries_kernel): every workgroup of the filter stages every query, and fetching them
 // through the query list (index -> point -> coordinates, a dependent round trip per chunk and workgroup) was most of its 1.7 ms
 __global__ __launch_bounds__(kBlock) void knn_pack_queries_kernel(const double* __restrict__ sxyz, const uint32_t* __restrict__ qlist, uint32_t nq,
@@ -743,10 +743,9 @@ __global__ __launch_bounds__(kBlock) void knn_pack_queries_kernel(const double* 
 }
 __global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __restrict__ sxyz, uint32_t nf, const double* __restrict__ qpack, uint32_t nq, uint32_t cap,
                                                             uint32_t* __restrict__ cand_count, uint32_t* __restrict__ cand) {
-  __shared__ double sq[4 * kFilterChunk];  // x, y, z, bound of the staged queries
   __shared__ double box[6];                // bounding box of the workgroup's points: consecutive SORTED points, a few grid cells
   __shared__ double scratch[(kBlock / 64) * 6];
-  __shared__ uint16_t act[kFilterChunk];   // staged queries whose ball reaches the box
+  __shared__ uint16_t act[kFilterChunk];   // the step's queries whose ball reaches the box
   __shared__ uint32_t n_act;
   const uint32_t p0 = (blockIdx.x * kBlock + threadIdx.x) * kFilterPts;
   double px[kFilterPts], py[kFilterPts], pz[kFilterPts];
@@ -774,26 +773,34 @@ __global__ __launch_bounds__(kBlock) void knn_filter_kernel(const double* __rest
   }
   block_reduce_minmax<double, 3>(mn, mx, scratch);
   if (threadIdx.x == 0) { box[0] = mn[0]; box[1] = mn[1]; box[2] = mn[2]; box[3] = mx[0]; box[4] = mx[1]; box[5] = mx[2]; }
+  // kFilterChunk queries per step, kFilterQPer per lane, all requested before the first is tested; only the numbers of the queries whose ball
+  // reaches the box go to LDS (a stray far from the cloud reaches a handful of the 10^5 boxes), their data is read again where it is used
   for (uint32_t q0 = 0; q0 < nq; q0 += kFilterChunk) {
     const uint32_t cnt = min(kFilterChunk, nq - q0);
     __syncthreads();
     if (threadIdx.x == 0) n_act = 0;
     __syncthreads();
-    if (threadIdx.x < cnt) {
-      typedef double d2a __attribute__((ext_vector_type(2)));
-      const d2a xy = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + threadIdx.x)), zb = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + threadIdx.x) + 2);
-      const double qx = xy.x, qy = xy.y, qz = zb.x, b = zb.y;
-      sq[threadIdx.x] = qx; sq[kFilterChunk + threadIdx.x] = qy; sq[2 * kFilterChunk + threadIdx.x] = qz; sq[3 * kFilterChunk + threadIdx.x] = b;
+    typedef double d2a __attribute__((ext_vector_type(2)));
+    d2a xy[kFilterQPer], zb[kFilterQPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kFilterQPer; ++u) {
+      const uint32_t ql = u * kBlock + threadIdx.x < cnt ? u * kBlock + threadIdx.x : 0u;
+      xy[u] = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + ql));
+      zb[u] = *reinterpret_cast<const d2a*>(qpack + 4 * (uint64_t)(q0 + ql) + 2);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kFilterQPer; ++u) {
+      const double qx = xy[u].x, qy = xy[u].y, qz = zb[u].x, b = zb[u].y;
       // squared distance from the query to the box: only a query whose bound reaches the box can find a candidate here
       const double ex = __builtin_fmax(0.0, __builtin_fmax(box[0] - qx, qx - box[3])), ey = __builtin_fmax(0.0, __builtin_fmax(box[1] - qy, qy - box[4])),
                    ez = __builtin_fmax(0.0, __builtin_fmax(box[2] - qz, qz - box[5]));
-      if (ex * ex + ey * ey + ez * ez <= b) act[atomicAdd(&n_act, 1u)] = (uint16_t)threadIdx.x;
+      if (u * kBlock + threadIdx.x < cnt && ex * ex + ey * ey + ez * ez <= b) act[atomicAdd(&n_act, 1u)] = (uint16_t)(u * kBlock + threadIdx.x);
     }
     __syncthreads();
     const uint32_t na = n_act;
-    for (uint32_t a = 0; a < na; ++a) {  // every lane reads the same query: LDS broadcast
+    for (uint32_t a = 0; a < na; ++a) {  // every lane reads the same query
       const uint32_t q = act[a];
-      const double qx = sq[q], qy = sq[kFilterChunk + q], qz = sq[2 * kFilterChunk + q], b = sq[3 * kFilterChunk + q];
+      const double qx = qpack[4 * (uint64_t)(q0 + q)], qy = qpack[4 * (uint64_t)(q0 + q) + 1], qz = qpack[4 * (uint64_t)(q0 + q) + 2], b = qpack[4 * (uint64_t)(q0 + q) + 3];
 #pragma unroll
       for (uint32_t u = 0; u < kFilterPts; ++u) {
         const double dx = px[u] - qx, dy = py[u] - qy, dz = pz[u] - qz;
