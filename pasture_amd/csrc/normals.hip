@@ -75,7 +75,9 @@ __global__ __launch_bounds__(kBlock) void gather_positions_kernel(const uint8_t*
 // laid out for volume-like clouds; a surface in a 3-D box (a few percent of the coarse cells occupied) keeps the global-memory search.
 constexpr uint32_t kAxisBins = 256;  // slices per axis of the point-count histograms behind the trimmed box
 constexpr uint32_t kOccBins = 32, kOccWords = kOccBins * kOccBins * kOccBins / 32;
-__global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restrict__ xyz, uint64_t n, double ox, double oy, double oz, double sx, double sy,
+// Every stride_pts-th point is looked at (n = the number of those): the 32^3 bitmask and the tail masses of the trimmed box are statistics -- 2^23
+// points say what 10^8 do, and a surface with strays takes this pass three times.
+__global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restrict__ xyz, uint64_t n, uint64_t stride_pts, double ox, double oy, double oz, double sx, double sy,
                                                            double sz, uint32_t* __restrict__ bits, double ax, double ay, double az, uint32_t* __restrict__ axis_hist,
                                                            GridParams frame) {
   __shared__ uint32_t local[kOccWords];
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(kBlock) void occupancy_kernel(const double* __restr
   __syncthreads();
   const uint64_t step = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
-    const double x0 = xyz[3 * i], y0 = xyz[3 * i + 1], z0 = xyz[3 * i + 2];
+    const uint64_t p = i * stride_pts;
+    const double x0 = xyz[3 * p], y0 = xyz[3 * p + 1], z0 = xyz[3 * p + 2];
     if (!finite3(x0, y0, z0)) continue;
     double x, y, z;  // in the grid's frame
     grid_frame(frame, x0, y0, z0, x, y, z);
@@ -1194,7 +1197,8 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         ax[c] = ext[c] > maxext * 1e-9 ? (double)kAxisBins / ext[c] * (1.0 - 1e-12) : 0.0;
       }
       uint32_t* axis_hist = occ.as<uint32_t>() + kOccWords;
-      hipLaunchKernelGGL(occupancy_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n, mn[0], mn[1], mn[2], sc[0], sc[1], sc[2],
+      const uint64_t S_occ = tune.occupancy_all ? 1 : (n + ((uint64_t)1 << 23) - 1) >> 23;  // (every S-th point: at most 2^23 of them)
+      hipLaunchKernelGGL(occupancy_kernel, dim3(std::min(sgrid, cus * 4)), dim3(kBlock), 0, stream, xyz.as<double>(), n / std::max<uint64_t>(S_occ, 1), std::max<uint64_t>(S_occ, 1), mn[0], mn[1], mn[2], sc[0], sc[1], sc[2],
                          occ.as<uint32_t>(), ax[0], ax[1], ax[2], axis_hist, frame);
       std::vector<uint32_t> hb(kOccWords + 3 * kAxisBins);
       MCK(hipMemcpyAsync(hb.data(), occ.p, occ_bytes, hipMemcpyDeviceToHost, stream));

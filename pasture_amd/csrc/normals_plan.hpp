@@ -25,6 +25,7 @@ struct KnnTuning {
   bool direct_out = true;      // PST_KNN_DIRECT=0: 32-byte records + split pass
   bool box_list = true;        // PST_KNN_BOX_LIST=0: one workgroup per box, empty ones included
   bool rounds = true;          // PST_KNN_ROUNDS=0: boxes are not shortened to whole rounds
+  bool occupancy_all = false;  // PST_KNN_OCC_ALL=1: the occupancy / trimmed-box pass looks at every point, not at a 2^23-point thinning
   bool side_stream = true;     // PST_KNN_SIDE_STREAM=0: the permutation of the points runs on the caller's stream, before the directory is built
   char variant = '\0';         // PST_KNN_VAR: '1', 'B', 'D', 'G'
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
@@ -46,7 +47,7 @@ struct KnnTuning {
     t.no_scale = set("PST_KNN_NO_SCALE"); t.no_trim = set("PST_KNN_NO_TRIM"); t.no_rotate = set("PST_KNN_NO_ROTATE");
     t.no_tile = set("PST_KNN_NO_TILE"); t.force_tile = set("PST_KNN_FORCE_TILE");
     if (const char* e = std::getenv("PST_KNN_DENSE")) t.dense = *e == '0' ? 0 : 1;
-    t.direct_out = !off("PST_KNN_DIRECT"); t.box_list = !off("PST_KNN_BOX_LIST"); t.rounds = !off("PST_KNN_ROUNDS"); t.side_stream = !off("PST_KNN_SIDE_STREAM");
+    t.direct_out = !off("PST_KNN_DIRECT"); t.box_list = !off("PST_KNN_BOX_LIST"); t.rounds = !off("PST_KNN_ROUNDS"); t.side_stream = !off("PST_KNN_SIDE_STREAM"); t.occupancy_all = num("PST_KNN_OCC_ALL") != 0.0;
     if (const char* e = std::getenv("PST_KNN_VAR")) t.variant = *e;
     if (const char* e = std::getenv("PST_KNN_TILE")) {
       unsigned x = 0, y = 0, z = 0;
