@@ -210,6 +210,40 @@ int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buf
 int pst_converter_convert_into_range_with_bounds_async(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst,
                                                        size_t t0, size_t t1, double* device_out6);
 
+/* ---- plan specialisation ------------------------------------------------------------------------------
+ * The reference's converter is layout-generic (buffer_conversion.rs:112-234) and walks its Vec<AttributeMapping> at run time.  Here a
+ * conversion takes one of these kernel families; pst_last_plan_kinds reports (one bit per family, 1u << PST_PLAN_*) which ones the calling
+ * thread's last pst_converter_convert* call launched.  PST_PLAN_JIT: the mapping list compiled into the kernel as a constant -- hipRTC at run
+ * time, cached per plan in memory and on disk (PST_JIT = 0 | async (default: compiled on a background thread once a call of at least
+ * PST_JIT_MIN_POINTS points has shown the plan, interpreted until then) | sync; PST_JIT_CACHE_DIR).  Results are identical whichever
+ * family runs. */
+enum {
+  PST_PLAN_NONE = 0,
+  PST_PLAN_INTERPRETED = 1, /* generic LDS-tile kernels interpreting the mapping list */
+  PST_PLAN_JIT = 2,         /* the plan as a compile-time constant, compiled at run time */
+  PST_PLAN_STATIC = 3,      /* the same kernels instantiated in-tree for the layouts of the reference's own benches */
+  PST_PLAN_LAS = 4,         /* LAS-format-specialised decoder / transposer (raw_readers.rs:31-167, las_types.rs) */
+  PST_PLAN_STREAM = 5,      /* columnar Vec3f64 stream kernel (copy / affine / AABB) */
+  PST_PLAN_COLUMN = 6,      /* one wide-vector launch per columnar -> columnar mapping */
+  PST_PLAN_COPY = 7,        /* identity between equal packed layouts: one byte copy of the records */
+  PST_PLAN_DIRECT = 8       /* strided fall-back without LDS staging (records too large for a tile) */
+};
+int pst_last_plan_kinds(uint32_t* mask);
+/* Compiles (or fetches from the cache) the specialised kernel for conversions between buffers of these storage kinds NOW, so that the first
+ * call already takes it.  *plan_kind: the family such a call will use (PST_PLAN_JIT when a specialised kernel is ready). */
+int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, uint32_t* plan_kind);
+/* Introspection of the run-time compiler (tests, tools): the translation unit generated for a converter (empty when the plan takes another
+ * family; *needed = bytes incl. the terminator); compilation of a translation unit against the embedded device headers for gfx950 WITHOUT a
+ * device (the code object is copied to code_buf when given; *code_bytes = its size); counters. */
+int pst_converter_jit_source(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, char* buf, size_t cap, size_t* needed);
+int pst_jit_compile_source(const char* source, void* code_buf, size_t code_cap, size_t* code_bytes, char* log, size_t log_cap);
+typedef struct pst_jit_stats {
+  uint64_t compiled, disk_hits, memory_hits, failures, launches;
+  double compile_seconds;
+} pst_jit_stats;
+int pst_jit_get_stats(pst_jit_stats* out);
+int pst_jit_set_mode(int mode); /* -1: back to the PST_JIT environment setting; 0 off; 1 async; 2 sync (tests, A/B harnesses) */
+
 /* ---- pasture-algorithms loops --------------------------------------------------------------------- */
 /* calculate_bounds, pasture-algorithms/src/bounds.rs:11-85.  has_value = 0 <=> None. */
 int pst_calculate_bounds(const pst_buffer* b, double out_min[3], double out_max[3], int* has_value);

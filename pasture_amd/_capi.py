@@ -69,6 +69,11 @@ class MappingInfoStruct(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class JitStatsStruct(C.Structure):
+    _fields_ = [("compiled", C.c_uint64), ("disk_hits", C.c_uint64), ("memory_hits", C.c_uint64), ("failures", C.c_uint64),
+                ("launches", C.c_uint64), ("compile_seconds", C.c_double)]
+
+
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _DT = C.POINTER(DataTypeStruct)
@@ -149,6 +154,12 @@ _PRODUCT_SIGNATURES = {
     "comm_destroy": [_P],
     "bounds_allreduce": [_P, _P],
     "bounds_allreduce_multi": [_P, _PP, _PP],
+    "last_plan_kinds": [C.POINTER(C.c_uint32)],
+    "converter_prepare": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)],
+    "converter_jit_source": [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _SZ, C.POINTER(_SZ)],
+    "jit_compile_source": [C.c_char_p, _P, _SZ, C.POINTER(_SZ), C.c_char_p, _SZ],
+    "jit_get_stats": [C.POINTER(JitStatsStruct)],
+    "jit_set_mode": [C.c_int],
 }
 
 PRODUCT_SYMBOLS = ["last_error"] + list(_SHARED_SIGNATURES) + list(_PRODUCT_SIGNATURES)

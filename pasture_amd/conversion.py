@@ -70,6 +70,39 @@ class MappingInfo:
     apply_to_source: bool
 
 
+# kernel families a conversion call can take (include/pasture_amd.h PST_PLAN_*)
+PLAN_NONE, PLAN_INTERPRETED, PLAN_JIT, PLAN_STATIC, PLAN_LAS, PLAN_STREAM, PLAN_COLUMN, PLAN_COPY, PLAN_DIRECT = range(9)
+PLAN_NAMES = ("none", "interpreted", "jit", "static", "las-specialised", "stream", "column", "copy", "direct")
+
+
+def last_plan_kinds(api=None) -> List[str]:
+    """Names of the kernel families the calling thread's last conversion call launched."""
+    api = api or _capi.product_api()
+    mask = C.c_uint32()
+    api.last_plan_kinds(C.byref(mask))
+    return [PLAN_NAMES[k] for k in range(len(PLAN_NAMES)) if mask.value >> k & 1]
+
+
+def jit_set_mode(mode: str, api=None) -> None:
+    """'off' | 'async' | 'sync' | 'env' (back to PST_JIT): when plan-specialised kernels are compiled (tests, A/B harnesses)."""
+    (api or _capi.product_api()).jit_set_mode({"env": -1, "off": 0, "async": 1, "sync": 2}[mode])
+
+
+def jit_stats(api=None) -> dict:
+    st = _capi.JitStatsStruct()
+    (api or _capi.product_api()).jit_get_stats(C.byref(st))
+    return {k: getattr(st, k) for k, _ in st._fields_}
+
+
+def jit_compile_source(source: str, api=None) -> bytes:
+    """hipRTC-compile a translation unit against the embedded device headers for gfx950 (no device needed); returns the code object."""
+    n = C.c_size_t()
+    log = C.create_string_buffer(1 << 16)
+    code = C.create_string_buffer(1 << 20)
+    (api or _capi.product_api()).jit_compile_source(source.encode(), code, len(code), C.byref(n), log, len(log))
+    return code.raw[:n.value]
+
+
 class RawPointConverter:
     """attribute_conversion.rs:62-109 — the point-major converter: `from_to` collects one `as` converter per attribute present in both
     layouts whose datatypes differ (equal datatypes: no converter, the attribute is SKIPPED, not copied); `convert` runs them on
@@ -168,6 +201,23 @@ class BufferLayoutConverter:
                                               target_range.start, target_range.stop)
 
     # ---- device-only extras ---------------------------------------------------------------------------------
+    def prepare(self, source_type: Type[_Buffer], target_type: Type[_Buffer], with_bounds: bool = False) -> int:
+        """Compile (hipRTC, cached) the plan-specialised kernel for conversions between buffers of these storage kinds NOW instead of on a
+        background thread after the first large call.  Returns the PLAN_* family such a conversion will take."""
+        kind = C.c_uint32()
+        self.api.converter_prepare(self._h, 1 if source_type._storage == HashMapBuffer._storage else 0,
+                                   1 if target_type._storage == HashMapBuffer._storage else 0, 1 if with_bounds else 0, C.byref(kind))
+        return kind.value
+
+    def jit_source(self, source_type: Type[_Buffer], target_type: Type[_Buffer], with_bounds: bool = False) -> str:
+        """The translation unit the run-time compiler is handed for this converter and storage pairing ('' if another family serves it)."""
+        need = C.c_size_t()
+        sc, dc = (1 if t._storage == HashMapBuffer._storage else 0 for t in (source_type, target_type))
+        self.api.converter_jit_source(self._h, sc, dc, 1 if with_bounds else 0, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        self.api.converter_jit_source(self._h, sc, dc, 1 if with_bounds else 0, buf, need.value, None)
+        return buf.value.decode()
+
     def convert_into_range_async(self, source_buffer, source_range, target_buffer, target_range) -> None:
         self.api.converter_convert_into_range_async(self._h, source_buffer._h, source_range.start, source_range.stop, target_buffer._h,
                                                     target_range.start, target_range.stop)

@@ -18,7 +18,9 @@
 //
 // HBM-bound integer/byte work: no MFMA.  Compiled with -ffp-contract=off (affine = two roundings).
 #include "convert_kernels.hpp"
+#include "jit.hpp"
 
+#include <cstring>
 
 namespace pstk {
 
@@ -71,7 +73,7 @@ static size_t tile_lds_bytes(const ConvertHeader& h, bool src_aos, bool dst_aos)
   return lds_bytes;
 }
 
-// grid of a conversion launch (the caller sizes the fused-bounds partials with it)
+// grid of an interpreted conversion launch
 unsigned convert_grid(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds) {
   const ConvertHeader& h = plan.h;
   const int cus = device_cus();
@@ -87,26 +89,112 @@ unsigned convert_grid(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool 
   return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((work + kBlock - 1) / kBlock, (uint64_t)cus * 8));
 }
 
-bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream) {
+// Upper bound of the AABB records a conversion launch (or the pair specialised kernel + interpreted tail) writes: the caller sizes the
+// fused-bounds partials with it; launch_convert reports the number actually written.
+unsigned convert_max_records(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds) {
+  const uint64_t jit_tiles = plan.h.n / 256 + 8;  // the smallest tile of the specialised kernels
+  return convert_grid(plan, src_aos, dst_aos, use_lds) + (unsigned)std::min<uint64_t>(jit_tiles, 1u << 24) + 8u;
+}
+
+// which kernel families the calling thread's last conversion call used (pst_last_plan_kinds)
+static thread_local uint32_t t_plan_kinds = 0;
+void reset_plan_kinds() { t_plan_kinds = 0; }
+void note_plan_kind(uint32_t kind) { t_plan_kinds |= 1u << kind; }
+uint32_t plan_kinds() { return t_plan_kinds; }
+
+// the same plan for the points [first, n) of its range
+static ConvertPlan plan_tail(const ConvertPlan& plan, bool src_aos, bool dst_aos, uint64_t first) {
+  ConvertPlan t = plan;
+  t.h.n = plan.h.n - first;
+  if (src_aos) t.h.src_aos += first * plan.h.src_stride;
+  if (dst_aos) t.h.dst_aos += first * plan.h.dst_stride;
+  for (uint32_t m = 0; m < plan.h.n_entries; ++m) {
+    if (!src_aos) t.e[m].src_col += first * plan.e[m].src_size;
+    if (!dst_aos) t.e[m].dst_col += first * plan.e[m].dst_size;
+  }
+  return t;
+}
+
+static bool launch_interpreted(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream, unsigned* n_records) {
   const ConvertHeader& h = plan.h;
-  if (h.n == 0 || h.n_entries == 0) return true;
   const PlanEntry* entries = upload_entries(plan, stream);
   if (!entries) return false;
   const unsigned grid = convert_grid(plan, src_aos, dst_aos, use_lds);
+  if (n_records) *n_records = grid;
   if (use_lds && (src_aos || dst_aos)) {
     const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
     // 256-thread blocks: 512 / 1024 measured 15-60 % slower (per-wave interpretation cost is amortised over fewer points)
-    if (launch_convert_static(plan, src_aos, dst_aos, grid, lds_bytes, entries, stream)) return hipGetLastError() == hipSuccess;
+    if (launch_convert_static(plan, src_aos, dst_aos, grid, lds_bytes, entries, stream)) { note_plan_kind(PST_PLAN_STATIC); return hipGetLastError() == hipSuccess; }
+    note_plan_kind(PST_PLAN_INTERPRETED);
     if (src_aos && dst_aos) launch_convert_tile_tt(grid, lds_bytes, stream, h, entries);
     else if (src_aos) launch_convert_tile_tf(grid, lds_bytes, stream, h, entries);
     else launch_convert_tile_ft(grid, lds_bytes, stream, h, entries);
     return hipGetLastError() == hipSuccess;
   }
+  note_plan_kind(PST_PLAN_DIRECT);
   if (src_aos && dst_aos) hipLaunchKernelGGL((convert_direct_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (src_aos) hipLaunchKernelGGL((convert_direct_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (dst_aos) hipLaunchKernelGGL((convert_direct_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else hipLaunchKernelGGL((convert_direct_kernel<false, false>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   return hipGetLastError() == hipSuccess;
+}
+
+// Plan-specialised kernel (jit.cpp) over the full tiles of the range; `done` = points it covered (0: not taken).
+static bool launch_specialised(const ConvertPlan& plan, bool src_aos, bool dst_aos, hipStream_t stream, unsigned* n_records, uint64_t* done) {
+  *done = 0;
+  const pstjit::Mode mode = pstjit::mode();
+  if (mode == pstjit::Mode::Off) return true;
+  pstjit::QuadSpec spec;
+  if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) return true;
+  pstjit::Kernel k;
+  // small calls never start a compilation; a kernel some larger call (or pst_converter_prepare) had compiled is used whatever the size
+  const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait
+                              : plan.h.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
+  if (!pstjit::acquire(spec, how, &k)) return true;  // not ready (or failed): interpret
+  const uint64_t n_tiles = plan.h.n / k.tile;
+  if (n_tiles == 0) return true;
+  if (n_tiles > (1ull << 30)) return true;
+  const PlanEntry* entries = upload_entries(plan, stream);
+  if (!entries) return false;
+  ConvertHeader h = plan.h;
+  h.n = n_tiles * k.tile;
+  const unsigned grid = (unsigned)((n_tiles + 7) / 8 * 8);
+  void* args[] = {(void*)&h, (void*)&entries};
+  if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) return false;
+  note_plan_kind(PST_PLAN_JIT);
+  if (n_records) *n_records = grid;
+  *done = h.n;
+  return true;
+}
+
+bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream, unsigned* n_records) {
+  const ConvertHeader& h = plan.h;
+  if (n_records) *n_records = 0;
+  if (h.n == 0 || h.n_entries == 0) return true;
+  if (use_lds && (src_aos || dst_aos)) {
+    unsigned rec = 0;
+    uint64_t done = 0;
+    if (!launch_specialised(plan, src_aos, dst_aos, stream, &rec, &done)) return false;
+    if (done == h.n) { if (n_records) *n_records = rec; return true; }
+    if (done > 0) {  // the ragged tail (less than one tile) is interpreted
+      ConvertPlan t = plan_tail(plan, src_aos, dst_aos, done);
+      if (t.h.bounds_partials) t.h.bounds_partials += (uint64_t)rec * 6 * sizeof(double);
+      unsigned rec_tail = 0;
+      if (!launch_interpreted(t, src_aos, dst_aos, use_lds, stream, &rec_tail)) return false;
+      if (n_records) *n_records = rec + rec_tail;
+      return true;
+    }
+  }
+  return launch_interpreted(plan, src_aos, dst_aos, use_lds, stream, n_records);
+}
+
+// Compile (or fetch) the specialised kernel this plan would take; true when a later launch_convert of the same plan shape will use it.
+bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error) {
+  if (pstjit::mode() == pstjit::Mode::Off) { if (error) *error = "PST_JIT=0"; return false; }
+  pstjit::QuadSpec spec;
+  if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) { if (error) *error = "plan not eligible for a specialised kernel"; return false; }
+  pstjit::Kernel k;
+  return pstjit::acquire(spec, pstjit::Acquire::Wait, &k, error);
 }
 
 }  // namespace pstk

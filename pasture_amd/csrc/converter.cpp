@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <optional>
 
+#include "jit.hpp"
 #include "las_layouts.hpp"
 #include "runtime.hpp"
 
@@ -120,6 +121,51 @@ static uint32_t pick_tile(bool src_aos, uint32_t src_stride, bool dst_aos, uint3
   return (uint32_t)t;  // 0 => records too large for LDS staging
 }
 
+// One launch's plan: header, entries, covered flag, wave scheduling of the interpreted tile kernels.
+static ConvertPlan build_plan(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride, uint64_t n,
+                              const PlanEntry* entries, size_t cnt, uint32_t tile, bool in_place, bool with_bounds, bool* wants_bounds) {
+  ConvertPlan plan{};
+  plan.h.src_aos = src_base;
+  plan.h.dst_aos = dst_base;
+  plan.h.n = n;
+  plan.h.src_stride = src_stride;
+  plan.h.dst_stride = dst_stride;
+  plan.h.n_entries = (uint32_t)cnt;
+  plan.h.tile = tile;
+  plan.h.in_place = in_place ? 1u : 0u;
+  // Four points per lane put the lanes of a wave `stride` DWORDS apart in the record tile: strides that are multiples of 32 bytes
+  // pile them onto the same LDS banks (measured 32 B: 5.96 -> 4.55 TB/s), every other stride gains (41 B: 4.20 -> 5.87).
+  // PST_TILE_QUAD=0 / 1 forces the mapping (tuning).
+  static const int quad_env = [] { const char* v = std::getenv("PST_TILE_QUAD"); return v && *v ? (*v == '0' ? 0 : 1) : -1; }();
+  plan.h.quad = quad_env >= 0 ? (uint32_t)quad_env : ((dst_stride % 32u != 0 && !(src_aos && src_stride % 32u == 0)) ? 1u : 0u);
+  std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
+  *wants_bounds = false;
+  for (size_t i = 0; i < cnt; ++i) {
+    plan.e[i] = entries[i];
+    if (!with_bounds) plan.e[i].bounds = 0;
+    *wants_bounds = *wants_bounds || plan.e[i].bounds;
+    if (dst_aos)
+      for (uint32_t b = 0; b < plan.e[i].dst_size; ++b) covered[plan.e[i].dst_off + b] = 1;
+  }
+  plan.h.dst_fully_covered = dst_aos && std::all_of(covered.begin(), covered.end(), [](uint8_t c) { return c != 0; });
+  // wave scheduling of the tile kernels (convert.hip): narrow attributes are owned by single waves, balanced by bytes
+  {
+    const long nwaves = 4;  // convert_tile_kernel runs 256-thread blocks
+    static const long own_max = [] { const char* v = std::getenv("PST_TILE_OWN_MAX_BYTES"); return v && *v ? std::strtol(v, nullptr, 10) : 4L; }();
+    uint64_t load[16] = {0};
+    for (size_t i = 0; i < cnt; ++i) {
+      const uint32_t col_bytes = (src_aos && !dst_aos) ? plan.e[i].dst_size : (!src_aos && dst_aos) ? plan.e[i].src_size
+                                                                                                  : std::max(plan.e[i].src_size, plan.e[i].dst_size);
+      if ((long)col_bytes > own_max || plan.e[i].bounds || nwaves == 1) { plan.masks[0] |= 1u << i; continue; }
+      long best = 0;
+      for (long w = 1; w < nwaves; ++w) if (load[w] < load[best]) best = w;
+      load[best] += col_bytes + 2;  // + fixed interpretation cost
+      plan.masks[1 + best] |= 1u << i;
+    }
+  }
+  return plan;
+}
+
 void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
                      uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6) {
   if (n == 0 || entries.empty()) return;
@@ -130,55 +176,18 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
   const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 1;
   for (size_t begin = 0; begin < entries.size(); begin += PST_PLAN_MAX_ENTRIES) {
     const size_t cnt = std::min<size_t>(PST_PLAN_MAX_ENTRIES, entries.size() - begin);
-    ConvertPlan plan{};
-    plan.h.src_aos = src_base;
-    plan.h.dst_aos = dst_base;
-    plan.h.n = n;
-    plan.h.src_stride = src_stride;
-    plan.h.dst_stride = dst_stride;
-    plan.h.n_entries = (uint32_t)cnt;
-    plan.h.tile = tile;
-    plan.h.in_place = in_place ? 1u : 0u;
-    // Four points per lane put the lanes of a wave `stride` DWORDS apart in the record tile: strides that are multiples of 32 bytes
-    // pile them onto the same LDS banks (measured 32 B: 5.96 -> 4.55 TB/s), every other stride gains (41 B: 4.20 -> 5.87).
-    // PST_TILE_QUAD=0 / 1 forces the mapping (tuning).
-    static const int quad_env = [] { const char* v = std::getenv("PST_TILE_QUAD"); return v && *v ? (*v == '0' ? 0 : 1) : -1; }();
-    plan.h.quad = quad_env >= 0 ? (uint32_t)quad_env : ((dst_stride % 32u != 0 && !(src_aos && src_stride % 32u == 0)) ? 1u : 0u);
-    std::vector<uint8_t> covered(dst_aos ? dst_stride : 0, 0);
     bool wants_bounds = false;
-    for (size_t i = 0; i < cnt; ++i) {
-      plan.e[i] = entries[begin + i];
-      if (!bounds_out6) plan.e[i].bounds = 0;
-      wants_bounds = wants_bounds || plan.e[i].bounds;
-      if (dst_aos)
-        for (uint32_t b = 0; b < plan.e[i].dst_size; ++b) covered[plan.e[i].dst_off + b] = 1;
-    }
-    plan.h.dst_fully_covered = dst_aos && std::all_of(covered.begin(), covered.end(), [](uint8_t c) { return c != 0; });
-    // wave scheduling of the tile kernels (convert.hip): narrow attributes are owned by single waves, balanced by bytes
-    {
-      const long nwaves = 4;  // convert_tile_kernel runs 256-thread blocks
-      static const long own_max = [] { const char* v = std::getenv("PST_TILE_OWN_MAX_BYTES"); return v && *v ? std::strtol(v, nullptr, 10) : 4L; }();
-      uint64_t load[16] = {0};
-      for (size_t i = 0; i < cnt; ++i) {
-        const uint32_t col_bytes = (src_aos && !dst_aos) ? plan.e[i].dst_size : (!src_aos && dst_aos) ? plan.e[i].src_size
-                                                                                                    : std::max(plan.e[i].src_size, plan.e[i].dst_size);
-        if ((long)col_bytes > own_max || plan.e[i].bounds || nwaves == 1) { plan.masks[0] |= 1u << i; continue; }
-        long best = 0;
-        for (long w = 1; w < nwaves; ++w) if (load[w] < load[best]) best = w;
-        load[best] += col_bytes + 2;  // + fixed interpretation cost
-        plan.masks[1 + best] |= 1u << i;
-      }
-    }
-    unsigned grid = 0;
+    ConvertPlan plan = build_plan(src_aos, src_base, src_stride, dst_aos, dst_base, dst_stride, n, entries.data() + begin, cnt, tile, in_place,
+                                  bounds_out6 != nullptr, &wants_bounds);
+    unsigned records = 0;
     double* partials = nullptr;
     if (wants_bounds) {
-      grid = pstk::convert_grid(plan, src_aos, dst_aos, use_lds);
-      partials = (double*)workspace().partials(pstk::bounds_partials_bytes(grid));
+      partials = (double*)workspace().partials(pstk::bounds_partials_bytes(pstk::convert_max_records(plan, src_aos, dst_aos, use_lds)));
       plan.h.bounds_partials = (uint64_t)(uintptr_t)partials;
     }
-    if (!pstk::launch_convert(plan, src_aos, dst_aos, use_lds, stream))
+    if (!pstk::launch_convert(plan, src_aos, dst_aos, use_lds, stream, &records))
       throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
-    if (wants_bounds) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
+    if (wants_bounds) pstk::launch_finalize_bounds(partials, records, bounds_out6, stream);
   }
 }
 
@@ -250,6 +259,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   if (t1 > dst.len) throw Error(PST_ERR_RANGE, "assertion failed: target_range.end <= target_buffer.len()");
   const uint64_t n = s1 - s0;
   ensure_device();
+  pstk::reset_plan_kinds();
 
   // position attribute of the target for the fused / trailing bounds
   int pos_slot = -1;
@@ -270,6 +280,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       e.ncomp = 1;
       if (!pstk::launch_column(e, n, nullptr, stream))
         throw Error(PST_ERR_HIP, std::string("record copy launch failed: ") + hipGetErrorString(hipGetLastError()));
+      pstk::note_plan_kind(PST_PLAN_COPY);
       return;
     }
   }
@@ -292,6 +303,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       if (!pstk::launch_las_transpose(c.las_typed_format, src.columnar, aos, cols.data(), (int)cols.size(), n, partials, stream))
         throw Error(PST_ERR_HIP, std::string("LAS transposition launch failed: ") + hipGetErrorString(hipGetLastError()));
       if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
+      pstk::note_plan_kind(PST_PLAN_LAS);
       return;
     }
   }
@@ -308,6 +320,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       if (!pstk::launch_las_decode_aos(c.las_decode_format, aos_addr(src, s0), aos_addr(dst, t0), n, pos->xf->scale, pos->xf->offset, partials, stream))
         throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
       if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
+      pstk::note_plan_kind(PST_PLAN_LAS);
       return;
     }
     std::vector<uint64_t> cols(c.to.members.size());
@@ -318,6 +331,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
                                  stream))
       throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
     if (bounds_out6) pstk::launch_finalize_bounds(partials, pstk::las_decode_grid(n), bounds_out6, stream);
+    pstk::note_plan_kind(PST_PLAN_LAS);
     return;
   }
   if (!c.mappings.empty() && n > 0) {  // no mappings => silent no-op (:308-313)
@@ -339,6 +353,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
           pstk::launch_vec3f64_stream((const double*)(uintptr_t)e.src_col, (double*)(uintptr_t)e.dst_col, n, e.scale, e.offset, mode,
                                       (double*)ws.partials(pstk::stream_partials_bytes(n, mode)), bounds_out6, stream);
           if (want_bounds) bounds_done = true;
+          pstk::note_plan_kind(PST_PLAN_STREAM);
           continue;
         }
         // every other columnar -> columnar mapping is its own wide-vector launch (columns.hip): plain copies move raw
@@ -352,6 +367,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
         }
         if (!pstk::launch_column(e, n, partials, stream))
           throw Error(PST_ERR_HIP, std::string("column conversion launch failed: ") + hipGetErrorString(hipGetLastError()));
+        pstk::note_plan_kind(PST_PLAN_COLUMN);
         if (fuse_bounds) {
           pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
           bounds_done = true;
@@ -372,6 +388,40 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   if (bounds_out6 && !bounds_done) {
     bounds_of_range(dst, t0, n, bounds_out6, stream);
   }
+}
+
+// The plan a conversion between buffers of the given storage kinds would hand to the generic tile kernels, with placeholder addresses
+// (only their equality pattern matters to the specialised kernels): what pst_converter_prepare compiles ahead of the first call.
+// Returns the PST_PLAN_* family the call would take WITHOUT a specialised kernel, and fills `plan` when that family is the generic one.
+static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool dst_columnar, bool with_bounds, ConvertPlan* plan) {
+  static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
+  if (c.mappings.empty()) return PST_PLAN_NONE;
+  if (!src_columnar && !dst_columnar && !with_bounds && match_identity_records(c)) return PST_PLAN_COPY;
+  if (las_fast && src_columnar != dst_columnar && match_identity_records(c))
+    for (uint32_t f = 0; f <= 10; ++f)
+      if (c.to == laslayout::typed_layout(f)) return PST_PLAN_LAS;
+  if (las_fast && !src_columnar && match_las_decode_plan(c) >= 0) return PST_PLAN_LAS;
+  if (src_columnar && dst_columnar) return PST_PLAN_COLUMN;
+  const Member* pm = with_bounds ? c.to.find_by_name("Position3D") : nullptr;
+  std::vector<PlanEntry> generic;
+  bool bounds_done = false;
+  for (const Mapping& m : c.mappings) {
+    PlanEntry e = entry_from_mapping(m);
+    const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
+    if (src_columnar) e.src_col = 0x100000ull * (uint64_t)(sslot + 1);
+    if (dst_columnar) e.dst_col = 0x100000ull * (uint64_t)(tslot + 1);
+    if (pm && &c.to.members[(size_t)tslot] == pm && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done) { e.bounds = 1; bounds_done = true; }
+    generic.push_back(e);
+  }
+  if (generic.size() > PST_PLAN_MAX_ENTRIES) return PST_PLAN_INTERPRETED;  // several launches: interpreted
+  const uint32_t ss = (uint32_t)c.from.size, ds = (uint32_t)c.to.size;
+  const uint32_t tile = pick_tile(!src_columnar, ss, !dst_columnar, ds);
+  if (tile < 1) return PST_PLAN_DIRECT;
+  bool wants_bounds = false;
+  *plan = build_plan(!src_columnar, src_columnar ? 0 : 0x10000000ull, ss, !dst_columnar, dst_columnar ? 0 : 0x20000000ull, ds, (uint64_t)1 << 30,
+                     generic.data(), generic.size(), tile, false, with_bounds, &wants_bounds);
+  if (wants_bounds) plan->h.bounds_partials = 0x30000000ull;
+  return PST_PLAN_INTERPRETED;
 }
 
 }  // namespace pst
@@ -499,6 +549,74 @@ int pst_converter_set_custom_mapping_with_transformation(pst_converter* c, const
   install_mapping(*c, std::move(m), ta);
   PST_API_END
 }
+// Ahead-of-time specialisation: compiles (hipRTC, cached) the kernel a conversion between buffers of these storage kinds will take, so
+// that the first call already runs it.  *plan_kind = the PST_PLAN_* family such a call will use.
+int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, uint32_t* plan_kind) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  ConvertPlan plan{};
+  uint32_t kind = plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan);
+  if (kind == PST_PLAN_INTERPRETED && plan.h.n_entries) {
+    std::string err;
+    if (pstk::prepare_convert(plan, !src_columnar, !dst_columnar, &err)) kind = PST_PLAN_JIT;
+    else if (!err.empty() && err.find("not eligible") == std::string::npos && err != "PST_JIT=0") set_last_error(err);
+  }
+  if (plan_kind) *plan_kind = kind;
+  PST_API_END
+}
+// The translation unit the run-time compiler is given for this converter and storage pairing (empty when the plan takes another family).
+int pst_converter_jit_source(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, char* buf, size_t cap, size_t* needed) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  ConvertPlan plan{};
+  std::string src;
+  if (plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan) == PST_PLAN_INTERPRETED && plan.h.n_entries) {
+    pstjit::QuadSpec spec;
+    if (pstjit::spec_from_plan(plan, !src_columnar, !dst_columnar, &spec)) src = pstjit::spec_source(spec);
+  }
+  if (needed) *needed = src.size() + 1;
+  if (buf && cap) {
+    const size_t k = std::min(cap - 1, src.size());
+    memcpy(buf, src.data(), k);
+    buf[k] = 0;
+  }
+  PST_API_END
+}
+// hipRTC compilation of a translation unit against the embedded device headers, for gfx950, WITHOUT a device (CPU check of the generator).
+int pst_jit_compile_source(const char* source, void* code_buf, size_t code_cap, size_t* code_bytes, char* log, size_t log_cap) {
+  PST_API_BEGIN
+  std::string err;
+  const std::vector<char> code = pstjit::compile_source(not_null(source, "source"), "gfx950", &err);
+  if (code_bytes) *code_bytes = code.size();
+  if (code_buf && code_cap) memcpy(code_buf, code.data(), std::min(code_cap, code.size()));
+  if (log && log_cap) {
+    const size_t k = std::min(log_cap - 1, err.size());
+    memcpy(log, err.data(), k);
+    log[k] = 0;
+  }
+  if (code.empty()) throw Error(PST_ERR_UNSUPPORTED, err.empty() ? "hipRTC produced no code" : err);
+  PST_API_END
+}
+int pst_jit_get_stats(pst_jit_stats* out) {
+  PST_API_BEGIN
+  const pstjit::Stats s = pstjit::stats();
+  not_null(out, "out");
+  out->compiled = s.compiled; out->disk_hits = s.disk_hits; out->memory_hits = s.memory_hits; out->failures = s.failures; out->launches = s.launches;
+  out->compile_seconds = s.compile_seconds;
+  PST_API_END
+}
+int pst_jit_set_mode(int mode) {
+  PST_API_BEGIN
+  if (mode < -1 || mode > 2) throw Error(PST_ERR_INVALID_ARGUMENT, "mode must be -1 (environment), 0 (off), 1 (async) or 2 (sync)");
+  pstjit::set_mode(mode);
+  PST_API_END
+}
+int pst_last_plan_kinds(uint32_t* mask) {
+  PST_API_BEGIN
+  *not_null(mask, "mask") = pstk::plan_kinds();
+  PST_API_END
+}
+
 int pst_converter_num_mappings(const pst_converter* c, size_t* out) { PST_API_BEGIN *not_null(out, "out") = not_null(c, "converter")->mappings.size(); PST_API_END }
 int pst_converter_get_mapping(const pst_converter* c, size_t index, pst_mapping_info* out) {
   PST_API_BEGIN

@@ -1,10 +1,14 @@
 // Device-side helpers shared by the gfx950 kernels.  wave = 64 lanes everywhere.
 #pragma once
+#ifdef __HIPCC_RTC__
+#include "rtc_prelude.hpp"  // compiled at run time by hipRTC (jit.cpp): no standard library headers there
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <limits>
 #include <type_traits>
+#endif
 
 #include "plan.h"
 

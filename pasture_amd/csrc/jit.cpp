@@ -1,0 +1,499 @@
+// Run-time specialisation of the layout-conversion kernels.
+//
+// The reference's converter is layout-generic (buffer_conversion.rs:112-234): any pair of PointLayouts, any mapping list.  The
+// interpreted tile kernels (convert_kernels.hpp) serve every plan at once and pay for it -- offsets, sizes and type pairs come out of
+// registers.  Here the plan becomes source text: `spec_source` writes the mapping list as a constexpr plan type for jit_quad.hpp's
+// kernel, hipRTC compiles it for the device's architecture, and the code object is cached in memory (per plan signature, per device)
+// and on disk (per hash of source + headers + options; PST_JIT_CACHE_DIR, default ~/.cache/pasture_amd/jit).  Compilation runs on a
+// background thread (PST_JIT=async, the default): the first calls of a new plan are interpreted, later ones take the specialised
+// kernel; PST_JIT=sync compiles in the calling thread, PST_JIT=0 switches the whole thing off.  hipRTC is bound with dlopen at first
+// use, so the library loads (and interprets) where it is absent.
+#include "jit.hpp"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include "jit_embedded.inc"  // kJitHeaderNames / kJitHeaderTexts / kJitHeaderCount: the device headers as text (tools/embed_headers.py)
+
+namespace pstjit {
+
+namespace {
+
+// ---- hipRTC, bound at first use ------------------------------------------------------------------------------------------------
+struct Rtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcVersion) version = nullptr;
+  std::string error;
+};
+const Rtc& rtc() {
+  static const Rtc r = [] {
+    Rtc x;
+    // hipRTC, comgr and the HIP runtime must come from ONE distribution: a process that imported torch runs on torch's bundled runtime
+    // (pasture_amd/_capi.py), so look next to the runtime that is actually loaded first
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir = info.dli_fname;
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash);
+        names.push_back(dir + "/libhiprtc.so");
+        names.push_back(dir + "/libhiprtc.so.7");
+      }
+    }
+    for (const char* n : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) names.push_back(n);
+    for (const std::string& name : names) {
+      x.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (x.lib) break;
+    }
+    if (!x.lib) { x.error = std::string("hipRTC not loadable: ") + dlerror(); return x; }
+#define PST_RTC_SYM(field, sym)                                                                   \
+  x.field = reinterpret_cast<decltype(x.field)>(dlsym(x.lib, #sym));                              \
+  if (!x.field) { x.error = "hipRTC lacks " #sym; return x; }
+    PST_RTC_SYM(create, hiprtcCreateProgram)
+    PST_RTC_SYM(compile, hiprtcCompileProgram)
+    PST_RTC_SYM(log_size, hiprtcGetProgramLogSize)
+    PST_RTC_SYM(log, hiprtcGetProgramLog)
+    PST_RTC_SYM(code_size, hiprtcGetCodeSize)
+    PST_RTC_SYM(code, hiprtcGetCode)
+    PST_RTC_SYM(destroy, hiprtcDestroyProgram)
+    PST_RTC_SYM(version, hiprtcVersion)
+#undef PST_RTC_SYM
+    return x;
+  }();
+  return r;
+}
+
+uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+std::string hash_hex(const std::string& s) {
+  const uint64_t a = fnv1a(s.data(), s.size(), 0xcbf29ce484222325ull), b = fnv1a(s.data(), s.size(), 0x9ae16a3b2f90404full);
+  char buf[40];
+  snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
+  return buf;
+}
+
+const std::vector<const char*>& compile_options(const std::string& arch, std::vector<std::string>& keep) {
+  static thread_local std::vector<const char*> out;
+  keep.clear();
+  keep.push_back("--offload-arch=" + arch);
+  keep.push_back("-O3");
+  keep.push_back("-std=c++17");
+  keep.push_back("-ffp-contract=off");  // (p * scale) + offset keeps its two roundings (raw_readers.rs:42-48), as in the in-tree build
+  out.clear();
+  for (const std::string& s : keep) out.push_back(s.c_str());
+  return out;
+}
+
+// hash of everything that decides the code object besides the plan source
+const std::string& toolchain_salt() {
+  static const std::string s = [] {
+    std::string t;
+    for (int i = 0; i < kJitHeaderCount; ++i) { t += kJitHeaderNames[i]; t += '\0'; t += kJitHeaderTexts[i]; t += '\0'; }
+    int major = 0, minor = 0;
+    if (rtc().version) rtc().version(&major, &minor);
+    t += "hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " -O3 -std=c++17 -ffp-contract=off";
+    return hash_hex(t);
+  }();
+  return s;
+}
+
+std::string cache_dir() {
+  static const std::string d = [] {
+    const char* off = std::getenv("PST_JIT_CACHE");
+    if (off && *off == '0') return std::string();
+    std::string dir;
+    if (const char* v = std::getenv("PST_JIT_CACHE_DIR")) dir = v;
+    else if (const char* x = std::getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/pasture_amd/jit";
+    else if (const char* h = std::getenv("HOME")) dir = std::string(h) + "/.cache/pasture_amd/jit";
+    if (dir.empty()) return dir;
+    std::string acc;
+    for (size_t i = 0; i <= dir.size(); ++i) {  // mkdir -p
+      if (i == dir.size() || dir[i] == '/') {
+        if (!acc.empty()) (void)mkdir(acc.c_str(), 0755);
+      }
+      if (i < dir.size()) acc += dir[i];
+    }
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return std::string();
+    return dir;
+  }();
+  return d;
+}
+
+std::vector<char> read_file(const std::string& path) {
+  std::vector<char> out;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return out;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n > 0) {
+    out.resize((size_t)n);
+    if (fread(out.data(), 1, (size_t)n, f) != (size_t)n) out.clear();
+  }
+  fclose(f);
+  return out;
+}
+void write_file_atomic(const std::string& path, const std::vector<char>& data) {
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+  fclose(f);
+  if (ok) (void)rename(tmp.c_str(), path.c_str());
+  else (void)unlink(tmp.c_str());
+}
+
+std::string device_arch() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) return prop.gcnArchName;
+  return "gfx950";
+}
+
+// ---- the cache --------------------------------------------------------------------------------------------------------------------
+struct Entry {
+  enum State { Queued, Ready, Failed } state = Queued;
+  std::string source, error;
+  std::vector<char> code;
+  std::map<int, std::pair<hipModule_t, hipFunction_t>> per_device;
+  unsigned blk = 256;
+  uint32_t lds_bytes = 0, tile = 1024;
+};
+
+struct Cache {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<std::string, std::shared_ptr<Entry>> by_source;
+  std::deque<std::shared_ptr<Entry>> queue;
+  bool worker_started = false;
+  Stats st;
+};
+Cache& cache() {
+  static Cache* c = new Cache;  // never destroyed: the compiler thread may outlive static destruction
+  return *c;
+}
+
+void compile_entry(const std::shared_ptr<Entry>& e) {
+  Cache& c = cache();
+  const std::string arch = device_arch();
+  std::string err;
+  std::vector<char> code;
+  bool from_disk = false;
+  const std::string dir = cache_dir();
+  std::string path;
+  if (!dir.empty()) {
+    path = dir + "/" + hash_hex(toolchain_salt() + arch + e->source) + ".hsaco";
+    code = read_file(path);
+    from_disk = !code.empty();
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (code.empty()) {
+    code = compile_source(e->source, arch, &err);
+    if (!code.empty() && !path.empty()) write_file_atomic(path, code);
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (code.empty()) {
+    e->state = Entry::Failed;
+    e->error = err;
+    c.st.failures++;
+    if (std::getenv("PST_JIT_DEBUG")) fprintf(stderr, "[pst jit] compilation failed:\n%s\n", err.c_str());
+  } else {
+    e->code = std::move(code);
+    e->state = Entry::Ready;
+    if (from_disk) c.st.disk_hits++;
+    else { c.st.compiled++; c.st.compile_seconds += secs; }
+    if (std::getenv("PST_JIT_DEBUG")) fprintf(stderr, "[pst jit] %s in %.2f s (%zu bytes)\n", from_disk ? "loaded from disk" : "compiled", secs, e->code.size());
+  }
+  c.cv.notify_all();
+}
+
+void worker_main() {
+  Cache& c = cache();
+  for (;;) {
+    std::shared_ptr<Entry> e;
+    {
+      std::unique_lock<std::mutex> lock(c.mu);
+      c.cv.wait(lock, [&] { return !c.queue.empty(); });
+      e = c.queue.front();
+      c.queue.pop_front();
+    }
+    compile_entry(e);
+  }
+}
+
+}  // namespace
+
+static std::atomic<int> g_mode_override{-1};
+void set_mode(int m) { g_mode_override.store(m); }
+Mode mode() {
+  const int o = g_mode_override.load(std::memory_order_relaxed);
+  if (o >= 0) return o == 0 ? Mode::Off : o == 2 ? Mode::Sync : Mode::Async;
+  static const Mode m = [] {
+    const char* v = std::getenv("PST_JIT");
+    if (!v || !*v) return Mode::Async;
+    if (*v == '0' || !strcmp(v, "off")) return Mode::Off;
+    if (!strcmp(v, "sync")) return Mode::Sync;
+    return Mode::Async;
+  }();
+  return m;
+}
+uint64_t min_points() {
+  static const uint64_t n = [] {
+    const char* v = std::getenv("PST_JIT_MIN_POINTS");
+    return v && *v ? (uint64_t)std::strtoull(v, nullptr, 10) : (uint64_t)1 << 20;
+  }();
+  return n;
+}
+
+uint32_t QuadSpec::lds_bytes() const {
+  const uint32_t b = tile() * lds_per_point;
+  return b < 256u ? 256u : b;
+}
+
+static long env_long(const char* name, long dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::strtol(v, nullptr, 10) : dflt;
+}
+
+bool spec_from_plan(const ConvertPlan& plan, bool src_aos, bool dst_aos, QuadSpec* spec) {
+  const ConvertHeader& h = plan.h;
+  if (!(src_aos || dst_aos) || h.in_place || h.n_entries == 0 || h.n_entries > PST_PLAN_MAX_ENTRIES) return false;
+  if (src_aos && (h.src_aos & 15u)) return false;  // record tiles travel as 16-byte chunks
+  if (dst_aos && (h.dst_aos & 15u)) return false;
+  // the lane holds four records of either side in registers
+  static const long max_words = env_long("PST_JIT_MAX_WORDS", 224);
+  QuadSpec s;
+  s.src_aos = src_aos; s.dst_aos = dst_aos;
+  s.src_stride = src_aos ? h.src_stride : 0; s.dst_stride = dst_aos ? h.dst_stride : 0;
+  s.covered = dst_aos ? (h.dst_fully_covered ? 1u : 0u) : 0u;
+  if ((src_aos && h.src_stride == 0) || (dst_aos && h.dst_stride == 0)) return false;
+  uint32_t src_words = 0;
+  // LDS bytes per point.  Incoming regions: the source record tile, the staged wide source columns (and the target record tile when its
+  // records are read-modify-written); outgoing regions: the target record tile, the staged wide target columns.  With `alias` the outgoing
+  // regions overlay the incoming ones (one more barrier, half the LDS: twice the workgroups per CU).
+  static const long alias_env = env_long("PST_JIT_ALIAS", 0);
+  s.alias = (alias_env != 0 && !(dst_aos && !s.covered)) ? 1u : 0u;
+  uint32_t in_stage = s.src_stride, out_stage = 0;
+  if (s.alias) { s.dst_tile_off = 0; out_stage = s.dst_stride; }
+  else { s.dst_tile_off = s.src_stride; in_stage += s.dst_stride; }
+  static const long wide_min = env_long("PST_JIT_WIDE_MIN", 8);
+  auto wide = [&](uint32_t size, uint64_t col) { return (long)size >= wide_min && size % 4u == 0 && (col & 15u) == 0; };
+  for (uint32_t m = 0; m < h.n_entries; ++m) {
+    const PlanEntry& e = plan.e[m];
+    if (e.src_size == 0 || e.dst_size == 0 || e.ncomp == 0) return false;
+    static const uint32_t ct_size[10] = {1, 1, 2, 2, 4, 4, 8, 8, 4, 8};
+    if (e.src_ct > 9 || e.dst_ct > 9 || ct_size[e.src_ct] * e.ncomp != e.src_size || ct_size[e.dst_ct] * e.ncomp != e.dst_size) return false;
+    if (!e.convert && e.src_ct != e.dst_ct) return false;
+    if (src_aos && e.src_off + e.src_size > h.src_stride) return false;
+    if (dst_aos && e.dst_off + e.dst_size > h.dst_stride) return false;
+    pstq::QEntry q{};
+    q.src_off = src_aos ? e.src_off : 0; q.dst_off = dst_aos ? e.dst_off : 0;
+    q.src_size = e.src_size; q.dst_size = e.dst_size; q.ncomp = e.ncomp;
+    q.src_ct = e.src_ct; q.dst_ct = e.dst_ct; q.convert = e.convert ? 1u : 0u;
+    q.xf_kind = e.xf_kind; q.xf_pre = e.xf_kind ? (e.xf_on_source ? 1u : 0u) : 0u;
+    q.bounds = (e.bounds && h.bounds_partials && e.dst_ct == 9 /*F64*/ && e.ncomp == 3) ? 1u : 0u;
+    if (e.bounds && h.bounds_partials && !q.bounds) return false;
+    if (!src_aos) {  // one image per distinct source column (one source -> many targets: the bit fields of raw_readers.rs:61-164)
+      q.src_load = 1;
+      for (uint32_t k = 0; k < m; ++k)
+        if (plan.e[k].src_col == e.src_col && plan.e[k].src_size == e.src_size) { q.src_load = 0; q.src_img = s.entries[k].src_img; break; }
+      if (q.src_load) {
+        q.src_img = src_words;
+        src_words += e.src_size;
+        if (wide(e.src_size, e.src_col)) { q.src_wide = 1; q.src_stage = in_stage; in_stage += e.src_size; }
+      }
+    }
+    if (!dst_aos && wide(e.dst_size, e.dst_col)) {
+      q.dst_wide = 1;
+      if (s.alias) { q.dst_stage = out_stage; out_stage += e.dst_size; }
+      else { q.dst_stage = in_stage; in_stage += e.dst_size; }
+    }
+    s.entries.push_back(q);
+  }
+  s.src_words = src_aos ? 0 : src_words;
+  s.lds_per_point = std::max(in_stage, out_stage);
+  const uint32_t sw = src_aos ? h.src_stride : src_words, dw = dst_aos ? h.dst_stride : 0;
+  if ((long)(sw + dw) > max_words) return false;
+  // tile = 4 x lanes points.  ONE WAVE per workgroup (256 points) measured best on every pairing (10^8 points, eight random layouts x three
+  // pairings: 64 lanes 0.74-0.80 of peak, 128 lanes 0.51-0.80, 256 lanes 0.26-0.77): the three phases of a tile -- request, shuffle, store --
+  // need no barrier inside one wave, a CU holds 4-12 tiles in different phases instead of 1-3, and a tile of records is 6-25 KiB of LDS.
+  static const long blk_env = env_long("PST_JIT_BLK", 64);
+  s.blk = (blk_env == 64 || blk_env == 128 || blk_env == 256 || blk_env == 512) ? (int)blk_env : 64;
+  if (s.lds_bytes() > 160u * 1024u - 1024u) return false;
+  if (h.n < s.tile()) return false;
+  // XCD-aware tile numbering (every XCD works on one contiguous eighth of the range): with one small tile per workgroup it pays on all
+  // three pairings (same run as above: means 0.726 / 0.726 -> 0.770 / 0.767 for columns -> records and records -> records, 0.763 -> 0.774 for
+  // records -> columns)
+  static const long xcd_env = env_long("PST_JIT_XCD", 1);
+  s.xcd = xcd_env != 0 ? 1u : 0u;
+  static const long nt_env = env_long("PST_JIT_NT", 1);
+  s.nt = nt_env != 0;
+  *spec = std::move(s);
+  return true;
+}
+
+std::string spec_source(const QuadSpec& s) {
+  std::ostringstream o;
+  o << "#include \"jit_quad.hpp\"\n";
+  o << "struct PstJitPlan {\n";
+  o << "  static constexpr int n = " << s.entries.size() << ";\n";
+  o << "  static constexpr bool src_aos = " << (s.src_aos ? "true" : "false") << ", dst_aos = " << (s.dst_aos ? "true" : "false") << ";\n";
+  o << "  static constexpr uint32_t src_stride = " << s.src_stride << ", dst_stride = " << s.dst_stride << ", covered = " << s.covered << ";\n";
+  o << "  static constexpr int blk = " << s.blk << ";\n";
+  o << "  static constexpr uint32_t xcd = " << s.xcd << ", nt = " << s.nt << ", src_words = " << (s.src_words ? s.src_words : 1u) << ", lds_per_point = " << s.lds_per_point
+    << ", dst_tile_off = " << s.dst_tile_off << ", alias = " << s.alias << ";\n";
+  o << "  __host__ __device__ static constexpr pstq::QEntry entry(int m) {\n";
+  o << "    constexpr pstq::QEntry t[n] = {\n";
+  for (const pstq::QEntry& e : s.entries)
+    o << "      {" << e.src_off << ", " << e.dst_off << ", " << e.src_size << ", " << e.dst_size << ", " << e.ncomp << ", " << e.src_ct << ", " << e.dst_ct << ", "
+      << e.convert << ", " << e.xf_kind << ", " << e.xf_pre << ", " << e.bounds << ", " << e.src_img << ", " << e.src_load << ", " << e.src_wide << ", " << e.dst_wide
+      << ", " << e.src_stage << ", " << e.dst_stage << "},\n";
+  o << "    };\n    return t[m];\n  }\n};\n";
+  o << "extern \"C\" __global__ __launch_bounds__(" << s.blk << ") void pst_jit_convert(const ConvertHeader h, const PlanEntry* __restrict__ entries) {\n";
+  o << "  pstq::quad_convert_body<PstJitPlan>(h, entries);\n}\n";
+  return o.str();
+}
+
+std::vector<char> compile_source(const std::string& source, const std::string& arch, std::string* error) {
+  std::vector<char> code;
+  const Rtc& r = rtc();
+  if (!r.error.empty()) { if (error) *error = r.error; return code; }
+  hiprtcProgram prog = nullptr;
+  if (r.create(&prog, source.c_str(), "pst_jit_plan.hip", kJitHeaderCount, kJitHeaderTexts, kJitHeaderNames) != HIPRTC_SUCCESS) {
+    if (error) *error = "hiprtcCreateProgram failed";
+    return code;
+  }
+  std::vector<std::string> keep;
+  const std::vector<const char*>& opts = compile_options(arch, keep);
+  const hiprtcResult res = r.compile(prog, (int)opts.size(), const_cast<const char**>(opts.data()));
+  if (res != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    r.log_size(prog, &n);
+    std::string log(n, '\0');
+    if (n) r.log(prog, &log[0]);
+    if (error) *error = "hipRTC compilation failed (" + std::to_string((int)res) + "):\n" + log;
+  } else {
+    size_t n = 0;
+    if (r.code_size(prog, &n) == HIPRTC_SUCCESS && n) {
+      code.resize(n);
+      if (r.code(prog, code.data()) != HIPRTC_SUCCESS) code.clear();
+    }
+    if (code.empty() && error) *error = "hipRTC returned no code object";
+  }
+  r.destroy(&prog);
+  return code;
+}
+
+bool acquire(const QuadSpec& spec, Acquire how, Kernel* out, std::string* error) {
+  const bool wait = how == Acquire::Wait;
+  Cache& c = cache();
+  const std::string src = spec_source(spec);
+  std::shared_ptr<Entry> e;
+  bool compile_here = false;
+  {
+    std::unique_lock<std::mutex> lock(c.mu);
+    auto it = c.by_source.find(src);
+    if (it == c.by_source.end()) {
+      if (how == Acquire::IfReady) return false;
+      e = std::make_shared<Entry>();
+      e->source = src;
+      e->blk = (unsigned)spec.blk;
+      e->lds_bytes = spec.lds_bytes();
+      e->tile = spec.tile();
+      c.by_source.emplace(src, e);
+      if (wait) {
+        compile_here = true;
+      } else {
+        c.queue.push_back(e);
+        if (!c.worker_started) {
+          c.worker_started = true;
+          std::thread(worker_main).detach();
+        }
+        c.cv.notify_all();
+        return false;
+      }
+    } else {
+      e = it->second;
+      if (e->state == Entry::Queued) {
+        if (!wait) return false;
+        // queued for the background thread (or being compiled by another caller): wait for it
+        bool still_queued = false;
+        for (auto q = c.queue.begin(); q != c.queue.end(); ++q)
+          if (*q == e) { c.queue.erase(q); still_queued = true; break; }
+        if (still_queued) compile_here = true;
+        else c.cv.wait(lock, [&] { return e->state != Entry::Queued; });
+      }
+    }
+  }
+  if (compile_here) compile_entry(e);
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (e->state != Entry::Ready) {
+    if (error) *error = e->error;
+    return false;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { if (error) *error = "no current device"; return false; }
+  auto pd = e->per_device.find(dev);
+  if (pd == e->per_device.end()) {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t err = hipModuleLoadData(&mod, e->code.data());
+    if (err == hipSuccess) err = hipModuleGetFunction(&fn, mod, "pst_jit_convert");
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      e->state = Entry::Failed;
+      e->error = std::string("loading the compiled plan failed: ") + hipGetErrorString(err);
+      c.st.failures++;
+      if (error) *error = e->error;
+      return false;
+    }
+    if (e->lds_bytes > 64u * 1024u) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+    (void)hipGetLastError();
+    pd = e->per_device.emplace(dev, std::make_pair(mod, fn)).first;
+  } else {
+    c.st.memory_hits++;
+  }
+  out->fn = pd->second.second;
+  out->blk = e->blk;
+  out->lds_bytes = e->lds_bytes;
+  out->tile = e->tile;
+  c.st.launches++;
+  return true;
+}
+
+Stats stats() {
+  Cache& c = cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  return c.st;
+}
+
+}  // namespace pstjit

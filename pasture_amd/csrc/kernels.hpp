@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
+#include "../../include/pasture_amd.h"
 #include "plan.h"
 
 namespace pstk {
@@ -10,9 +13,16 @@ namespace pstk {
 // K2/K3/K3' generic conversion.  src_aos / dst_aos select the interleaved arms of buffer_conversion.rs:418-662.
 // use_lds: stage interleaved records through LDS tiles (plan.tile must be set); otherwise direct strided access.
 // Returns false when the launch (or the plan upload) failed; inspect hipGetLastError().
-bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream);
-// grid launch_convert will use: a plan with fused bounds needs convert_grid() records of 6 doubles (+ finalize room)
-unsigned convert_grid(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds);
+// n_records: number of per-block AABB records written behind plan.h.bounds_partials (plans with fused bounds).
+bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream, unsigned* n_records = nullptr);
+// upper bound of those records: a plan with fused bounds needs room for convert_max_records() records of 6 doubles (+ finalize room)
+unsigned convert_max_records(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds);
+// which kernel families (PST_PLAN_* bits) the calling thread's last conversion call launched
+void reset_plan_kinds();
+void note_plan_kind(uint32_t kind);
+uint32_t plan_kinds();
+// compile (or fetch) the plan-specialised kernel this plan would take (jit.cpp); false + message when it cannot have one
+bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error);
 size_t bounds_partials_bytes(unsigned n_records);
 // fold n_records per-block {min xyz, max xyz} records into out6
 void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream);

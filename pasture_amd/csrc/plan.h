@@ -2,7 +2,9 @@
 // A ConvertPlan is the flattened form of the reference's Vec<AttributeMapping> (buffer_conversion.rs:41-55, 98-102)
 // for one convert_into_range call.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #define PST_PLAN_MAX_ENTRIES 30
 
@@ -69,3 +71,20 @@ struct ReduceParams {
   uint64_t n;           // elements
   void* partials;       // [gridDim.x][2*NCOMP] of ACC
 };
+
+// Compile-time part of one mapping for the plan-specialised kernels (jit_quad.hpp; written out as source text by jit.cpp).
+namespace pstq {
+struct QEntry {
+  uint32_t src_off, dst_off;    // interleaved side: offset of the attribute in its record; columnar side: 0
+  uint32_t src_size, dst_size;  // attribute sizes in bytes
+  uint32_t ncomp;               // components per value (1, 3; `size` for opaque byte strings)
+  uint32_t src_ct, dst_ct;      // component types (pstd::CT_*)
+  uint32_t convert;             // datatypes differ: Rust `as` per component
+  uint32_t xf_kind, xf_pre;     // PST_XF_* and "applied to the source value" (buffer_conversion.rs:446-456)
+  uint32_t bounds;              // fold the written Vec3f64 values into the launch's AABB record
+  uint32_t src_img;             // columnar source: first dword of this attribute's quad image among the lane's source words
+  uint32_t src_load;            // columnar source: this entry loads the image (0: an earlier entry reads the same column)
+  uint32_t src_wide, dst_wide;  // columnar side: the column's tile is staged in LDS (values of >= 8 bytes, 16-byte aligned column)
+  uint32_t src_stage, dst_stage;  // ... at LDS byte T * stage (T = points per tile)
+};
+}  // namespace pstq

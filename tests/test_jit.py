@@ -1,0 +1,347 @@
+"""Plan-specialised conversion kernels (pasture_amd/csrc/jit.cpp, jit_quad.hpp): the generator and the device headers under hipRTC on the
+CPU (no GPU needed: hipRTC cross-compiles for gfx950), and on the GPU the specialised kernels against the oracle and against the interpreted
+kernels.  The reference's converter is layout-generic (buffer_conversion.rs:112-234); whichever kernel family serves a plan, the target
+bytes must be the oracle's."""
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from harness import BUFFER_KINDS
+from pasture_amd import conversion as cv
+from pasture_amd import las
+from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+from pasture_amd.conversion import BufferLayoutConverter, Transform
+from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FUZZ = int(os.environ.get("PST_FUZZ_SCALE", "1"))
+SC = [T.U8, T.I8, T.U16, T.I16, T.U32, T.I32, T.U64, T.I64, T.F32, T.F64]
+V3 = [T.Vec3u8, T.Vec3u16, T.Vec3f32, T.Vec3i32, T.Vec3f64]
+OPAQUE = [T.Vec4u8, T.ByteArray(5), T.ByteArray(16)]
+
+
+def random_converter(api, seed, transforms=True):
+    """Random source / target layouts (every datatype; packed or repr(C)), name-matched defaults with type changes, unmapped target
+    attributes (read-modify-written records), custom mappings with affine / bit-field transformations on either side."""
+    rng = np.random.default_rng(seed)
+    n_src = int(rng.integers(1, 13))
+    src_attrs = []
+    for i in range(n_src):
+        fam = rng.integers(0, 10)
+        dt = SC[rng.integers(0, 10)] if fam < 6 else (V3[rng.integers(0, 5)] if fam < 9 else OPAQUE[rng.integers(0, 3)])
+        src_attrs.append(PointAttributeDefinition(f"a{i}", dt))
+
+    def other(dt):
+        if dt in SC:
+            return SC[rng.integers(0, 10)]
+        if dt in V3:
+            return V3[rng.integers(0, 5)]
+        return dt
+    order = rng.permutation(n_src)[: int(rng.integers(1, n_src + 1))]
+    tgt_attrs = [PointAttributeDefinition(src_attrs[i].name(), other(src_attrs[i].datatype()) if rng.random() < 0.5 else src_attrs[i].datatype())
+                 for i in order]
+    with_default = rng.random() < 0.4
+    if with_default and rng.random() < 0.7:
+        tgt_attrs.append(PointAttributeDefinition("only_in_target", SC[rng.integers(0, 10)]))
+
+    def make_layout(attrs):
+        if rng.integers(0, 3) == 0:
+            return PointLayout.from_attributes(attrs, api=api)
+        return PointLayout.from_attributes_packed(attrs, int([1, 2, 4][rng.integers(0, 3)]), api=api)
+    sl, tl = make_layout(src_attrs), make_layout(tgt_attrs)
+    conv = (BufferLayoutConverter.for_layouts_with_default if with_default else BufferLayoutConverter.for_layouts)(sl, tl)
+    for _ in range(int(rng.integers(0, 4)) if transforms else 0):
+        t = tgt_attrs[rng.integers(0, len(tgt_attrs))]
+        cands = [a for a in src_attrs if (a.datatype() in SC and t.datatype() in SC) or (a.datatype() in V3 and t.datatype() in V3)
+                 or a.datatype() == t.datatype()]
+        if not cands:
+            continue
+        a = cands[rng.integers(0, len(cands))]
+        if rng.random() < 0.3:
+            conv.set_custom_mapping(a, t)
+            continue
+        on_source = bool(rng.random() < 0.5)
+        xt = a.datatype() if on_source else t.datatype()
+        if xt in (T.F64, T.F32):
+            conv.set_custom_mapping_with_transformation(a, t, Transform.affine(xt, (float(rng.uniform(-3, 3)),) * 3, (float(rng.uniform(-50, 50)),) * 3), on_source)
+        elif xt in (T.Vec3f64, T.Vec3f32):
+            conv.set_custom_mapping_with_transformation(a, t, Transform.affine(xt, tuple(rng.uniform(-3, 3, 3)), tuple(rng.uniform(-50, 50, 3))), on_source)
+        elif xt in (T.U8, T.U16, T.U32, T.U64):
+            bits = 8 * xt.size()
+            conv.set_custom_mapping_with_transformation(a, t, Transform.bitfield(xt, int(rng.integers(0, bits)), int(rng.integers(1, 1 << min(bits, 16)))), on_source)
+        else:
+            conv.set_custom_mapping(a, t)
+    return sl, tl, conv, rng
+
+
+def random_source_records(sl, n, rng):
+    rec = np.zeros(n, dtype=sl.numpy_record_dtype())
+    for a in sl.attributes():
+        npdt = a.datatype().numpy_dtype()
+        nc = a.datatype().num_components()
+        shape = (n, nc) if nc > 1 else (n,)
+        if npdt.kind == "f":
+            v = rng.uniform(-1e4, 1e4, shape)
+            special = rng.random(shape) < 0.02
+            v = np.where(special, rng.choice([np.nan, np.inf, -np.inf, 0.0, -0.0, 3e38, -1e300 if npdt.itemsize == 8 else -3e38, 0.5]), v)
+            rec[a.name()] = v.astype(npdt)
+        elif npdt.kind in "iu":
+            info = np.iinfo(npdt)
+            rec[a.name()] = rng.integers(info.min, info.max, size=shape, dtype=npdt, endpoint=True)
+        else:
+            rec[a.name()] = rng.integers(0, 256, size=(n, a.size()), dtype=np.uint8).view(npdt).reshape(shape if nc > 1 else (n,))
+    return rec
+
+
+def assert_same_columns(h, o):
+    for k in o:
+        a, b = h[k], o[k]
+        if a.dtype.kind == "f":  # NaN payload bits of f64 -> f32 are not pinned by Rust `as`
+            assert np.array_equal(np.isnan(a), np.isnan(b)), k
+            fin = ~np.isnan(b)
+            assert np.array_equal(a[fin].view(f"u{a.dtype.itemsize}"), b[fin].view(f"u{b.dtype.itemsize}")), k
+        else:
+            assert np.array_equal(a, b), k
+
+
+# ---- CPU: the generator and the headers under hipRTC ---------------------------------------------------------------------------------------
+def _scratch_bytes(code: bytes) -> int:
+    """.private_segment_fixed_size of the (only) kernel in a code object: msgpack int behind the key in the metadata note."""
+    i = code.find(b".private_segment_fixed_size")
+    assert i >= 0
+    b = code[i + len(b".private_segment_fixed_size"):]
+    if b[0] <= 0x7f:
+        return b[0]
+    return {0xcc: lambda: b[1], 0xcd: lambda: int.from_bytes(b[1:3], "big"), 0xce: lambda: int.from_bytes(b[1:5], "big")}[b[0]]()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_generated_plans_compile_under_hiprtc(hip, seed):
+    """Host logic only: random converters -> the translation unit jit.cpp would hand to hipRTC -> compiled for gfx950 against the embedded
+    headers.  Every quad image must end up in registers: no scratch memory."""
+    sl, tl, conv, _ = random_converter(hip, 7000 + seed)
+    compiled = 0
+    for st, dt in ((VectorBuffer, HashMapBuffer), (HashMapBuffer, VectorBuffer), (VectorBuffer, VectorBuffer)):
+        for with_bounds in (False, True):
+            if with_bounds and not any(a.name() == "Position3D" for a in tl.attributes()):
+                continue
+            src = conv.jit_source(st, dt, with_bounds)
+            if not src:
+                continue  # records too large for the register images, or a plan another family serves
+            assert "pstq::quad_convert_body<PstJitPlan>" in src
+            code = cv.jit_compile_source(src, api=hip)
+            assert code[:4] == b"\x7fELF"
+            assert _scratch_bytes(code) == 0, src
+            compiled += 1
+    if sl.size_of_point_entry() + tl.size_of_point_entry() <= 200:
+        assert compiled >= 3
+
+
+def test_known_plan_source_text(hip):
+    """The plan of the reference's bench layouts (layout_conversion_bench.rs:15-39) as the generator writes it: three `as` casts, records -> columns."""
+    src_l = PointLayout.from_attributes_packed([A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY, A.GPS_TIME], 1, api=hip)
+    dst_l = PointLayout.from_attributes_packed([A.GPS_TIME, A.POSITION_3D.with_custom_datatype(T.Vec3f32), A.CLASSIFICATION.with_custom_datatype(T.U32),
+                                                A.INTENSITY.with_custom_datatype(T.U8)], 1, api=hip)
+    conv = BufferLayoutConverter.for_layouts(src_l, dst_l)
+    text = conv.jit_source(VectorBuffer, HashMapBuffer)
+    assert "src_aos = true, dst_aos = false" in text and "src_stride = 35, dst_stride = 0" in text
+    rows = re.findall(r"\{([0-9, ]+)\},", text)
+    assert len(rows) == 4
+    first = [int(x) for x in rows[0].split(",")]
+    assert first[:8] == [27, 0, 8, 8, 1, 9, 9, 0]  # GpsTime F64 @27 -> column, plain copy
+    second = [int(x) for x in rows[1].split(",")]
+    assert second[:8] == [0, 0, 24, 12, 3, 9, 8, 1]  # Position3D Vec3f64 @0 -> Vec3f32, converted
+    # an identity between equal packed layouts is a byte copy of the records, never a compiled plan
+    same = BufferLayoutConverter.for_layouts(src_l, src_l)
+    assert same.jit_source(VectorBuffer, VectorBuffer) == ""
+    # the LAS reader's plan has its own format-specialised kernels
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=hip)
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    assert las.get_default_las_converter(raw, typed, (1, 1, 1), (0, 0, 0)).jit_source(VectorBuffer, HashMapBuffer) == ""
+
+
+def test_bad_source_reports_the_compiler_log(hip):
+    from pasture_amd._capi import PastureError
+    with pytest.raises(PastureError) as e:
+        cv.jit_compile_source('#include "jit_quad.hpp"\nthis is not C++\n', api=hip)
+    assert "error" in str(e.value)
+
+
+# ---- GPU -----------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def jit_sync(hip):
+    cv.jit_set_mode("sync", api=hip)
+    yield
+    cv.jit_set_mode("env", api=hip)
+
+
+def _run_case(api, seed, n, aligned, kinds, jit):
+    """One random conversion of n points between buffers of the given kinds; range starts either at 16-point multiples (the specialised
+    kernels' precondition for interleaved sides) or anywhere."""
+    sl, tl, conv, rng = random_converter(api, seed)
+    rec = random_source_records(sl, n, rng)
+    src = BUFFER_KINDS[kinds[0]].from_numpy(rec, sl)
+    pad = 16 * int(rng.integers(0, 3)) if aligned else int(rng.integers(0, 3))
+    dst = BUFFER_KINDS[kinds[1]].new_from_layout(tl)
+    dst.resize(n + 2 * pad)
+    a0 = (16 * int(rng.integers(0, max(1, n // 64)))) if aligned else int(rng.integers(0, max(1, n // 4)))
+    a0 = min(a0, n)
+    conv.convert_into_range(src, range(a0, n), dst, range(pad + a0, pad + n))
+    plan = cv.last_plan_kinds(api) if jit else []
+    return {a.name(): dst.view_attribute(a.attribute_definition()) for a in tl.attributes()}, plan
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(90 * FUZZ))
+def test_specialised_conversions_vs_oracle(hip, oracle, jit_sync, seed):
+    """Differential fuzz with every eligible plan compiled (PST_JIT=sync): byte-identical to the oracle, full tiles on the specialised
+    kernel and the ragged tail on the interpreter."""
+    rng = np.random.default_rng(99000 + seed)
+    n = int(rng.choice([256, 257, 1000, 4099, 20_011, 70_001]))
+    aligned = bool(rng.random() < 0.75)
+    kinds = [("V", "H"), ("H", "V"), ("V", "V")][seed % 3]
+    h, plan = _run_case(hip, 99000 + seed, n, aligned, kinds, True)
+    o, _ = _run_case(oracle, 99000 + seed, n, aligned, kinds, False)
+    assert_same_columns(h, o)
+    test_specialised_conversions_vs_oracle.plans.append(tuple(plan))
+
+
+test_specialised_conversions_vs_oracle.plans = []
+
+
+@pytest.mark.gpu
+def test_specialised_kernels_were_taken(hip):
+    """Of the fuzz cases above a good share must really have run on compiled plans (aligned ranges, records that fit the images)."""
+    plans = test_specialised_conversions_vs_oracle.plans
+    if not plans:
+        pytest.skip("runs after test_specialised_conversions_vs_oracle")
+    taken = sum(1 for p in plans if "jit" in p)
+    assert taken >= len(plans) // 3, (taken, len(plans))
+    st = cv.jit_stats(hip)
+    assert st["failures"] == 0 and st["compiled"] + st["disk_hits"] >= taken // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kinds", [("V", "H"), ("H", "V"), ("V", "V")])
+def test_las_reader_plan_into_a_custom_layout_specialised(hip, oracle, jit_sync, kinds):
+    """The reader's "different layout" case (raw_readers.rs:820-905) with the affine position mapping and the bit fields of
+    get_default_las_converter, plus the fused AABB: specialised kernel == oracle, bounds == calculate_bounds of the result."""
+    from pasture_amd.algorithms import calculate_bounds
+    n = 300_011
+
+    def run(api):
+        raw = las.point_layout_from_las_point_format(las.Format(1), True, api=api)
+        tgt = PointLayout.from_attributes_packed([A.INTENSITY.with_custom_datatype(T.U32), A.POSITION_3D, A.RETURN_NUMBER, A.GPS_TIME,
+                                                  A.NUMBER_OF_RETURNS.with_custom_datatype(T.U16), A.CLASSIFICATION], 1, api=api)
+        conv = las.get_default_las_converter(raw, tgt, (0.001, 0.01, 0.25), (500000.0, -5400000.0, 100.0))
+        src_v = VectorBuffer.new_from_layout(raw)
+        src_v.resize(n)
+        src_v.synth_fill(11, 5)
+        if kinds[0] == "H":
+            src = BufferLayoutConverter.for_layouts(raw, raw).convert(src_v, HashMapBuffer)
+        else:
+            src = src_v
+        dst = BUFFER_KINDS[kinds[1]].new_from_layout(tgt)
+        dst.resize(n)
+        if api is hip:
+            bounds = conv.convert_into_with_bounds(src, dst)
+            plan = cv.last_plan_kinds(api)
+        else:
+            conv.convert_into(src, dst)
+            bounds, plan = calculate_bounds(dst), []
+        return {a.name(): dst.view_attribute(a.attribute_definition()) for a in tgt.attributes()}, bounds, plan
+    (h, hb, plan), (o, ob, _) = run(hip), run(oracle)
+    assert "jit" in plan, plan
+    assert_same_columns(h, o)
+    assert hb == ob
+
+
+@pytest.mark.gpu
+def test_async_mode_interprets_first_then_takes_the_compiled_plan(hip, oracle):
+    """PST_JIT=async: a large call shows the plan to the compiler thread and is interpreted; once the code object is there the same call takes
+    it -- with identical bytes."""
+    cv.jit_set_mode("async", api=hip)
+    try:
+        n = (1 << 20) + 77
+        lay = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, PointAttributeDefinition("weird", T.ByteArray(5)), A.GPS_TIME], 1, api=hip)
+        tgt = PointLayout.from_attributes_packed([A.GPS_TIME, PointAttributeDefinition("weird", T.ByteArray(5)), A.INTENSITY.with_custom_datatype(T.F32),
+                                                  A.POSITION_3D.with_custom_datatype(T.Vec3f32)], 1, api=hip)
+        src = VectorBuffer.new_from_layout(lay)
+        src.resize(n)
+        src.synth_fill(1234, 0)
+        conv = BufferLayoutConverter.for_layouts(lay, tgt)
+        first = conv.convert(src, VectorBuffer)
+        seen = [cv.last_plan_kinds(hip)]
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            again = conv.convert(src, VectorBuffer)
+            seen.append(cv.last_plan_kinds(hip))
+            if "jit" in seen[-1]:
+                break
+            time.sleep(0.05)
+        assert "jit" in seen[-1], seen[-5:]
+        assert seen[0] == ["interpreted"] or "jit" in seen[0]  # (a warm disk cache may serve the very first call)
+        a = first.get_point_range(range(0, n)).tobytes()
+        b = again.get_point_range(range(0, n)).tobytes()
+        assert a == b
+    finally:
+        cv.jit_set_mode("env", api=hip)
+
+
+@pytest.mark.gpu
+def test_disk_cache_serves_a_second_process(tmp_path):
+    """Code objects are cached on disk per hash of source + headers + options: a second process loads instead of compiling."""
+    prog = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pasture_amd as pa\n"
+        "from pasture_amd import conversion as cv\n"
+        "from pasture_amd.layout import PointLayout, attributes as A, PointAttributeDataType as T\n"
+        "a = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], 1)\n"
+        "b = PointLayout.from_attributes_packed([A.CLASSIFICATION, A.POSITION_3D.with_custom_datatype(T.Vec3f32), A.INTENSITY], 1)\n"
+        "c = pa.BufferLayoutConverter.for_layouts(a, b)\n"
+        "print(c.prepare(pa.VectorBuffer, pa.HashMapBuffer), cv.jit_stats())\n" % ROOT)
+    env = dict(os.environ, PST_JIT_CACHE_DIR=str(tmp_path / "jit"), PST_JIT="async")
+    out1 = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+    out2 = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+    assert out1.returncode == 0 and out2.returncode == 0, out1.stderr + out2.stderr
+    assert out1.stdout.startswith("2 ") and "'compiled': 1" in out1.stdout and "'disk_hits': 0" in out1.stdout, out1.stdout
+    assert out2.stdout.startswith("2 ") and "'compiled': 0" in out2.stdout and "'disk_hits': 1" in out2.stdout, out2.stdout
+    assert len(list((tmp_path / "jit").glob("*.hsaco"))) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 7])
+def test_full_size_1e8_specialised_equals_interpreted(hip, seed):
+    """10^8 points, random packed layouts with about a third of the datatypes changed, the three pairings with an interleaved side: the
+    specialised kernel and the interpreted one leave byte-identical targets (compared on the device), and columns -> records -> columns
+    through the specialised kernels is the identity on every mapped column."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exp_jit_layouts as X
+    n = 100_000_000
+    sl, tl = X.random_layouts(seed)
+    for pairing in ("VH", "HV", "VV"):
+        ST, DT = BUFFER_KINDS[pairing[0]], BUFFER_KINDS[pairing[1]]
+        src = ST.new_from_layout(sl)
+        src.resize(n)
+        src.synth_fill(4242 + seed, 0)
+        conv = BufferLayoutConverter.for_layouts(sl, tl)
+        outs = {}
+        for mode in ("off", "sync"):
+            cv.jit_set_mode(mode, api=hip)
+            try:
+                dst = DT.new_from_layout(tl)
+                dst.resize(n)
+                conv.convert_into(src, dst)
+                outs[mode] = (dst, cv.last_plan_kinds(hip))
+            finally:
+                cv.jit_set_mode("env", api=hip)
+        assert "jit" in outs["sync"][1] and "jit" not in outs["off"][1], (outs["sync"][1], outs["off"][1])
+        for a, b in zip(X.raw_bytes(outs["off"][0]), X.raw_bytes(outs["sync"][0])):
+            assert torch.equal(a, b), (seed, pairing)
+        del outs, src, dst

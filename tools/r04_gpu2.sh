@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_jit.py -m gpu -x -q 2>&1 | tail -15
+timeout 1500 python -m pytest tests -m gpu -x -q --deselect tests/test_jit.py 2>&1 | tail -8
