@@ -45,10 +45,14 @@ WORKLOADS = {
     "rawlas_to_columns_bounds": (55, "raw LAS-0 records -> 10 SoA columns + AABB of the result, fused (20 R + 35 W)"),
     "rawlas_to_records": (55, "raw LAS-0 records (20 B) -> interleaved typed LAS-0 records (VectorBuffer of LasPointFormat0, 35 B): 20 R + 35 W"),
     "columns_to_las0": (70, "10 SoA columns -> AoS LAS format-0 (35 R + 35 W)"),
-    "columns_to_custom41": (82, "INTERPRETED plan: CustomPointTypeBig (41 B, 5 attrs, packed) columnar -> VectorBuffer (41 R + 41 W); "
-                                "generic tile kernel, four points per lane"),
-    "las1_records_to_custom27": (70, "INTERPRETED plan: typed LAS-1 records (43 B) -> packed records {Position3D, Intensity, Classification} "
-                                     "(27 B): 43 R + 27 W; generic interleaved -> interleaved tile kernel"),
+    "columns_to_custom41": (82, "CustomPointTypeBig (test_utils.rs:19-31: 41 B, 5 attrs, packed) HashMapBuffer -> VectorBuffer (41 R + 41 W); "
+                                "generic converter: config.plan says which kernel family ran (--plan interpreted | specialised)"),
+    "las1_records_to_custom27": (70, "typed LAS-1 records (43 B) -> packed records {Position3D, Intensity, Classification} (27 B), VectorBuffer -> "
+                                     "VectorBuffer: 43 R + 27 W; generic converter, config.plan says which kernel family ran"),
+    "randomlayout_records_to_columns": (None, "random packed layout (--layout-seed; tools/exp_jit_layouts.py random_layouts: 2-12 attributes of every "
+                                              "datatype, target = the same attributes permuted with a third of the datatypes changed) VectorBuffer -> HashMapBuffer"),
+    "randomlayout_columns_to_records": (None, "the same random layouts HashMapBuffer -> VectorBuffer"),
+    "randomlayout_records_to_records": (None, "the same random layouts VectorBuffer -> VectorBuffer"),
     "benchlayout_records_to_columns": (60, "layout_conversion_bench.rs: PointTypeSource (35 B packed) VectorBuffer -> PointTypeTarget (25 B) HashMapBuffer, "
                                            "three `as` casts (Vec3f64->Vec3f32, u8->u32, u16->u8): 35 R + 25 W"),
     "benchlayout_columns_to_records": (60, "the same conversion HashMapBuffer -> VectorBuffer"),
@@ -86,6 +90,10 @@ def parse():
     p.add_argument("--no-north-star", action="store_true", help="skip the 10^9-point single-GPU leg (north_star size) appended at N=1")
     p.add_argument("--north-star-points", type=int, default=1_000_000_000)
     p.add_argument("--workload", default="convert_affine_bounds", choices=sorted(WORKLOADS))
+    p.add_argument("--plan", default="auto", choices=["auto", "interpreted", "specialised"],
+                   help="generic conversion workloads: auto / specialised = the plan-specialised kernel (in-tree instantiation or hipRTC, compiled before the "
+                        "timed region with pst_converter_prepare); interpreted = the generic tile kernels interpreting the mapping list (PST_JIT=0)")
+    p.add_argument("--layout-seed", type=int, default=0, help="randomlayout_* workloads: which random layout pair")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-points", type=int, default=100_000_000, help="CPU baseline sample (default: the whole 10^8-point workload, ~10 s of CPU work)")
     return p.parse_args()
@@ -273,6 +281,10 @@ def main():
     api.set_device(local_rank)
     stream = torch.cuda.current_stream()
     api.set_stream(ctypes.c_void_p(stream.cuda_stream))  # kernels run on torch's current stream => torch events see them
+    from pasture_amd import conversion as cv
+    if args.plan == "interpreted":
+        cv.jit_set_mode("off")  # neither the in-tree instantiations nor the run-time compiler: every generic plan is interpreted
+    conv = None  # generic-conversion workloads leave their converter here: prepared before the timed region, its kernel family reported
 
     if args.global_points:
         # BASELINE.json configs[3]: ONE cloud sharded by index range; the ranks' shards differ by at most one tile
@@ -480,6 +492,24 @@ def main():
 
         def step():
             conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    elif args.workload.startswith("randomlayout_"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from exp_jit_layouts import moved_bytes, random_layouts
+        src_layout, dst_layout = random_layouts(args.layout_seed)
+        src_kind = pa.VectorBuffer if args.workload.split("_")[1] == "records" else pa.HashMapBuffer
+        dst_kind = pa.VectorBuffer if args.workload.endswith("_records") else pa.HashMapBuffer
+        bytes_per_point = moved_bytes(src_layout, dst_layout, src_kind is pa.HashMapBuffer, dst_kind is pa.HashMapBuffer)
+        desc += (f"; seed {args.layout_seed}: {len(src_layout.attributes())} attributes, records of {src_layout.size_of_point_entry()} -> "
+                 f"{dst_layout.size_of_point_entry()} B, {bytes_per_point} B moved per point")
+        src = src_kind.new_from_layout(src_layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = dst_kind.new_from_layout(dst_layout)
+        dst.resize(n)
+        conv = pa.BufferLayoutConverter.for_layouts(src_layout, dst_layout)
+
+        def step():
+            conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
     elif args.workload == "columns_to_las0":
         layout = las.point_layout_from_las_point_format(las.Format(0), False)
         src = pa.HashMapBuffer.new_from_layout(layout)
@@ -515,6 +545,10 @@ def main():
                 conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
 
     has_reduction = args.workload in ("convert_affine_bounds", "bounds") or args.workload.endswith("_bounds")
+    prepared_plan = None
+    if conv is not None and args.plan != "interpreted":
+        # the run-time compiler normally works on a background thread while the first calls are interpreted; a benchmark wants the steady state
+        prepared_plan = cv.PLAN_NAMES[conv.prepare(type(src), type(dst), has_reduction)]
 
     def full_step():
         step()
@@ -555,6 +589,8 @@ def main():
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    # which kernel families the last step's conversion / compaction call launched, as the library reports it (pst_last_plan_kinds)
+    plan_kinds = cv.last_plan_kinds() if (conv is not None or args.workload.startswith("filter_")) else None
     if after is not None:
         after()  # (a workload's own check of what its stream-ordered steps left behind; outside the timed region)
     if distributed:
@@ -682,7 +718,7 @@ def main():
                        "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16", "normals_knn16_sheet") else "LAS format 0",
                        "parallelism": (f"index-range shard x{world} of one {global_points}-point cloud (configs[3]), one all-reduce of the 6-f64 AABB" if args.global_points
                                        else f"index-range shard x{world}, one all-reduce of the 6-f64 AABB") if distributed else "1 GPU",
-                       "seed": SEED, "bounds": result},
+                       "seed": SEED, "bounds": result, "plan": plan_kinds, "plan_requested": args.plan},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_point": bytes_per_point, "kernel_ms_avg": round(kernel_ms_avg, 4),

@@ -28,7 +28,7 @@ namespace pstk {
 void launch_convert_tile_tt(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
 void launch_convert_tile_tf(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
 void launch_convert_tile_ft(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
-bool launch_convert_static(const ConvertPlan& plan, bool src_aos, bool dst_aos, unsigned grid, size_t lds_bytes, const PlanEntry* entries, hipStream_t stream);
+bool launch_convert_static(const std::string& source, uint32_t* tile, bool tile_only, unsigned grid, const ConvertHeader& h, const PlanEntry* entries, hipStream_t stream);
 
 int device_cus() {
   static int cus = [] {
@@ -124,7 +124,6 @@ static bool launch_interpreted(const ConvertPlan& plan, bool src_aos, bool dst_a
   if (use_lds && (src_aos || dst_aos)) {
     const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
     // 256-thread blocks: 512 / 1024 measured 15-60 % slower (per-wave interpretation cost is amortised over fewer points)
-    if (launch_convert_static(plan, src_aos, dst_aos, grid, lds_bytes, entries, stream)) { note_plan_kind(PST_PLAN_STATIC); return hipGetLastError() == hipSuccess; }
     note_plan_kind(PST_PLAN_INTERPRETED);
     if (src_aos && dst_aos) launch_convert_tile_tt(grid, lds_bytes, stream, h, entries);
     else if (src_aos) launch_convert_tile_tf(grid, lds_bytes, stream, h, entries);
@@ -146,22 +145,34 @@ static bool launch_specialised(const ConvertPlan& plan, bool src_aos, bool dst_a
   if (mode == pstjit::Mode::Off) return true;
   pstjit::QuadSpec spec;
   if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) return true;
+  const std::string source = pstjit::spec_source(spec);
+  // 1. the in-tree instantiations for the reference's bench layouts (a warm cache); 2. the run-time compiler's cache
+  uint32_t tile = 0;
   pstjit::Kernel k;
-  // small calls never start a compilation; a kernel some larger call (or pst_converter_prepare) had compiled is used whatever the size
-  const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait
-                              : plan.h.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
-  if (!pstjit::acquire(spec, how, &k)) return true;  // not ready (or failed): interpret
-  const uint64_t n_tiles = plan.h.n / k.tile;
-  if (n_tiles == 0) return true;
-  if (n_tiles > (1ull << 30)) return true;
+  const bool in_tree = launch_convert_static(source, &tile, true, 0, plan.h, nullptr, stream);
+  if (!in_tree) {
+    // small calls never start a compilation; a kernel some larger call (or pst_converter_prepare) had compiled is used whatever the size
+    const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait
+                                : plan.h.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
+    if (!pstjit::acquire(spec, source, how, &k)) return true;  // not ready (or failed): interpret
+    tile = k.tile;
+  }
+  const uint64_t n_tiles = plan.h.n / tile;
+  if (n_tiles == 0 || n_tiles > (1ull << 30)) return true;
   const PlanEntry* entries = upload_entries(plan, stream);
   if (!entries) return false;
   ConvertHeader h = plan.h;
-  h.n = n_tiles * k.tile;
+  h.n = n_tiles * tile;
   const unsigned grid = (unsigned)((n_tiles + 7) / 8 * 8);
-  void* args[] = {(void*)&h, (void*)&entries};
-  if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) return false;
-  note_plan_kind(PST_PLAN_JIT);
+  if (in_tree) {
+    launch_convert_static(source, &tile, false, grid, h, entries, stream);
+    if (hipGetLastError() != hipSuccess) return false;
+    note_plan_kind(PST_PLAN_STATIC);
+  } else {
+    void* args[] = {(void*)&h, (void*)&entries};
+    if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) return false;
+    note_plan_kind(PST_PLAN_JIT);
+  }
   if (n_records) *n_records = grid;
   *done = h.n;
   return true;
@@ -189,12 +200,16 @@ bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool us
 }
 
 // Compile (or fetch) the specialised kernel this plan would take; true when a later launch_convert of the same plan shape will use it.
-bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error) {
+bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error, bool* in_tree) {
+  if (in_tree) *in_tree = false;
   if (pstjit::mode() == pstjit::Mode::Off) { if (error) *error = "PST_JIT=0"; return false; }
   pstjit::QuadSpec spec;
   if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) { if (error) *error = "plan not eligible for a specialised kernel"; return false; }
+  const std::string source = pstjit::spec_source(spec);
+  uint32_t tile = 0;
+  if (launch_convert_static(source, &tile, true, 0, plan.h, nullptr, nullptr)) { if (in_tree) *in_tree = true; return true; }
   pstjit::Kernel k;
-  return pstjit::acquire(spec, pstjit::Acquire::Wait, &k, error);
+  return pstjit::acquire(spec, source, pstjit::Acquire::Wait, &k, error);
 }
 
 }  // namespace pstk

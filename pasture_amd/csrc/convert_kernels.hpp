@@ -795,86 +795,4 @@ __global__ __launch_bounds__(BLK) void convert_tile_kernel(const ConvertHeader h
 }
 
 
-// ---- compile-time plans ------------------------------------------------------------------------------------------------------------
-// The tile kernel above INTERPRETS its mapping list: offsets, sizes, component types and the wave that owns a narrow attribute come out of
-// scalar registers, type pairs are dispatched by wave-uniform switches.  For the plans the reference's own benches and tests build over and
-// over (layout_conversion_bench.rs:15-39, buffer_filter_bench.rs:71-74, test_utils.rs:19-31) the same body is instantiated with the plan as
-// a compile-time constant -- the way the eleven LAS formats are -- so that every offset is an immediate and every dispatch is folded; only
-// the column addresses and the point count stay run-time values.  The interpreter remains the general path: a plan is recognised by
-// comparing it field by field with the registered constants (static_plans.hpp), anything else is interpreted.
-struct StaticEntry {
-  uint32_t src_off, dst_off, src_size, dst_size, ncomp;
-  uint8_t src_ct, dst_ct;
-  uint16_t convert;
-  uint32_t owner;  // 0: every wave works on it; 1 + w: owned by wave w
-};
-// A plan type SP provides: static constexpr int n; uint32_t src_stride, dst_stride, tile, quad, covered; and
-// `__host__ __device__ static constexpr StaticEntry entry(int m)`.
-template <int BLK, bool SRC_AOS, bool DST_AOS, typename SP>
-__global__ __launch_bounds__(BLK) void convert_tile_static_kernel(const ConvertHeader hr, const PlanEntry* __restrict__ entries) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  lptr_t lds = (lptr_t)lds_raw;
-  ConvertHeader h = hr;
-  h.src_stride = SP::src_stride; h.dst_stride = SP::dst_stride; h.tile = SP::tile; h.quad = SP::quad; h.dst_fully_covered = SP::covered; h.in_place = 0;
-  constexpr uint32_t T = SP::tile;
-  constexpr uint32_t src_cap = SRC_AOS ? ((T * SP::src_stride + 32u + 15u) & ~15u) : 0u;
-  lptr_t lds_s = lds;
-  lptr_t lds_d = lds + src_cap;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-  BoundsAcc acc;
-  acc.init();
-  const uint64_t n_tiles = (h.n + T - 1) / T;
-  for (uint64_t tile = (SRC_AOS && !DST_AOS) ? xcd_block_id() : blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint64_t first = tile * T;
-    const uint32_t cnt = (uint32_t)((h.n - first) < T ? (h.n - first) : T);
-    uint32_t s_mis = 0, d_mis = 0;
-    gptr_t g_dst = nullptr;
-    if constexpr (SRC_AOS) {
-      const uint64_t ga = h.src_aos + first * SP::src_stride;
-      s_mis = (uint32_t)(ga & 15u);
-      tile_load<BLK>(lds_s, as_global(ga - s_mis), round_up16(s_mis + cnt * SP::src_stride));
-    }
-    if constexpr (DST_AOS) {
-      const uint64_t ga = h.dst_aos + first * SP::dst_stride;
-      d_mis = (uint32_t)(ga & 15u);
-      g_dst = as_global(ga - d_mis);
-      if (!SP::covered) tile_load<BLK>(lds_d, g_dst, round_up16(d_mis + cnt * SP::dst_stride));
-    }
-    clptr_t tile_src = (clptr_t)(lds_s + s_mis);
-    wait_tile_loads();
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < SP::n; ++m) {
-      const StaticEntry se = SP::entry(m);
-      const bool shared_entry = se.owner == 0;
-      if (!shared_entry && se.owner - 1u != wave) continue;
-      const LaneSpan span = shared_entry ? LaneSpan{threadIdx.x, (uint32_t)BLK} : LaneSpan{lane, 64u};
-      PlanEntry e{};
-      {  // run-time part of the entry: the column addresses
-        const PST_AS_CONST uint64_t* w = (const PST_AS_CONST uint64_t*)(entries + m);
-        e.src_col = w[0]; e.dst_col = w[1];
-      }
-      e.src_off = se.src_off; e.dst_off = se.dst_off; e.src_size = se.src_size; e.dst_size = se.dst_size;
-      e.ncomp = se.ncomp; e.src_ct = se.src_ct; e.dst_ct = se.dst_ct; e.convert = se.convert;
-      e.xf_kind = 0; e.xf_on_source = 0; e.mask = ~0ull; e.shift = 0; e.bounds = 0;
-      e.scale[0] = e.scale[1] = e.scale[2] = 1.0; e.offset[0] = e.offset[1] = e.offset[2] = 0.0;
-      dispatch_ct(e.src_ct, [&](auto s) __attribute__((always_inline)) {
-        using S = decltype(s);
-        if (!e.convert) {
-          run_tile<SRC_AOS, DST_AOS, S, S>(h, e, tile_src, lds_d + d_mis, first, cnt, span, acc);
-        } else {
-          dispatch_ct(e.dst_ct, [&](auto d) __attribute__((always_inline)) {
-            run_tile<SRC_AOS, DST_AOS, S, decltype(d)>(h, e, tile_src, lds_d + d_mis, first, cnt, span, acc);
-          });
-        }
-      });
-    }
-    __syncthreads();
-    if constexpr (DST_AOS) {
-      tile_store<BLK>(lds_d, g_dst, d_mis, cnt * SP::dst_stride);
-      __syncthreads();
-    }
-  }
-}
-
 }  // namespace

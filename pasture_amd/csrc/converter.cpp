@@ -558,7 +558,8 @@ int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_colu
   uint32_t kind = plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan);
   if (kind == PST_PLAN_INTERPRETED && plan.h.n_entries) {
     std::string err;
-    if (pstk::prepare_convert(plan, !src_columnar, !dst_columnar, &err)) kind = PST_PLAN_JIT;
+    bool in_tree = false;
+    if (pstk::prepare_convert(plan, !src_columnar, !dst_columnar, &err, &in_tree)) kind = in_tree ? PST_PLAN_STATIC : PST_PLAN_JIT;
     else if (!err.empty() && err.find("not eligible") == std::string::npos && err != "PST_JIT=0") set_last_error(err);
   }
   if (plan_kind) *plan_kind = kind;

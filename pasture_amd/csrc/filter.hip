@@ -545,7 +545,9 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
   }
     static const bool static_plans = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
     // interleaved targets only: same-box A/B 0.6075 -> 0.6267 of peak; the columnar target LOST with constants (0.663 -> 0.626) and stays interpreted
+    if (g == 0) reset_plan_kinds();
     if (static_plans && dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, dst_aos)) {
+      note_plan_kind(PST_PLAN_STATIC);
       // point-major record assembly (filter_big_records_kernel): same-box A/B against the granule-major constants 0.657 -> 0.673 of peak
       // (PST_FILTER_PM=0 switches back), 0.680 with a 24 KiB record tile (8 / 16 / 24 / 32 KiB: 0.671 / 0.674 / 0.680 / 0.676)
       static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 1; }();
@@ -559,6 +561,7 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
       }
       continue;
     }
+    note_plan_kind(PST_PLAN_INTERPRETED);
     switch (tile / kBlock) {
       case 8: if (dst_aos) PST_FILTER(8, true) else PST_FILTER(8, false) break;
       case 4: if (dst_aos) PST_FILTER(4, true) else PST_FILTER(4, false) break;

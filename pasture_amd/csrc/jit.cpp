@@ -355,8 +355,11 @@ bool spec_from_plan(const ConvertPlan& plan, bool src_aos, bool dst_aos, QuadSpe
   // records -> columns)
   static const long xcd_env = env_long("PST_JIT_XCD", 1);
   s.xcd = xcd_env != 0 ? 1u : 0u;
-  static const long nt_env = env_long("PST_JIT_NT", 1);
-  s.nt = nt_env != 0;
+  // non-temporal accesses: bit 0 narrow column loads, 1 narrow column stores, 2 tile stores (LDS -> HBM), 3 tile loads (LDS-DMA).  Same-box
+  // sweep (12 random layouts x 3 pairings, 10^8 points, means): all four 0.810 / 0.785 / 0.806 (records -> columns / columns -> records /
+  // records -> records); without the DMA bit 0.776 / 0.775 / 0.779; none 0.770 / 0.752 / 0.772: a tile is read once, by one wave.
+  static const long nt_env = env_long("PST_JIT_NT", -1);
+  s.nt = nt_env >= 0 ? (uint32_t)nt_env & 15u : 15u;
   *spec = std::move(s);
   return true;
 }
@@ -413,10 +416,9 @@ std::vector<char> compile_source(const std::string& source, const std::string& a
   return code;
 }
 
-bool acquire(const QuadSpec& spec, Acquire how, Kernel* out, std::string* error) {
+bool acquire(const QuadSpec& spec, const std::string& src, Acquire how, Kernel* out, std::string* error) {
   const bool wait = how == Acquire::Wait;
   Cache& c = cache();
-  const std::string src = spec_source(spec);
   std::shared_ptr<Entry> e;
   bool compile_here = false;
   {

@@ -43,7 +43,7 @@ struct Kernel {
 // is queued for the compiler thread and the call returns false at once (the caller interprets the plan meanwhile); Wait: compiles in the
 // calling thread (or waits for the compiler thread if it already has this plan).
 enum class Acquire { IfReady, Enqueue, Wait };
-bool acquire(const QuadSpec& spec, Acquire how, Kernel* out, std::string* error = nullptr);
+bool acquire(const QuadSpec& spec, const std::string& source, Acquire how, Kernel* out, std::string* error = nullptr);  // source = spec_source(spec)
 
 // Compile without touching a device (CPU test of the generator and of the headers under hipRTC): code object bytes, or empty + error.
 std::vector<char> compile_source(const std::string& source, const std::string& arch, std::string* error);

@@ -199,7 +199,7 @@ __device__ __forceinline__ void lds_write_image(lptr_t p, const uint32_t (&w)[NW
 
 // LDS -> global copy of a whole tile of NBYTES (a multiple of 16, both sides 16-byte aligned): the trip count is a constant, so the
 // copy is straight-line code -- every LDS read of a batch issued before its stores, no per-chunk bounds test.
-template <int BLK, uint32_t NBYTES>
+template <int BLK, uint32_t NBYTES, bool NT>
 __device__ __forceinline__ void tile_store_const(clptr_t lds, gptr_t gbase) {
   static_assert(NBYTES % 16u == 0, "whole 16-byte chunks");
   constexpr uint32_t NV = NBYTES / 16u, FULL = NV / (uint32_t)BLK, REM = NV % (uint32_t)BLK;
@@ -212,11 +212,28 @@ __device__ __forceinline__ void tile_store_const(clptr_t lds, gptr_t gbase) {
 #pragma unroll
     for (uint32_t u = 0; u < kBatch; ++u) if (i0 + u < FULL) v[u] = l[(i0 + u) * BLK];
 #pragma unroll
-    for (uint32_t u = 0; u < kBatch; ++u) if (i0 + u < FULL) __builtin_nontemporal_store(v[u], &g[(i0 + u) * BLK]);
+    for (uint32_t u = 0; u < kBatch; ++u) {
+      if (i0 + u < FULL) {
+        if constexpr (NT) __builtin_nontemporal_store(v[u], &g[(i0 + u) * BLK]);
+        else g[(i0 + u) * BLK] = v[u];
+      }
+    }
   }
   if constexpr (REM != 0) {
-    if (threadIdx.x < REM) __builtin_nontemporal_store(l[FULL * BLK], &g[FULL * BLK]);
+    if (threadIdx.x < REM) {
+      if constexpr (NT) __builtin_nontemporal_store(l[FULL * BLK], &g[FULL * BLK]);
+      else g[FULL * BLK] = l[FULL * BLK];
+    }
   }
+}
+
+// tile_load (tile_io.hpp) with the cache policy as a constant: AUX = 2 requests the tile non-temporally (read once, by this workgroup)
+template <int BLK, int AUX>
+__device__ __forceinline__ void tile_load_const(lptr_t lds, cgptr_t gbase, uint32_t nbytes16) {
+  const uint32_t nvec = nbytes16 >> 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i = threadIdx.x; i < nvec; i += BLK)
+    __builtin_amdgcn_global_load_lds((const PST_AS_GLOBAL void*)(gbase + (uint64_t)i * 16), (PST_AS_LDS void*)(lds + (i - lane) * 16u), 16, 0, AUX);
 }
 
 // One value: optional pre-transform, `as` D, optional post-transform (buffer_conversion.rs:446-456), the kind a constant
@@ -314,7 +331,7 @@ __device__ __forceinline__ void lds_read_words(clptr_t p, uint32_t (&w)[NW], uin
 //   static constexpr uint32_t src_stride, dst_stride;        // record sizes of the interleaved sides (0 on a columnar side)
 //   static constexpr uint32_t covered;                       // interleaved target: every byte of a record is written by some mapping
 //   static constexpr int blk;                                // lanes per workgroup (tile = 4 blk points)
-//   static constexpr uint32_t xcd, nt;                       // XCD-aware tile numbering; non-temporal column accesses
+//   static constexpr uint32_t xcd, nt;                       // XCD-aware tile numbering; non-temporal accesses: bit 0 narrow column loads, 1 narrow column stores, 2 tile stores, 3 tile loads (LDS-DMA)
 //   static constexpr uint32_t src_words;                     // columnar source: dwords of the lane's source images (sum of the loaded attributes' sizes)
 //   static constexpr uint32_t lds_per_point;                 // LDS bytes per point of the tile: record tiles + staged wide columns
 //   static constexpr uint32_t dst_tile_off, alias;           // target record tile at LDS byte T * dst_tile_off; alias: the outgoing regions overlay the incoming ones
@@ -331,6 +348,7 @@ __device__ __forceinline__ void quad_convert_body(const ConvertHeader& h, const 
   constexpr uint32_t SS = P::src_stride, DS = P::dst_stride;
   constexpr int SW = P::src_aos ? (int)SS : (int)P::src_words;
   constexpr int DW = P::dst_aos ? (int)DS : 1;
+  constexpr int kDmaAux = (P::nt & 8u) != 0 ? 2 : 0;
   lptr_t lds = (lptr_t)pstq_lds;
   lptr_t lds_s = lds;
   lptr_t lds_d = lds + T * P::dst_tile_off;
@@ -342,8 +360,8 @@ __device__ __forceinline__ void quad_convert_body(const ConvertHeader& h, const 
     const uint64_t first = tile * T;
     const uint64_t p0 = first + 4u * tid;  // this lane's first point
     // ---- phase 1: everything that comes from HBM is requested at once ----------------------------------------------------------------
-    if constexpr (P::src_aos) tile_load<BLK>(lds_s, as_global(h.src_aos + first * SS), T * SS);
-    if constexpr (P::dst_aos && !P::covered) tile_load<BLK>(lds_d, as_global(h.dst_aos + first * DS), T * DS);
+    if constexpr (P::src_aos) tile_load_const<BLK, kDmaAux>(lds_s, as_global(h.src_aos + first * SS), T * SS);
+    if constexpr (P::dst_aos && !P::covered) tile_load_const<BLK, 0>(lds_d, as_global(h.dst_aos + first * DS), T * DS);
     uint32_t sw[SW];
     bool staged_in = P::src_aos || (P::dst_aos && !P::covered);
     if constexpr (!P::src_aos) {
@@ -352,10 +370,10 @@ __device__ __forceinline__ void quad_convert_body(const ConvertHeader& h, const 
         if constexpr (e.src_load != 0) {
           const uint64_t col = ((const PST_AS_CONST PlanEntry*)(entries + decltype(I)::value))->src_col;
           if constexpr (e.src_wide != 0) {
-            tile_load<BLK>(lds + T * e.src_stage, (cgptr_t)as_global(col) + first * e.src_size, T * e.src_size);
+            tile_load_const<BLK, kDmaAux>(lds + T * e.src_stage, (cgptr_t)as_global(col) + first * e.src_size, T * e.src_size);
             staged_in = true;
           } else {
-            load_words<e.src_size, P::nt != 0>((cgptr_t)as_global(col) + p0 * e.src_size, sw, e.src_img);
+            load_words<e.src_size, (P::nt & 1u) != 0>((cgptr_t)as_global(col) + p0 * e.src_size, sw, e.src_img);
           }
         }
       });
@@ -405,20 +423,20 @@ __device__ __forceinline__ void quad_convert_body(const ConvertHeader& h, const 
           staged_out = true;
         } else {
           const uint64_t col = ((const PST_AS_CONST PlanEntry*)(entries + M))->dst_col;
-          store_words<e.dst_size, P::nt != 0>(as_global(col) + p0 * e.dst_size, cw);
+          store_words<e.dst_size, (P::nt & 2u) != 0>(as_global(col) + p0 * e.dst_size, cw);
         }
       }
     });
     // ---- phase 3: tiles leave flat -----------------------------------------------------------------------------------------------------
     if constexpr (P::dst_aos) lds_write_image<DW>(lds_d + tid * (4u * DS), dw);
     if (staged_out) __syncthreads();
-    if constexpr (P::dst_aos) tile_store_const<BLK, T * DS>(lds_d, as_global(h.dst_aos + first * DS));
+    if constexpr (P::dst_aos) tile_store_const<BLK, T * DS, (P::nt & 4u) != 0>(lds_d, as_global(h.dst_aos + first * DS));
     if constexpr (!P::dst_aos) {
       static_for<0, P::n>([&](auto I) __attribute__((always_inline)) {
         constexpr QEntry e = P::entry(decltype(I)::value);
         if constexpr (e.dst_wide != 0) {
           const uint64_t col = ((const PST_AS_CONST PlanEntry*)(entries + decltype(I)::value))->dst_col;
-          tile_store_const<BLK, T * e.dst_size>(lds + T * e.dst_stage, as_global(col) + first * e.dst_size);
+          tile_store_const<BLK, T * e.dst_size, (P::nt & 4u) != 0>(lds + T * e.dst_stage, as_global(col) + first * e.dst_size);
         }
       });
     }

@@ -165,6 +165,20 @@ def test_known_plan_source_text(hip):
     assert las.get_default_las_converter(raw, typed, (1, 1, 1), (0, 0, 0)).jit_source(VectorBuffer, HashMapBuffer) == ""
 
 
+def test_static_plans_match_the_generator(hip):
+    """pasture_amd/csrc/static_plans.inc (the in-tree instantiations for the reference's bench layouts) is what the generator writes today,
+    and those converters are routed to the in-tree kernels without the run-time compiler."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_static_plans as G
+    with open(os.path.join(ROOT, "pasture_amd", "csrc", "static_plans.inc")) as f:
+        assert f.read() == G.render(), "stale static_plans.inc: run python tools/gen_static_plans.py and rebuild"
+    before = cv.jit_stats(hip)
+    for name, conv, st, dt in G.bench_converters():
+        assert conv.prepare(st, dt) == cv.PLAN_STATIC, name
+    after = cv.jit_stats(hip)
+    assert after["compiled"] == before["compiled"] and after["disk_hits"] == before["disk_hits"]
+
+
 def test_bad_source_reports_the_compiler_log(hip):
     from pasture_amd._capi import PastureError
     with pytest.raises(PastureError) as e:
