@@ -12,7 +12,7 @@ hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
 TYPES = {"int": "c_int", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "int64_t": "i64", "void": "c_void",
          "char": "c_char", "pst_layout": "pst_layout", "pst_buffer": "pst_buffer", "pst_converter": "pst_converter",
          "pst_datatype": "pst_datatype", "pst_member": "pst_member", "pst_transform": "pst_transform", "pst_mapping_info": "pst_mapping_info",
-         "pst_point_converter": "pst_point_converter", "pst_comm": "pst_comm", "pst_comm_id": "pst_comm_id"}
+         "pst_point_converter": "pst_point_converter", "pst_comm": "pst_comm", "pst_comm_id": "pst_comm_id", "pst_jit_stats": "pst_jit_stats"}
 # C parameter names that are Rust keywords (`self` as a parameter NAME of an extern fn is a compile error)
 RENAME = {"type": "ty", "self": "this", "in": "input", "ref": "reference", "fn": "func", "move": "mv", "match": "matched"}
 
@@ -63,6 +63,8 @@ STRUCTS = [
     ("pst_mapping_info", "Clone, Copy", [("source_name", "*const c_char"), ("target_name", "*const c_char"), ("source_datatype", "pst_datatype"),
                                          ("target_datatype", "pst_datatype"), ("source_offset", "u64"), ("target_offset", "u64"), ("has_converter", "i32"),
                                          ("transform_kind", "u32"), ("apply_to_source", "i32"), ("reserved", "i32")]),
+    ("pst_jit_stats", "Clone, Copy, Debug, Default", [("compiled", "u64"), ("disk_hits", "u64"), ("memory_hits", "u64"), ("failures", "u64"), ("launches", "u64"),
+                                                      ("compile_seconds", "f64")]),
 ]
 LAYOUT = {}
 
