@@ -89,54 +89,10 @@ struct KBest {
 // ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
 struct Fit { double nx, ny, nz, curvature; int ok; };
 
-// KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
-// compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
-// FINITE: the caller guarantees finite coordinates (the grid search only ever sees the finite points): the NaN / finiteness tests per
-// neighbour, which then cannot change anything, are not compiled in.
-template <int KMAX = 0, bool FINITE = false, typename GetPoint>
-__device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
+// Everything of the fit behind the covariance matrix (upper triangle, NOT divided by the count): eigen_3x3 :429-453 with solve_polynomial
+// :328-392, get_largest_eigen_vector :395-426, solve_plane_parameter :456-467.
+__device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, double c02, double c11, double c12, double c22) {
   Fit f{0, 0, 0, 0, 1};
-  auto for_each = [&](auto&& body) __attribute__((always_inline)) {
-    if constexpr (KMAX > 0) {
-#pragma unroll
-      for (int t = 0; t < KMAX; ++t) if ((uint32_t)t < m) body((uint32_t)t);
-    } else {
-      for (uint32_t t = 0; t < m; ++t) body(t);
-    }
-  };
-  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points) and compute_centroid :198-237 in ONE
-  // pass over the neighbours (each pass re-gathers 16 points): both candidate sums are accumulated in point order -- over all points
-  // (the dense path) and over the finite ones (the other path) -- and the one `dense` selects is used, so every sum is the same sequence
-  // of additions as in the reference.
-  bool dense = true;
-  double ax = 0, ay = 0, az = 0, fx = 0, fy = 0, fz = 0;
-  long long cnt = 0;
-  for_each([&](uint32_t t) __attribute__((always_inline)) {
-    double x, y, z; get(t, x, y, z);
-    ax += x; ay += y; az += z;
-    if constexpr (!FINITE) {
-      if (x != x || y != y || z != z) dense = false;
-      if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
-    }
-  });
-  const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
-  const double div = dense ? (double)m : (double)cnt;
-  const double cx = sx / div, cy = sy / div, cz = sz / div;
-  // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
-  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
-  long long used = 0;
-  for_each([&](uint32_t t) __attribute__((always_inline)) {
-    double x, y, z; get(t, x, y, z);
-    if (FINITE || dense || finite3(x, y, z)) {
-      double d0 = x - cx, d1 = y - cy, d2 = z - cz;
-      c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
-      const double dx = d0;
-      d0 *= dx; d1 *= dx; d2 *= dx;
-      c00 += d0; c01 += d1; c02 += d2;
-      used += 1;
-    }
-  });
-  if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
   const double c10 = c01, c20 = c02, c21 = c12;
   // eigen_3x3 :429-453
   double scale = __builtin_fabs(c00);  // covariance_matrix.abs().max(), column-major order
@@ -203,6 +159,88 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
   const double eigen_sum = c00 + c11 + c22;
   f.curvature = eigen_sum != 0.0 ? __builtin_fabs(eigen_value / eigen_sum) : 0.0;
   return f;
+}
+
+// KMAX > 0: the neighbour list lives in registers (get(t) selects among KMAX of them): the loops over t are unrolled so that t is a
+// compile-time constant and the selection folds away; the order of the floating-point sums is unchanged.
+// FINITE: the caller guarantees finite coordinates (the grid search only ever sees the finite points): the NaN / finiteness tests per
+// neighbour, which then cannot change anything, are not compiled in.
+template <int KMAX = 0, bool FINITE = false, typename GetPoint>
+__device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
+  Fit f{0, 0, 0, 0, 1};
+  auto for_each = [&](auto&& body) __attribute__((always_inline)) {
+    if constexpr (KMAX > 0) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) if ((uint32_t)t < m) body((uint32_t)t);
+    } else {
+      for (uint32_t t = 0; t < m; ++t) body(t);
+    }
+  };
+  // is_dense :133-140 (any NaN coordinate => the "not dense" path that skips non-FINITE points) and compute_centroid :198-237 in ONE
+  // pass over the neighbours (each pass re-gathers 16 points): both candidate sums are accumulated in point order -- over all points
+  // (the dense path) and over the finite ones (the other path) -- and the one `dense` selects is used, so every sum is the same sequence
+  // of additions as in the reference.
+  bool dense = true;
+  double ax = 0, ay = 0, az = 0, fx = 0, fy = 0, fz = 0;
+  long long cnt = 0;
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
+    double x, y, z; get(t, x, y, z);
+    ax += x; ay += y; az += z;
+    if constexpr (!FINITE) {
+      if (x != x || y != y || z != z) dense = false;
+      if (finite3(x, y, z)) { fx += x; fy += y; fz += z; cnt += 1; }
+    }
+  });
+  const double sx = dense ? ax : fx, sy = dense ? ay : fy, sz = dense ? az : fz;
+  const double div = dense ? (double)m : (double)cnt;
+  const double cx = sx / div, cy = sy / div, cz = sz / div;
+  // compute_covariance_matrix :240-305 (upper triangle, NOT divided by the count)
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+  long long used = 0;
+  for_each([&](uint32_t t) __attribute__((always_inline)) {
+    double x, y, z; get(t, x, y, z);
+    if (FINITE || dense || finite3(x, y, z)) {
+      double d0 = x - cx, d1 = y - cy, d2 = z - cz;
+      c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+      const double dx = d0;
+      d0 *= dx; d1 *= dx; d2 *= dx;
+      c00 += d0; c01 += d1; c02 += d2;
+      used += 1;
+    }
+  });
+  if ((dense ? (long long)m : used) < 3) { f.ok = 0; return f; }  // Err(...) :293-295 -> unwrap panic :471
+  return fit_from_covariance(c00, c01, c02, c11, c12, c22);
+}
+
+// The same fit from ONE pass over the neighbours: sums about a PIVOT near the neighbourhood (the query itself), u_t = p_t - pivot,
+//   S = sum u_t,  M = sum u_t u_t^T,  covariance = M - S S^T / m   (= sum (p_t - centroid)(p_t - centroid)^T, :240-305, in exact arithmetic).
+// Why: the reference's two passes (centroid, then the moments of p_t - centroid) need every neighbour TWICE -- gathered twice, or held in
+// 6 k registers per lane, which at k = 16 is 96 of a 128-register budget and went through scratch memory (33.5 GB of write-back per 10^8
+// points, round 3).  This form holds 12 running sums and whatever loads are in flight.  Accuracy: |u_t| is at most the k-th neighbour
+// distance r, so every product and sum carries an absolute rounding error of ~eps m r^2 -- the same size as the errors of the reference's
+// own sum of (p_t - c)^2 terms, which are of that magnitude too; the subtraction M - S S^T / m cancels at most a factor
+// (sigma^2 + mu^2) / sigma^2 with |mu| <= r (the pivot lies inside the neighbourhood), not the catastrophic |p|^2 / sigma^2 of raw moments.
+// The sums are NOT the reference's sequence of operations (12 instead of 18 f64 operations per neighbour, fused multiply-adds): results agree
+// to ~1e-14 relative, inside the north star's 1e-9; PST_KNN_FIT=seq selects the reference-order instance for bit comparison.
+// Finite coordinates only (the grid searches never see another kind).
+template <int KMAX, typename GetPoint>
+__device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py, double pz, GetPoint&& get) {
+  double sx = 0, sy = 0, sz = 0, mxx = 0, mxy = 0, mxz = 0, myy = 0, myz = 0, mzz = 0;
+#pragma unroll
+  for (int t = 0; t < KMAX; ++t) {
+    if ((uint32_t)t < m) {
+      double x, y, z; get((uint32_t)t, x, y, z);
+      const double ux = x - px, uy = y - py, uz = z - pz;
+      sx += ux; sy += uy; sz += uz;
+      mxx = __builtin_fma(ux, ux, mxx); mxy = __builtin_fma(ux, uy, mxy); mxz = __builtin_fma(ux, uz, mxz);
+      myy = __builtin_fma(uy, uy, myy); myz = __builtin_fma(uy, uz, myz); mzz = __builtin_fma(uz, uz, mzz);
+    }
+  }
+  if (m < 3) { Fit f{0, 0, 0, 0, 0}; return f; }  // Err(...) :293-295 -> unwrap panic :471
+  const double inv = 1.0 / (double)m;
+  const double tx = sx * inv, ty = sy * inv, tz = sz * inv;  // centroid - pivot
+  return fit_from_covariance(__builtin_fma(-sx, tx, mxx), __builtin_fma(-sx, ty, mxy), __builtin_fma(-sx, tz, mxz),
+                             __builtin_fma(-sy, ty, myy), __builtin_fma(-sy, tz, myz), __builtin_fma(-sz, tz, mzz));
 }
 
 // Where the results of a search kernel go.  Two forms:

@@ -528,7 +528,10 @@ struct Tile2Args {
   uint32_t f_max;  // the k-th entry's bin must lie below this one: upper edge + eps < tau0 * s2
 };
 
-template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN, bool ROT>
+// FIT: 1 = the plane fit in ONE pass about the query (plane_fit_pivot: 12 running sums, every neighbour fetched once and not kept);
+//      0 = the reference's order of operations (plane_fit: centroid, then moments -- the 16 neighbours are held across the two passes, which
+//          at 128 registers means scratch memory; kept for bit comparison and the A/B, PST_KNN_FIT=seq)
+template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN, bool ROT, int FIT>
 __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args aa) {
   const TileArgs& a = aa.t;
   constexpr int CS = CAP + BATCH;
@@ -883,7 +886,11 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           amb |= d < aa.gap ? 1u << t : 0u;
         }
       }
-      const uint32_t k_last = best.at(kk - 1u);
+      // key[kk - 1] without an indexed read: the compiler turns a chain of `t == index` selects back into an array in scratch memory (17 dwords
+      // stored per query for one indexed load: 13.6 GB of write-back per 10^8 points); `t < kk` selects, ascending, end on the same entry
+      uint32_t k_last = best.key[0];
+#pragma unroll
+      for (int t = 1; t < K; ++t) k_last = (uint32_t)t < kk ? best.key[t] : k_last;
       ok = k_last != 0xFFFFFFFFu && (k_last >> SLOT_BITS) < aa.f_max;   // k entries, the k-th inside tau0
       ok = ok && !(amb & (amb >> 1)) && !((amb >> (kk - 1u)) & 1u);      // no chain of close pairs, none at the boundary
       amb = ok ? amb : 0u;
@@ -938,7 +945,16 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         }
       }
       Fit f{0, 0, 0, 0, 1};
-      if constexpr (!P3LDS && K <= 16) {
+      if constexpr (FIT == 1) {
+        double qx, qy, qz;
+        exact_xyz(slot, qx, qy, qz);
+        if (!(a.ablate & 2u)) f = plane_fit_pivot<K>(m, qx, qy, qz, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+          uint32_t pl = 0;
+#pragma unroll
+          for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = nb[u];
+          exact_xyz(pl, x, y, z);
+        });
+      } else if constexpr (!P3LDS && K <= 16) {
         // f64 coordinates from global memory: every neighbour is fetched ONCE (the plane fit walks the neighbours twice, and a gather of
         // 64 scattered 24-byte points keeps the texture path busy for ~64 cycles whether it hits the cache or not)
         double nx[K], ny[K], nz[K];
@@ -1348,18 +1364,20 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
       b.f_max = fm > 0.0 ? (uint32_t)fm : 0u;
     }
     b.t = a;
-#define PST_TILE2_LAUNCH(KK, TT, CC, P3, BB, WW)                                                                               \
+#define PST_TILE2_LAUNCH(KK, TT, CC, P3, BB, WW, FF)                                                                             \
     do {                                                                                                                       \
-      if (knn && g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, true>), dim3(grid), dim3(TT), 0, stream, b);        \
-      else if (knn) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, false>), dim3(grid), dim3(TT), 0, stream, b);              \
-      else if (g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, true>), dim3(grid), dim3(TT), 0, stream, b);        \
-      else hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, false>), dim3(grid), dim3(TT), 0, stream, b);                      \
+      if (knn && g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, true, FF>), dim3(grid), dim3(TT), 0, stream, b);    \
+      else if (knn) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, true, false, FF>), dim3(grid), dim3(TT), 0, stream, b);          \
+      else if (g.rotated) hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, true, FF>), dim3(grid), dim3(TT), 0, stream, b);    \
+      else hipLaunchKernelGGL((knn_tile2_kernel<KK, TT, CC, P3, BB, WW, false, false, FF>), dim3(grid), dim3(TT), 0, stream, b);                  \
     } while (0)
 #define PST_TILE2_K(TT, CC, P3, BB, WW)                                                                                        \
     do {                                                                                                                       \
-      if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW);                                                                     \
-      else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW);                                                                           \
+      if (fit_seq) { if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 0); else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 0); }   \
+      else if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 1);                                                             \
+      else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 1);                                                                        \
     } while (0)
+    const bool fit_seq = knn_tuning().fit_seq;
     switch (t.tag) {
       case 'D': PST_TILE2_K(512, 3000, false, 4, 4); break;
       case 'G': PST_TILE2_K(256, 1536, false, 4, 4); break;
