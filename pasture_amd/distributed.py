@@ -255,12 +255,24 @@ class Communicator:
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)  # group-local rank: the rank of the new communicator
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"  # "cuda" = torch's CURRENT device: the caller has set the rank's GPU
-        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        # 128 id bytes + one flag byte.  Rank 0 ALWAYS takes part in the broadcast: if it cannot create the id (RCCL not loadable is the case
+        # bench.py falls back from) it sends flag = 1 and every rank raises AFTER the broadcast, so all ranks leave this function the same
+        # way and their next collective (the caller's agreement all-reduce) matches -- raising before the broadcast on rank 0 alone left the
+        # other ranks blocked in it.
+        t = torch.zeros(129, dtype=torch.uint8, device=dev)
+        err0 = None
         if rank == 0:
-            t = torch.tensor(list(cls.unique_id(api)), dtype=torch.uint8, device=dev)
+            try:
+                t = torch.tensor(list(cls.unique_id(api)) + [0], dtype=torch.uint8, device=dev)
+            except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+                err0 = e
+                t[128] = 1
         # broadcast's `src` is a GLOBAL rank: the group's rank 0 is not global rank 0 for a sub-group
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls.from_unique_id(world, rank, bytes(t.cpu().tolist()), api)
+        raw = bytes(t.cpu().tolist())
+        if raw[128]:
+            raise RuntimeError(f"pst_comm_unique_id failed on rank 0 of the group: {err0 if err0 is not None else 'see rank 0'}")
+        return cls.from_unique_id(world, rank, raw[:128], api)
 
     @classmethod
     def single_process(cls, n_gpus: int, api=None) -> "Communicator":

@@ -293,6 +293,44 @@ def test_comm_entry_points_fail_loudly_without_a_device():
     assert e.value.code == 21
 
 
+def _failed_bootstrap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pasture_amd.distributed import Communicator
+    err = None
+    try:
+        Communicator.from_torch_group()
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    # what bench.py does next: an agreement all-reduce.  It only matches if EVERY rank left from_torch_group through the broadcast.
+    bad = torch.tensor([1 if err else 0], dtype=torch.int64)
+    dist.all_reduce(bad)
+    q.put((rank, err, int(bad.item())))
+    dist.destroy_process_group()
+
+
+def test_comm_bootstrap_failure_on_rank0_reaches_every_rank_gloo():
+    """Without a GPU pst_comm_unique_id fails on rank 0.  Rank 0 must still take part in the id broadcast (flag byte set) so that all
+    ranks raise together and the caller's next collective matches -- raising before the broadcast left rank 1 blocked in it (advisor, r3)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the id is created")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failed_bootstrap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[2] for g in got] == [2, 2], got
+    assert all(g[1] and "pst_comm_unique_id failed on rank 0" in g[1] for g in got), got
+
+
 @pytest.mark.gpu
 def test_capi_bounds_allreduce_world_size_1_rccl(hip):
     """pst_comm_unique_id -> pst_comm_init_rank(1, 0) -> pst_bounds_allreduce on the record pst_calculate_bounds_async wrote: with ONE rank
