@@ -141,6 +141,13 @@ int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, p
 int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbytes, pst_buffer** out);
 /* Columnar view over caller-owned columns (one device pointer per layout attribute, layout order), `len` points. */
 int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_ptrs, size_t len, pst_buffer** out);
+/* SliceBuffer::slice / SliceBufferMut::slice_mut, pasture-core/src/containers/slice.rs:16-43 (BufferSlice :76-330): a non-owning view of
+ * points [first, first + count) of `parent` with the parent's layout and storage kind.  Every entry point that takes a buffer takes a
+ * slice: calculate_bounds(&buf.slice(a..b)), the chunked minmax_attribute of pasture-tools/src/bin/info.rs:66-78, transform_attribute on
+ * slice_mut, compute_normals, conversions from / into it.  A range outside the parent is PST_ERR_RANGE (the slice's index assertions
+ * :52-75); a slice cannot be resized (PST_ERR_UNSUPPORTED: it is not an OwningBuffer).  It borrows the parent's memory: destroy it
+ * before the parent is resized or destroyed (what the borrow checker enforces in Rust). */
+int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_buffer** out);
 int pst_buffer_destroy(pst_buffer* b);
 int pst_buffer_len(const pst_buffer* b, size_t* out);                 /* BorrowedBuffer::len :29 */
 int pst_buffer_resize(pst_buffer* b, size_t count);                   /* OwningBuffer::resize :263 — new points zero-filled */
@@ -153,6 +160,13 @@ int pst_buffer_write_points(pst_buffer* b, size_t first, size_t count, const voi
 int pst_buffer_read_points(const pst_buffer* b, size_t first, size_t count, void* host_dst);   /* get_point_range :45 */
 int pst_buffer_write_attribute(pst_buffer* b, const char* name, const pst_datatype* dt, size_t first, size_t count, const void* host_src); /* set_attribute_range :110 */
 int pst_buffer_read_attribute(const pst_buffer* b, const char* name, const pst_datatype* dt, size_t first, size_t count, void* host_dst);  /* get_attribute_range :71 */
+/* view_attribute_with_conversion::<T>(attribute).into_iter().collect(), point_buffer.rs:322-330 / buffer_views.rs:533-650: the attribute `name`
+ * of points [first, first + count) converted from its stored datatype to `target_dt` with the Rust-`as` table (convert_unit when they are
+ * equal).  Not in the layout -> PST_ERR_MISSING_ATTRIBUTE (:549-552); no conversion between the datatypes -> PST_ERR_INVALID_CONVERSION
+ * ("Conversion between attribute types is impossible", :553-561).  _device: the dense array of `target_dt` values lands in device memory,
+ * stream-ordered. */
+int pst_buffer_read_attribute_converted(const pst_buffer* b, const char* name, const pst_datatype* target_dt, size_t first, size_t count, void* host_dst);
+int pst_buffer_read_attribute_converted_device(const pst_buffer* b, const char* name, const pst_datatype* target_dt, size_t first, size_t count, void* device_dst);
 /* deterministic synthetic points generated on the device (DESIGN.md "Synthetic inputs") */
 int pst_buffer_synth_fill(pst_buffer* b, uint64_t seed, uint64_t first_index);
 
@@ -252,6 +266,10 @@ int pst_calculate_bounds_async(const pst_buffer* b, double* device_out6);
 int pst_minmax_attribute(const pst_buffer* b, const char* name, const pst_datatype* dt, void* out_min, void* out_max, int* has_value);
 /* BorrowedMutBufferExt::transform_attribute, point_buffer.rs:391-404, with a closed-set transformation */
 int pst_transform_attribute(pst_buffer* b, const char* name, const pst_datatype* dt, const pst_transform* xf);
+/* compute_centroid, pasture-algorithms/src/normal_estimation.rs:198-237: mean of Position3D (Vec3f64) over all points, or over the
+ * finite ones when some coordinate is NaN (is_dense :133-140).  Empty buffer -> PST_ERR_TOO_FEW_POINTS ("The point cloud is empty!").
+ * A parallel sum: equal to the reference's left-to-right sum within rounding (1e-9 relative), not bit for bit. */
+int pst_compute_centroid(const pst_buffer* b, double out_centroid[3]);
 /* compute_normals, pasture-algorithms/src/normal_estimation.rs:79-130: per point (normal[3] f64, curvature f64) to
  * host arrays; out_knn (nullable, n*k int64, -1 padded) receives the neighbour indices in ascending distance. */
 int pst_compute_normals(const pst_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);

@@ -276,6 +276,42 @@ int orc_buffer_read_attribute(const orc_buffer* b, const char* name, const orc_d
   ORC_CATCH
 }
 
+// SliceBuffer::slice / SliceBufferMut::slice_mut — pasture-core/src/containers/slice.rs:16-43 (the view borrows the parent: the caller keeps it alive)
+int orc_buffer_slice(const orc_buffer* parent, size_t first, size_t count, orc_buffer** out) {
+  ORC_TRY
+  Buffer& p = *need(parent, "parent")->b;
+  if (first + count < first) throw Panic(ERR_RANGE, "slice index starts at " + std::to_string(first) + " but ends at " + std::to_string(first + count));
+  auto* b = new orc_buffer();
+  try { b->b = make_slice(p, Range{first, first + count}); } catch (...) { delete b; throw; }
+  *need(out, "out") = b;
+  ORC_CATCH
+}
+
+// view_attribute_with_conversion::<T>(attribute).into_iter().collect() — point_buffer.rs:322-330, buffer_views.rs:533-650: the attribute is
+// looked up BY NAME (:549-552), the stored datatype converted to T with the `as` table (:553-561; convert_unit for equal datatypes), one
+// get_attribute_unchecked + one converter call per value (:572-587)
+int orc_buffer_read_attribute_converted(const orc_buffer* b, const char* name, const orc_datatype* target_dt, size_t first, size_t count, void* dst) {
+  ORC_TRY
+  const Buffer& buf = *need(b, "buffer")->b;
+  const DataType t = to_dt(target_dt);
+  const AttributeMember* m = buf.point_layout().get_attribute_by_name(need(name, "name"));
+  if (!m) throw Panic(ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  AttributeConversionFn fn = nullptr;
+  if (!(m->def.datatype == t)) {
+    fn = get_converter_for_attributes(m->def, AttributeDef{m->def.name, t});
+    if (!fn) throw Panic(ERR_INVALID_CONVERSION, "Conversion between attribute types is impossible");
+  }
+  if (first + count < first || first + count > buf.len()) throw Panic(ERR_RANGE, "point range out of bounds");
+  std::vector<uint8_t> converter_buffer(m->size);
+  const size_t ts = t.size();
+  for (size_t i = 0; i < count; ++i) {
+    buf.get_attribute_unchecked(*m, first + i, converter_buffer.data());
+    if (fn) fn(converter_buffer.data(), (uint8_t*)need(dst, "dst") + i * ts);
+    else std::memcpy((uint8_t*)need(dst, "dst") + i * ts, converter_buffer.data(), ts);
+  }
+  ORC_CATCH
+}
+
 // Deterministic synthetic fill (DESIGN.md "Synthetic inputs").  Must match
 // pasture_amd/csrc/synth.hip bit for bit.
 static inline uint64_t synth_extra(uint64_t seed, uint64_t g, uint64_t slot, uint64_t c) {
@@ -432,6 +468,11 @@ int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_dataty
 int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf) {
   ORC_TRY
   transform_attribute(*need(b, "buffer")->b, AttributeDef{need(name, "name"), to_dt(dt)}, to_xf(xf));
+  ORC_CATCH
+}
+int orc_compute_centroid(const orc_buffer* b, double out_centroid[3]) {
+  ORC_TRY
+  compute_centroid(*need(b, "buffer")->b, need(out_centroid, "out_centroid"));
   ORC_CATCH
 }
 int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn) {

@@ -109,6 +109,11 @@ int orc_calculate_bounds(const orc_buffer* b, double out_min[3], double out_max[
 int orc_minmax_attribute(const orc_buffer* b, const char* name, const orc_datatype* dt, void* out_min, void* out_max, int* has_value);
 int orc_transform_attribute(orc_buffer* b, const char* name, const orc_datatype* dt, const orc_transform* xf);
 int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, double* out_curvature, int64_t* out_knn);
+/* compute_centroid, normal_estimation.rs:198-237 */
+int orc_compute_centroid(const orc_buffer* b, double out_centroid[3]);
+/* SliceBuffer::slice, slice.rs:16-43; view_attribute_with_conversion, point_buffer.rs:322-330 */
+int orc_buffer_slice(const orc_buffer* parent, size_t first, size_t count, orc_buffer** out);
+int orc_buffer_read_attribute_converted(const orc_buffer* b, const char* name, const orc_datatype* target_dt, size_t first, size_t count, void* dst);
 
 /* voxelgrid_filter (pasture-algorithms/src/voxel_grid.rs:109-166): appends one centroid point per occupied voxel to `filtered` */
 int orc_voxelgrid_filter(const orc_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, orc_buffer* filtered);

@@ -64,6 +64,7 @@ enum Status : int {
   ERR_K_TOO_SMALL = 12,
   ERR_NOT_ENOUGH_NEIGHBOURS = 13,
   ERR_UNSUPPORTED_ATTRIBUTE = 14,
+  ERR_UNSUPPORTED = 23,
 };
 
 struct Panic : std::runtime_error {
@@ -404,6 +405,62 @@ struct HashMapBuffer : ColumnarBuffer {
   }
   ColumnarBuffer* as_columnar() override { return this; }  // :1237-1239
 };
+
+// BufferSlice / BufferSliceMut — pasture-core/src/containers/slice.rs:76-330: a view of `point_range` of another buffer with the same memory
+// layout capabilities (an interleaved buffer's slice is interleaved, a columnar buffer's columnar).  Local indices are checked against
+// the slice's own length and shifted by point_range.start (get_and_check_global_point_index :52-55, _range :64-75).
+inline size_t slice_global_index(size_t local_index, const Range& point_range) {
+  if (!(local_index < point_range.len())) throw Panic(ERR_RANGE, "assertion failed: local_index < point_range.len()");
+  return local_index + point_range.start;
+}
+inline Range slice_global_range(const Range& local_range, const Range& point_range) {
+  if (!(local_range.end <= point_range.len())) throw Panic(ERR_RANGE, "assertion failed: local_range.end <= point_range.len()");
+  if (local_range.start >= local_range.end) return Range{point_range.end, point_range.end};
+  return Range{local_range.start + point_range.start, local_range.end + point_range.start};
+}
+struct InterleavedSlice : InterleavedBuffer {
+  InterleavedBuffer* buffer;
+  Range point_range;
+  InterleavedSlice(InterleavedBuffer* b, Range r) : buffer(b), point_range(r) {}
+  size_t len() const override { return point_range.end - point_range.start; }
+  const PointLayout& point_layout() const override { return buffer->point_layout(); }
+  void get_attribute_unchecked(const AttributeMember& m, size_t index, uint8_t* out) const override {
+    buffer->get_attribute_unchecked(m, slice_global_index(index, point_range), out);
+  }
+  void set_attribute(const AttributeDef& d, size_t index, const uint8_t* data) override {
+    buffer->set_attribute(d, slice_global_index(index, point_range), data);
+  }
+  void resize(size_t) override { throw Panic(ERR_UNSUPPORTED, "a buffer slice is not an OwningBuffer: it cannot be resized"); }
+  uint8_t* get_point_range_mut(Range r) override { return buffer->get_point_range_mut(slice_global_range(r, point_range)); }
+  InterleavedBuffer* as_interleaved() override { return this; }
+};
+struct ColumnarSlice : ColumnarBuffer {
+  ColumnarBuffer* buffer;
+  Range point_range;
+  ColumnarSlice(ColumnarBuffer* b, Range r) : buffer(b), point_range(r) {}
+  size_t len() const override { return point_range.end - point_range.start; }
+  const PointLayout& point_layout() const override { return buffer->point_layout(); }
+  void get_attribute_unchecked(const AttributeMember& m, size_t index, uint8_t* out) const override {
+    buffer->get_attribute_unchecked(m, slice_global_index(index, point_range), out);
+  }
+  void set_attribute(const AttributeDef& d, size_t index, const uint8_t* data) override {
+    buffer->set_attribute(d, slice_global_index(index, point_range), data);
+  }
+  void resize(size_t) override { throw Panic(ERR_UNSUPPORTED, "a buffer slice is not an OwningBuffer: it cannot be resized"); }
+  uint8_t* get_attribute_range_mut(const AttributeDef& d, Range r) override {
+    return buffer->get_attribute_range_mut(d, slice_global_range(r, point_range));
+  }
+  ColumnarBuffer* as_columnar() override { return this; }
+};
+// SliceBuffer::slice :16-29 for VectorBuffer / HashMapBuffer / slices of them ("May panic if `range` is out of bounds": the index
+// assertions above fire at the first access; here the range is checked when the slice is taken, like a Rust slice index)
+inline std::unique_ptr<Buffer> make_slice(Buffer& parent, Range r) {
+  if (r.start > r.end || r.end > parent.len())
+    throw Panic(ERR_RANGE, "range end index " + std::to_string(r.end) + " out of range for buffer of length " + std::to_string(parent.len()));
+  if (InterleavedBuffer* i = parent.as_interleaved()) return std::make_unique<InterleavedSlice>(i, r);
+  if (ColumnarBuffer* c = parent.as_columnar()) return std::make_unique<ColumnarSlice>(c, r);
+  throw Panic(ERR_UNSUPPORTED, "buffer is neither interleaved nor columnar");
+}
 
 // ----------------------------------------------------------------------------------
 // Rust `as` semantics — the language definition of numeric casts, which
@@ -1164,6 +1221,15 @@ inline void compute_centroid(const double (*pts)[3], size_t n, double centroid[3
       if (is_finite3(pts[i])) { temp[0] += pts[i][0]; temp[1] += pts[i][1]; temp[2] += pts[i][2]; cnt += 1; }
     for (int c = 0; c < 3; ++c) centroid[c] = temp[c] / (double)cnt;
   }
+}
+// compute_centroid(&buffer) :198-237 on a point buffer: view_attribute::<Vector3<f64>>(&POSITION_3D) (exact datatype, buffer_views.rs:301-310)
+inline void compute_centroid(const Buffer& point_cloud, double centroid[3]) {
+  if (point_cloud.len() == 0) throw Panic(ERR_TOO_FEW_POINTS, "The point cloud is empty!");
+  const AttributeMember* m = point_cloud.point_layout().get_attribute(POSITION_3D);
+  if (!m) throw Panic(ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  std::vector<double> pts(point_cloud.len() * 3);
+  for (size_t i = 0; i < point_cloud.len(); ++i) point_cloud.get_attribute_unchecked(*m, i, reinterpret_cast<uint8_t*>(&pts[3 * i]));
+  compute_centroid(reinterpret_cast<const double (*)[3]>(pts.data()), point_cloud.len(), centroid);
 }
 // compute_covariance_matrix :240-305.  Returns false for Err("... not enough to span a plane!").
 inline bool compute_covariance_matrix(const double (*pts)[3], size_t n, Mat3& cov) {

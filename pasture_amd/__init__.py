@@ -9,7 +9,7 @@ from .layout import (FieldAlignment, PointAttributeDataType, PointAttributeDefin
                      attributes)
 from .buffers import ExternalColumnsBuffer, ExternalMemoryBuffer, HashMapBuffer, VectorBuffer  # noqa: F401
 from .conversion import BufferLayoutConverter, RawPointConverter, Transform  # noqa: F401
-from .algorithms import (AABB, calculate_bounds, calculate_bounds_async, compute_normals, compute_normals_into, minmax_attribute, voxelgrid_filter,  # noqa: F401
+from .algorithms import (AABB, calculate_bounds, calculate_bounds_async, compute_centroid, compute_normals, compute_normals_into, minmax_attribute, voxelgrid_filter,  # noqa: F401
                          transform_attribute)
 
 product_api()  # load libpasture_amd.so now: a missing HIP extension must fail loudly, not at first use

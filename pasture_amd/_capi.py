@@ -124,6 +124,9 @@ _SHARED_SIGNATURES = {
     "buffer_filter": [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)],
     "voxelgrid_filter": [_P, C.c_double, C.c_double, C.c_double, _P],
     "las_encode_points": [_P, C.c_uint32, _D3, _D3, _P, _SZ, _D3, C.POINTER(C.c_uint64), C.c_uint32],
+    "buffer_slice": [_P, _SZ, _SZ, _PP],
+    "buffer_read_attribute_converted": [_P, C.c_char_p, _DT, _SZ, _SZ, _P],
+    "compute_centroid": [_P, _D3],
 }
 
 # entry points only the HIP library has
@@ -145,6 +148,7 @@ _PRODUCT_SIGNATURES = {
     "compute_normals_into": [_P, _SZ, _P],
     "compute_normals_device": [_P, _SZ, _P, _P, _P],
     "buffer_filter_into_async": [_P, _P, _P, C.c_size_t, _P],
+    "buffer_read_attribute_converted_device": [_P, C.c_char_p, _DT, _SZ, _SZ, _P],
     "release_scratch": [],
     "reload_tuning": [],
     "comm_unique_id": [_P],

@@ -4,6 +4,7 @@
   minmax_attribute   pasture-algorithms/src/minmax.rs:13-51
   transform_attribute  pasture-core/src/containers/point_buffer.rs:391-404 (closed-set transformations)
   compute_normals    pasture-algorithms/src/normal_estimation.rs:79-130
+  compute_centroid   pasture-algorithms/src/normal_estimation.rs:198-237
 """
 from __future__ import annotations
 
@@ -80,6 +81,14 @@ def compute_normals(point_cloud: _Buffer, k_nn: int, return_knn: bool = False):
                                     curv.ctypes.data_as(C.POINTER(C.c_double)),
                                     knn.ctypes.data_as(C.POINTER(C.c_int64)) if knn is not None else None)
     return (normals, curv, knn) if return_knn else (normals, curv)
+
+
+def compute_centroid(point_cloud: _Buffer) -> Tuple[float, float, float]:
+    """normal_estimation.rs:198-237: mean Position3D (Vec3f64) over all points, over the finite ones when some coordinate is NaN;
+    panics (status 11) on an empty cloud."""
+    c = (C.c_double * 3)()
+    point_cloud.api.compute_centroid(point_cloud._h, c)
+    return tuple(c)
 
 
 def compute_normals_into(point_cloud: _Buffer, k_nn: int, target: _Buffer) -> None:

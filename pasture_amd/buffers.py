@@ -115,6 +115,30 @@ class _Buffer:
         """view_attribute::<T>(attr).into_iter().collect() — the whole attribute as a host array (buffer_views.rs:291-369)."""
         return self.get_attribute_range(attribute, range(0, self.len()))
 
+    def view_attribute_with_conversion(self, attribute: PointAttributeDefinition, point_range: Optional[range] = None) -> np.ndarray:
+        """view_attribute_with_conversion::<T>(attr).into_iter().collect() (point_buffer.rs:322-330, buffer_views.rs:533-650): the
+        attribute NAMED like `attribute`, converted from its stored datatype to attribute.datatype() with the Rust-`as` table."""
+        first, count = _range(point_range if point_range is not None else range(0, self.len()))
+        dt = attribute.datatype()
+        nc = dt.num_components()
+        out = np.zeros((count, nc) if nc > 1 else (count,), dtype=dt.numpy_dtype())
+        cdt = dt.to_c()
+        self.api.buffer_read_attribute_converted(self._h, attribute.name().encode(), C.byref(cdt), first, count, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    # SliceBuffer / SliceBufferMut, slice.rs:16-43 -----------------------------------------------------------
+    def slice(self, point_range: range):
+        """A view of `point_range` with the same layout and storage kind; every algorithm / conversion takes it like a buffer.  It borrows
+        this buffer's memory (kept alive through the view); resizing the parent while a view exists is what Rust's borrow checker forbids."""
+        first, count = _range(point_range)
+        h = C.c_void_p()
+        self.api.buffer_slice(self._h, first, count, C.byref(h))
+        view = _Buffer.__new__(HashMapBuffer if self.as_columnar() is not None else VectorBuffer)
+        _Buffer.__init__(view, h.value, self.api, keepalive=self)
+        return view
+
+    slice_mut = slice
+
     # BorrowedMutBuffer ---------------------------------------------------------------------------------
     def set_point_range(self, point_range: range, point_data: np.ndarray) -> None:  # :90
         first, count = _range(point_range)

@@ -1,6 +1,7 @@
 // pasture-algorithms loops on the device: calculate_bounds, minmax_attribute, transform_attribute.
 // Reference: pasture-algorithms/src/bounds.rs:11-85, minmax.rs:13-51, pasture-core/src/containers/point_buffer.rs:391-404.
 #include <cmath>
+#include <vector>
 
 #include "runtime.hpp"
 
@@ -113,6 +114,37 @@ int pst_minmax_attribute(const pst_buffer* b, const char* name, const pst_dataty
     }
   }
   *has_value = 1;
+  PST_API_END
+}
+
+// compute_centroid, normal_estimation.rs:198-237.  Panics: empty cloud ("The point cloud is empty!"); no Position3D of datatype Vec3f64
+// (view_attribute::<Vector3<f64>>: exact match, buffer_views.rs:301-310).
+int pst_compute_centroid(const pst_buffer* b, double out_centroid[3]) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  not_null(out_centroid, "out_centroid");
+  if (b->len == 0) throw Error(PST_ERR_TOO_FEW_POINTS, "The point cloud is empty!");
+  DataType v3; v3.kind = PST_VEC3F64;
+  const int slot = b->layout.index_of(AttributeDef{"Position3D", v3});
+  if (slot < 0) throw Error(PST_ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  ensure_device();
+  const Member& m = b->layout.members[(size_t)slot];
+  Workspace& ws = workspace();
+  hipStream_t s = current_stream();
+  const uint64_t base = b->columnar ? col_addr(*b, (size_t)slot, 0) : aos_addr(*b, 0) + m.offset;
+  const uint64_t stride = b->columnar ? m.size : b->layout.size;
+  double* partials = (double*)ws.partials(pstk::centroid_partials_bytes());
+  const unsigned n_rec = pstk::launch_centroid((const uint8_t*)(uintptr_t)base, stride, b->len, partials, s);
+  PST_HIP_CHECK(hipGetLastError());
+  std::vector<double> h((size_t)n_rec * 8);
+  PST_HIP_CHECK(hipMemcpyAsync(h.data(), partials, h.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  stream_sync(s);
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (unsigned r = 0; r < n_rec; ++r)
+    for (int c = 0; c < 8; ++c) a[c] += h[(size_t)r * 8 + c];
+  const bool dense = a[7] == 0.0;  // is_dense :133-140
+  const double div = dense ? (double)b->len : a[6];  // (0 finite points: 0.0 / 0.0 = NaN, as in the reference)
+  for (int c = 0; c < 3; ++c) out_centroid[c] = (dense ? a[c] : a[3 + c]) / div;
   PST_API_END
 }
 

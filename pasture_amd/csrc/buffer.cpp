@@ -310,6 +310,26 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
   *not_null(out, "out") = b.release();
   PST_API_END
 }
+// SliceBuffer::slice / SliceBufferMut::slice_mut, slice.rs:16-43: a non-owning view (owns = false, like ExternalMemoryBuffer) whose
+// base addresses are the parent's shifted by `first` points -- every kernel then works on it unchanged
+int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_buffer** out) {
+  PST_API_BEGIN
+  check_range(*not_null(parent, "parent"), first, count);
+  auto b = std::make_unique<pst_buffer>();
+  b->layout = parent->layout;
+  b->columnar = parent->columnar;
+  b->owns = false;
+  b->memkind = parent->memkind;
+  b->len = b->capacity = count;
+  if (parent->columnar) {
+    for (size_t a = 0; a < parent->layout.members.size(); ++a)
+      b->columns.push_back(parent->columns[a] ? parent->columns[a] + first * parent->layout.members[a].size : nullptr);
+  } else {
+    b->data = parent->data ? parent->data + first * parent->layout.size : nullptr;
+  }
+  *not_null(out, "out") = b.release();
+  PST_API_END
+}
 int pst_buffer_destroy(pst_buffer* b) { delete b; return PST_OK; }
 int pst_buffer_len(const pst_buffer* b, size_t* out) { PST_API_BEGIN *not_null(out, "out") = not_null(b, "buffer")->len; PST_API_END }
 int pst_buffer_resize(pst_buffer* b, size_t count) { PST_API_BEGIN resize_buffer(*not_null(b, "buffer"), count, true); PST_API_END }

@@ -718,3 +718,59 @@ int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buf
 }
 
 }  // extern "C"
+
+// view_attribute_with_conversion::<T>(attribute) collected, point_buffer.rs:322-330 / buffer_views.rs:533-650: the attribute is looked up
+// BY NAME (:549-552, expect), the stored datatype is converted to T with the `as` table (:553-561: convert_unit for equal datatypes, an
+// unlisted pair is Err("Conversion between attribute types is impossible")).  One launch of the column kernels (columnar source) or of
+// the interleaved -> columnar tile kernel into a dense array of T.
+namespace pst {
+static void read_attribute_converted(const pst_buffer& b, const char* name, const pst_datatype* target_dt, size_t first, size_t count, void* device_dst,
+                                     hipStream_t s) {
+  const DataType t = DataType::from_c(target_dt);
+  const Member* m = b.layout.find_by_name(not_null(name, "name"));
+  if (!m) throw Error(PST_ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  if (m->def.datatype != t && !convertible(m->def.datatype, t))
+    throw Error(PST_ERR_INVALID_CONVERSION, "Conversion between attribute types is impossible (" + m->def.datatype.display() + " -> " + t.display() + ")");
+  if (first + count < first || first + count > b.len)
+    throw Error(PST_ERR_RANGE, "range end index " + std::to_string(first + count) + " out of range for buffer of length " + std::to_string(b.len));
+  if (count == 0 || t.size() == 0) return;
+  ensure_device();
+  Member target{AttributeDef{m->def.name, t}, 0, t.size()};
+  PlanEntry e = identity_entry(*m, target);
+  e.dst_ct = (uint8_t)t.comp_type();
+  e.convert = m->def.datatype != t ? 1u : 0u;
+  e.dst_col = (uint64_t)(uintptr_t)not_null(device_dst, "dst");
+  const size_t slot = (size_t)(m - b.layout.members.data());
+  if (b.columnar) {
+    e.src_col = col_addr(b, slot, first);
+    execute_entries(false, 0, 0, false, 0, 0, count, {e}, false, s);
+  } else {
+    execute_entries(true, aos_addr(b, first), (uint32_t)b.layout.size, false, 0, 0, count, {e}, true, s);
+  }
+  PST_HIP_CHECK(hipGetLastError());
+}
+}  // namespace pst
+
+extern "C" {
+int pst_buffer_read_attribute_converted_device(const pst_buffer* b, const char* name, const pst_datatype* target_dt, size_t first, size_t count,
+                                               void* device_dst) {
+  PST_API_BEGIN
+  read_attribute_converted(*not_null(b, "buffer"), name, target_dt, first, count, device_dst, current_stream());
+  PST_API_END
+}
+int pst_buffer_read_attribute_converted(const pst_buffer* b, const char* name, const pst_datatype* target_dt, size_t first, size_t count, void* host_dst) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  const size_t bytes = count * DataType::from_c(target_dt).size();
+  hipStream_t s = current_stream();
+  uint8_t* tmp = bytes ? dev_alloc(bytes, PST_MEM_DEVICE) : nullptr;
+  struct Free { uint8_t* p; ~Free() { if (p) dev_free(p, PST_MEM_DEVICE); } } guard{tmp};
+  static uint8_t dummy;
+  read_attribute_converted(*b, name, target_dt, first, count, tmp ? (void*)tmp : (void*)&dummy, s);
+  if (bytes) {
+    PST_HIP_CHECK(hipMemcpyAsync(not_null(host_dst, "host_dst"), tmp, bytes, hipMemcpyDeviceToHost, s));
+    PST_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  PST_API_END
+}
+}  // extern "C"

@@ -43,6 +43,11 @@ size_t minmax_partials_bytes();
 void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials,
                    void* out, hipStream_t stream);
 
+// compute_centroid (normal_estimation.rs:198-237): per-block records {sum xyz over all points, sum xyz over the finite points, finite count,
+// NaN seen} of Vec3f64 values at base + e * stride; returns the number of records written to `partials` (centroid_partials_bytes())
+size_t centroid_partials_bytes();
+unsigned launch_centroid(const uint8_t* base, uint64_t stride, uint64_t n, double* partials, hipStream_t stream);
+
 // deterministic synthetic fill of one attribute (see synth.hip)
 struct SynthAttr {
   uint64_t base;    // address of the attribute of point 0

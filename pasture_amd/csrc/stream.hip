@@ -268,6 +268,43 @@ void launch_minmax_typed(const ReduceParams& p, bool acc_f64, void* out, unsigne
   }
 }
 
+
+// compute_centroid, normal_estimation.rs:198-237: the sums of BOTH branches in one pass -- over all points (is_dense: no coordinate is NaN)
+// and over the finite points (the other branch), with the finite count and a "some coordinate is NaN" flag; the host picks the branch.
+// Record per block: {ax, ay, az, fx, fy, fz, finite count, NaN seen}.  A parallel sum is not the reference's left-to-right sum: the
+// centroid agrees to a few ulps of sum |x| / n (the north star's 1e-9 relative for f64 results), not bit for bit.
+__global__ __launch_bounds__(kBlock) void centroid_kernel(const ReduceParams p) {
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t step = (uint64_t)gridDim.x * kBlock;
+  cgptr_t base = (cgptr_t)(uint64_t)p.base;
+  for (uint64_t e = (uint64_t)blockIdx.x * kBlock + threadIdx.x; e < p.n; e += step) {
+    cgptr_t q = base + e * p.stride;
+    const double x = load_un<double>(q), y = load_un<double>(q + 8), z = load_un<double>(q + 16);
+    a[0] += x; a[1] += y; a[2] += z;
+    const bool fin = __builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z);
+    if (fin) { a[3] += x; a[4] += y; a[5] += z; a[6] += 1.0; }
+    if (x != x || y != y || z != z) a[7] = 1.0;
+  }
+  __shared__ double scratch[(kBlock / 64) * 8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    double v = a[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    a[c] = v;
+  }
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) scratch[wave * 8 + c] = a[c];
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double v = 0;
+    for (unsigned w = 0; w < kBlock / 64; ++w) v += scratch[w * 8 + threadIdx.x];
+    ((double*)p.partials)[(uint64_t)blockIdx.x * 8 + threadIdx.x] = v;
+  }
+}
+
 }  // namespace
 
 namespace pstk {
@@ -324,6 +361,14 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
   }
 #undef PST_STREAM
   if (bounds) launch_finalize<double, 3>(partials, grid, out6, kF64Max, -kF64Max, stream);
+}
+
+size_t centroid_partials_bytes() { return (size_t)reduce_grid() * 8 * sizeof(double); }
+unsigned launch_centroid(const uint8_t* base, uint64_t stride, uint64_t n, double* partials, hipStream_t stream) {
+  ReduceParams p{base, stride, n, partials};
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)reduce_grid()));
+  hipLaunchKernelGGL(centroid_kernel, dim3(grid), dim3(kBlock), 0, stream, p);
+  return grid;
 }
 
 size_t bounds_partials_bytes(unsigned n_records) { return (size_t)(n_records + kFoldBlocks) * 6 * sizeof(double); }

@@ -6,7 +6,9 @@
 //!   DeviceVectorBuffer, DeviceHashMapBuffer         ~ VectorBuffer, HashMapBuffer      (containers/point_buffer.rs), storage in HBM
 //!   PinnedVectorBuffer, PinnedHashMapBuffer         ~ the same with `&[u8]` views: pinned host memory both pasture's CPU code and the kernels address
 //!   DeviceBufferLayoutConverter                     ~ BufferLayoutConverter            (layout/conversion/buffer_conversion.rs)
-//!   calculate_bounds, minmax_attribute, compute_normals, transform_attribute           (pasture-algorithms)
+//!   calculate_bounds, minmax_attribute, compute_centroid, compute_normals, voxelgrid_filter (pasture-algorithms)
+//!   SliceDeviceBuffer::slice / slice_mut            ~ SliceBuffer / SliceBufferMut     (containers/slice.rs)
+//!   view_attribute_with_conversion                  ~ BorrowedBufferExt::view_attribute_with_conversion (containers/point_buffer.rs:322)
 use pasture_amd_sys::*;
 use pasture_core::containers::{
     BorrowedBuffer, BorrowedMutBuffer, ColumnarBuffer, ColumnarBufferMut, InterleavedBuffer, InterleavedBufferMut, MakeBufferFromLayout, OwningBuffer,
@@ -40,27 +42,27 @@ fn datatype_to_c(dt: PointAttributeDataType) -> pst_datatype {
 
 struct LayoutHandle(*mut pst_layout);
 impl LayoutHandle {
-    /// Exact transfer of a `PointLayout` (attribute order, offsets, size, alignment) via pst_layout_from_members.
-    fn new(layout: &PointLayout) -> Self {
+    /// Exact transfer of a `PointLayout` (attribute order, offsets, size) via pst_layout_from_members; the type alignment is the caller's.
+    fn new(layout: &PointLayout, type_alignment: u64) -> Self {
         let names: Vec<CString> = layout.attributes().map(|a| CString::new(a.name()).unwrap()).collect();
         let members: Vec<pst_member> = layout.attributes().zip(names.iter())
             .map(|(a, n)| pst_member { name: n.as_ptr(), datatype: datatype_to_c(a.datatype()), offset: a.offset(), size: a.size() })
             .collect();
         let mut h = std::ptr::null_mut();
-        // size_of_point_entry is a multiple of the type alignment; the alignment itself is recovered as the largest power of
-        // two <= max field alignment that divides the size (PointLayout does not expose it directly in 0.5).
-        let align = layout_alignment(layout);
-        check(unsafe { pst_layout_from_members(members.as_ptr(), members.len(), align, &mut h) });
+        check(unsafe { pst_layout_from_members(members.as_ptr(), members.len(), type_alignment, &mut h) });
         LayoutHandle(h)
     }
 }
 impl Drop for LayoutHandle { fn drop(&mut self) { unsafe { pst_layout_destroy(self.0) }; } }
-/// pasture-core 0.5 keeps `memory_layout` private, so the alignment is reconstructed: the largest power of two that is at most the
-/// largest `min_alignment` of the attribute datatypes and divides the point size and every attribute offset.  This is the value
-/// `add_attribute` / the derive macro produce for `repr(C)` and `repr(packed(n))` layouts whose packing is visible in the offsets; a
-/// `packed(1)` layout whose fields happen to sit at naturally aligned offsets is indistinguishable from its unpacked twin here (the two
-/// then compare equal on the device side although `PointLayout::eq` separates them) -- an upstream accessor would remove the guess.
-fn layout_alignment(layout: &PointLayout) -> u64 {
+
+/// The alignment of the point type, which pasture-core 0.5 keeps private (`PointLayout::memory_layout`).  It is an explicit ARGUMENT of every
+/// constructor here (`new_from_layout_aligned`, `for_layouts_aligned`) -- `std::mem::align_of::<P>()` for a `#[derive(PointType)]` struct,
+/// 1 for `#[repr(packed)]`, the `max_alignment` that was passed to `PointLayout::add_attribute` otherwise.  Round 3 reconstructed it
+/// from the offsets, which cannot tell a `packed(1)` layout whose fields happen to sit at naturally aligned offsets from its unpacked
+/// twin (`pst_layout_equals` and `PointLayout::eq` then disagreed).  `natural_alignment` is the default the `MakeBufferFromLayout`
+/// impls use -- right for every `repr(C)` layout and for packed layouts whose packing shows in the offsets; pass the true value when
+/// in doubt.
+pub fn natural_alignment(layout: &PointLayout) -> u64 {
     let max_field = layout.attributes().map(|a| a.datatype().min_alignment()).max().unwrap_or(1).max(1);
     let mut align = 1u64;
     while align * 2 <= max_field
@@ -74,14 +76,21 @@ fn layout_alignment(layout: &PointLayout) -> u64 {
 macro_rules! device_buffer {
     ($name:ident, $storage:expr) => {
         pub struct $name { handle: *mut pst_buffer, layout: PointLayout }
-        impl $name { pub fn raw(&self) -> *mut pst_buffer { self.handle } }
-        impl Drop for $name { fn drop(&mut self) { unsafe { pst_buffer_destroy(self.handle) }; } }
-        impl<'a> MakeBufferFromLayout<'a> for $name {
-            fn new_from_layout(point_layout: PointLayout) -> Self {
-                let l = LayoutHandle::new(&point_layout);
+        impl $name {
+            pub fn raw(&self) -> *mut pst_buffer { self.handle }
+            /// `new_from_layout` with the point type's alignment stated (see `natural_alignment`)
+            pub fn new_from_layout_aligned(point_layout: PointLayout, type_alignment: u64) -> Self {
+                let l = LayoutHandle::new(&point_layout, type_alignment);
                 let mut h = std::ptr::null_mut();
                 check(unsafe { pst_buffer_create(l.0, $storage, 0 /* PST_MEM_DEVICE */, &mut h) });
                 Self { handle: h, layout: point_layout }
+            }
+        }
+        impl Drop for $name { fn drop(&mut self) { unsafe { pst_buffer_destroy(self.handle) }; } }
+        impl<'a> MakeBufferFromLayout<'a> for $name {
+            fn new_from_layout(point_layout: PointLayout) -> Self {
+                let align = natural_alignment(&point_layout);
+                Self::new_from_layout_aligned(point_layout, align)
             }
         }
         impl<'a> BorrowedBuffer<'a> for $name {
@@ -149,7 +158,11 @@ pub struct DeviceBufferLayoutConverter { handle: *mut pst_converter }
 impl Drop for DeviceBufferLayoutConverter { fn drop(&mut self) { unsafe { pst_converter_destroy(self.handle) }; } }
 impl DeviceBufferLayoutConverter {
     fn create(from: &PointLayout, to: &PointLayout, with_default: bool) -> Self {
-        let (f, t) = (LayoutHandle::new(from), LayoutHandle::new(to));
+        Self::for_layouts_aligned(from, natural_alignment(from), to, natural_alignment(to), with_default)
+    }
+    /// `for_layouts` / `for_layouts_with_default` with both point types' alignments stated (see `natural_alignment`)
+    pub fn for_layouts_aligned(from: &PointLayout, from_alignment: u64, to: &PointLayout, to_alignment: u64, with_default: bool) -> Self {
+        let (f, t) = (LayoutHandle::new(from, from_alignment), LayoutHandle::new(to, to_alignment));
         let mut h = std::ptr::null_mut();
         check(unsafe { pst_converter_create(f.0, t.0, with_default as c_int, &mut h) });
         Self { handle: h }
@@ -183,6 +196,50 @@ pub fn calculate_bounds(buffer: &impl DeviceBuffer) -> Option<AABB<f64>> {
     let (mut mn, mut mx, mut has) = ([0f64; 3], [0f64; 3], 0 as c_int);
     check(unsafe { pst_calculate_bounds(buffer.handle(), mn.as_mut_ptr(), mx.as_mut_ptr(), &mut has) });
     if has == 0 { None } else { Some(AABB::from_min_max_unchecked(Point3::new(mn[0], mn[1], mn[2]), Point3::new(mx[0], mx[1], mx[2]))) }
+}
+
+/// pasture-algorithms/src/normal_estimation.rs:198 -- panics on an empty cloud like the reference
+pub fn compute_centroid(buffer: &impl DeviceBuffer) -> Vector3<f64> {
+    let mut c = [0f64; 3];
+    check(unsafe { pst_compute_centroid(buffer.handle(), c.as_mut_ptr()) });
+    Vector3::new(c[0], c[1], c[2])
+}
+
+/// pasture-algorithms/src/minmax.rs:13 for the stored datatype `T`
+pub fn minmax_attribute<T: PrimitiveType + Default + Copy>(buffer: &impl DeviceBuffer, attribute: &PointAttributeDefinition) -> Option<(T, T)> {
+    let name = CString::new(attribute.name()).unwrap();
+    let (mut mn, mut mx, mut has) = (T::default(), T::default(), 0 as c_int);
+    check(unsafe { pst_minmax_attribute(buffer.handle(), name.as_ptr(), &datatype_to_c(T::data_type()), (&mut mn as *mut T).cast(), (&mut mx as *mut T).cast(), &mut has) });
+    if has == 0 { None } else { Some((mn, mx)) }
+}
+
+/// SliceBuffer::slice / SliceBufferMut::slice_mut (containers/slice.rs:16-43): a view of `range` that every function of this file takes like
+/// a buffer -- `calculate_bounds(&buf.slice(a..b))`, the chunked `minmax_attribute` of pasture-tools/src/bin/info.rs:66-78, conversions from
+/// and into ranges.  The lifetime ties it to the parent, as BufferSlice<'a, T> does.
+pub struct DeviceBufferSlice<'p> { handle: *mut pst_buffer, _parent: std::marker::PhantomData<&'p ()> }
+impl<'p> Drop for DeviceBufferSlice<'p> { fn drop(&mut self) { unsafe { pst_buffer_destroy(self.handle) }; } }
+impl<'p> DeviceBuffer for DeviceBufferSlice<'p> { fn handle(&self) -> *mut pst_buffer { self.handle } }
+pub trait SliceDeviceBuffer: DeviceBuffer {
+    fn slice<'p>(&'p self, range: Range<usize>) -> DeviceBufferSlice<'p> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { pst_buffer_slice(self.handle(), range.start, range.len(), &mut h) });   // out of bounds: PST_ERR_RANGE -> panic
+        DeviceBufferSlice { handle: h, _parent: std::marker::PhantomData }
+    }
+    fn slice_mut<'p>(&'p mut self, range: Range<usize>) -> DeviceBufferSlice<'p> { self.slice(range) }
+}
+impl<B: DeviceBuffer> SliceDeviceBuffer for B {}
+
+/// BorrowedBufferExt::view_attribute_with_conversion::<T>(attribute).into_iter().collect() (point_buffer.rs:322-330, buffer_views.rs:533-650)
+pub fn view_attribute_with_conversion<T: PrimitiveType + Default + Clone>(buffer: &impl DeviceBuffer, attribute: &PointAttributeDefinition) -> Result<Vec<T>, String> {
+    assert_eq!(T::data_type(), attribute.datatype());   // buffer_views.rs:548
+    let mut n = 0usize;
+    check(unsafe { pst_buffer_len(buffer.handle(), &mut n) });
+    let mut out = vec![T::default(); n];
+    let name = CString::new(attribute.name()).unwrap();
+    let rc = unsafe { pst_buffer_read_attribute_converted(buffer.handle(), name.as_ptr(), &datatype_to_c(T::data_type()), 0, n, out.as_mut_ptr().cast()) };
+    if rc == 5 /* PST_ERR_INVALID_CONVERSION */ { return Err("Conversion between attribute types is impossible".into()); }   // the reference's Err(..) :553-561
+    check(rc);
+    Ok(out)
 }
 
 /// pasture-algorithms/src/normal_estimation.rs:79
@@ -260,7 +317,7 @@ macro_rules! pinned_common {
         impl DeviceBuffer for $name { fn handle(&self) -> *mut pst_buffer { self.raw() } }
         impl<'a> MakeBufferFromLayout<'a> for $name {
             fn new_from_layout(point_layout: PointLayout) -> Self {
-                let l = LayoutHandle::new(&point_layout);
+                let l = LayoutHandle::new(&point_layout, natural_alignment(&point_layout));
                 let mut h = std::ptr::null_mut();
                 check(unsafe { pst_buffer_create(l.0, $storage, PST_MEM_PINNED_HOST, &mut h) });
                 Self { handle: h, layout: point_layout }
@@ -407,6 +464,9 @@ impl<'a> BorrowedMutBuffer<'a> for PinnedHashMapBuffer {
         self.get_attribute_range_mut(attribute, point_range).copy_from_slice(attribute_data)
     }
     fn swap(&mut self, from_index: usize, to_index: usize) {
+        let len = self.len_();
+        assert!(from_index < len && to_index < len, "swap index out of bounds");   // HashMapBuffer::swap panics likewise (slice indexing); without it
+                                                                                    // the raw-pointer swap below would write outside the allocation
         let members: Vec<PointAttributeMember> = self.layout.attributes().cloned().collect();
         for a in &members {
             let (p, size) = self.column(a.attribute_definition());
