@@ -573,7 +573,7 @@ def main():
         ev[i][1].record(stream)
         if has_reduction:
             if distributed:
-                ring.submit()
+                ring.submit(timed=(i == args.steps - 1))  # the last step's exchange is the one nothing hides: its exposed time is reported
             else:
                 ring.i += 1
     final = ring.finish() if (distributed and has_reduction) else None
@@ -593,10 +593,30 @@ def main():
     plan_kinds = cv.last_plan_kinds() if (conv is not None or args.workload.startswith("filter_")) else None
     if after is not None:
         after()  # (a workload's own check of what its stream-ordered steps left behind; outside the timed region)
+    per_rank = None
     if distributed:
-        t = torch.tensor([kernel_ms_avg], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kernel_ms_avg = float(t.item())
+        # per-rank kernel time and the exposed part of the last exchange, gathered so that rank 0's line shows every rank
+        mine = torch.tensor([kernel_ms_avg, (ring.exposed_us() or -1.0) if has_reduction else -1.0], dtype=torch.float64, device="cuda")
+        rows = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = {"kernel_ms_avg": [round(float(r[0]), 4) for r in rows],
+                    "last_exchange_exposed_us": [round(float(r[1]), 1) if float(r[1]) >= 0 else None for r in rows]}
+        kernel_ms_avg = max(float(r[0]) for r in rows)
+
+    # Self-check of the sharded run (N > 1 has never been seen on hardware by the builder: the first run must not be silently wrong): the
+    # all-reduced AABB of the LAST step must equal affine(union of the ranks' local source bounds) bit for bit on every rank -- the
+    # local bounds are computed now, outside the timed region, and gathered through torch.distributed, not through the exchange under test.
+    self_check = None
+    if distributed and has_reduction and final is not None and args.workload in ("convert_affine_bounds", "bounds"):
+        from pasture_amd.distributed import F64_MAX, verify_global_bounds
+        src_rec = torch.tensor([F64_MAX] * 3 + [-F64_MAX] * 3, dtype=torch.float64, device="cuda")
+        if n:
+            pa.calculate_bounds_async(src, src_rec.data_ptr())
+        torch.cuda.synchronize()
+        affine = args.workload == "convert_affine_bounds"
+        self_check = verify_global_bounds(src_rec, final, SCALE if affine else (1.0, 1.0, 1.0), OFFSET if affine else (0.0, 0.0, 0.0))
+        self_check["comm_size"] = transport.size() if transport is not None else world
+        assert self_check["comm_size"] == world, self_check
 
     if final is not None:
         rec = final
@@ -641,11 +661,18 @@ def main():
         t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c3_elapsed = float(t.item())
+        # the same self-check for the sharded 10^9-point cloud: global AABB == affine(union of the shards' source bounds), on every rank
+        from pasture_amd.distributed import F64_MAX as _F64_MAX, verify_global_bounds as _verify
+        s_rec = torch.tensor([_F64_MAX] * 3 + [-_F64_MAX] * 3, dtype=torch.float64, device="cuda")
+        if len(sh):
+            pa.calculate_bounds_async(s_src, s_rec.data_ptr())
+        torch.cuda.synchronize()
+        c3_check = _verify(s_rec, rec3, SCALE, OFFSET)
         configs3 = {"global_points": g3, "n_gpus": n_ranks_seen, "scaling": "strong", "steps": c3_steps,
                     "ms_per_step": round(c3_elapsed / c3_steps * 1e3, 4), "value": round(g3 * c3_steps / c3_elapsed / 1e6, 2), "unit": "Mpoints/s",
                     "aggregate_GBps": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9, 1),
                     "frac_of_aggregate_peak": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
-                    "points_rank0": len(sh), "bounds": bounds_from_record(rec3.cpu()),
+                    "points_rank0": len(sh), "bounds": bounds_from_record(rec3.cpu()), "self_check": c3_check,
                     "note": "BASELINE.json configs[3]: ONE cloud sharded by index range, rank r owns [r*ceil(G/N), min(G,(r+1)*ceil(G/N))); "
                             "one AABB all-reduce per step; wall time between barriers, max over ranks"}
         del s_src, s_dst
@@ -749,6 +776,10 @@ def main():
             line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
             if collective_note:
                 line["config"]["collective_note"] = collective_note
+            if per_rank is not None:
+                line["per_rank"] = per_rank
+            if self_check is not None:
+                line["self_check"] = self_check
         if configs3 is not None:
             line["configs3_1e9"] = configs3
         if north_star is not None:

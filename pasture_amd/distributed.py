@@ -50,7 +50,10 @@ class PipelinedBoundsReduce:
             self.work[b] = None
         return self.recs[b]
 
-    def submit(self) -> None:
+    def exposed_us(self):
+        return None  # (torch's own collectives: no event pair of ours around them)
+
+    def submit(self, timed: bool = False) -> None:
         import torch.distributed as dist
         b = self.i % len(self.recs)
         rec = self.recs[b]
@@ -153,18 +156,22 @@ class BoundsExchange:
             self._done[b] = None
         return self.recs[b]
 
-    def submit(self) -> None:
+    def submit(self, timed: bool = False) -> None:
+        """timed: keep a timing event pair around this reduction (`exposed_us()` after `finish()`: from the moment the step's kernels were
+        done to the moment the global record was there -- for the LAST step of a run that is the part of the exchange nothing hides)."""
         b = self.i % len(self.recs)
         rec = self.recs[b]
         if self._cuda:
             import torch
-            ready = torch.cuda.Event()
+            ready = torch.cuda.Event(enable_timing=timed)
             ready.record(self._main)
             self._side.wait_event(ready)
             self.transport.allreduce(rec, self._side.cuda_stream, self._main.cuda_stream)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=timed)
             done.record(self._side)
             self._done[b] = done
+            if timed:
+                self._timed = (ready, done)
         else:
             self.transport.allreduce(rec)
         self.i += 1
@@ -174,6 +181,49 @@ class BoundsExchange:
             self._side.synchronize()
             self._done = [None] * len(self.recs)
         return self.recs[(self.i - 1) % len(self.recs)] if self.i else None
+
+    def exposed_us(self):
+        """Microseconds between "the timed step's kernels are done" and "its global record is there" (None without a timed submit)."""
+        t = getattr(self, "_timed", None)
+        if t is None:
+            return None
+        t[1].synchronize()
+        return 1e3 * t[0].elapsed_time(t[1])
+
+
+def verify_global_bounds(local_source_rec, global_result_rec, scale=(1.0, 1.0, 1.0), offset=(0.0, 0.0, 0.0), group=None) -> dict:
+    """Self-check of a sharded convert + AABB run, through a path that shares nothing with the exchange under test.
+
+    Every rank contributes its LOCAL SOURCE bounds {min xyz, max xyz} (6 f64, seeds for an empty shard); they are all-gathered with
+    torch.distributed (not the AABB all-reduce), their union is the global source AABB, and -- the affine map x -> (x * scale) + offset
+    (two roundings) being monotone per component -- bounds(affine(P)) == affine(bounds(P)) EXACTLY, so the all-reduced result record must
+    equal affine(union) bit for bit, on every rank, and must be the same on every rank.  Raises AssertionError with the records otherwise;
+    returns {"verified": True, "ranks": N, "expected": [...]}.  Used by bench.py at N > 1 (the first multi-GPU runs must not be silently
+    wrong) and by the gloo tests."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.cat([local_source_rec.detach().to(dev, torch.float64).reshape(6), global_result_rec.detach().to(dev, torch.float64).reshape(6)])
+    everyone = [torch.zeros(12, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(everyone, mine, group=group)
+    rows = np.array([t.cpu().numpy() for t in everyone])
+    src, res = rows[:, :6], rows[:, 6:]
+    src_min, src_max = src[:, :3].min(axis=0), src[:, 3:].max(axis=0)
+    empty = bool((src_min == F64_MAX).all() and (src_max == -F64_MAX).all())
+    s, o = np.array(scale, dtype=np.float64), np.array(offset, dtype=np.float64)
+    if empty:
+        expected = np.array([F64_MAX] * 3 + [-F64_MAX] * 3)
+    else:
+        lo, hi = (src_min * s) + o, (src_max * s) + o  # numpy: a product and a sum, each rounded -- the kernel's two roundings
+        expected = np.concatenate([np.where(s >= 0, lo, hi), np.where(s >= 0, hi, lo)])
+    same_everywhere = bool((res == res[0]).all())
+    ok = same_everywhere and bool((res[0] == expected).all())
+    if not ok:
+        raise AssertionError(f"global AABB self-check failed over {world} ranks: all-reduced records per rank {res.tolist()}, expected affine(union of the "
+                             f"local source bounds) {expected.tolist()}, local source bounds per rank {src.tolist()}")
+    return {"verified": True, "ranks": world, "expected": expected.tolist()}
 
 
 def shard_output_offsets(local_count: int, group=None):

@@ -293,6 +293,66 @@ def test_comm_entry_points_fail_loudly_without_a_device():
     assert e.value.code == 21
 
 
+def _self_check_worker(rank, world, port, n, corrupt, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import _load_oracle
+    from pasture_amd.algorithms import calculate_bounds
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.conversion import BufferLayoutConverter, Transform
+    from pasture_amd.distributed import F64_MAX, allreduce_bounds_record, shard_range, verify_global_bounds
+    from pasture_amd.layout import PointAttributeDataType as T, PointLayout, attributes as A
+    orc = _load_oracle()
+    scale, offset = (0.001, 0.001, 0.001), (500000.0, 5400000.0, 100.0)
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=orc)
+    r = shard_range(n, rank, world)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(len(r))
+    src.synth_fill(42, r.start)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, scale, offset), False)
+    dst = conv.convert(src, HashMapBuffer)
+
+    def record(b):
+        bb = calculate_bounds(b)
+        return torch.tensor(list(bb.min()) + list(bb.max()) if bb is not None else [F64_MAX] * 3 + [-F64_MAX] * 3, dtype=torch.float64)
+    src_rec, res = record(src), record(dst)
+    allreduce_bounds_record(res)  # what the exchange under test produces
+    if corrupt and rank == corrupt - 1:
+        res[4] = res[4] + 1e-9  # one rank with a stale / wrong record, in the last bits
+    try:
+        out = verify_global_bounds(src_rec, res, scale, offset)
+    except AssertionError as e:
+        out = {"verified": False, "error": str(e)[:80]}
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,corrupt", [(100_001, 0), (3, 0), (1, 0), (0, 0), (100_001, 1), (100_001, 2)])
+def test_sharded_run_self_check_gloo(oracle, n, corrupt):
+    """bench.py's N > 1 self-check on CPU: the all-reduced AABB of the converted shards equals affine(union of the shards' source bounds)
+    exactly (monotone map), incl. an empty shard and the all-empty cloud; one rank holding a record that differs in the last bits is caught
+    ON EVERY RANK."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_self_check_worker, args=(r, world, port, n, corrupt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r]["verified"] == (corrupt == 0), got
+    if not corrupt:
+        assert got[0]["expected"] == got[1]["expected"] and got[0]["ranks"] == 2
+
+
 def _failed_bootstrap_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -443,7 +503,54 @@ def test_bench_n_gt_1_code_path_with_one_forced_rank():
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert got["config"]["collective"].startswith("pst_bounds_allreduce") and "collective_note" not in got["config"]
     assert got["config"]["bounds"] == want["config"]["bounds"] and got["n_gpus"] == 1
+    # the in-run self-check (all-reduced AABB == affine(union of the ranks' source bounds), through an independent gather) ran for both legs
+    assert got["self_check"]["verified"] and got["self_check"]["comm_size"] == 1 and got["configs3_1e9"]["self_check"]["verified"]
+    assert len(got["per_rank"]["kernel_ms_avg"]) == 1 and got["per_rank"]["last_exchange_exposed_us"][0] is not None
     c3 = got["configs3_1e9"]
     assert c3["global_points"] == 30000001 and c3["points_rank0"] == 30000001 and c3["scaling"] == "strong" and c3["value"] > 0
     # the exchange must not dominate the step (a cold record buffer once cost 40 ms inside the timed region)
     assert got["ms_per_step"] < 3.0 * want["ms_per_step"] + 0.2
+
+
+@pytest.mark.gpu
+def test_single_process_two_devices_allreduce_multi_and_device_switch(hip):
+    """ONE process driving two GPUs (needs two; skipped on the 1-GPU boxes): pst_comm_init(2) + pst_bounds_allreduce_multi over records
+    that differ in every slot (the result on BOTH devices is their union), and set_device(0) -> compute_normals -> set_device(1) ->
+    compute_normals in one thread (per-device scratch caches, workspaces and pools) with identical results."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import ctypes as C
+    from pasture_amd.algorithms import AABB, compute_normals
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.distributed import Communicator
+    from pasture_amd.layout import PointLayout, attributes as A
+    comm = Communicator.single_process(2, hip)
+    assert comm.size() == 2
+    recs, want = [], None
+    for d in range(2):
+        v = _exchange_records(d, 1)
+        recs.append(torch.tensor(v, dtype=torch.float64, device=f"cuda:{d}"))
+        box = AABB(tuple(v[:3]), tuple(v[3:]))
+        want = box if want is None else AABB.union(want, box)
+    comm.allreduce_bounds_multi([r.data_ptr() for r in recs])
+    for d in range(2):
+        torch.cuda.synchronize(d)
+        assert recs[d].cpu().tolist() == list(want.min()) + list(want.max())
+    comm.destroy()
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(0, 100, (300_000, 3))
+    out = []
+    for d in (0, 1, 0):
+        hip.set_device(d)
+        torch.cuda.set_device(d)
+        hip.set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+        buf.resize(len(pts))
+        buf.set_attribute_range(A.POSITION_3D, range(0, len(pts)), pts)
+        out.append(compute_normals(buf, 16, return_knn=True))
+        del buf
+    hip.set_device(0)
+    torch.cuda.set_device(0)
+    hip.set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for o in out[1:]:
+        assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])

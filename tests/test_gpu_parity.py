@@ -424,8 +424,27 @@ def _compare_normals(hn, hc, on, oc, rel=1e-9, scales=None):
     # The reference multiplies the smallest eigenvalue of the UNSCALED matrix by `scale` once more (:443, sic), so that noise
     # (~eps * trace from the cancellation in the cubic) is amplified to ~eps * scale in the curvature: the floor scales with it.
     floor = 1e-12 if scales is None else np.maximum(1e-12, 1e-13 * scales)
-    cerr = np.abs(hc - oc) > rel * np.abs(oc) + floor
+    cdiff = np.abs(hc - oc)
+    cerr = cdiff > rel * np.abs(oc) + floor
+    # how much of the window is really used (reported by test_zz_curvature_floor_report): curvatures that pass ONLY thanks to the absolute
+    # floor, split by which floor they needed
+    beyond_rel = cdiff > rel * np.abs(oc)
+    FLOOR_USE["curvatures_compared"] += int(cdiff.size)
+    FLOOR_USE["normals_compared"] += int(err.size)
+    FLOOR_USE["needed_a_floor"] += int(beyond_rel.sum())
+    FLOOR_USE["needed_more_than_1e-12"] += int((cdiff > rel * np.abs(oc) + 1e-12).sum() - cerr.sum())
+    FLOOR_USE["failed"] += int(cerr.sum()) + int(bad.sum())
+    if cdiff.size:
+        FLOOR_USE["worst_abs_curvature_diff"] = max(FLOOR_USE["worst_abs_curvature_diff"], float(np.nanmax(cdiff)))
+        if beyond_rel.any():
+            FLOOR_USE["worst_diff_over_scaled_floor"] = max(FLOOR_USE["worst_diff_over_scaled_floor"], float(np.nanmax((cdiff / floor)[beyond_rel])) if np.ndim(floor) else float(np.nanmax(cdiff[beyond_rel]) / floor))
+    if err.size:
+        FLOOR_USE["worst_rel_normal_diff"] = max(FLOOR_USE["worst_rel_normal_diff"], float(np.nanmax(err)))
     return bad, cerr
+
+
+FLOOR_USE = {"curvatures_compared": 0, "normals_compared": 0, "needed_a_floor": 0, "needed_more_than_1e-12": 0, "failed": 0, "worst_abs_curvature_diff": 0.0,
+             "worst_diff_over_scaled_floor": 0.0, "worst_rel_normal_diff": 0.0}
 
 
 @pytest.mark.parametrize("shape,n,k", [("volume", 20_000, 16), ("surface", 30_000, 16), ("volume", 5_000, 8), ("volume", 3_000, 33), ("volume", 1_500, 5), ("volume", 20_000, 40), ("surface", 25_000, 64),
@@ -1844,3 +1863,23 @@ def random_records_like(layout, n, seed):
 def make_buffer_like(kind, layout, records):
     from harness import make_buffer
     return make_buffer(kind, layout, records)
+
+
+def test_zz_curvature_floor_report(hip):
+    """Runs last in this module: how many of the curvatures compared above passed only because of the absolute floor (values that are
+    analytically zero: planar neighbourhoods), and how many of those needed the part of it that scales with the covariance (> 1e-12).  The
+    tally goes to gpurun_out/curvature_floor_use.json (copied to profiles/ by the builder) -- the window's real use, not just its width."""
+    import json
+    u = dict(FLOOR_USE)
+    if u["curvatures_compared"] == 0:
+        pytest.skip("no kNN comparison ran before this test")
+    u["share_needing_a_floor"] = u["needed_a_floor"] / u["curvatures_compared"]
+    out = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "gpurun_out")
+    try:
+        _os.makedirs(out, exist_ok=True)
+        with open(_os.path.join(out, "curvature_floor_use.json"), "w") as f:
+            json.dump(u, f, indent=1)
+    except OSError:
+        pass
+    print("curvature floor use:", json.dumps(u))
+    assert u["failed"] == 0
