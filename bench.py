@@ -63,6 +63,8 @@ WORKLOADS = {
     "filter_big_interleaved": (63.5, "buffer_filter_bench: HashMapBuffer::filter_into, CustomPointTypeBig columnar -> VectorBuffer, density 0.5"),
     "voxelgrid_xyz": (24, "voxelgrid_filter, columnar POSITION_3D, leaf 2.5 (about 15 points per voxel): keys + radix sort + run-length + "
                           "per-voxel sequential centroid sums (sort-bound; 24 B/pt is only the unavoidable read)"),
+    "voxelgrid_xyz_async": (24, "the same through pst_voxelgrid_filter_async (round 4): planned once, then bounds + markers + keys + sort + run heads + "
+                               "reduction stream-ordered, no host round trip, no allocation (24 R lower bound)"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
@@ -437,6 +439,24 @@ def main():
         def step():
             out = pa.HashMapBuffer.new_from_layout(layout)
             pa.voxelgrid_filter(src, 2.5, 2.5, 2.5, out)
+    elif args.workload == "voxelgrid_xyz_async":
+        from pasture_amd.algorithms import VoxelGridPlan
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+        vplan = VoxelGridPlan(src, 2.5, 2.5, 2.5)
+        vout = pa.HashMapBuffer.new_from_layout(layout)
+        vout.resize(vplan.max_voxels)
+        vcs = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+        def step():
+            vplan.filter_async(src, vout, 0, vcs.data_ptr())
+
+        def after():
+            cnt, st = (int(x) for x in vcs.tolist())
+            assert st == 0 and 0 < cnt <= vplan.max_voxels, (cnt, st)
     elif args.workload == "rawlas_to_records":
         src_layout = las.point_layout_from_las_point_format(las.Format(0), True)
         dst_layout = las.point_layout_from_las_point_format(las.Format(0), False)

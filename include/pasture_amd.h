@@ -290,6 +290,22 @@ int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals,
  * filtered's length is final on return; the attribute reductions are enqueued on the current stream (no final synchronisation). */
 int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, pst_buffer* filtered);
 
+/* Stream-ordered voxelgrid_filter (round 4).  pst_voxelgrid_filter reads three things back between its kernels (the bounds for the axis
+ * markers, the voxel count for the output, the count of very large voxels): on a busy host each round trip costs more than the kernels.
+ * pst_voxelgrid_plan_create runs ONE synchronous pass over `buffer` and allocates every scratch buffer for capacities derived from it (points
+ * = len(buffer); an eighth more axis markers, a quarter more occupied voxels: *max_voxels).  pst_voxelgrid_filter_async then enqueues
+ * calculate_bounds -> markers (create_markers_for_axis :55-83 by one lane: the same sequential additions) -> keys -> sort -> run heads ->
+ * reductions on the current stream with NO host synchronisation and NO allocation (hipGraph-capturable); one centroid per occupied voxel
+ * lands in filtered[dst_first ..) (filtered must already hold dst_first + max_voxels points; the tail behind the count is not written),
+ * device_count_and_status[0] = number of voxels, [1] = status: 0 = the result is the reference's; bit 0 bounds invalid (an all-NaN
+ * component: the reference panics), bit 1 more axis markers than planned, bit 2 more voxels than planned, bit 3 a leaf size that does not
+ * advance the markers -- with any bit set nothing useful was written and the caller falls back to pst_voxelgrid_filter.  The buffer may be
+ * ANOTHER cloud of the same length (the plan fixes capacities, not contents).  One call per plan in flight at a time. */
+typedef struct pst_voxel_plan pst_voxel_plan;
+int pst_voxelgrid_plan_create(const pst_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, pst_voxel_plan** out, size_t* max_voxels);
+int pst_voxelgrid_plan_destroy(pst_voxel_plan* plan);
+int pst_voxelgrid_filter_async(pst_voxel_plan* plan, const pst_buffer* buffer, pst_buffer* filtered, size_t dst_first, uint64_t* device_count_and_status);
+
 /* ---- LAS record encoder (the writer side of the hot path) ---------------------------- */
 /* RawLASWriter::write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 (+ write_helpers.rs:10-55):
  * `src` holds points in the DEFAULT typed layout of `point_format` (LasPointFormatN::layout(), las_types.rs; interleaved or

@@ -149,6 +149,9 @@ _PRODUCT_SIGNATURES = {
     "compute_normals_device": [_P, _SZ, _P, _P, _P],
     "buffer_filter_into_async": [_P, _P, _P, C.c_size_t, _P],
     "buffer_read_attribute_converted_device": [_P, C.c_char_p, _DT, _SZ, _SZ, _P],
+    "voxelgrid_plan_create": [_P, C.c_double, C.c_double, C.c_double, _PP, C.POINTER(_SZ)],
+    "voxelgrid_plan_destroy": [_P],
+    "voxelgrid_filter_async": [_P, _P, _P, _SZ, _P],
     "release_scratch": [],
     "reload_tuning": [],
     "comm_unique_id": [_P],

@@ -123,3 +123,30 @@ def voxelgrid_filter(buffer: _Buffer, leafsize_x: float, leafsize_y: float, leaf
     """voxel_grid.rs:109-166: down-samples `buffer` to one centroid per occupied voxel (cells centred on the axis markers),
     appended to `filtered_buffer` in (x, y, z) voxel order; per-attribute reductions of set_all_attributes (:459-689)."""
     buffer.api.voxelgrid_filter(buffer._h, leafsize_x, leafsize_y, leafsize_z, filtered_buffer._h)
+
+
+class VoxelGridPlan:
+    """Stream-ordered voxelgrid_filter (pst_voxelgrid_plan_create / pst_voxelgrid_filter_async): ONE synchronous pass over `buffer` sizes every
+    scratch buffer; `filter_async` then runs bounds -> markers -> keys -> sort -> run heads -> reductions on the current stream without a
+    host round trip or an allocation (hipGraph-capturable).  `filtered_buffer` must already hold dst_first + max_voxels points; the voxel
+    count and a status word (0 = ok) land in the two uint64 at `count_and_status_ptr` (device-accessible memory) in stream order."""
+
+    def __init__(self, buffer: _Buffer, leafsize_x: float, leafsize_y: float, leafsize_z: float):
+        self.api = buffer.api
+        h, mv = C.c_void_p(), C.c_size_t()
+        self.api.voxelgrid_plan_create(buffer._h, leafsize_x, leafsize_y, leafsize_z, C.byref(h), C.byref(mv))
+        self._h, self.max_voxels = h, mv.value
+
+    def filter_async(self, buffer: _Buffer, filtered_buffer: _Buffer, dst_first: int, count_and_status_ptr: int) -> None:
+        self.api.voxelgrid_filter_async(self._h, buffer._h, filtered_buffer._h, dst_first, C.c_void_p(int(count_and_status_ptr)))
+
+    def destroy(self) -> None:
+        if self._h is not None and self._h.value:
+            self.api.voxelgrid_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,5 +1,6 @@
 // pasture-algorithms loops on the device: calculate_bounds, minmax_attribute, transform_attribute.
 // Reference: pasture-algorithms/src/bounds.rs:11-85, minmax.rs:13-51, pasture-core/src/containers/point_buffer.rs:391-404.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -9,7 +10,10 @@ namespace pst {
 
 static bool position_convertible_to_vec3f64(const DataType& d) { return d.is_vec3(); }
 
-void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* out6, hipStream_t stream) {
+// partials: scratch for the per-block records (bounds_partials_scratch_bytes); null = the calling thread's workspace for this (device,
+// stream) -- which is created on first use, so a caller that must not allocate (a hipGraph capture runs on a stream of its own) brings its own
+size_t bounds_partials_scratch_bytes(size_t count) { return std::max(pstk::stream_partials_bytes(count, 4u), pstk::minmax_partials_bytes()); }
+void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* out6, hipStream_t stream, void* partials) {
   const Member* pm = b.layout.find_by_name("Position3D");
   if (!pm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "buffer has no Position3D attribute");
   const size_t slot = (size_t)(pm - b.layout.members.data());
@@ -18,16 +22,15 @@ void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* ou
   // get_generic_converter (attribute_conversion.rs:267-269)
   if (dt.kind != PST_VEC3F64 && !position_convertible_to_vec3f64(dt))
     throw Error(PST_ERR_INVALID_CONVERSION, "Invalid conversion " + dt.display() + " -> Vec3<f64>");
-  Workspace& ws = workspace();
   const uint64_t base = b.columnar ? col_addr(b, slot, first) : aos_addr(b, first) + pm->offset;
   const uint64_t stride = b.columnar ? pm->size : b.layout.size;
   if (b.columnar && dt.kind == PST_VEC3F64 && base % 8 == 0) {
     // K1: coalesced 16-byte stream over the column
     pstk::launch_vec3f64_stream((const double*)(uintptr_t)base, nullptr, count, nullptr, nullptr, 4u,
-                                (double*)ws.partials(pstk::stream_partials_bytes(count, 4u)), out6, stream);
+                                (double*)(partials ? partials : workspace().partials(pstk::stream_partials_bytes(count, 4u))), out6, stream);
   } else {
     pstk::launch_minmax((const uint8_t*)(uintptr_t)base, stride, count, dt.comp_type(), 3, /*acc_f64=*/true,
-                        ws.partials(pstk::minmax_partials_bytes()), out6, stream);
+                        partials ? partials : workspace().partials(pstk::minmax_partials_bytes()), out6, stream);
   }
   PST_HIP_CHECK(hipGetLastError());
 }

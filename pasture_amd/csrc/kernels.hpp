@@ -107,7 +107,14 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
 
 // voxel-grid down-sampling (voxel.hip)
 enum : uint32_t { VX_AVG_VEC = 1, VX_AVG_NUM = 2, VX_MOST_COMMON = 3, VX_MOST_COMMON_BOOL = 4, VX_MAX_POOL = 5 };
+enum : uint32_t { VX_STATUS_BOUNDS_INVALID = 1, VX_STATUS_MARKER_CAPACITY = 2, VX_STATUS_VOXEL_CAPACITY = 4, VX_STATUS_LEAF = 8 };
 struct VoxelGridState;
+// capacities a stream-ordered plan is built for (voxel_plan_create): points, key bits per axis (>= the bits the marker counts need),
+// markers in total, occupied voxels, LDS points per 64-voxel group of the reduction, the leaf sizes
+struct VoxelPlanShape { uint64_t n; uint32_t bits[3]; uint32_t cap_markers; uint64_t cap_voxels; uint32_t stage_cap; double leaf[3]; };
+VoxelGridState* voxel_plan_create(const VoxelPlanShape& shape, hipStream_t stream);
+bool voxel_grid_build_async(VoxelGridState* st, const uint8_t* pos_base, uint64_t pos_stride, const double* bounds6, unsigned long long* count_and_status,
+                            hipStream_t stream);
 long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, const double* markers_x, uint32_t nx,
                            const double* markers_y, uint32_t ny, const double* markers_z, uint32_t nz, const double origin[3], const double leaf[3],
                            hipStream_t stream);

@@ -1088,7 +1088,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         BCK(sort_pairs_u64(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), cnt, key_bits, stream));
       }
       {
-        static const int unroll = [] { const char* e = std::getenv("PST_REORDER_UNROLL"); return e && *e ? std::atoi(e) : 2; }();  // (same box, whole kNN call at 10^8 points: 32.6 / 32.3 / 32.4 ms for 1 / 2 / 4)
+        const int unroll = tune.reorder_unroll;  // (same box, whole kNN call at 10^8 points: 32.6 / 32.3 / 32.4 ms for 1 / 2 / 4)
         // one step per workgroup (a grid of cnt / (256 * unroll) workgroups): a plain random gather of 10^8 points measured 2.41 ms that way and
         // 2.58 ms with 2048 workgroups looping (tools/exp_locality.hip)
         const int u = unroll >= 4 ? 4 : (unroll == 2 ? 2 : 1);
@@ -1436,15 +1436,16 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
             // (PST_KNN_SORT_FALLBACK=0: the A/B switch; same box, 10^8 points: uniform cloud 32.9 -> 32.45 ms, but the sheet 45.0 -> 46.2 --
             // volume-like clouds only).  The unsorted key / index buffers of the index build are free by now.
             const uint32_t* fb_q = fb_list.as<uint32_t>();
-            static const bool sort_fb = [] { const char* e = std::getenv("PST_KNN_SORT_FALLBACK"); return !(e && *e == '0'); }();
+            const bool sort_fb = tune.sort_fallback;
             if (sort_fb && fills && n_fb >= 4096) {
               uint32_t *ka = fb_list.as<uint32_t>(), *kb = keys.as<uint32_t>(), *va = keys.as<uint32_t>() + n, *vb = idx.as<uint32_t>();
               unsigned bits = 1;
               while (bits < 32 && (1ull << bits) <= nf) ++bits;
               size_t sb = 0;
-              NCK(sort_pairs_u32(nullptr, sb, ka, kb, va, vb, n_fb, bits, stream));
+              // (only the sorted keys are used: iota = true lets the first scatter number the values instead of reading `va`, which is uninitialised scratch)
+              NCK(sort_pairs_u32(nullptr, sb, ka, kb, va, vb, n_fb, bits, stream, true));
               NCK(tmp.alloc(sb, stream));
-              NCK(sort_pairs_u32(tmp.p, sb, ka, kb, va, vb, n_fb, bits, stream));
+              NCK(sort_pairs_u32(tmp.p, sb, ka, kb, va, vb, n_fb, bits, stream, true));
               fb_q = kb;
             }
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);

@@ -28,6 +28,8 @@ struct KnnTuning {
   bool occupancy_all = false;  // PST_KNN_OCC_ALL=1: the occupancy / trimmed-box pass looks at every point, not at a 2^23-point thinning
   bool side_stream = true;     // PST_KNN_SIDE_STREAM=0: the permutation of the points runs on the caller's stream, before the directory is built
   char variant = '\0';         // PST_KNN_VAR: '1', 'B', 'D', 'G'
+  bool sort_fallback = true;   // PST_KNN_SORT_FALLBACK=0: the exact fallback search takes its queries in the order the box kernel's workgroups finished
+  int reorder_unroll = 2;      // PST_REORDER_UNROLL: points per lane in flight in the permutation kernel (1 / 2 / 4)
   bool fit_seq = false;        // PST_KNN_FIT=seq: the box search's plane fit in the reference's order of operations (two passes) instead of one pass about the query
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
   unsigned ablate = 0;         // PST_KNN_ABLATE (tuning only)
@@ -51,6 +53,8 @@ struct KnnTuning {
     t.direct_out = !off("PST_KNN_DIRECT"); t.box_list = !off("PST_KNN_BOX_LIST"); t.rounds = !off("PST_KNN_ROUNDS"); t.side_stream = !off("PST_KNN_SIDE_STREAM"); t.occupancy_all = num("PST_KNN_OCC_ALL") != 0.0;
     if (const char* e = std::getenv("PST_KNN_VAR")) t.variant = *e;
     if (const char* e = std::getenv("PST_KNN_FIT")) t.fit_seq = e[0] == 's';
+    t.sort_fallback = !off("PST_KNN_SORT_FALLBACK");
+    if (const char* e = std::getenv("PST_REORDER_UNROLL")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) t.reorder_unroll = v; }
     if (const char* e = std::getenv("PST_KNN_TILE")) {
       unsigned x = 0, y = 0, z = 0;
       if (std::sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x && y && z) { t.tile[0] = x; t.tile[1] = y; t.tile[2] = z; }

@@ -65,7 +65,8 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill);
 
 // {min xyz, max xyz} of POSITION_3D over points [first, first+count) written to out6 (device-accessible); seeds
 // +/-f64::MAX (bounds.rs:31-32).  The buffer must have a Position3D attribute.
-void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* out6, hipStream_t stream);
+size_t bounds_partials_scratch_bytes(size_t count);
+void bounds_of_range(const pst_buffer& b, size_t first, size_t count, double* out6, hipStream_t stream, void* partials = nullptr);
 // AABB::from_min_max (math/bounds.rs:21-26): throws PST_ERR_BOUNDS_INVALID if min > max on any axis
 void check_bounds_record(const double r[6], double out_min[3], double out_max[3]);
 

@@ -19,6 +19,7 @@
 // Gather-bound (points of a voxel are scattered in the source) + sort-bound: no MFMA.
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "device_common.hpp"
@@ -39,7 +40,17 @@ struct VoxelAttr {
   uint32_t reduce;                 // pstk::VX_*
   uint32_t kind;                   // datatype kind of the attribute (PST_U8 ...)
 };
+// Stream-ordered form (pst_voxelgrid_filter_async): what the host of the synchronous call reads back between kernels stays in device memory.
+// Written by voxel_plan_markers_kernel / voxel_count_kernel, read by the key, head and reduction kernels of the same call.
+struct VoxelDyn {
+  double origin[3];               // the cloud's minimum (find_leaf's arithmetic guess starts from it)
+  uint32_t n_markers[3];          // markers per axis; the three arrays are consecutive in the marker buffer
+  uint32_t status;                // pstk::VX_STATUS_* bits; 0 = the results are the reference's
+  unsigned long long n_voxels;    // occupied voxels (clamped to the plan's capacity when VX_STATUS_VOXEL_CAPACITY is set)
+};
+
 struct VoxelArgs {
+  const VoxelDyn* dyn;                   // null: n_voxels below is the host's count
   const uint32_t* sorted_idx;            // point indices sorted by voxel key
   const unsigned long long* starts;      // [n_voxels + 1] offsets into sorted_idx
   uint64_t n_voxels;
@@ -87,9 +98,15 @@ struct AxisGrid { const double* markers; uint32_t n; uint32_t shift; double orig
 constexpr uint32_t kLdsMarkers = 6144;  // 48 KiB
 template <typename KeyT, bool LDS_MARKERS>
 __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __restrict__ pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy,
-                                                            AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx, pstk::RadixFirstPass first) {
+                                                            AxisGrid gz, KeyT* __restrict__ keys, uint32_t* __restrict__ idx, pstk::RadixFirstPass first,
+                                                            const VoxelDyn* __restrict__ dyn) {
   extern __shared__ double lds_markers[];
   __shared__ uint32_t hist[512];
+  if (dyn) {  // stream-ordered form: marker counts and the origin were worked out on the device (voxel_plan_markers_kernel)
+    gx.n = dyn->n_markers[0]; gy.n = dyn->n_markers[1]; gz.n = dyn->n_markers[2];
+    gx.origin = dyn->origin[0]; gy.origin = dyn->origin[1]; gz.origin = dyn->origin[2];
+    gy.markers = gx.markers + gx.n; gz.markers = gy.markers + gy.n;
+  }
   if constexpr (LDS_MARKERS) {
     // gx.markers, gy.markers, gz.markers are consecutive in one device array (voxel_grid_build)
     const uint32_t total = gx.n + gy.n + gz.n;
@@ -140,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void voxel_keys_kernel(const uint8_t* __res
 constexpr int kHeadsPerThread = 8;
 template <typename KeyT, bool WRITE>
 __global__ __launch_bounds__(kBlock) void voxel_heads_kernel(const KeyT* __restrict__ keys, uint64_t n, uint32_t* __restrict__ tile_counts,
-                                                             const unsigned long long* __restrict__ tile_first, unsigned long long* __restrict__ starts) {
+                                                             const unsigned long long* __restrict__ tile_first, unsigned long long* __restrict__ starts,
+                                                             unsigned long long starts_cap) {  // WRITE: starts[] holds starts_cap + 1 entries
   __shared__ uint32_t wave_sums[kBlock / 64];
   const uint64_t tile0 = (uint64_t)blockIdx.x * (kBlock * kHeadsPerThread);
   const uint64_t j0 = tile0 + (uint64_t)threadIdx.x * kHeadsPerThread;
@@ -187,8 +205,9 @@ __global__ __launch_bounds__(kBlock) void voxel_heads_kernel(const KeyT* __restr
     unsigned long long rank = tile_first[blockIdx.x] + before + (inc - cnt);
 #pragma unroll
     for (int u = 0; u < kHeadsPerThread; ++u)
-      if (flags & (1u << u)) starts[rank++] = j0 + u;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) starts[tile_first[blockIdx.x] + total] = n;
+      if (flags & (1u << u)) { if (rank < starts_cap) starts[rank] = j0 + u; ++rank; }
+    // (more voxels than the stream-ordered plan provided for: the count kernel flags it; starts[cap] then ends the last voxel kept)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { const unsigned long long e = tile_first[blockIdx.x] + total; starts[e < starts_cap ? e : starts_cap] = n; }
   }
 }
 
@@ -295,13 +314,13 @@ __device__ __forceinline__ void reduce_voxel_by_lane(const VoxelAttr& at, const 
 // The 64 voxels of group `grp`, by the waves of one workgroup WITHOUT staging: every wave computes the voxels' sizes, wave 0 takes the small
 // voxels one per lane, and the waves share the voxels that need a whole wave (most-common attributes; everything of large voxels) round robin.
 // `skip_avg`: the averages and max-pools of this group have been reduced from LDS already (voxel_reduce_kernel below).
-__device__ __forceinline__ void reduce_group_by_waves(const VoxelArgs& a, uint64_t grp, uint32_t lane, uint32_t wave, uint32_t n_waves, bool any_mode, bool skip_avg) {
+__device__ __forceinline__ void reduce_group_by_waves(const VoxelArgs& a, uint64_t n_voxels, uint64_t grp, uint32_t lane, uint32_t wave, uint32_t n_waves, bool any_mode, bool skip_avg) {
   {
     // ---- phase 1: lane l owns voxel 64*grp + l; averages and max-pools of small voxels ----
     const uint64_t lv = grp * 64 + lane;
     uint32_t lm = 0;
     uint64_t ls = 0;
-    if (lv < a.n_voxels) { ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); }
+    if (lv < n_voxels) { ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); }
     const bool small = lm != 0 && (lm <= kSmallVoxel || skip_avg);
     if (small && !skip_avg && wave == 0) {
       for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
@@ -432,7 +451,9 @@ __global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a,
     any_mode = any_mode || r == pstk::VX_MOST_COMMON || r == pstk::VX_MOST_COMMON_BOOL;
     any_avg = any_avg || r == pstk::VX_AVG_VEC || r == pstk::VX_AVG_NUM || r == pstk::VX_MAX_POOL;
   }
-  const uint64_t v0 = grp * 64, v1 = v0 + 64 < a.n_voxels ? v0 + 64 : a.n_voxels;
+  const uint64_t n_voxels = a.dyn ? a.dyn->n_voxels : a.n_voxels;
+  if (grp * 64 >= n_voxels) return;  // (stream-ordered form: the grid is the plan's capacity)
+  const uint64_t v0 = grp * 64, v1 = v0 + 64 < n_voxels ? v0 + 64 : n_voxels;
   const uint64_t p0 = a.starts[v0];
   const uint64_t cnt64 = a.starts[v1] - p0;
   const bool stage = any_avg && cnt64 <= (uint64_t)cap;
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a,
     const uint32_t cnt = (uint32_t)cnt64;
     const uint64_t lv = v0 + lane;
     uint32_t lm = 0, lo = 0;  // lane l: voxel v0 + l has lm points, the first is staged at `lo`
-    if (lv < a.n_voxels) { const uint64_t ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); lo = (uint32_t)(ls - p0); }
+    if (lv < n_voxels) { const uint64_t ls = a.starts[lv]; lm = (uint32_t)(a.starts[lv + 1] - ls); lo = (uint32_t)(ls - p0); }
     const uint32_t* __restrict__ idx = a.sorted_idx + p0;
     for (uint32_t ai = 0; ai < a.n_attrs; ++ai) {
       const VoxelAttr& at = a.attrs[ai];
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void voxel_reduce_kernel(const VoxelArgs a,
     }
     if (!any_mode) return;
   }
-  reduce_group_by_waves(a, grp, lane, wave, kBlock / 64, any_mode, stage);
+  reduce_group_by_waves(a, n_voxels, grp, lane, wave, kBlock / 64, any_mode, stage);
 }
 
 // One block per voxel with more than kMidVoxel points: 65536-bin histogram (ascending bins are ascending values) in the block's private global scratch.
@@ -540,25 +561,73 @@ __global__ __launch_bounds__(kBlock) void voxel_mode_big_kernel(const VoxelArgs 
   }
 }
 
+
+// Stream-ordered form, step 1: what voxelgrid_filter's host code does between calculate_bounds and the key kernel -- AABB::from_min_max's
+// check (math/bounds.rs:21-26) and create_markers_for_axis (voxel_grid.rs:55-83: curr = min; while curr < max { curr += leaf; push }), the
+// same sequential f64 additions, by ONE lane: a few hundred to a few thousand dependent adds (microseconds).  The three marker arrays are
+// written back to back.  Overflowing the plan's capacities (total markers, key bits per axis) sets a status bit; the arrays are cut there.
+__global__ void voxel_plan_markers_kernel(const double* __restrict__ bounds6, double lx, double ly, double lz, double* __restrict__ markers, uint32_t cap_markers,
+                                          uint32_t bits_x, uint32_t bits_y, uint32_t bits_z, VoxelDyn* __restrict__ dyn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t status = 0, total = 0;
+  const double leaf[3] = {lx, ly, lz};
+  const uint32_t bits[3] = {bits_x, bits_y, bits_z};
+  if (bounds6[0] > bounds6[3] || bounds6[1] > bounds6[4] || bounds6[2] > bounds6[5]) status |= pstk::VX_STATUS_BOUNDS_INVALID;
+  for (int a = 0; a < 3; ++a) {
+    const double mn = bounds6[a], mx = bounds6[3 + a];
+    dyn->origin[a] = mn;
+    uint32_t cnt = 0;
+    double curr = mn;
+    while (!status && curr < mx) {
+      const double next = curr + leaf[a];
+      if (!(next > curr)) { status |= pstk::VX_STATUS_LEAF; break; }
+      if (total >= cap_markers || cnt >= (1u << bits[a])) { status |= pstk::VX_STATUS_MARKER_CAPACITY; break; }
+      curr = next;
+      markers[total++] = curr;
+      cnt += 1;
+    }
+    dyn->n_markers[a] = cnt;
+  }
+  dyn->status = status;
+  dyn->n_voxels = 0;
+}
+// step 2, behind the scan of the run heads: the voxel count stays on the device
+__global__ void voxel_count_kernel(const unsigned long long* __restrict__ total_runs, unsigned long long cap_voxels, VoxelDyn* __restrict__ dyn,
+                                   unsigned long long* __restrict__ count_and_status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long runs = dyn->status ? 0ull : *total_runs;
+  uint32_t status = dyn->status;
+  if (runs > cap_voxels) { status |= pstk::VX_STATUS_VOXEL_CAPACITY; runs = cap_voxels; }
+  dyn->n_voxels = runs;
+  dyn->status = status;
+  if (count_and_status) { count_and_status[0] = runs; count_and_status[1] = status; }
+}
+
 }  // namespace
 
 namespace pstk {
 
 struct VoxelGridState {
-  DevBuf keys, keys2, idx, idx2, tmp, markers, unique, counts, starts, big_list, big_count, hist;
+  DevBuf keys, keys2, idx, idx2, tmp, markers, unique, counts, starts, big_list, big_count, hist, dyn;
   uint64_t n = 0, n_voxels = 0;
+  // stream-ordered plan (voxel_plan_create): every buffer above is allocated once for these capacities and no call allocates
+  bool planned = false;
+  VoxelPlanShape shape{};
+  size_t tmp_sort = 0, tmp_scan = 0;
 };
 
 // Phase 1: keys, sort, voxel segmentation.  Returns the number of voxels (>= 1), or -1 on a HIP failure.
 // KeyT = uint32_t when the packed (x, y, z) key fits 32 bits (half the key traffic of the radix sort), else uint64_t.
 template <typename KeyT>
 static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, AxisGrid gx, AxisGrid gy, AxisGrid gz,
-                                        unsigned end_bit, hipStream_t stream) {
+                                        unsigned end_bit, hipStream_t stream, unsigned long long* count_and_status = nullptr) {
 #define VCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
-  VCK(st->keys.alloc(n * sizeof(KeyT), stream)); VCK(st->keys2.alloc(n * sizeof(KeyT), stream));
-  VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
+  // planned (stream-ordered form): the buffers exist (voxel_plan_create), nothing is allocated and nothing is read back; the voxel count
+  // stays in st->dyn and the run-head table is capped at the plan's capacity
+  const bool planned = st->planned;
+  const VoxelDyn* dyn = planned ? st->dyn.as<VoxelDyn>() : nullptr;
   const uint64_t tiles = (n + (uint64_t)kBlock * kHeadsPerThread - 1) / ((uint64_t)kBlock * kHeadsPerThread);
-  size_t tmp_sort = 0, tmp_scan = 0;
+  size_t tmp_sort = st->tmp_sort, tmp_scan = st->tmp_scan;
   constexpr bool own_keys = sizeof(KeyT) == 4;  // (32-bit keys: the library's own sort numbers the points and takes its first histogram from the key kernel)
   RadixFirstPass first{nullptr, 0, 0, 0};
   auto sort = [&](void* tmp, size_t& bytes) {
@@ -567,35 +636,48 @@ static long long voxel_grid_build_typed(VoxelGridState* st, const uint8_t* pos_b
     else
       return sort_pairs_u64(tmp, bytes, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream);
   };
-  VCK(sort(nullptr, tmp_sort));
-  VCK(st->counts.alloc((tiles + 1) * 4, stream));
-  VCK(st->unique.alloc((tiles + 1) * 8, stream));  // exclusive scan of the tile counts (+ the total)
-  VCK(exclusive_sum_u32_u64(nullptr, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
-  VCK(st->tmp.alloc(std::max(tmp_sort, tmp_scan), stream));
+  if (!planned) {
+    VCK(st->keys.alloc(n * sizeof(KeyT), stream)); VCK(st->keys2.alloc(n * sizeof(KeyT), stream));
+    VCK(st->idx.alloc(n * 4, stream)); VCK(st->idx2.alloc(n * 4, stream));
+    tmp_sort = tmp_scan = 0;
+    VCK(sort(nullptr, tmp_sort));
+    VCK(st->counts.alloc((tiles + 1) * 4, stream));
+    VCK(st->unique.alloc((tiles + 1) * 8, stream));  // exclusive scan of the tile counts (+ the total)
+    VCK(exclusive_sum_u32_u64(nullptr, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
+    VCK(st->tmp.alloc(std::max(tmp_sort, tmp_scan), stream));
+    st->tmp_sort = tmp_sort; st->tmp_scan = tmp_scan;
+  }
   if constexpr (own_keys) first = sort_first_pass(st->tmp.p, n, end_bit);
   RadixFirstPass walk = first;  // (no histogram wanted: the same walk, nothing counted)
   if (!walk.counts) { walk.tile_size = 8192; walk.tiles = (uint32_t)((n + 8191) / 8192); walk.bits = 0; }
   uint32_t* idx_out = own_keys ? nullptr : st->idx.as<uint32_t>();
   const unsigned grid = (unsigned)std::max<uint32_t>(1, walk.tiles);
-  const uint32_t n_markers = gx.n + gy.n + gz.n;
+  const uint32_t n_markers = planned ? st->shape.cap_markers : gx.n + gy.n + gz.n;  // (planned: LDS for the plan's capacity)
   if (n_markers <= kLdsMarkers)
     hipLaunchKernelGGL((voxel_keys_kernel<KeyT, true>), dim3(grid), dim3(kBlock), (size_t)n_markers * 8, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(),
-                       idx_out, walk);
+                       idx_out, walk, dyn);
   else
-    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, false>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(), idx_out, walk);
+    hipLaunchKernelGGL((voxel_keys_kernel<KeyT, false>), dim3(grid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, gx, gy, gz, st->keys.as<KeyT>(), idx_out, walk, dyn);
   VCK(sort(st->tmp.p, tmp_sort));
   VCK(hipMemsetAsync(st->counts.as<uint32_t>() + tiles, 0, 4, stream));
   hipLaunchKernelGGL((voxel_heads_kernel<KeyT, false>), dim3((unsigned)tiles), dim3(kBlock), 0, stream, (const KeyT*)st->keys2.as<KeyT>(), n,
-                     st->counts.as<uint32_t>(), (const unsigned long long*)nullptr, (unsigned long long*)nullptr);
+                     st->counts.as<uint32_t>(), (const unsigned long long*)nullptr, (unsigned long long*)nullptr, 0ull);
   VCK(exclusive_sum_u32_u64(st->tmp.p, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
-  unsigned long long runs = 0;
-  VCK(hipMemcpyAsync(&runs, st->unique.as<unsigned long long>() + tiles, 8, hipMemcpyDeviceToHost, stream));
-  VCK(hipStreamSynchronize(stream));
-  st->n_voxels = runs;
-  VCK(st->starts.alloc((runs + 1) * 8, stream));
+  unsigned long long runs = 0, starts_cap = ~0ull;
+  if (planned) {
+    starts_cap = st->shape.cap_voxels;
+    hipLaunchKernelGGL(voxel_count_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)(st->unique.as<unsigned long long>() + tiles), starts_cap,
+                       st->dyn.as<VoxelDyn>(), count_and_status);
+    st->n_voxels = starts_cap;
+  } else {
+    VCK(hipMemcpyAsync(&runs, st->unique.as<unsigned long long>() + tiles, 8, hipMemcpyDeviceToHost, stream));
+    VCK(hipStreamSynchronize(stream));
+    st->n_voxels = runs;
+    VCK(st->starts.alloc((runs + 1) * 8, stream));
+  }
   hipLaunchKernelGGL((voxel_heads_kernel<KeyT, true>), dim3((unsigned)tiles), dim3(kBlock), 0, stream, (const KeyT*)st->keys2.as<KeyT>(), n,
-                     (uint32_t*)nullptr, (const unsigned long long*)st->unique.as<unsigned long long>(), st->starts.as<unsigned long long>());
-  return (long long)runs;
+                     (uint32_t*)nullptr, (const unsigned long long*)st->unique.as<unsigned long long>(), st->starts.as<unsigned long long>(), starts_cap);
+  return planned ? (long long)starts_cap : (long long)runs;
 #undef VCK
 }
 
@@ -622,12 +704,13 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
                        const uint32_t* reduce, const uint32_t* kind, int n_attrs, uint64_t dst_first, hipStream_t stream) {
   if (n_attrs > kMaxVoxelAttrs) return false;
   VoxelArgs a{};
+  a.dyn = st->planned ? st->dyn.as<VoxelDyn>() : nullptr;
   a.sorted_idx = st->idx2.as<uint32_t>();
   a.starts = st->starts.as<unsigned long long>();
-  a.n_voxels = st->n_voxels;
+  a.n_voxels = st->n_voxels;  // (planned: the plan's capacity = the launch grid; the kernels read the count from a.dyn)
   a.dst_first = dst_first;
   const size_t max_big = (size_t)(st->n / kMidVoxel) + 1;
-  if (st->big_list.alloc(max_big * 4, stream) != hipSuccess || st->big_count.alloc(16, stream) != hipSuccess) return false;
+  if (!st->planned && (st->big_list.alloc(max_big * 4, stream) != hipSuccess || st->big_count.alloc(16, stream) != hipSuccess)) return false;
   if (hipMemsetAsync(st->big_count.p, 0, 16, stream) != hipSuccess) return false;
   a.big_list = st->big_list.as<uint32_t>();
   a.big_count = st->big_count.as<unsigned int>();
@@ -645,11 +728,15 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
   static const uint32_t cap_env = [] { const char* e = std::getenv("PST_VOXEL_STAGE"); return e && *e ? (uint32_t)std::strtoul(e, nullptr, 10) : ~0u; }();  // 0 = never stage (A/B)
   uint32_t cap = (uint32_t)std::min<uint64_t>(6144, std::max<uint64_t>(1024, (st->n * 8 / 5) / groups + 63)) & ~63u;
   if (cap_env != ~0u) cap = std::min<uint32_t>(cap_env, 6144) & ~63u;
+  if (st->planned) cap = st->shape.stage_cap;  // (sized for the voxel count the plan measured, not for its capacity)
   const size_t lds = (size_t)std::max<uint32_t>(cap, 64) * 3 * sizeof(double);
   static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 3 * 8) == hipSuccess;
   if (!lds_ok) return false;
   hipLaunchKernelGGL(voxel_reduce_kernel, dim3((unsigned)groups), dim3(kBlock), lds, stream, a, cap);
-  if (any_mode && st->n > kMidVoxel) {
+  if (any_mode && st->n > kMidVoxel && st->planned) {
+    // stream-ordered: the big-voxel pass always runs on its fixed grid; its blocks read the count on the device and most find nothing
+    hipLaunchKernelGGL(voxel_mode_big_kernel, dim3(kBigBlocks), dim3(kBlock), 0, stream, a, st->hist.as<uint32_t>());
+  } else if (any_mode && st->n > kMidVoxel) {
     unsigned int n_big = 0;
     if (hipMemcpyAsync(&n_big, st->big_count.p, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
     if (hipStreamSynchronize(stream) != hipSuccess) return false;
@@ -660,6 +747,60 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
     }
   }
   return hipGetLastError() == hipSuccess;
+}
+
+// ---- stream-ordered form -------------------------------------------------------------------------------------------------------------
+// voxel_plan_create allocates every buffer of a call for the capacities in `shape` (chosen by voxel_api.cpp from ONE synchronous run over
+// the cloud); voxel_grid_build_async then enqueues markers -> keys -> sort -> run heads -> count without a host round trip or an
+// allocation (hipGraph-capturable), and voxel_grid_reduce works off the device-side count.
+VoxelGridState* voxel_plan_create(const VoxelPlanShape& shape, hipStream_t stream) {
+  auto st = std::make_unique<VoxelGridState>();
+  st->n = shape.n;
+  st->shape = shape;
+  const uint64_t n = shape.n;
+  const unsigned end_bit = shape.bits[0] + shape.bits[1] + shape.bits[2];
+  const size_t key_bytes = end_bit <= 32 ? 4 : 8;
+  const uint64_t tiles = (n + (uint64_t)kBlock * kHeadsPerThread - 1) / ((uint64_t)kBlock * kHeadsPerThread);
+#define PCK(x) do { if ((x) != hipSuccess) return nullptr; } while (0)
+  PCK(st->markers.alloc(((size_t)shape.cap_markers + 1) * 8, stream));
+  PCK(st->dyn.alloc(sizeof(VoxelDyn), stream));
+  PCK(st->keys.alloc(n * key_bytes, stream)); PCK(st->keys2.alloc(n * key_bytes, stream));
+  PCK(st->idx.alloc(n * 4, stream)); PCK(st->idx2.alloc(n * 4, stream));
+  size_t tmp_sort = 0, tmp_scan = 0;
+  RadixFirstPass none{nullptr, 0, 0, 0};
+  if (key_bytes == 4) PCK(sort_pairs_u32(nullptr, tmp_sort, st->keys.as<uint32_t>(), st->keys2.as<uint32_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream, true, &none));
+  else PCK(sort_pairs_u64(nullptr, tmp_sort, st->keys.as<uint64_t>(), st->keys2.as<uint64_t>(), st->idx.as<uint32_t>(), st->idx2.as<uint32_t>(), n, end_bit, stream));
+  PCK(st->counts.alloc((tiles + 1) * 4, stream));
+  PCK(st->unique.alloc((tiles + 1) * 8, stream));
+  PCK(exclusive_sum_u32_u64(nullptr, tmp_scan, st->counts.as<uint32_t>(), st->unique.as<unsigned long long>(), tiles + 1, stream));
+  PCK(st->tmp.alloc(std::max(tmp_sort, tmp_scan), stream));
+  st->tmp_sort = tmp_sort; st->tmp_scan = tmp_scan;
+  PCK(st->starts.alloc((shape.cap_voxels + 1) * 8, stream));
+  PCK(st->big_list.alloc(((size_t)(n / kMidVoxel) + 1) * 4, stream));
+  PCK(st->big_count.alloc(16, stream));
+  if (n > kMidVoxel) PCK(st->hist.alloc((size_t)kBigBlocks * 65536u * 4u, stream));
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 3 * 8) == hipSuccess;
+  if (!lds_ok) return nullptr;
+#undef PCK
+  st->planned = true;
+  return st.release();
+}
+
+// bounds6: the cloud's {min xyz, max xyz} in device memory (calculate_bounds on the same stream).  count_and_status: two device words.
+bool voxel_grid_build_async(VoxelGridState* st, const uint8_t* pos_base, uint64_t pos_stride, const double* bounds6, unsigned long long* count_and_status,
+                            hipStream_t stream) {
+  if (!st || !st->planned) return false;
+  const VoxelPlanShape& sh = st->shape;
+  double* dm = st->markers.as<double>();
+  hipLaunchKernelGGL(voxel_plan_markers_kernel, dim3(1), dim3(64), 0, stream, bounds6, sh.leaf[0], sh.leaf[1], sh.leaf[2], dm, sh.cap_markers, sh.bits[0], sh.bits[1],
+                     sh.bits[2], st->dyn.as<VoxelDyn>());
+  const uint32_t bx = sh.bits[0], by = sh.bits[1], bz = sh.bits[2];
+  const unsigned end_bit = bx + by + bz;
+  // (marker counts, origins and the y / z array positions come from st->dyn inside the key kernel)
+  AxisGrid gx{dm, 0, by + bz, 0.0, 1.0 / sh.leaf[0]}, gy{dm, 0, bz, 0.0, 1.0 / sh.leaf[1]}, gz{dm, 0, 0, 0.0, 1.0 / sh.leaf[2]};
+  const long long r = end_bit <= 32 ? voxel_grid_build_typed<uint32_t>(st, pos_base, pos_stride, sh.n, gx, gy, gz, end_bit, stream, count_and_status)
+                                    : voxel_grid_build_typed<uint64_t>(st, pos_base, pos_stride, sh.n, gx, gy, gz, end_bit, stream, count_and_status);
+  return r >= 0 && hipGetLastError() == hipSuccess;
 }
 
 void voxel_grid_free(VoxelGridState* st) { delete st; }

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from harness import BUFFER_KINDS
-from pasture_amd._capi import PasturePanic
+from pasture_amd._capi import PastureError, PasturePanic
 from pasture_amd.algorithms import voxelgrid_filter
 from pasture_amd.buffers import HashMapBuffer, VectorBuffer
 from pasture_amd.layout import PointLayout, attributes as A
@@ -266,3 +266,138 @@ def test_voxel_reduction_paths_agree(stage):
                         "-p", "no:cacheprovider"], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+# ---- stream-ordered form: pst_voxelgrid_plan_create / pst_voxelgrid_filter_async (round 4) -------------------------------------------------
+def _async_layouts(hip, packed):
+    from pasture_amd.layout import PointLayout
+    attrs = [A.INTENSITY, A.POSITION_3D, A.CLASSIFICATION, A.GPS_TIME, A.COLOR_RGB, A.RETURN_NUMBER]
+    return PointLayout.from_attributes_packed(attrs, 1, api=hip) if packed else PointLayout.from_attributes(attrs, api=hip)
+
+
+def _sync_result(src, leaf, out_kind):
+    out = out_kind.new_from_layout(src.point_layout())
+    voxelgrid_filter(src, *leaf, out)
+    return out.len(), out.get_point_range(range(0, out.len()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kinds", ["HH", "VV", "HV"])
+@pytest.mark.parametrize("n,leaf", [(100_000, (25.0, 25.0, 10.0)), (300_001, (3.0, 3.0, 3.0)), (5000, (2000.0, 2000.0, 2000.0))])
+def test_voxelgrid_filter_async_equals_the_synchronous_call(hip, kinds, n, leaf):
+    """Same cloud, then ANOTHER cloud of the same length through the same plan (capacities, not contents, are planned): points, count and
+    status word equal what pst_voxelgrid_filter produces; nothing behind the count is written."""
+    import torch
+    from pasture_amd.algorithms import VoxelGridPlan
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    K = {"H": HashMapBuffer, "V": VectorBuffer}
+    layout = _async_layouts(hip, packed=(kinds == "VV"))
+    src = K[kinds[0]].new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(7, 0)
+    plan = VoxelGridPlan(src, *leaf)
+    out = K[kinds[1]].new_from_layout(layout)
+    first = 3
+    out.resize(first + plan.max_voxels)
+    cs = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for seed in (7, 8, 9):
+        src.synth_fill(seed, 0)
+        want_n, want = _sync_result(src, leaf, K[kinds[1]])
+        sentinel = np.full((first + plan.max_voxels, layout.size_of_point_entry()), 0xAB, dtype=np.uint8)
+        out.set_point_range(range(0, first + plan.max_voxels), sentinel)
+        plan.filter_async(src, out, first, cs.data_ptr())
+        torch.cuda.synchronize()
+        count, status = (int(x) for x in cs.tolist())
+        assert status == 0 and count == want_n <= plan.max_voxels
+        got = out.get_point_range(range(0, first + plan.max_voxels))
+        if layout.size_of_point_entry() == sum(a.size() for a in layout.attributes()):  # packed: every byte of a record is an attribute
+            assert np.array_equal(got[first:first + count], want)
+        else:  # repr(C): padding bytes keep the sentinel here and are zero in a freshly appended point
+            for a in layout.attributes():
+                o, sz = a.offset(), a.size()
+                assert np.array_equal(got[first:first + count, o:o + sz], want[:, o:o + sz]), a.name()
+        for a in layout.attributes():  # (attribute bytes only: a columnar buffer stores no padding)
+            o, sz = a.offset(), a.size()
+            assert (got[:first, o:o + sz] == 0xAB).all() and (got[first + count:, o:o + sz] == 0xAB).all(), a.name()
+    plan.destroy()
+
+
+@pytest.mark.gpu
+def test_voxelgrid_filter_async_flags_what_the_plan_did_not_provide_for(hip):
+    import torch
+    from pasture_amd.algorithms import VoxelGridPlan
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.layout import PointLayout
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    n = 50_000
+    rng = np.random.default_rng(3)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    small = rng.uniform(0, 100, (n, 3))
+    src.set_attribute_range(A.POSITION_3D, range(0, n), small)
+    plan = VoxelGridPlan(src, 10.0, 10.0, 10.0)  # ~1000 voxels, 10 markers per axis
+    out = HashMapBuffer.new_from_layout(layout)
+    out.resize(plan.max_voxels)
+    cs = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def run(pts):
+        src.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+        plan.filter_async(src, out, 0, cs.data_ptr())
+        torch.cuda.synchronize()
+        return tuple(int(x) for x in cs.tolist())
+    assert run(small)[1] == 0
+    assert run(small * 100.0)[1] & 2          # a hundred times the extent: more axis markers than planned
+    c, st = run(small * 1.7)                  # 17 markers per axis (18 planned) but 17^3 voxels where ~1000 + a quarter + 1024 were planned
+    assert st == 4 and c == plan.max_voxels
+    c, st = run(small * 1.2)                  # inside every capacity: a different grid through the same plan
+    assert st == 0 and 1000 < c <= 12 ** 3
+    nanx = small.copy(); nanx[:, 1] = np.nan   # calculate_bounds panics in the reference (min > max)
+    assert run(nanx)[1] & 1
+    assert run(small) == (run(small)[0], 0)    # and the plan is still good afterwards
+    with pytest.raises(PastureError):          # another length is refused on the host
+        src.resize(n + 1)
+        plan.filter_async(src, out, 0, cs.data_ptr())
+    short = HashMapBuffer.new_from_layout(layout)
+    short.resize(plan.max_voxels - 1)
+    src.resize(n)
+    with pytest.raises(PastureError):
+        plan.filter_async(src, short, 0, cs.data_ptr())
+
+
+@pytest.mark.gpu
+def test_voxelgrid_filter_async_is_graph_capturable(hip):
+    """The whole call recorded into a hipGraph (no host synchronisation, no allocation inside it) and replayed over new contents of the same
+    buffers: identical to the synchronous call each time."""
+    import ctypes
+    import torch
+    from pasture_amd.algorithms import VoxelGridPlan
+    from pasture_amd.buffers import HashMapBuffer
+    from pasture_amd.layout import PointLayout
+    layout = PointLayout.from_attributes([A.POSITION_3D, A.INTENSITY, A.CLASSIFICATION], api=hip)
+    n, leaf = 400_000, (12.5, 12.5, 5.0)
+    src = HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(21, 0)
+    plan = VoxelGridPlan(src, *leaf)
+    out = HashMapBuffer.new_from_layout(layout)
+    out.resize(plan.max_voxels)
+    cs = torch.zeros(2, dtype=torch.int64, device="cuda")
+    plan.filter_async(src, out, 0, cs.data_ptr())  # warm: every lazily sized scratch exists before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    main = torch.cuda.current_stream().cuda_stream
+    try:
+        with torch.cuda.graph(g):
+            hip.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            plan.filter_async(src, out, 0, cs.data_ptr())
+    finally:
+        hip.set_stream(ctypes.c_void_p(main))
+    for seed in (21, 22, 23):
+        src.synth_fill(seed, 0)
+        want_n, want = _sync_result(src, leaf, HashMapBuffer)
+        cs.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        count, status = (int(x) for x in cs.tolist())
+        assert (count, status) == (want_n, 0)
+        assert np.array_equal(out.get_point_range(range(0, count)), want)
