@@ -178,6 +178,23 @@ static bool launch_specialised(const ConvertPlan& plan, bool src_aos, bool dst_a
   return true;
 }
 
+// Is a plan-specialised kernel (in-tree instantiation or run-time compiled) at hand for this plan?  A missing one is queued for the compiler
+// thread (or compiled here in PST_JIT=sync), exactly as a launch would.  converter.cpp asks before it prefers the generic path over a
+// format-specialised LAS kernel that the plan-specialised kernels have overtaken (round 4).
+bool convert_specialised_ready(const ConvertPlan& plan, bool src_aos, bool dst_aos) {
+  const pstjit::Mode mode = pstjit::mode();
+  if (mode == pstjit::Mode::Off) return false;
+  pstjit::QuadSpec spec;
+  if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) return false;
+  const std::string source = pstjit::spec_source(spec);
+  uint32_t tile = 0;
+  if (launch_convert_static(source, &tile, true, 0, plan.h, nullptr, nullptr)) return true;
+  pstjit::Kernel k;
+  const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait
+                              : plan.h.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
+  return pstjit::acquire(spec, source, how, &k);
+}
+
 bool launch_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, bool use_lds, hipStream_t stream, unsigned* n_records) {
   const ConvertHeader& h = plan.h;
   if (n_records) *n_records = 0;

@@ -194,6 +194,37 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
 // Identity between two buffers of the same layout in which the mappings cover every byte of the record (no padding, no
 // unmapped attribute): interleaved -> interleaved is then a plain byte copy of the records (what the reference's per-attribute
 // loops add up to, buffer_conversion.rs:606-662).
+// Round 4: the plan-specialised kernels (jit.cpp / convert_static.hip) have overtaken two of the format-specialised LAS kernels -- typed
+// LAS records -> columns (same box: 0.81 against 0.78 of peak) and raw LAS records -> typed records (0.74 against 0.65).  Those two plans take
+// the generic path WHEN a specialised kernel for them is at hand (in-tree, compiled, or PST_JIT=sync), and the LAS kernel otherwise
+// (PST_JIT=0, hipRTC missing, the first calls while the compiler thread works).  The mappings of such a plan, as the generic path lists them:
+static std::vector<PlanEntry> interleaved_source_entries(const pst_converter& c, const pst_buffer* dst, size_t t0, bool dst_columnar, int pos_slot, bool with_bounds) {
+  std::vector<PlanEntry> out;
+  bool bounds_done = false;
+  for (const Mapping& m : c.mappings) {
+    PlanEntry e = entry_from_mapping(m);
+    const int tslot = c.to.index_of(m.target.def);
+    if (dst_columnar) e.dst_col = dst ? col_addr(*dst, (size_t)tslot, t0) : 0x100000ull * (uint64_t)(tslot + 1);
+    if (with_bounds && tslot == pos_slot && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done) { e.bounds = 1; bounds_done = true; }
+    out.push_back(e);
+  }
+  return out;
+}
+static bool las_plan_prefers_generic(const pst_converter& c, const pst_buffer& src, size_t s0, const pst_buffer& dst, size_t t0, uint64_t n, int pos_slot,
+                                     bool with_bounds) {
+  static const bool on = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();  // the A/B switch
+  if (!on || src.columnar) return false;
+  const std::vector<PlanEntry> entries = interleaved_source_entries(c, &dst, t0, dst.columnar, pos_slot, with_bounds);
+  if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES) return false;
+  const uint32_t tile = pick_tile(true, (uint32_t)c.from.size, !dst.columnar, (uint32_t)c.to.size);
+  if (tile < 1) return false;
+  bool wants_bounds = false;
+  ConvertPlan plan = build_plan(true, aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar, dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n,
+                                entries.data(), entries.size(), tile, false, with_bounds, &wants_bounds);
+  if (wants_bounds) plan.h.bounds_partials = 0x30000000ull;  // (a placeholder: only whether there is one enters the kernel's signature)
+  return pstk::convert_specialised_ready(plan, true, !dst.columnar);
+}
+
 static bool match_identity_records(const pst_converter& c) {
   if (!(c.from == c.to) || c.mappings.size() != c.to.members.size()) return false;
   uint64_t covered = 0;
@@ -292,7 +323,8 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
         for (uint32_t f = 0; f <= 10; ++f)
           if (c.to == laslayout::typed_layout(f)) { c.las_typed_format = (int)f; break; }
     }
-    if (c.las_typed_format >= 0) {  // typed LAS points, columns <-> packed records: format-specialised transposition
+    if (c.las_typed_format >= 0 && !(!src.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr))) {
+      // typed LAS points, columns <-> packed records: format-specialised transposition
       const pst_buffer& soa = src.columnar ? src : dst;
       const size_t p0 = src.columnar ? s0 : t0;
       std::vector<uint64_t> cols(c.to.members.size());
@@ -309,7 +341,8 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   }
   std::vector<PlanEntry> generic;
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
-  if (las_fast && n > 0 && !src.columnar && c.las_decode_format >= 0) {
+  if (las_fast && n > 0 && !src.columnar && c.las_decode_format >= 0 &&
+      !(!dst.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr))) {
     // the production plan of the LAS readers: format-specialised kernel (las_decode.hip)
     const Mapping* pos = nullptr;
     for (const Mapping& m : c.mappings)
@@ -397,10 +430,14 @@ static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool
   static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
   if (c.mappings.empty()) return PST_PLAN_NONE;
   if (!src_columnar && !dst_columnar && !with_bounds && match_identity_records(c)) return PST_PLAN_COPY;
-  if (las_fast && src_columnar != dst_columnar && match_identity_records(c))
+  // (typed LAS records -> columns and raw LAS records -> typed records prefer a plan-specialised kernel when the run-time compiler is on:
+  //  las_plan_prefers_generic above; pst_converter_prepare then compiles the generic plan, and the LAS kernel stays the stand-in)
+  static const bool prefer_generic = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();
+  const bool jit_on = prefer_generic && pstjit::mode() != pstjit::Mode::Off;
+  if (las_fast && src_columnar != dst_columnar && match_identity_records(c) && !(jit_on && !src_columnar))
     for (uint32_t f = 0; f <= 10; ++f)
       if (c.to == laslayout::typed_layout(f)) return PST_PLAN_LAS;
-  if (las_fast && !src_columnar && match_las_decode_plan(c) >= 0) return PST_PLAN_LAS;
+  if (las_fast && !src_columnar && match_las_decode_plan(c) >= 0 && !(jit_on && !dst_columnar)) return PST_PLAN_LAS;
   if (src_columnar && dst_columnar) return PST_PLAN_COLUMN;
   const Member* pm = with_bounds ? c.to.find_by_name("Position3D") : nullptr;
   std::vector<PlanEntry> generic;

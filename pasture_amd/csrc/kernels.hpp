@@ -23,6 +23,7 @@ void note_plan_kind(uint32_t kind);
 uint32_t plan_kinds();
 // compile (or fetch) the plan-specialised kernel this plan would take (jit.cpp); false + message when it cannot have one
 bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error, bool* in_tree = nullptr);
+bool convert_specialised_ready(const ConvertPlan& plan, bool src_aos, bool dst_aos);
 size_t bounds_partials_bytes(unsigned n_records);
 // fold n_records per-block {min xyz, max xyz} records into out6
 void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream);

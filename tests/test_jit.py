@@ -173,8 +173,8 @@ def test_static_plans_match_the_generator(hip):
     with open(os.path.join(ROOT, "pasture_amd", "csrc", "static_plans.inc")) as f:
         assert f.read() == G.render(), "stale static_plans.inc: run python tools/gen_static_plans.py and rebuild"
     before = cv.jit_stats(hip)
-    for name, conv, st, dt in G.bench_converters():
-        assert conv.prepare(st, dt) == cv.PLAN_STATIC, name
+    for name, conv, st, dt, *rest in G.bench_converters():
+        assert conv.prepare(st, dt, bool(rest and rest[0])) == cv.PLAN_STATIC, name
     after = cv.jit_stats(hip)
     assert after["compiled"] == before["compiled"] and after["disk_hits"] == before["disk_hits"]
 
