@@ -2,6 +2,7 @@
 // Reference: pasture-algorithms/src/bounds.rs:11-85, minmax.rs:13-51, pasture-core/src/containers/point_buffer.rs:391-404.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "runtime.hpp"
@@ -189,7 +190,24 @@ int pst_transform_attribute(pst_buffer* b, const char* name, const pst_datatype*
     // in place on interleaved records: the record tile is staged once in LDS, transformed there (each component is read and
     // written by the same lane) and written back with 16-byte stores — whole cache lines move either way, so this beats
     // strided 8-byte accesses (1.72 -> ~1.3 ms at 10^8 LAS-0 points)
-    execute_entries(true, aos_addr(*b, 0), (uint32_t)b->layout.size, true, aos_addr(*b, 0), (uint32_t)b->layout.size, b->len, {e}, true, s);
+    // Round 4: on a layout without padding the same transformation is a records -> records conversion whose other attributes are identity
+    // copies -- every byte of a record is written, so nothing is read-modify-written -- and the plan-specialised kernels (one wave per tile,
+    // four records per lane in registers) run it faster than the interpreter's in-LDS form (same box, 10^8 LAS-0 records: see DESIGN.md);
+    // taken when such a kernel is at hand (compiled, or PST_JIT=sync), the in-LDS form otherwise.
+    bool done = false;
+    uint64_t attr_bytes = 0;
+    for (const Member& mm : b->layout.members) attr_bytes += mm.size;
+    static const bool whole_env = [] { const char* v = std::getenv("PST_TRANSFORM_WHOLE_RECORDS"); return !(v && *v == '0'); }();  // the A/B switch
+    if (whole_env && attr_bytes == b->layout.size && b->layout.members.size() <= PST_PLAN_MAX_ENTRIES) {
+      std::vector<PlanEntry> all;
+      for (size_t a = 0; a < b->layout.members.size(); ++a) all.push_back((int)a == slot ? e : identity_entry(b->layout.members[a], b->layout.members[a]));
+      const uint64_t base = aos_addr(*b, 0);
+      if (specialised_kernel_ready(true, base, (uint32_t)b->layout.size, true, base, (uint32_t)b->layout.size, b->len, all, false)) {
+        execute_entries(true, base, (uint32_t)b->layout.size, true, base, (uint32_t)b->layout.size, b->len, all, true, s, nullptr, /*whole_records_in_place=*/true);
+        done = true;
+      }
+    }
+    if (!done) execute_entries(true, aos_addr(*b, 0), (uint32_t)b->layout.size, true, aos_addr(*b, 0), (uint32_t)b->layout.size, b->len, {e}, true, s);
   }
   PST_HIP_CHECK(hipGetLastError());
   stream_sync(s);

@@ -166,12 +166,28 @@ static ConvertPlan build_plan(bool src_aos, uint64_t src_base, uint32_t src_stri
   return plan;
 }
 
+// Whether a plan-specialised kernel (convert.hip: in-tree or run-time compiled) is at hand for ONE launch over these entries; a missing one is
+// queued for the compiler thread like a launch would.
+bool specialised_kernel_ready(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride, uint64_t n,
+                              const std::vector<PlanEntry>& entries, bool with_bounds) {
+  if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES || !(src_aos || dst_aos)) return false;
+  const uint32_t tile = pick_tile(src_aos, src_stride, dst_aos, dst_stride);
+  if (tile < 1) return false;
+  bool wants_bounds = false;
+  ConvertPlan plan = build_plan(src_aos, src_base, src_stride, dst_aos, dst_base, dst_stride, n, entries.data(), entries.size(), tile, false, with_bounds, &wants_bounds);
+  if (wants_bounds) plan.h.bounds_partials = 0x30000000ull;  // (a placeholder: only whether there is one enters the kernel's signature)
+  return pstk::convert_specialised_ready(plan, src_aos, dst_aos);
+}
+
+// whole_records_in_place: source and target are the SAME interleaved range and the entries copy every byte of a record (identity entries
+// around the transformed one): the plan runs as an ordinary records -> records conversion -- every tile is read into LDS before it is
+// written and tiles are disjoint -- which lets the plan-specialised kernels take it (transform_attribute on a packed VectorBuffer)
 void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
-                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6) {
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6, bool whole_records_in_place) {
   if (n == 0 || entries.empty()) return;
   ensure_device();
   // interleaved in place (transform_attribute on a VectorBuffer): one record tile, transformed in LDS
-  const bool in_place = src_aos && dst_aos && src_base == dst_base && src_stride == dst_stride;
+  const bool in_place = src_aos && dst_aos && src_base == dst_base && src_stride == dst_stride && !whole_records_in_place;
   const uint32_t tile = pick_tile(src_aos && !in_place, src_stride, dst_aos, dst_stride);
   const bool use_lds = allow_lds && (src_aos || dst_aos) && tile >= 1;
   for (size_t begin = 0; begin < entries.size(); begin += PST_PLAN_MAX_ENTRIES) {
@@ -216,13 +232,8 @@ static bool las_plan_prefers_generic(const pst_converter& c, const pst_buffer& s
   if (!on || src.columnar) return false;
   const std::vector<PlanEntry> entries = interleaved_source_entries(c, &dst, t0, dst.columnar, pos_slot, with_bounds);
   if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES) return false;
-  const uint32_t tile = pick_tile(true, (uint32_t)c.from.size, !dst.columnar, (uint32_t)c.to.size);
-  if (tile < 1) return false;
-  bool wants_bounds = false;
-  ConvertPlan plan = build_plan(true, aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar, dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n,
-                                entries.data(), entries.size(), tile, false, with_bounds, &wants_bounds);
-  if (wants_bounds) plan.h.bounds_partials = 0x30000000ull;  // (a placeholder: only whether there is one enters the kernel's signature)
-  return pstk::convert_specialised_ready(plan, true, !dst.columnar);
+  return specialised_kernel_ready(true, aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar, dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, entries,
+                                  with_bounds);
 }
 
 static bool match_identity_records(const pst_converter& c) {

@@ -54,7 +54,10 @@ inline uint64_t col_addr(const pst_buffer& b, size_t slot, size_t point) {
 // into launches of <= PST_PLAN_MAX_ENTRIES, picks the LDS tile and the kernel body, and enqueues on `stream`.
 // If an entry has .bounds set, its AABB record {min xyz, max xyz} is written to bounds_out6 (device-accessible).
 void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride,
-                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6 = nullptr);
+                     uint64_t n, const std::vector<PlanEntry>& entries, bool allow_lds, hipStream_t stream, double* bounds_out6 = nullptr,
+                     bool whole_records_in_place = false);
+bool specialised_kernel_ready(bool src_aos, uint64_t src_base, uint32_t src_stride, bool dst_aos, uint64_t dst_base, uint32_t dst_stride, uint64_t n,
+                              const std::vector<PlanEntry>& entries, bool with_bounds);
 
 // identity (same datatype, no transformation) entry between two members
 PlanEntry identity_entry(const Member& src, const Member& dst);

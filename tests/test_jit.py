@@ -359,3 +359,27 @@ def test_full_size_1e8_specialised_equals_interpreted(hip, seed):
         for a, b in zip(X.raw_bytes(outs["off"][0]), X.raw_bytes(outs["sync"][0])):
             assert torch.equal(a, b), (seed, pairing)
         del outs, src, dst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1023, 1024, 4099, 1_300_001])
+@pytest.mark.parametrize("fmt", [0, 1, 6])
+def test_in_place_transform_on_packed_records_takes_the_specialised_kernel(hip, oracle, jit_sync, fmt, n):
+    """transform_attribute on a VectorBuffer without padding runs as a whole-record records -> records plan on the plan-specialised kernel
+    (algorithms.cpp): same bytes as the oracle's in-place loop, every other attribute untouched, ragged tail included."""
+    from pasture_amd import las
+    from pasture_amd.algorithms import transform_attribute
+    from pasture_amd.conversion import Transform
+    from pasture_amd.layout import PointAttributeDataType as T, attributes as A
+    xf_args = (T.Vec3f64, (1.0001, 0.9999, 2.0), (1.0, -2.0, 0.5))
+    out = {}
+    for name, api in (("hip", hip), ("oracle", oracle)):
+        layout = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+        buf = VectorBuffer.new_from_layout(layout)
+        buf.resize(n)
+        buf.synth_fill(5, 0)
+        transform_attribute(buf, A.POSITION_3D, Transform.affine(*xf_args))
+        if name == "hip":
+            assert "jit" in cv.last_plan_kinds(hip) or "static" in cv.last_plan_kinds(hip), cv.last_plan_kinds(hip)
+        out[name] = buf.get_point_range(range(0, n))
+    assert np.array_equal(out["hip"], out["oracle"])
