@@ -62,6 +62,7 @@ struct StreamParams {
   double offset[3];
   double* partials;    // [gridDim.x][6] = {min xyz, max xyz}
   uint32_t xcd_chunk;  // 0 = tile = blockIdx; else tiles per XCD: workgroups are dealt round-robin to the 8 XCDs, tile = (b % 8) * xcd_chunk + b / 8
+  uint32_t xcd_block;  // with xcd_chunk: 0 = every XCD owns ONE contiguous eighth of the stream; B > 0 = runs of B tiles dealt round-robin to the XCDs
 };
 
 // generic strided min/max

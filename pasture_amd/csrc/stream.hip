@@ -88,8 +88,9 @@ __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamPara
   uint64_t tile0 = blockIdx.x;
   if (p.xcd_chunk) {
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    tile0 = (uint64_t)xcd * p.xcd_chunk + k;
-    if (tile0 >= n_tiles) tile0 = n_tiles;  // the up to seven surplus blocks still write their (identity) partial record
+    if (p.xcd_block) tile0 = ((uint64_t)(k / p.xcd_block) * 8u + xcd) * p.xcd_block + k % p.xcd_block;  // runs of xcd_block tiles, round-robin
+    else tile0 = (uint64_t)xcd * p.xcd_chunk + k;
+    if (tile0 >= n_tiles) tile0 = n_tiles;  // the surplus blocks still write their (identity) partial record
   }
   for (uint64_t tile = tile0; tile < n_tiles; tile += gridDim.x) {
     const uint64_t base = tile * kTileVec + t;
@@ -323,10 +324,22 @@ static bool stream_xcd_aware() {
   static const bool on = [] { const char* v = std::getenv("PST_STREAM_XCD"); return !(v && *v == '0'); }();  // on by default: +2-5 % on the fused convert + AABB (same-box A/B)
   return on;
 }
+// PST_STREAM_XCD_BLOCK = B: the XCD-aware numbering deals runs of B tiles (24 KiB each) to the XCDs round-robin instead of giving each XCD one
+// contiguous eighth of the stream.  Why it matters: with eighths, the eight XCDs' streams are n/8 points apart, and the rate depends on that
+// DISTANCE (same box: 6.06 TB/s at 10^8 points, 6.71 at 5 10^8, 6.05 at 6 10^8, 6.58 at 10^9 -- the streams' relative position in the HBM
+// channel / bank interleave), not on the buffers' base alignment (profiles/r04_ab_placement.txt).  Runs keep the streams a fixed distance apart.
+static uint64_t stream_xcd_block() {
+  static const uint64_t b = [] { const char* v = std::getenv("PST_STREAM_XCD_BLOCK"); return v && *v ? (uint64_t)std::strtoull(v, nullptr, 10) : 0ull; }();
+  return b;
+}
 static uint64_t stream_launch_grid(uint64_t n_points, unsigned mode) {
   const uint64_t n_vec = (3 * n_points) / 2;
   const uint64_t n_tiles = std::max<uint64_t>(1, (n_vec + kStreamTileVec - 1) / kStreamTileVec);
-  if (mode & 2u) return stream_xcd_aware() ? 8 * ((n_tiles + 7) / 8) : n_tiles;
+  if (mode & 2u) {
+    if (!stream_xcd_aware()) return n_tiles;
+    const uint64_t b = stream_xcd_block();
+    return b ? 8 * b * ((n_tiles + 8 * b - 1) / (8 * b)) : 8 * ((n_tiles + 7) / 8);
+  }
   return std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
 }
 size_t stream_partials_bytes(uint64_t n_points, unsigned mode) {
@@ -348,6 +361,7 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
   p.partials = partials;
   const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
   p.xcd_chunk = (write && stream_xcd_aware()) ? grid / 8u : 0u;  // the read-only persistent grid loses 1.5 % with it
+  p.xcd_block = p.xcd_chunk ? (uint32_t)stream_xcd_block() : 0u;
 #define PST_STREAM(A, W, B) \
   hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p)
   switch (mode & 7u) {
