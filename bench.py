@@ -66,6 +66,8 @@ WORKLOADS = {
     "voxelgrid_xyz_async": (24, "the same through pst_voxelgrid_filter_async (round 4): planned once, then bounds + markers + keys + sort + run heads + "
                                "reduction stream-ordered, no host round trip, no allocation (24 R lower bound)"),
     "narrow_f64_f32": (36, "SoA POSITION_3D Vec3f64 -> Vec3f32 `as` narrowing (24 R + 12 W)"),
+    "normals_knn16_async": (44, "configs[4] through pst_compute_normals_into_async (round 4): planned once, then keys + sort + permutation + directory + box "
+                               "search + exact search of the hand-backs stream-ordered, no host round trip, no measurement passes"),
     "normals_knn16": (44, "configs[4]: kNN(k=16) normal estimation, NORMAL Vec3f32 + curvature f64 written to columns "
                           "(lower-bound traffic 24 R + 12 W + 8 W; the search itself is latency/compute-bound)"),
     "normals_knn16_sheet": (44, "the same on a LiDAR-like sheet (a noisy 2-D manifold z = f(x, y) in a 3-D box, 23 % of the box occupied) with 0.001 % "
@@ -379,6 +381,24 @@ def main():
 
         def step():
             pa.compute_normals_into(src, 16, dst)
+    elif args.workload == "normals_knn16_async":
+        from pasture_amd.algorithms import NormalsPlan
+        from pasture_amd.layout import PointAttributeDefinition
+        layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(SEED, first_index)
+        dst = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.NORMAL, PointAttributeDefinition("Curvature", T.F64)]))
+        dst.resize(n)
+        pa.calculate_bounds_async(src, rec.data_ptr())
+        nplan = NormalsPlan(src, 16, dst)
+        nst = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+        def step():
+            nplan.compute_into_async(src, dst, nst.data_ptr())
+
+        def after():
+            assert nst.tolist() == [0, 0], nst.tolist()
     elif args.workload == "normals_knn16_sheet":
         from pasture_amd.layout import PointAttributeDefinition
         g = torch.Generator(device="cuda")

@@ -280,6 +280,21 @@ int pst_compute_normals_into(const pst_buffer* b, size_t k, pst_buffer* dst);
  * curvature f64 [n], neighbour lists uint32 [n][k] in ascending distance (normal_estimation.rs:103-108; 0xFFFFFFFF pads clouds of
  * fewer than k points).  10^8 points, k = 16: 2.4 GB + 0.8 GB + 6.4 GB. */
 int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals, double* d_curvature, uint32_t* d_knn);
+/* Stream-ordered compute_normals (round 4).  The synchronous call measures the cloud between its kernels (bounds, occupancy, local scale, a
+ * probe and a census of the built index) and reads five to eight values back; pst_compute_normals_plan_create runs it ONCE (dst holds the
+ * result) and keeps what it decided -- the grid's frame, box and cell edges, the LDS box shape, the capacities of the occupied-box list and
+ * of the hand-back list.  pst_compute_normals_into_async then runs keys -> sort -> permutation -> directory -> box search -> exact search of
+ * the hand-backs on the current stream with no host round trip and no allocation (hipGraph-capturable), on this cloud or on ANOTHER cloud of
+ * the same length: the grid is fixed by the plan, points outside it are clamped into boundary cells and their queries go to the exact
+ * search, so the result is exact for any data.  device_status2[0] = 0 when it is complete; bit 0: the number of finite points differs from
+ * the plan's, bit 1 / bit 2: more occupied boxes / more hand-backs than the plan provided for, bit 3: the exact search handed queries back
+ * (far points: the coarser levels are host-driven), bit 4: degenerate neighbourhoods ([1] = how many: PST_ERR_NOT_ENOUGH_NEIGHBOURS of the
+ * synchronous call) -- with any of bits 0-3 set the caller falls back to pst_compute_normals_into.  Clouds whose synchronous call did not
+ * take the box search or left queries open (fewer than 2^20 points, far outliers) have no plan: PST_ERR_UNSUPPORTED. */
+typedef struct pst_normals_plan pst_normals_plan;
+int pst_compute_normals_plan_create(const pst_buffer* b, size_t k, pst_buffer* dst, pst_normals_plan** out);
+int pst_normals_plan_destroy(pst_normals_plan* plan);
+int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, pst_buffer* dst, uint64_t* device_status2);
 /* voxelgrid_filter, pasture-algorithms/src/voxel_grid.rs:109-166: one centroid point per occupied voxel (cells centred on the
  * axis markers min + k*leafsize, find_leaf :21-52), appended to `filtered` in (x, y, z) voxel order.  Reductions per attribute
  * of filtered's layout (set_all_attributes :459-689): average (Position3D, ColorRGB, Normal, Intensity, NIR; sequential f64

@@ -152,6 +152,9 @@ _PRODUCT_SIGNATURES = {
     "voxelgrid_plan_create": [_P, C.c_double, C.c_double, C.c_double, _PP, C.POINTER(_SZ)],
     "voxelgrid_plan_destroy": [_P],
     "voxelgrid_filter_async": [_P, _P, _P, _SZ, _P],
+    "compute_normals_plan_create": [_P, _SZ, _P, _PP],
+    "normals_plan_destroy": [_P],
+    "compute_normals_into_async": [_P, _P, _P, _P],
     "release_scratch": [],
     "reload_tuning": [],
     "comm_unique_id": [_P],

@@ -150,3 +150,29 @@ class VoxelGridPlan:
             self.destroy()
         except Exception:
             pass
+
+
+class NormalsPlan:
+    """Stream-ordered compute_normals_into (pst_compute_normals_plan_create / pst_compute_normals_into_async): the constructor runs the
+    synchronous call once (`target` holds its result) and keeps its decisions; `compute_into_async` replays the pipeline on the current stream
+    without a host round trip or an allocation.  Two uint64 at `status_ptr` (device-accessible): [0] = 0 when the result is complete."""
+
+    def __init__(self, point_cloud: _Buffer, k_nn: int, target: _Buffer):
+        self.api = point_cloud.api
+        h = C.c_void_p()
+        self.api.compute_normals_plan_create(point_cloud._h, k_nn, target._h, C.byref(h))
+        self._h = h
+
+    def compute_into_async(self, point_cloud: _Buffer, target: _Buffer, status_ptr: int) -> None:
+        self.api.compute_normals_into_async(self._h, point_cloud._h, target._h, C.c_void_p(int(status_ptr)))
+
+    def destroy(self) -> None:
+        if self._h is not None and self._h.value:
+            self.api.normals_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -70,9 +70,19 @@ bool launch_column(const PlanEntry& e, uint64_t n, double* bounds_partials, hipS
 // attribute (F64) of a target buffer.  Returns 0, -1 on a HIP failure, -2 beyond 2^32 - 16 points, or the number of neighbourhoods with
 // < 3 usable points.
 void release_normals_scratch();
+struct KnnPlanRecord;  // normals_host.hpp
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
                       long long* out_knn_dev, uint32_t* out_knn_u32_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr,
-                      uint64_t curv_stride, hipStream_t stream);
+                      uint64_t curv_stride, hipStream_t stream, KnnPlanRecord* record = nullptr);
+// Stream-ordered replay of a recorded call (no host round trip, no allocation: hipGraph-capturable).  KnnPlan owns the scratch of the
+// pipeline for its record's capacities; status2 = two device words: [0] = KNN_STATUS_* bits (0: the results are complete and exact),
+// [1] = neighbourhoods with fewer than 3 usable points.
+struct KnnPlan;
+KnnPlan* knn_plan_create(const KnnPlanRecord& rec, bool packed_source, hipStream_t stream);
+void knn_plan_free(KnnPlan* p);
+const KnnPlanRecord& knn_plan_record(const KnnPlan* p);
+bool run_normals_replay(KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride, double* out_normals_dev, double* out_curv_dev, uint32_t* out_knn_u32_dev,
+                        uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride, unsigned long long* status2, hipStream_t stream);
 
 // LAS record encoder (las_encode.hip)
 uint32_t las_raw_record_size(int format);

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "device_sort.hpp"
@@ -485,9 +486,10 @@ __global__ __launch_bounds__(kBlock, K <= 16 ? 4 : 1) void knn_grid_kernel(const
                                                           GridParams g, CellTable table, const uint32_t* __restrict__ cell_start,
                                                           const uint32_t* __restrict__ qlist, uint32_t nq, RecOut out, int shell_cap,
                                                           uint8_t* __restrict__ unres_flag, uint32_t* __restrict__ unres_count, uint32_t crowd,
-                                                          uint32_t* __restrict__ open_lists, uint32_t open_cap) {
+                                                          uint32_t* __restrict__ open_lists, uint32_t open_cap, const uint32_t* __restrict__ nq_dev) {
   const uint32_t t0 = blockIdx.x * kBlock + threadIdx.x;
-  if (t0 >= nq) return;
+  // nq_dev (stream-ordered replay of a plan): the list's length is only known on the device; nq is then the capacity the grid was sized for
+  if (t0 >= (nq_dev ? (*nq_dev < nq ? *nq_dev : nq) : nq)) return;
   const uint32_t j = LIST ? qlist[t0] : t0;
   const double qx = sxyz[3 * (uint64_t)j], qy = sxyz[3 * (uint64_t)j + 1], qz = sxyz[3 * (uint64_t)j + 2];
   double qu, qv, qw;  // the query in the grid's frame: cells and shell margins; distances use (qx, qy, qz)
@@ -955,8 +957,15 @@ void release_normals_scratch() { scratch_cache().release_all(); }  // (the curre
 // or the number of degenerate neighbourhoods (> 0).
 long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, uint32_t k, double* out_normals_dev, double* out_curv_dev,
                       long long* out_knn_dev, uint32_t* out_knn_u32_dev, uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr,
-                      uint64_t curv_stride, hipStream_t stream) {
+                      uint64_t curv_stride, hipStream_t stream, KnnPlanRecord* record) {
 #define NCK(x) do { if ((x) != hipSuccess) return -1; } while (0)
+  if (record) { *record = KnnPlanRecord{}; record->why_not = "the call did not take the LDS box search"; }
+  bool rec_open = false;         // some query was handed back by a capped search (coarser levels / all-points search ran)
+  bool rec_tiled = false, rec_list = false;
+  uint32_t rec_n_list = 0, rec_n_fb = 0;
+  TileShape rec_shape{};
+  GridParams rec_g{};
+  uint64_t rec_cells = 0, rec_nf = 0;
   if (n >= 0xFFFFFFF0ull) return -2;  // sorted indices and directory entries are uint32_t
   const unsigned cus = (unsigned)device_cus();
   const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
@@ -1425,6 +1434,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           uint32_t n_fb = 0;
           NCK(hipMemcpyAsync(&n_fb, fb_count, 4, hipMemcpyDeviceToHost, stream));
           NCK(hipStreamSynchronize(stream));
+          rec_tiled = true; rec_list = list_ptr != nullptr; rec_n_list = n_list; rec_n_fb = n_fb; rec_shape = shape; rec_g = g; rec_cells = cells; rec_nf = nf;
           mark("box-search");
           if (debug)
             fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u kernel=%c threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
@@ -1450,17 +1460,17 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
             }
             const unsigned grid = (unsigned)((n_fb + kBlock - 1) / kBlock);
             KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                              fb_q, n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
+                              fb_q, n_fb, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap, (const uint32_t*)nullptr);
           }
         } else {
           const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
           KNN_DISPATCH_GRID(true, false, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, cell_start,
-                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
+                            (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap, (const uint32_t*)nullptr);
         }
       } else {
         const unsigned grid = (unsigned)((nf + kBlock - 1) / kBlock);
         KNN_DISPATCH_GRID(false, false, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table,
-                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap);
+                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)nf, sorted, kShellCap, unres.as<uint8_t>(), unres_count, 0u, open_lists.as<uint32_t>(), kOpenCap, (const uint32_t*)nullptr);
       }
       // Queries a capped search handed back (flag 1: outliers; regions far sparser than the grid was made for): again on a grid with six
       // times the cell edge, laid over the FULL bounding box (the trimmed or rotated box of the first level clamps exactly the points these
@@ -1523,6 +1533,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         NCK(hipMemcpyAsync(n_open, unres_count, 8, hipMemcpyDeviceToHost, stream));
         NCK(hipStreamSynchronize(stream));
         NCK(hipMemsetAsync(unres_count, 0, 8, stream));
+        if (n_open[0] || n_open[1]) rec_open = true;
         if (n_open[1] && !all_points(2, n_open[1])) return -1;
         const uint32_t n_un = n_open[0];
         if (!n_un) break;
@@ -1553,10 +1564,10 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
         const int cap = last ? 0 : kShellCap;
         if (up_dense) {
           KNN_DISPATCH_GRID(true, true, grid, sorted_xyz.as<double>(), (const uint64_t*)nullptr, (uint32_t)nf, k, g, table, (const uint32_t*)directory.as<uint32_t>(),
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap, (const uint32_t*)nullptr);
         } else {
           KNN_DISPATCH_GRID(false, true, grid, sorted_xyz.as<double>(), (const uint64_t*)keys2.as<uint64_t>(), (uint32_t)nf, k, g, table, (const uint32_t*)nullptr,
-                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap);
+                            (const uint32_t*)fb_list.as<uint32_t>(), n_un, sorted, cap, unres.as<uint8_t>(), unres_count, kCrowd, open_lists.as<uint32_t>(), kOpenCap, (const uint32_t*)nullptr);
         }
         mark("coarser");
       }
@@ -1580,11 +1591,158 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
   int errors = 0;
   NCK(hipMemcpyAsync(&errors, out.error_count, 4, hipMemcpyDeviceToHost, stream));
   NCK(hipStreamSynchronize(stream));
+  if (record && rec_tiled) {
+    if (rec_open) record->why_not = "some queries were handed back by a capped search (far points, sparse regions): the coarser levels are host-driven";
+    else if (rec_nf != n) record->why_not = "the cloud holds non-finite points";
+    else if (!knn_tuning().direct_out) record->why_not = "PST_KNN_DIRECT=0";
+    else if (out_knn_dev) record->why_not = "int64 neighbour lists are a host-side format";
+    else {
+      record->valid = true; record->why_not = "";
+      record->n = n; record->nf = rec_nf; record->cells = rec_cells; record->k = k; record->g = rec_g; record->shape = rec_shape;
+      record->use_list = rec_list; record->n_list = rec_n_list; record->n_fb = rec_n_fb;
+      unsigned kb = 1; while (kb < 32 && (1ull << kb) <= rec_cells) ++kb;
+      record->key_bits = kb;
+    }
+  }
 #undef KNN_DISPATCH_GRID
 #undef KNN_DISPATCH
 #undef KNN_DISPATCH_T
 #undef NCK
   return errors;
+}
+
+
+// ---- stream-ordered replay of a recorded call ------------------------------------------------------------------------------------------------
+struct KnnPlan {
+  KnnPlanRecord rec;
+  bool packed_source = true;
+  DevBuf xyz_own, partials, keys, keys2, idx, idx2, sorted_xyz, tmp, directory, dir_blocks, fb_list, box_list, counters, unres, open_lists;
+  size_t tmp_sort = 0, tmp_suffix = 0;
+  uint32_t list_cap = 0, fb_cap = 0, all_boxes = 0;
+  uint64_t n_dblocks = 0;
+  unsigned sgrid = 1;
+};
+
+namespace {
+constexpr uint32_t kReplayOpenCap = 1u << 16;
+// the device-side end of a replay: what the synchronous call checks on the host
+__global__ void knn_replay_status_kernel(const unsigned long long* __restrict__ n_finite, unsigned long long nf, const uint32_t* __restrict__ fb_count, uint32_t fb_cap,
+                                         const uint32_t* __restrict__ box_count, uint32_t list_cap, const uint32_t* __restrict__ unres_count,
+                                         const int* __restrict__ error_count, unsigned long long* __restrict__ status2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long st = 0;
+  if (*n_finite != nf) st |= KNN_STATUS_FINITE_COUNT;
+  if (box_count && *box_count > list_cap) st |= KNN_STATUS_BOX_CAPACITY;
+  if (*fb_count > fb_cap) st |= KNN_STATUS_FALLBACK_CAPACITY;
+  if (unres_count[0] || unres_count[1]) st |= KNN_STATUS_OPEN_QUERIES;
+  if (*error_count) st |= KNN_STATUS_DEGENERATE;
+  status2[0] = st;
+  status2[1] = (unsigned long long)*error_count;
+}
+}  // namespace
+
+KnnPlan* knn_plan_create(const KnnPlanRecord& rec, bool packed_source, hipStream_t stream) {
+  if (!rec.valid) return nullptr;
+  auto p = std::make_unique<KnnPlan>();
+  p->rec = rec;
+  p->packed_source = packed_source;
+  const uint64_t n = rec.n;
+  const unsigned cus = (unsigned)device_cus();
+  p->sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)cus * 8));
+#define PCK(x) do { if ((x) != hipSuccess) return nullptr; } while (0)
+  if (!packed_source) { PCK(p->xyz_own.alloc(n * 24, stream)); PCK(p->partials.alloc((size_t)p->sgrid * 48, stream)); }
+  PCK(p->counters.alloc(128, stream));
+  PCK(p->keys.alloc(n * 4, stream)); PCK(p->keys2.alloc(n * 4, stream)); PCK(p->idx.alloc(n * 4, stream)); PCK(p->idx2.alloc(n * 4, stream));
+  PCK(p->sorted_xyz.alloc(n * 24, stream));
+  PCK(sort_pairs_u32(nullptr, p->tmp_sort, p->keys.as<uint32_t>(), p->keys2.as<uint32_t>(), p->idx.as<uint32_t>(), p->idx2.as<uint32_t>(), n, rec.key_bits, stream));
+  PCK(p->directory.alloc((rec.cells + 2) * 4, stream));
+  if (rec.cells > 3 * rec.nf) {
+    p->n_dblocks = (rec.cells + 1 + kDirBlock - 1) / kDirBlock;
+    PCK(p->dir_blocks.alloc(p->n_dblocks * 4, stream));
+    PCK(suffix_min_u32(nullptr, p->tmp_suffix, p->dir_blocks.as<uint32_t>(), p->n_dblocks, stream));
+  }
+  PCK(p->tmp.alloc(std::max(p->tmp_sort, p->tmp_suffix), stream));
+  PCK(p->fb_list.alloc(rec.nf * 4, stream));
+  p->all_boxes = knn_box_count(rec.shape, rec.g);
+  if (rec.use_list) {
+    PCK(p->box_list.alloc((size_t)p->all_boxes * 4, stream));
+    p->list_cap = (uint32_t)std::min<uint64_t>(p->all_boxes, (uint64_t)rec.n_list + rec.n_list / 4 + 1024);  // a quarter more occupied boxes than recorded
+  }
+  p->fb_cap = (uint32_t)std::min<uint64_t>(rec.nf, (uint64_t)rec.n_fb + rec.n_fb / 2 + 65536);  // half as many more hand-backs than recorded
+  PCK(p->unres.alloc(n, stream));
+  PCK(p->open_lists.alloc((size_t)2 * kReplayOpenCap * 4, stream));
+#undef PCK
+  return p.release();
+}
+void knn_plan_free(KnnPlan* p) { delete p; }
+const KnnPlanRecord& knn_plan_record(const KnnPlan* p) { return p->rec; }
+
+bool run_normals_replay(KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride, double* out_normals_dev, double* out_curv_dev, uint32_t* out_knn_u32_dev,
+                        uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride, unsigned long long* status2, hipStream_t stream) {
+#define RCK(x) do { if ((x) != hipSuccess) return false; } while (0)
+  const KnnPlanRecord& r = p->rec;
+  const uint64_t n = r.n, nf = r.nf, cells = r.cells;
+  const uint32_t k = r.k;
+  const GridParams& g = r.g;
+  const unsigned cus = (unsigned)device_cus(), sgrid = p->sgrid;
+  RCK(hipMemsetAsync(p->counters.p, 0, 128, stream));
+  const double* src = (const double*)pos_base;
+  if (!p->packed_source) {
+    hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, p->xyz_own.as<double>(), p->partials.as<double>());
+    src = p->xyz_own.as<double>();
+  }
+  unsigned long long* n_finite = (unsigned long long*)p->counters.p;
+  uint32_t* fb_count = (uint32_t*)((uint8_t*)p->counters.p + 16);
+  int* error_count = (int*)((uint8_t*)p->counters.p + 32);
+  uint32_t* unres_count = (uint32_t*)((uint8_t*)p->counters.p + 64);
+  uint32_t* box_count = (uint32_t*)((uint8_t*)p->counters.p + 76);
+  // index: keys (+ the sort's first histogram), sort, permutation, directory -- what build_index does for a dense grid, with the recorded grid
+  {
+    RadixFirstPass walk{nullptr, (uint32_t)((n + 8191) / 8192), 0, 8192};
+    const RadixFirstPass first = sort_first_pass(p->tmp.p, n, r.key_bits);
+    if (first.counts) walk = first;
+    hipLaunchKernelGGL(keys_kernel<uint32_t>, dim3(std::max(1u, std::min(walk.tiles, cus * 16u))), dim3(kBlock), 0, stream, src, n, g, p->keys.as<uint32_t>(), (uint32_t*)nullptr,
+                       n_finite, walk);
+    size_t tb = p->tmp_sort;
+    RCK(sort_pairs_u32(p->tmp.p, tb, p->keys.as<uint32_t>(), p->keys2.as<uint32_t>(), p->idx.as<uint32_t>(), p->idx2.as<uint32_t>(), n, r.key_bits, stream, true, &first));
+    const unsigned rgrid = (unsigned)std::max<uint64_t>(1, (n + (uint64_t)kBlock * 2 - 1) / ((uint64_t)kBlock * 2));
+    hipLaunchKernelGGL(reorder_kernel<2>, dim3(rgrid), dim3(kBlock), 0, stream, src, p->idx2.as<uint32_t>(), n, p->sorted_xyz.as<double>());
+    if (cells > 3 * nf) {
+      RCK(hipMemsetAsync(p->dir_blocks.p, 0xFF, p->n_dblocks * 4, stream));
+      hipLaunchKernelGGL(dir_block_heads_kernel, dim3(sgrid), dim3(kBlock), 0, stream, p->keys2.as<uint32_t>(), nf, cells, p->dir_blocks.as<uint32_t>());
+      size_t sb = p->tmp_suffix;
+      RCK(suffix_min_u32(p->tmp.p, sb, p->dir_blocks.as<uint32_t>(), p->n_dblocks, stream));
+      hipLaunchKernelGGL(dir_fill_kernel, dim3((unsigned)((p->n_dblocks + kDirPerGroup - 1) / kDirPerGroup)), dim3(kBlock), 0, stream, p->keys2.as<uint32_t>(), nf, cells,
+                         (const uint32_t*)p->dir_blocks.as<uint32_t>(), p->n_dblocks, p->directory.as<uint32_t>());
+    } else {
+      hipLaunchKernelGGL(build_directory_kernel, dim3(sgrid), dim3(kBlock), 0, stream, p->keys2.as<uint32_t>(), nf, cells, p->directory.as<uint32_t>());
+    }
+  }
+  const uint32_t* cell_start = p->directory.as<uint32_t>();
+  const uint32_t* list_ptr = nullptr;
+  if (r.use_list) {
+    if (!knn_box_list_async(r.shape, cell_start, g, p->box_list.as<uint32_t>(), box_count, stream)) return false;
+    list_ptr = p->box_list.as<uint32_t>();
+  }
+  RCK(hipMemsetAsync(p->unres.p, 0, n, stream));
+  RecOut sorted{nullptr, p->idx2.as<uint32_t>(), nullptr, out_knn_u32_dev, error_count, out_normals_dev, out_curv_dev, normal_attr, normal_stride, curv_attr, curv_stride};
+  launch_knn_tile(r.shape, p->sorted_xyz.as<double>(), cell_start, g, k, (uint32_t)nf, sorted, p->fb_list.as<uint32_t>(), fb_count, list_ptr, p->list_cap, stream,
+                  list_ptr ? box_count : nullptr);
+  // what the box kernel handed back: the exact search over the dense directory, its length read on the device (the list is not sorted by
+  // position here: that sort takes its length on the host)
+  {
+    const unsigned grid = (unsigned)((p->fb_cap + kBlock - 1) / kBlock);
+    CellTable table{nullptr, nullptr, 0};
+#define RDISPATCH(K) hipLaunchKernelGGL((knn_grid_kernel<K, true, true>), dim3(grid), dim3(kBlock), 0, stream, (const double*)p->sorted_xyz.as<double>(), (const uint64_t*)nullptr, \
+                                        (uint32_t)nf, k, g, table, cell_start, (const uint32_t*)p->fb_list.as<uint32_t>(), p->fb_cap, sorted, kShellCap, p->unres.as<uint8_t>(), \
+                                        unres_count, 0u, p->open_lists.as<uint32_t>(), kReplayOpenCap, (const uint32_t*)fb_count)
+    if (k <= 8) RDISPATCH(8); else if (k <= 16) RDISPATCH(16); else if (k <= 32) RDISPATCH(32); else RDISPATCH(64);
+#undef RDISPATCH
+  }
+  hipLaunchKernelGGL(knn_replay_status_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)n_finite, (unsigned long long)nf, (const uint32_t*)fb_count, p->fb_cap,
+                     r.use_list ? (const uint32_t*)box_count : (const uint32_t*)nullptr, p->list_cap, (const uint32_t*)unres_count, (const int*)error_count, status2);
+  return hipGetLastError() == hipSuccess;
+#undef RCK
 }
 
 }  // namespace pstk

@@ -1,5 +1,6 @@
 // compute_normals (pasture-algorithms/src/normal_estimation.rs:79-130) — argument checks + host/device plumbing; the
 // neighbour search and the plane fit run in normals.hip.
+#include "normals_host.hpp"
 #include "normals_plan.hpp"
 #include "runtime.hpp"
 
@@ -104,6 +105,80 @@ int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals,
   const uint64_t base = b->columnar ? col_addr(*b, slot, 0) : aos_addr(*b, 0) + pm.offset;
   const uint64_t stride = b->columnar ? pm.size : b->layout.size;
   raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)base, stride, b->len, (uint32_t)k, d_normals, d_curvature, nullptr, d_knn, 0, 0, 0, 0, s));
+  PST_API_END
+}
+
+// ---- stream-ordered form (round 4) -------------------------------------------------------------------------------------------------------------
+struct pst_normals_plan {
+  pstk::KnnPlan* plan = nullptr;
+  size_t k = 0;
+  ~pst_normals_plan() { if (plan) pstk::knn_plan_free(plan); }
+};
+
+namespace {
+struct NormalTargets { uint64_t base, stride, na, nst, ca, cst; };
+NormalTargets resolve_normal_targets(const pst_buffer& b, size_t k, pst_buffer& dst) {
+  const Member& pm = checked_position(b, k);
+  if (dst.len != b.len) throw Error(PST_ERR_RANGE, "target buffer length must equal the point cloud length");
+  AttributeDef nd{"Normal", DataType{}}, cd{"Curvature", DataType{}};
+  nd.datatype.kind = PST_VEC3F32;
+  cd.datatype.kind = PST_F64;
+  const int ns = dst.layout.index_of(nd), cs = dst.layout.index_of(cd);
+  if (ns < 0 && cs < 0) throw Error(PST_ERR_MISSING_ATTRIBUTE, "target PointLayout has neither Normal (Vec3f32) nor Curvature (F64)");
+  const size_t slot = (size_t)(&pm - b.layout.members.data());
+  NormalTargets t{};
+  t.base = b.columnar ? col_addr(b, slot, 0) : aos_addr(b, 0) + pm.offset;
+  t.stride = b.columnar ? pm.size : b.layout.size;
+  auto attr_addr = [&](int sl, uint64_t& addr, uint64_t& st) {
+    if (sl < 0) { addr = 0; st = 0; return; }
+    const Member& m = dst.layout.members[(size_t)sl];
+    addr = dst.columnar ? col_addr(dst, (size_t)sl, 0) : aos_addr(dst, 0) + m.offset;
+    st = dst.columnar ? m.size : dst.layout.size;
+  };
+  attr_addr(ns, t.na, t.nst);
+  attr_addr(cs, t.ca, t.cst);
+  return t;
+}
+}  // namespace
+
+// One synchronous pst_compute_normals_into (dst holds its results) whose decisions -- frame, grid, box shape, capacities -- are kept.
+int pst_compute_normals_plan_create(const pst_buffer* b, size_t k, pst_buffer* dst, pst_normals_plan** out) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  not_null(dst, "dst");
+  not_null(out, "out");
+  const NormalTargets t = resolve_normal_targets(*b, k, *dst);
+  ensure_device();
+  hipStream_t s = current_stream();
+  pstk::KnnPlanRecord rec;
+  raise_degenerate(pstk::run_normals((const uint8_t*)(uintptr_t)t.base, t.stride, b->len, (uint32_t)k, nullptr, nullptr, nullptr, nullptr, t.na, t.nst, t.ca, t.cst, s, &rec));
+  if (!rec.valid)
+    throw Error(PST_ERR_UNSUPPORTED, std::string("pst_compute_normals_plan_create: this cloud has no stream-ordered plan (") + rec.why_not +
+                                         "); dst holds the result of the synchronous call");
+  auto plan = std::make_unique<pst_normals_plan>();
+  plan->k = k;
+  const bool packed = t.stride == 24 && (t.base & 7u) == 0;
+  plan->plan = pstk::knn_plan_create(rec, packed, s);
+  if (!plan->plan) throw Error(PST_ERR_HIP, std::string("normals plan: allocation failed: ") + hipGetErrorString(hipGetLastError()));
+  stream_sync(s);
+  *out = plan.release();
+  PST_API_END
+}
+int pst_normals_plan_destroy(pst_normals_plan* plan) { delete plan; return PST_OK; }
+
+int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, pst_buffer* dst, uint64_t* device_status2) {
+  PST_API_BEGIN
+  not_null(plan, "plan");
+  not_null(b, "buffer");
+  not_null(dst, "dst");
+  not_null(device_status2, "device_status2");
+  const NormalTargets t = resolve_normal_targets(*b, plan->k, *dst);
+  const pstk::KnnPlanRecord& r = pstk::knn_plan_record(plan->plan);
+  if (b->len != r.n) throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made for " + std::to_string(r.n) + " points, the buffer holds " + std::to_string(b->len));
+  ensure_device();
+  if (!pstk::run_normals_replay(plan->plan, (const uint8_t*)(uintptr_t)t.base, t.stride, nullptr, nullptr, nullptr, t.na, t.nst, t.ca, t.cst,
+                                (unsigned long long*)device_status2, current_stream()))
+    throw Error(PST_ERR_HIP, std::string("normal estimation (stream-ordered) failed: ") + hipGetErrorString(hipGetLastError()));
   PST_API_END
 }
 

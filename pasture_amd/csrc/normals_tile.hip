@@ -72,6 +72,7 @@ struct TileArgs {
   unsigned long long* dbg;     // -DPST_KNN_STATS builds only: [0] scan steps, [1] insertion steps, [2] query waves, [3] candidates tested, [4] queued
   double tau0_below;           // the largest double below tau0
   const uint32_t* box_list;    // the boxes to search (null: all n_boxes of them, box = workgroup id); n_boxes = its length then
+  const uint32_t* n_boxes_dev; // stream-ordered replay of a plan: the list's length lives on the device (n_boxes = the capacity the grid was sized for)
   uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 48
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan, 8 = nothing queued, 16 = no copy, 32 = no records, 64 = empty kernel
 };
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(THREADS, (K <= 16 ? 3 : 2) * THREADS / 256) void kn
   constexpr int NW = THREADS / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t wg = xcd_block_id();
-  if (wg >= a.n_boxes) return;
+  if (wg >= a.n_boxes || (a.n_boxes_dev && wg >= *a.n_boxes_dev)) return;
   if (a.ablate & 64u) return;
   const uint32_t box = a.box_list ? a.box_list[wg] : wg;
   const GridParams& g = a.g;
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
   constexpr int NW = THREADS / 64;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t wg = xcd_block_id();
-  if (wg >= a.n_boxes) return;
+  if (wg >= a.n_boxes || (a.n_boxes_dev && wg >= *a.n_boxes_dev)) return;
   if (a.ablate & 64u) return;
   const uint32_t box = a.box_list ? a.box_list[wg] : wg;
   PST_KNN_STAT(const long long t_start = clock64(); long long t_flush = 0;)
@@ -1301,12 +1302,21 @@ uint32_t knn_box_list(const TileShape& t, const uint32_t* cell_start, const pstn
   if (hipMemcpyAsync(&n, count_dev, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0xFFFFFFFFu;
   return n;
 }
+// the same list, its length left in *count_dev (stream-ordered replay of a plan: no read-back)
+bool knn_box_list_async(const TileShape& t, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t* list, uint32_t* count_dev, hipStream_t stream) {
+  const uint32_t nbx = (g.dim[0] + t.bx - 1) / t.bx, nby = (g.dim[1] + t.by - 1) / t.by, nbz = (g.dim[2] + t.bz - 1) / t.bz;
+  const uint32_t n_boxes = nbx * nby * nbz;
+  if (hipMemsetAsync(count_dev, 0, 4, stream) != hipSuccess) return false;
+  hipLaunchKernelGGL(knn_box_list_kernel, dim3((n_boxes + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, cell_start, g, t.bx, t.by, t.bz, nbx, nby, n_boxes, list, count_dev);
+  return hipGetLastError() == hipSuccess;
+}
 uint32_t knn_box_count(const TileShape& t, const pstn::GridParams& g) {
   return ((g.dim[0] + t.bx - 1) / t.bx) * ((g.dim[1] + t.by - 1) / t.by) * ((g.dim[2] + t.bz - 1) / t.bz);
 }
 
 void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cell_start, const pstn::GridParams& g, uint32_t k, uint32_t nf,
-                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, const uint32_t* box_list, uint32_t n_list, hipStream_t stream) {
+                     const pstn::RecOut& out, uint32_t* fb_list, uint32_t* fb_count, const uint32_t* box_list, uint32_t n_list, hipStream_t stream,
+                     const uint32_t* n_list_dev) {
   TileArgs a{};
   a.sxyz = sxyz; a.cell_start = cell_start; a.g = g;
   a.bx = t.bx; a.by = t.by; a.bz = t.bz;
@@ -1314,6 +1324,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   const uint32_t nbz = (g.dim[2] + t.bz - 1) / t.bz;
   a.n_boxes = box_list ? n_list : a.nbx * a.nby * nbz;
   a.box_list = box_list;
+  a.n_boxes_dev = box_list ? n_list_dev : nullptr;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
   a.ablate = knn_tuning().ablate;
   a.flush_at = knn_tuning().flush_at;

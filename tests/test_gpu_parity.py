@@ -6,7 +6,7 @@ import pytest
 
 from harness import BUFFER_KINDS, PAIRINGS
 from pasture_amd import las
-from pasture_amd._capi import PasturePanic
+from pasture_amd._capi import PastureError, PasturePanic
 from pasture_amd.algorithms import calculate_bounds, transform_attribute
 from pasture_amd.buffers import HashMapBuffer, VectorBuffer
 from pasture_amd.conversion import BufferLayoutConverter, Transform
@@ -1883,3 +1883,124 @@ def test_zz_curvature_floor_report(hip):
         pass
     print("curvature floor use:", json.dumps(u))
     assert u["failed"] == 0
+
+
+# ---- stream-ordered compute_normals: pst_compute_normals_plan_create / pst_compute_normals_into_async (round 4) --------------------------------
+def _normal_targets(hip, n):
+    from pasture_amd.layout import PointAttributeDefinition
+    dst = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.NORMAL, PointAttributeDefinition("Curvature", T.F64)], api=hip))
+    dst.resize(n)
+    return dst
+
+
+def _cloud_buffer(hip, pts):
+    buf = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    buf.resize(len(pts))
+    buf.set_attribute_range(A.POSITION_3D, range(0, len(pts)), pts)
+    return buf
+
+
+def _planned_clouds(seed, n, shape):
+    rng = np.random.default_rng(seed)
+    if shape == "volume":
+        return rng.uniform(0, 1, (n, 3)) * np.array([400.0, 300.0, 100.0])
+    xy = rng.uniform(0, 1, (n, 2)) * np.array([900.0, 700.0])  # a surface in a 3-D box: one workgroup per OCCUPIED box (the list path)
+    return np.column_stack([xy, 8.0 * np.sin(xy[:, 0] / 40.0) * np.cos(xy[:, 1] / 60.0) + 40.0 + 0.01 * rng.normal(size=n)])
+
+
+@pytest.mark.parametrize("shape", ["volume", "surface"])
+def test_compute_normals_into_async_equals_the_synchronous_call(hip, shape):
+    """The plan's replay on the cloud it was made from, then on two OTHER clouds of the same length and shape: NORMAL / Curvature columns
+    bit-identical to pst_compute_normals_into on the same cloud (the neighbour lists are exact for any grid; the fit is the same code), status 0."""
+    import torch
+    from pasture_amd.algorithms import NormalsPlan, compute_normals_into
+    from pasture_amd.layout import PointAttributeDefinition
+    n, k = 1_300_000, 16
+    curv = PointAttributeDefinition("Curvature", T.F64)
+    src = _cloud_buffer(hip, _planned_clouds(1, n, shape))
+    dst = _normal_targets(hip, n)
+    plan = NormalsPlan(src, k, dst)
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for seed in (1, 2, 3):
+        src.set_attribute_range(A.POSITION_3D, range(0, n), _planned_clouds(seed, n, shape))
+        want = _normal_targets(hip, n)
+        compute_normals_into(src, k, want)
+        got = _normal_targets(hip, n)
+        plan.compute_into_async(src, got, st.data_ptr())
+        torch.cuda.synchronize()
+        assert st.tolist() == [0, 0], (seed, st.tolist())
+        gn, wn, gc, wc = got.view_attribute(A.NORMAL), want.view_attribute(A.NORMAL), got.view_attribute(curv), want.view_attribute(curv)
+        if seed == 1:  # the plan's own cloud: the same grid, the same queries on the same code paths
+            assert np.array_equal(gn, wn) and np.array_equal(gc, wc)
+        else:
+            # another cloud: the synchronous call lays ITS grid, so other queries take the exact search, whose plane fit adds in the
+            # reference's order while the box search's adds about the query (1e-15 apart, normals_device.hpp): equal to f32 / 1e-12
+            assert np.array_equal(gn, wn) or np.max(np.abs(gn.astype(np.float64) - wn)) <= 1e-6 * np.max(np.abs(wn))
+            assert np.all(np.abs(gc - wc) <= 1e-12 * np.maximum(1.0, np.abs(wc)))
+    plan.destroy()
+
+
+def test_compute_normals_into_async_status_and_refusals(hip):
+    import torch
+    from pasture_amd.algorithms import NormalsPlan
+    n, k = 1_200_000, 16
+    pts = _planned_clouds(5, n, "volume")
+    src = _cloud_buffer(hip, pts)
+    dst = _normal_targets(hip, n)
+    plan = NormalsPlan(src, k, dst)
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    bad = pts.copy(); bad[7, 1] = np.nan  # one non-finite point: the index holds one point fewer than planned
+    src.set_attribute_range(A.POSITION_3D, range(0, n), bad)
+    plan.compute_into_async(src, dst, st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(st[0]) & 1
+    far = pts.copy(); far[:3] += np.array([[1e7, 0, 0], [0, -2e7, 0], [0, 0, 3e7]])  # three lone far points: clamped into the plan's grid, their queries are handed back by the capped exact search
+    src.set_attribute_range(A.POSITION_3D, range(0, n), far)
+    plan.compute_into_async(src, dst, st.data_ptr())
+    torch.cuda.synchronize()
+    assert int(st[0]) & 8
+    src.set_attribute_range(A.POSITION_3D, range(0, n), pts)
+    plan.compute_into_async(src, dst, st.data_ptr())
+    torch.cuda.synchronize()
+    assert st.tolist() == [0, 0]
+    # clouds the synchronous call does not run through the box search, or that leave queries open, have no plan
+    small = _cloud_buffer(hip, _planned_clouds(6, 1500, "volume"))  # (a brute-force cloud)
+    with pytest.raises(PastureError) as e:
+        NormalsPlan(small, k, _normal_targets(hip, 1500))
+    assert e.value.code == 23
+    with pytest.raises(PastureError) as e:
+        NormalsPlan(_cloud_buffer(hip, far), k, _normal_targets(hip, n))
+    assert e.value.code == 23 and "handed back" in e.value.message
+
+
+def test_compute_normals_into_async_is_graph_capturable(hip):
+    import ctypes
+    import torch
+    from pasture_amd.algorithms import NormalsPlan, compute_normals_into
+    from pasture_amd.layout import PointAttributeDefinition
+    n, k = 1_100_000, 16
+    curv = PointAttributeDefinition("Curvature", T.F64)
+    src = _cloud_buffer(hip, _planned_clouds(11, n, "volume"))
+    dst = _normal_targets(hip, n)
+    plan = NormalsPlan(src, k, dst)
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    plan.compute_into_async(src, dst, st.data_ptr())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    main = torch.cuda.current_stream().cuda_stream
+    try:
+        with torch.cuda.graph(g):
+            hip.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            plan.compute_into_async(src, dst, st.data_ptr())
+    finally:
+        hip.set_stream(ctypes.c_void_p(main))
+    for seed in (12, 13):
+        src.set_attribute_range(A.POSITION_3D, range(0, n), _planned_clouds(seed, n, "volume"))
+        want = _normal_targets(hip, n)
+        compute_normals_into(src, k, want)
+        st.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        assert st.tolist() == [0, 0]
+        gn, wn, gc, wc = dst.view_attribute(A.NORMAL), want.view_attribute(A.NORMAL), dst.view_attribute(curv), want.view_attribute(curv)
+        assert np.max(np.abs(gn.astype(np.float64) - wn)) <= 1e-6 * np.max(np.abs(wn)) and np.all(np.abs(gc - wc) <= 1e-12 * np.maximum(1.0, np.abs(wc)))

@@ -12,7 +12,7 @@ hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
 TYPES = {"int": "c_int", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "int64_t": "i64", "void": "c_void",
          "char": "c_char", "pst_layout": "pst_layout", "pst_buffer": "pst_buffer", "pst_converter": "pst_converter",
          "pst_datatype": "pst_datatype", "pst_member": "pst_member", "pst_transform": "pst_transform", "pst_mapping_info": "pst_mapping_info",
-         "pst_point_converter": "pst_point_converter", "pst_comm": "pst_comm", "pst_comm_id": "pst_comm_id", "pst_jit_stats": "pst_jit_stats", "pst_voxel_plan": "pst_voxel_plan"}
+         "pst_point_converter": "pst_point_converter", "pst_comm": "pst_comm", "pst_comm_id": "pst_comm_id", "pst_jit_stats": "pst_jit_stats", "pst_voxel_plan": "pst_voxel_plan", "pst_normals_plan": "pst_normals_plan"}
 # C parameter names that are Rust keywords (`self` as a parameter NAME of an extern fn is a compile error)
 RENAME = {"type": "ty", "self": "this", "in": "input", "ref": "reference", "fn": "func", "move": "mv", "match": "matched"}
 
@@ -105,6 +105,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct pst_point_converter { _private: [u8; 0] }
 #[repr(C)] pub struct pst_comm { _private: [u8; 0] }
 #[repr(C)] pub struct pst_voxel_plan { _private: [u8; 0] }
+#[repr(C)] pub struct pst_normals_plan { _private: [u8; 0] }
 
 """ + rust_structs + """
 
