@@ -22,7 +22,7 @@ for w in filter_big_columnar filter_big_interleaved; do
   python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out
 done
 if [ -z "${GENERIC_ONLY:-}" ]; then
-for w in convert_affine_bounds bounds las0_encode voxelgrid_xyz narrow_f64_f32 normals_knn16 normals_knn16_sheet; do
+for w in convert_affine_bounds bounds las0_encode voxelgrid_xyz voxelgrid_xyz_async narrow_f64_f32 normals_knn16 normals_knn16_async normals_knn16_sheet; do
   python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out
 done
 fi

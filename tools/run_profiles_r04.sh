@@ -39,6 +39,29 @@ for spec in "${SPECS_ARR[@]}"; do
   done
   python tools/rocprof_summary.py --round r04 --workload $w --key $key --kernel "$kern" --out $out --kt gpurun_out/prof/$key/kt/bench_results.db \
     --fetch gpurun_out/prof/$key/fetch/bench_results.db --write gpurun_out/prof/$key/write/bench_results.db --cmd "python bench.py --no-cpu-baseline --workload $w $extra" > /dev/null
+  if [[ $w == normals_knn* ]]; then
+    d=gpurun_out/prof/$key/valu; mkdir -p $d
+    timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU -d $d -o bench -- python bench.py --no-cpu-baseline --no-north-star --workload $w $extra --steps 3 --warmup 1 > $d/bench.log 2>&1
+    python - "$w" "$kern" "$d/bench_results.db" "gpurun_out/prof/$key/kt/bench_results.db" "$out/knn_valu.json" <<'PY'
+import json, os, sqlite3, sys
+w, kern, pmc_db, kt_db, path = sys.argv[1:6]
+cur = sqlite3.connect(pmc_db).cursor()
+rows = list(cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like ? group by kernel_name, counter_name", (f"%{kern}%",)))
+kt = sqlite3.connect(kt_db).cursor()
+ms = {r[0]: r[1] / 1e3 for r in kt.execute("select name, average from top_kernels where name like ?", (f"%{kern}%",))}  # (average is in microseconds)
+allv = json.load(open(path)) if os.path.exists(path) else {}
+for name, counter, val, cnt in rows:
+    if counter == "SQ_INSTS_VALU":
+        allv[w] = {"kernel": name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], "valu_wave_instructions_per_launch": round(val), "launches": cnt, "points": 100000000,
+                   "kernel_ms": round(ms.get(name, 0.0), 4) or None, "round": "r04"}
+        for n2, c2, v2, _ in rows:
+            if n2 == name and c2 != "SQ_INSTS_VALU": allv[w][c2.lower()] = round(v2)
+json.dump(allv, open(path, "w"), indent=1)
+print(w, allv.get(w))
+PY
+  fi
   rm -rf gpurun_out/prof/$key
 done
+cp $out/knn_valu.json profiles/knn_valu.json 2>/dev/null
+cp $out/hbm_traffic.json profiles/hbm_traffic.json 2>/dev/null
 ls $out
