@@ -106,32 +106,47 @@ static bool pool_ready() {
 // Pool blocks remember the stream they were allocated on.  hipFreeAsync orders the release behind THAT stream's work only, so a
 // buffer destroyed while another stream is current (a different thread whose stream is the default one, or after pst_set_stream)
 // first waits for the whole device: work enqueued by the asynchronous entry points may still be using the block.
+// The owner is remembered with its DEVICE: after pst_set_device(d') a buffer that lives on device d is synchronised and released there.
+struct AllocOwner { int device; hipStream_t stream; };
 static std::mutex g_alloc_mu;
-static std::unordered_map<void*, hipStream_t> g_alloc_stream;
+static std::unordered_map<void*, AllocOwner> g_alloc_stream;
 
 hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s) {
   *p = nullptr;
   if (!pool_ready()) return hipMalloc(p, bytes);
   const hipError_t e = hipMallocAsync(p, bytes, s);
   if (e == hipSuccess) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_alloc_mu);
-    g_alloc_stream[*p] = s;
+    g_alloc_stream[*p] = AllocOwner{dev, s};
   }
   return e;
 }
 void dev_free_stream(void* p, hipStream_t s) {
   if (!p) return;
-  if (!pool_ready()) { (void)hipFree(p); return; }
-  hipStream_t owner = s;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  AllocOwner owner{cur, s};
+  bool pooled = false;
   {
     std::lock_guard<std::mutex> lock(g_alloc_mu);
     auto it = g_alloc_stream.find(p);
-    if (it != g_alloc_stream.end()) { owner = it->second; g_alloc_stream.erase(it); }
+    if (it != g_alloc_stream.end()) { owner = it->second; g_alloc_stream.erase(it); pooled = true; }
+  }
+  if (!pooled) { (void)hipFree(p); return; }  // (allocated without the pool: PST_NO_POOL, or a device without pool support)
+  if (owner.device != cur) {
+    // the block lives on another device: wait for that device's work and hand the block back there; the caller's device stays current
+    (void)hipSetDevice(owner.device);
+    (void)hipDeviceSynchronize();
+    if (hipFree(p) != hipSuccess) (void)hipGetLastError();
+    (void)hipSetDevice(cur);
+    return;
   }
   // Freed on the stream it was allocated on when that is the current one.  Otherwise the whole device is synchronised first (work the
   // asynchronous entry points enqueued on the owner may still use the block) and after that ANY live stream is a safe place for the
   // release: the current one is used, never the remembered handle -- the caller may have destroyed that stream since.
-  if (owner != s) (void)hipDeviceSynchronize();
+  if (owner.stream != s) (void)hipDeviceSynchronize();
   if (hipFreeAsync(p, s) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipFree(p);

@@ -668,17 +668,18 @@ __device__ __forceinline__ void block_select_and_fit(const double* __restrict__ 
     }
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
-  if (kth_out) { *kth_out = last; return; }  // (+inf when fewer than k points were visited)
+  if (kth_out) { if (threadIdx.x == 0) *kth_out = last; return; }  // (+inf when fewer than k points were visited)
+  if (wave != 0) return;
+  // the plane fit as a wave-level operation (plane_fit_wave): lane t fetches neighbour t -- ONE parallel gather instead of 2 m dependent
+  // loads by a single lane --, the sums run across the lanes in point order (v_readlane): the reference's order of operations
   const uint32_t m = nf < k ? nf : k;
   const uint64_t orig = out.sidx[j];
-  if (out.knn || out.knn_u32)
-    for (uint32_t t = 0; t < k; ++t) write_knn(out, orig, k, t, t < m ? out.sidx[res[t]] : kNoIndex);
-  const Fit f = plane_fit<0, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
-    const uint32_t p = res[t];
-    x = sxyz[3 * (uint64_t)p]; y = sxyz[3 * (uint64_t)p + 1]; z = sxyz[3 * (uint64_t)p + 2];
-  });
-  write_record(out, orig, f);
+  const bool have = lane < m;
+  const uint32_t pn = have ? res[lane] : j;
+  const double nx = sxyz[3 * (uint64_t)pn], ny = sxyz[3 * (uint64_t)pn + 1], nz = sxyz[3 * (uint64_t)pn + 2];
+  if ((out.knn || out.knn_u32) && lane < k) write_knn(out, orig, k, lane, have ? out.sidx[pn] : kNoIndex);
+  const Fit f = plane_fit_wave(m, nx, ny, nz);
+  if (lane == 0) write_record(out, orig, f);
 }
 
 template <int K>

@@ -243,6 +243,29 @@ __device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py,
                              __builtin_fma(-sy, ty, myy), __builtin_fma(-sy, tz, myz), __builtin_fma(-sz, tz, mzz));
 }
 
+// The fit as a WAVE-LEVEL operation (BASELINE.json configs[4]: "per-point 3x3 covariance wavefront reduction") for kernels that spend a whole
+// wave or workgroup on ONE query (knn_select_kernel: the exact search of far points against all points): lane t fetches neighbour t -- ONE
+// parallel gather instead of 2 m dependent loads by a single lane, which left 63 lanes idle --, and the centroid and the six moments are
+// accumulated across the lanes with v_readlane IN POINT ORDER (every lane runs the same wave-uniform chain), i.e. in the reference's order
+// of operations: the result is bit-identical to the lane-sequential plane_fit.  A shuffle TREE (six xor stages per sum) was built first and
+// is what the name suggests; the differential fuzz rejected it: on ill-conditioned neighbourhoods (a 10^4 x 1 x 10^-2 slab at coordinates of
+// 5 10^6) the reference's trigonometric cubic solver amplifies last-bit differences of the covariance into curvature differences far beyond
+// 1e-9 -- 808 of 2049 in one case --, so the one place where a whole wave serves one query keeps the reference's order.  The box search
+// (one query per LANE) does not use a cross-lane form at all: it is bound by its vector-instruction count, and a lane-parallel fit costs
+// 9 sums x 6 stages x 3 instructions per query against 12 m / 64.
+__device__ __forceinline__ double wave_readlane_f64(double v, uint32_t lane) {  // lane is wave-uniform
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)lane);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+// m <= 64 neighbours, neighbour t in lane t of the calling wave (all 64 lanes call; finite coordinates)
+__device__ __forceinline__ Fit plane_fit_wave(uint32_t m, double x, double y, double z) {
+  return plane_fit<0, true>(m, [&](uint32_t t, double& px, double& py, double& pz) __attribute__((always_inline)) {
+    const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    px = wave_readlane_f64(x, tu); py = wave_readlane_f64(y, tu); pz = wave_readlane_f64(z, tu);
+  });
+}
+
 // Where the results of a search kernel go.  Two forms:
 //   * rec != null: ONE aligned 32-byte record {normal xyz, curvature} per point at the point's ORIGINAL index (a full-sector store);
 //     split_results_kernel (normals.hip) then streams the records into the caller's outputs;

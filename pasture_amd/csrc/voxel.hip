@@ -699,6 +699,34 @@ long long voxel_grid_build(VoxelGridState*& st, const uint8_t* pos_base, uint64_
                        : voxel_grid_build_typed<uint64_t>(st, pos_base, pos_stride, n, gx, gy, gz, end_bit, stream);
 }
 
+// How many points of dynamic LDS (3 doubles each) voxel_reduce_kernel may stage on the CURRENT device: the opt-in is per device (the kernel's
+// attribute is set once for each), and a device that offers less than the 144 KiB the largest groups use gets a smaller cap -- 0 (the
+// unstaged path) when even the smallest staging does not fit.  gfx950: 160 KiB per workgroup => 6144 points.
+static uint32_t voxel_stage_limit() {
+  static uint32_t per_device[64];
+  static bool known[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!known[dev]) {
+    // the full 144 KiB first (gfx950 grants it); a device that refuses gets what its per-block limit allows, or nothing
+    uint32_t pts = 6144;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pts * 24)) != hipSuccess) {
+      (void)hipGetLastError();
+      int limit = 0;
+      if (hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); limit = 0; }
+      pts = (uint32_t)std::max<long long>(0, ((long long)limit - 2048) / 24) & ~63u;  // (2 KiB of static LDS in the kernel)
+      if (pts > 6144) pts = 6144;
+      if (pts < 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(pts * 24)) != hipSuccess) {
+        (void)hipGetLastError();
+        pts = 0;
+      }
+    }
+    per_device[dev] = pts;
+    known[dev] = true;
+  }
+  return per_device[dev];
+}
+
 // Phase 2: reductions into target points [dst_first, dst_first + n_voxels).
 bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_stride,
                        const uint32_t* reduce, const uint32_t* kind, int n_attrs, uint64_t dst_first, hipStream_t stream) {
@@ -729,9 +757,8 @@ bool voxel_grid_reduce(VoxelGridState* st, const uint64_t* src_addr, const uint3
   uint32_t cap = (uint32_t)std::min<uint64_t>(6144, std::max<uint64_t>(1024, (st->n * 8 / 5) / groups + 63)) & ~63u;
   if (cap_env != ~0u) cap = std::min<uint32_t>(cap_env, 6144) & ~63u;
   if (st->planned) cap = st->shape.stage_cap;  // (sized for the voxel count the plan measured, not for its capacity)
+  cap = std::min(cap, voxel_stage_limit());  // (0: this device cannot stage -- every group takes the unstaged path)
   const size_t lds = (size_t)std::max<uint32_t>(cap, 64) * 3 * sizeof(double);
-  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 3 * 8) == hipSuccess;
-  if (!lds_ok) return false;
   hipLaunchKernelGGL(voxel_reduce_kernel, dim3((unsigned)groups), dim3(kBlock), lds, stream, a, cap);
   if (any_mode && st->n > kMidVoxel && st->planned) {
     // stream-ordered: the big-voxel pass always runs on its fixed grid; its blocks read the count on the device and most find nothing
@@ -779,8 +806,7 @@ VoxelGridState* voxel_plan_create(const VoxelPlanShape& shape, hipStream_t strea
   PCK(st->big_list.alloc(((size_t)(n / kMidVoxel) + 1) * 4, stream));
   PCK(st->big_count.alloc(16, stream));
   if (n > kMidVoxel) PCK(st->hist.alloc((size_t)kBigBlocks * 65536u * 4u, stream));
-  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(voxel_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 3 * 8) == hipSuccess;
-  if (!lds_ok) return nullptr;
+  (void)voxel_stage_limit();  // (the per-device opt-in happens here, not inside a stream-ordered call)
 #undef PCK
   st->planned = true;
   return st.release();
