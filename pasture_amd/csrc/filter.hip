@@ -457,6 +457,123 @@ __global__ __launch_bounds__(kBlock) void filter_big_records_kernel(const Filter
   }
 }
 
+// Streaming form for the same layout (round 4).  The gather above issues seven loads per SELECTED point at scattered indices -- but at the
+// densities a filter is used at, every cache line of the columns is touched anyway (density 0.5: every other point), so the columns can be READ
+// like a conversion reads them: a lane owns four consecutive points and fetches their 32 + 24 + 96 + 4 + 8 bytes with eleven vector loads
+// (lane-contiguous across the wave), all in flight before the ranks are known.  Selected points become 41-byte record images in registers and are
+// written to the LDS record tile at their rank; the tile leaves with 16-byte stores.  512 lanes x 4 points = the 2048-point tile of the count /
+// scan kernels; the record tile holds kStreamCap records, a tile with more matches takes another round over the same registers.
+#ifndef PST_FILTER_STREAM_CAP
+#define PST_FILTER_STREAM_CAP 1280  // (at density 0.5 a tile has 1024 +- 23 matches: 1024 sent half the tiles through a second round)
+#endif
+constexpr uint32_t kStreamThreads = 512, kStreamCap = PST_FILTER_STREAM_CAP;
+__global__ __launch_bounds__(kStreamThreads) void filter_big_records_stream_kernel(const FilterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+  lptr_t lds = (lptr_t)lds_raw;
+  __shared__ uint32_t wave_tot[kStreamThreads / 64];
+  constexpr uint32_t STRIDE = 41;
+  const uint64_t first = (uint64_t)blockIdx.x * 2048u;
+  const uint32_t cnt = (uint32_t)((a.n - first) < 2048u ? (a.n - first) : 2048u);
+  const uint64_t out0 = a.offsets[blockIdx.x];
+  uint32_t m = a.counts[blockIdx.x];
+  if (m == 0 || out0 >= a.limit) return;
+  if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
+  const uint32_t p0 = threadIdx.x * 4u;
+  cgptr_t mp = (cgptr_t)((uint64_t)(uintptr_t)a.mask + first);
+  cgptr_t gps = (cgptr_t)as_global(a.attrs[0].src) + first * 8, col = (cgptr_t)as_global(a.attrs[1].src) + first * 6, pos = (cgptr_t)as_global(a.attrs[2].src) + first * 24,
+          cls = (cgptr_t)as_global(a.attrs[3].src) + first, inten = (cgptr_t)as_global(a.attrs[4].src) + first * 2;
+  // the lane's four points, as byte strings: gps 32 B, colour 24 B, position 96 B, classification 4 B, intensity 8 B
+  uint32_t wg[8], wc[6], wp[24], wcl = 0, wi[2] = {0, 0}, mw = 0;
+  if (p0 + 4u <= cnt) {
+    mw = load_un<uint32_t>(mp + p0);
+    const u32x4 g0 = load_un<u32x4>(gps + p0 * 8u), g1 = load_un<u32x4>(gps + p0 * 8u + 16);
+    const u32x4 c0 = load_un<u32x4>(col + p0 * 6u);
+    const uint64_t c1 = load_un<uint64_t>(col + p0 * 6u + 16);
+    u32x4 pv[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) pv[q] = load_un<u32x4>(pos + p0 * 24u + 16u * q);
+    wcl = load_un<uint32_t>(cls + p0);
+    const uint64_t iv = load_un<uint64_t>(inten + p0 * 2u);
+    wg[0] = g0.x; wg[1] = g0.y; wg[2] = g0.z; wg[3] = g0.w; wg[4] = g1.x; wg[5] = g1.y; wg[6] = g1.z; wg[7] = g1.w;
+    wc[0] = c0.x; wc[1] = c0.y; wc[2] = c0.z; wc[3] = c0.w; wc[4] = (uint32_t)c1; wc[5] = (uint32_t)(c1 >> 32);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { wp[4 * q] = pv[q].x; wp[4 * q + 1] = pv[q].y; wp[4 * q + 2] = pv[q].z; wp[4 * q + 3] = pv[q].w; }
+    wi[0] = (uint32_t)iv; wi[1] = (uint32_t)(iv >> 32);
+  } else {  // the cloud's last, partly filled tile: point by point
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wg[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) wc[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 24; ++q) wp[q] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      if (p0 + i < cnt) {
+        const uint32_t pi = p0 + i;
+        mw |= (uint32_t)mp[pi] << (8u * i);
+        const uint64_t g = load_un<uint64_t>(gps + pi * 8u);
+        wg[2 * i] = (uint32_t)g; wg[2 * i + 1] = (uint32_t)(g >> 32);
+        const uint64_t c = (uint64_t)load_un<uint32_t>(col + pi * 6u) | ((uint64_t)load_un<uint16_t>(col + pi * 6u + 4) << 32);
+        // colour i occupies bytes [6 i, 6 i + 6) of the 24-byte string
+        const uint32_t bo = 6u * i, wi0 = bo >> 2, sh = (bo & 3u) * 8u;
+        wc[wi0] |= (uint32_t)(c << sh);
+        if (wi0 + 1 < 6) wc[wi0 + 1] |= (uint32_t)(sh ? (c >> (32u - sh)) : (c >> 32));
+#pragma unroll
+        for (uint32_t q = 0; q < 6; ++q) wp[6 * i + q] = load_un<uint32_t>(pos + pi * 24u + 4u * q);
+        wcl |= (uint32_t)load_un<uint8_t>(cls + pi) << (8u * i);
+        wi[i >> 1] |= (uint32_t)load_un<uint16_t>(inten + pi * 2u) << (16u * (i & 1u));
+      }
+    }
+  }
+  // ranks: matches before this lane's points, within the tile
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) c += ((mw >> (8u * i)) & 0xFFu) != 0u;
+  uint32_t incl = c;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t r0 = incl - c;
+  for (uint32_t w = 0; w < wave; ++w) r0 += wave_tot[w];
+  // record images of the lane's four points (compile-time offsets into the byte strings)
+  auto colour = [&](uint32_t i) __attribute__((always_inline)) -> uint64_t {  // 6 bytes at byte 6 i of wc
+    const uint32_t bo = 6u * i, w0 = bo >> 2, sh = (bo & 3u) * 8u;
+    uint64_t v = (uint64_t)wc[w0] >> sh;
+    if (w0 + 1 < 6) v |= sh ? ((uint64_t)wc[w0 + 1] << (32u - sh)) : ((uint64_t)wc[w0 + 1] << 32);
+    return v & 0xFFFFFFFFFFFFull;
+  };
+  for (uint32_t base = 0; base < m; base += kStreamCap) {
+    const uint32_t cm = (m - base) < kStreamCap ? (m - base) : kStreamCap;
+    const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
+    const uint32_t mis = (uint32_t)(ga & 15u);
+    uint32_t r = r0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+      if (on && r >= base && r < base + cm) {
+        pstlas::RecordImage<STRIDE> img;
+        img.put(0, 8, (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
+        img.put(8, 6, colour(i));
+        img.put(14, 8, (uint64_t)wp[6 * i] | ((uint64_t)wp[6 * i + 1] << 32));
+        img.put(22, 8, (uint64_t)wp[6 * i + 2] | ((uint64_t)wp[6 * i + 3] << 32));
+        img.put(30, 8, (uint64_t)wp[6 * i + 4] | ((uint64_t)wp[6 * i + 5] << 32));
+        img.put(38, 1, (wcl >> (8u * i)) & 0xFFu);
+        img.put(39, 2, (wi[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu);
+        img.store(lds + (mis + (r - base) * STRIDE));
+      }
+      r += on ? 1u : 0u;
+    }
+    __syncthreads();
+    tile_store<kStreamThreads>(lds, as_global(ga - mis), mis, cm * STRIDE);
+    if (base + kStreamCap < m) __syncthreads();
+  }
+}
+
 template <typename SP>
 static bool filter_plan_equals(const FilterArgs& a, bool dst_aos) {
   if (a.n_attrs != (uint32_t)SP::n || a.tile != 2048u) return false;
@@ -550,8 +667,11 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
       note_plan_kind(PST_PLAN_STATIC);
       // point-major record assembly (filter_big_records_kernel): same-box A/B against the granule-major constants 0.657 -> 0.673 of peak
       // (PST_FILTER_PM=0 switches back), 0.680 with a 24 KiB record tile (8 / 16 / 24 / 32 KiB: 0.671 / 0.674 / 0.680 / 0.676)
-      static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 1; }();
-      if (pm) {
+      static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 2; }();
+      if (pm == 2) {  // streaming form (round 4): PST_FILTER_PM=1 is the gather form, 0 the granule-major constants
+        const size_t lds_st = (size_t)kStreamCap * 41 + 64;
+        hipLaunchKernelGGL(filter_big_records_stream_kernel, dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
+      } else if (pm) {
         FilterArgs b = a;
         b.chunk = filter_chunk(dst_stride, 24L * 1024L);
         const size_t lds_pm = (((size_t)tile * 2 + 15) & ~(size_t)15) + (size_t)b.chunk * dst_stride + 48;
