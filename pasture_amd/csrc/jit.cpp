@@ -364,7 +364,29 @@ bool spec_from_plan(const ConvertPlan& plan, bool src_aos, bool dst_aos, QuadSpe
   return true;
 }
 
+static std::string spec_source_uncached(const QuadSpec& s);
+// The text is a pure function of the spec, and a converter hands the same plan to every call: a small per-thread memo keyed by the spec's
+// bytes saves the ~15 us of formatting per conversion call (two of them since converter.cpp asks whether a kernel is at hand before it
+// prefers the generic path) -- a multiple of the launch itself for the 1 MiB chunks pasture-io's readers convert.
 std::string spec_source(const QuadSpec& s) {
+  std::string key;
+  key.reserve(64 + s.entries.size() * sizeof(pstq::QEntry));
+  auto put = [&](const void* p, size_t n) { key.append((const char*)p, n); };
+  const uint32_t head[] = {s.src_aos ? 1u : 0u, s.dst_aos ? 1u : 0u, s.src_stride, s.dst_stride, s.covered, (uint32_t)s.blk, s.xcd, s.nt, s.src_words, s.lds_per_point,
+                           s.dst_tile_off, s.alias, (uint32_t)s.entries.size()};
+  put(head, sizeof(head));
+  for (const pstq::QEntry& e : s.entries) {  // (field by field: the struct's padding bytes are not part of the key)
+    const uint32_t f[] = {e.src_off, e.dst_off, e.src_size, e.dst_size, e.ncomp, e.src_ct, e.dst_ct, e.convert, e.xf_kind, e.xf_pre, e.bounds, e.src_load, e.src_img, e.src_wide,
+                          e.src_stage, e.dst_wide, e.dst_stage};
+    put(f, sizeof(f));
+  }
+  thread_local std::unordered_map<std::string, std::string> memo;
+  auto it = memo.find(key);
+  if (it != memo.end()) return it->second;
+  if (memo.size() >= 256) memo.clear();
+  return memo.emplace(std::move(key), spec_source_uncached(s)).first->second;
+}
+static std::string spec_source_uncached(const QuadSpec& s) {
   std::ostringstream o;
   o << "#include \"jit_quad.hpp\"\n";
   o << "struct PstJitPlan {\n";
