@@ -1374,6 +1374,12 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           box_sink.list = nullptr; box_sink.n = 0;
           box_sink.sorted_cells = keys2.as<uint32_t>();  // (dense grids: 32-bit row-major cell numbers, sorted)
           tiled = knn_tile_shape(g, nf, cells, k, fills, directory.as<uint32_t>(), scratch3, stream, shape, (!fills && tune.box_list) ? &box_sink : nullptr);
+          // Which plane fit the box search runs.  One pass about the query (plane_fit_pivot) agrees with the reference's two passes to a few
+          // ulps of the covariance -- enough wherever the neighbourhood spans three dimensions.  On surfaces and strips the neighbourhoods are
+          // nearly planar, the smallest eigenvalue is the difference of large numbers in the reference's cubic solver, and those ulps become
+          // 1e-8 of the curvature (the deep fuzz: one curvature of 1.4 10^5 on a strip, 1.4e-12 absolute): such clouds keep the reference's
+          // ORDER of operations, which reproduces its rounding.
+          shape.fit_seq = tune.fit >= 0 ? tune.fit == 1 : !fills;
           mark("census");
           break;
         }

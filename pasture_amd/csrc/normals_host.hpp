@@ -9,7 +9,7 @@
 
 namespace pstk {
 
-struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; char tag = '1'; };  // tag: which instance of the box kernel (normals_tile.hip)
+struct TileShape { uint32_t bx = 0, by = 0, bz = 0, threads = 256, cap = 0; char tag = '1'; bool fit_seq = false; };  // tag: which instance of the box kernel (normals_tile.hip); fit_seq: its plane fit in the reference's order
 // false: no box fits (k > 32, or even a single query row with its halo exceeds the LDS budget at this density)
 // (measured: census kernels over the dense directory; scratch3 = 32 bytes of device memory; synchronises the stream)
 // sink (nullable): every census also lists the boxes that hold a query; on success list / n describe the winning shape (list == null: none

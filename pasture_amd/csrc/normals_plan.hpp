@@ -30,7 +30,8 @@ struct KnnTuning {
   char variant = '\0';         // PST_KNN_VAR: '1', 'B', 'D', 'G'
   bool sort_fallback = true;   // PST_KNN_SORT_FALLBACK=0: the exact fallback search takes its queries in the order the box kernel's workgroups finished
   int reorder_unroll = 2;      // PST_REORDER_UNROLL: points per lane in flight in the permutation kernel (1 / 2 / 4)
-  bool fit_seq = false;        // PST_KNN_FIT=seq: the box search's plane fit in the reference's order of operations (two passes) instead of one pass about the query
+  int fit = -1;                // PST_KNN_FIT=seq|pivot: the box search's plane fit in the reference's order of operations (two passes) / in one pass about the query; default (-1): by cloud --
+                               // one pass for clouds that fill their box, the reference's order for surfaces and strips (near-planar neighbourhoods: see normals_device.hpp)
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
   unsigned ablate = 0;         // PST_KNN_ABLATE (tuning only)
   unsigned flush_at = 48;      // PST_KNN_FLUSH_AT
@@ -52,7 +53,7 @@ struct KnnTuning {
     if (const char* e = std::getenv("PST_KNN_DENSE")) t.dense = *e == '0' ? 0 : 1;
     t.direct_out = !off("PST_KNN_DIRECT"); t.box_list = !off("PST_KNN_BOX_LIST"); t.rounds = !off("PST_KNN_ROUNDS"); t.side_stream = !off("PST_KNN_SIDE_STREAM"); t.occupancy_all = num("PST_KNN_OCC_ALL") != 0.0;
     if (const char* e = std::getenv("PST_KNN_VAR")) t.variant = *e;
-    if (const char* e = std::getenv("PST_KNN_FIT")) t.fit_seq = e[0] == 's';
+    if (const char* e = std::getenv("PST_KNN_FIT")) t.fit = e[0] == 's' ? 1 : (e[0] == 'p' ? 0 : -1);
     t.sort_fallback = !off("PST_KNN_SORT_FALLBACK");
     if (const char* e = std::getenv("PST_REORDER_UNROLL")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) t.reorder_unroll = v; }
     if (const char* e = std::getenv("PST_KNN_TILE")) {

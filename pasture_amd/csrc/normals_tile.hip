@@ -1388,7 +1388,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
       else if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 1);                                                             \
       else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 1);                                                                        \
     } while (0)
-    const bool fit_seq = knn_tuning().fit_seq;
+    const bool fit_seq = t.fit_seq;
     switch (t.tag) {
       case 'D': PST_TILE2_K(512, 3000, false, 4, 4); break;
       case 'G': PST_TILE2_K(256, 1536, false, 4, 4); break;
