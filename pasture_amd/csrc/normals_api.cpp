@@ -112,6 +112,7 @@ int pst_compute_normals_device(const pst_buffer* b, size_t k, double* d_normals,
 struct pst_normals_plan {
   pstk::KnnPlan* plan = nullptr;
   size_t k = 0;
+  int device = 0;  // the plan's scratch lives there
   ~pst_normals_plan() { if (plan) pstk::knn_plan_free(plan); }
 };
 
@@ -160,6 +161,7 @@ int pst_compute_normals_plan_create(const pst_buffer* b, size_t k, pst_buffer* d
   const bool packed = t.stride == 24 && (t.base & 7u) == 0;
   plan->plan = pstk::knn_plan_create(rec, packed, s);
   if (!plan->plan) throw Error(PST_ERR_HIP, std::string("normals plan: allocation failed: ") + hipGetErrorString(hipGetLastError()));
+  PST_HIP_CHECK(hipGetDevice(&plan->device));
   stream_sync(s);
   *out = plan.release();
   PST_API_END
@@ -176,6 +178,10 @@ int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, 
   const pstk::KnnPlanRecord& r = pstk::knn_plan_record(plan->plan);
   if (b->len != r.n) throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made for " + std::to_string(r.n) + " points, the buffer holds " + std::to_string(b->len));
   ensure_device();
+  int dev = 0;
+  PST_HIP_CHECK(hipGetDevice(&dev));
+  if (dev != plan->device)
+    throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made on device " + std::to_string(plan->device) + ", the current device is " + std::to_string(dev));
   if (!pstk::run_normals_replay(plan->plan, (const uint8_t*)(uintptr_t)t.base, t.stride, nullptr, nullptr, nullptr, t.na, t.nst, t.ca, t.cst,
                                 (unsigned long long*)device_status2, current_stream()))
     throw Error(PST_ERR_HIP, std::string("normal estimation (stream-ordered) failed: ") + hipGetErrorString(hipGetLastError()));

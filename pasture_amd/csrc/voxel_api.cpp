@@ -246,6 +246,10 @@ extern "C" int pst_voxelgrid_filter_async(pst_voxel_plan* plan, const pst_buffer
                                    " points (it holds " + std::to_string(filtered->len) + "): the voxel count is only known on the device");
   const AttrPlan ap = attribute_plan(*buffer, filtered->layout);
   ensure_device();
+  int dev = 0;
+  PST_HIP_CHECK(hipGetDevice(&dev));
+  if (dev != plan->device)  // the plan's scratch lives on the device it was made on
+    throw Error(PST_ERR_INVALID_ARGUMENT, "voxelgrid_filter_async: the plan was made on device " + std::to_string(plan->device) + ", the current device is " + std::to_string(dev));
   hipStream_t s = current_stream();
   bounds_of_range(*buffer, 0, buffer->len, plan->bounds6, s, plan->partials);
   const size_t pslot = (size_t)(pos - buffer->layout.members.data());
