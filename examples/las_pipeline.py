@@ -35,6 +35,11 @@ def main(path):
     pa.transform_attribute(points, A.POSITION_3D, pa.Transform.affine(T.Vec3f64, (1.0, 1.0, 1.0), (100.0, 200.0, 0.0)))
     bounds = pa.calculate_bounds(points)
     print("bounds after the shift:", bounds.min(), bounds.max())
+    # (round 4: slices are views every algorithm takes -- the chunked min-max of pasture-tools' `info`; the centroid; a converting view)
+    half = points.len() // 2
+    lo, hi = pa.calculate_bounds(points.slice(range(0, max(1, half)))), pa.calculate_bounds(points.slice(range(half, points.len())))
+    assert pa.AABB.union(lo, hi) == bounds
+    print("centroid:", pa.compute_centroid(points), " intensity as f32:", points.view_attribute_with_conversion(A.INTENSITY.with_custom_datatype(T.F32))[:3])
     thinned = pa.HashMapBuffer.new_from_layout(typed)
     pa.voxelgrid_filter(points, 2.0, 2.0, 2.0, thinned)
     print(f"voxel grid 2.0: {points.len()} -> {thinned.len()} points")
