@@ -2004,3 +2004,35 @@ def test_compute_normals_into_async_is_graph_capturable(hip):
         assert st.tolist() == [0, 0]
         gn, wn, gc, wc = dst.view_attribute(A.NORMAL), want.view_attribute(A.NORMAL), dst.view_attribute(curv), want.view_attribute(curv)
         assert np.max(np.abs(gn.astype(np.float64) - wn)) <= 1e-6 * np.max(np.abs(wn)) and np.all(np.abs(gc - wc) <= 1e-12 * np.maximum(1.0, np.abs(wc)))
+
+
+def test_one_pass_fit_agrees_with_the_reference_order_fit(hip):
+    """The box search's two plane fits on the same neighbour lists, 2 10^7 uniform points (a cloud that fills its box takes the one-pass fit by
+    default): normals and curvature of EVERY query within 1e-9 relative of the instance that adds in the reference's order (PST_KNN_FIT=seq),
+    and the worst deviation is reported -- the north star's tolerance with six orders of magnitude to spare on well-conditioned neighbourhoods."""
+    import torch
+    from pasture_amd.algorithms import compute_normals_device, reload_tuning
+    n, k = 20_000_000, 16
+    src = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    src.resize(n)
+    src.synth_fill(77, 0)  # uniform in [0, 1000) x [0, 1000) x [0, 100), generated on the device
+    res = {}
+    try:
+        for fit in ("pivot", "seq"):
+            _os.environ["PST_KNN_FIT"] = fit
+            reload_tuning(hip)
+            nrm = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+            cur = torch.zeros(n, dtype=torch.float64, device="cuda")
+            knn = torch.zeros(n, k, dtype=torch.int32, device="cuda")
+            compute_normals_device(src, k, nrm.data_ptr(), cur.data_ptr(), knn.data_ptr())
+            torch.cuda.synchronize()
+            res[fit] = (nrm, cur, knn)
+    finally:
+        _os.environ.pop("PST_KNN_FIT", None)
+        reload_tuning(hip)
+    (pn, pc, pk), (sn, sc, sk) = res["pivot"], res["seq"]
+    assert torch.equal(pk, sk)
+    rel_n = ((pn - sn).norm(dim=1) / sn.norm(dim=1).clamp_min(1e-300)).max().item()
+    rel_c = ((pc - sc).abs() / sc.abs().clamp_min(1e-300)).max().item()
+    print(f"one-pass against reference-order fit over {n} queries: worst relative difference normals {rel_n:.2e}, curvature {rel_c:.2e}")
+    assert rel_n <= 1e-9 and rel_c <= 1e-9, (rel_n, rel_c)
