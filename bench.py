@@ -89,6 +89,10 @@ def parse():
     p.add_argument("--collective", default="capi", choices=["capi", "torch"],
                    help="N > 1: the AABB exchange per step. capi (default) = the boundary's own pst_bounds_allreduce (pst_comm_init_rank bootstrapped from "
                         "the launcher's rendezvous); torch = torch.distributed.all_reduce")
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="N > 1 on a ONE-GPU box: every rank uses GPU 0, the ranks talk over gloo (torch's collectives; the C ABI's RCCL collective needs a GPU "
+                        "per rank).  Exercises the sharding, the per-step exchange path, the in-run self-check and the configs[3] leg with real kernels; "
+                        "the ranks share the GPU, so the timings mean nothing and the line says so")
     p.add_argument("--no-configs3", action="store_true", help="N > 1: skip the configs[3] leg (ONE 10^9-point cloud sharded over the ranks) appended to the weak-scaling line")
     p.add_argument("--configs3-points", type=int, default=1_000_000_000)
     p.add_argument("--no-north-star", action="store_true", help="skip the 10^9-point single-GPU leg (north_star size) appended at N=1")
@@ -202,7 +206,7 @@ def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks of this file under torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) and hand back their exit code.  Refuses when the box has fewer than N devices."""
     import subprocess
-    if args.backend == "nccl":
+    if args.backend == "nccl" and not args.rehearse_on_one_gpu:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
@@ -256,6 +260,9 @@ def main():
         dist.destroy_process_group()
         return
     assert torch.cuda.is_available(), "bench.py needs a GPU: pasture_amd has no CPU fallback"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+        args.collective = "torch"
     if local_rank >= torch.cuda.device_count():
         sys.stderr.write(f"bench.py: rank {rank} wants device {local_rank} but this node has {torch.cuda.device_count()} GPUs\n")
         sys.exit(2)
@@ -263,13 +270,17 @@ def main():
     # torchrun with one rank (or PASTURE_FORCE_DIST=1) still exercises the RCCL path: init, all-reduce, barrier
     distributed = world > 1 or (os.environ.get("PASTURE_FORCE_DIST") == "1" and "RANK" in os.environ)
     n_ranks_seen = 1
+    ctl = "cpu" if args.rehearse_on_one_gpu else "cuda"  # where the run's own control tensors live (gloo gathers on the host)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the 48-byte AABB collectives must not queue behind the 97k-workgroup conversion kernels: high-priority RCCL stream
         # (measured with one rank: step 0.806 -> 0.774 ms, kernel-only 0.767 ms; tools/exp_dist_overhead.py)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        census = torch.ones(1, dtype=torch.int64, device="cuda")
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        census = torch.ones(1, dtype=torch.int64, device=ctl)
         dist.all_reduce(census)  # n_gpus in the JSON line = the ranks RCCL really saw
         n_ranks_seen = int(census.item())
         if n_ranks_seen != world:
@@ -318,7 +329,7 @@ def main():
                 err = f"pst_comm_size = {transport.size()}, expected {world}"
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"
-        bad = torch.tensor([1 if err else 0], dtype=torch.int64, device="cuda")
+        bad = torch.tensor([1 if err else 0], dtype=torch.int64, device=ctl)
         dist.all_reduce(bad)
         if int(bad.item()):
             if transport is not None:
@@ -624,7 +635,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -636,8 +647,8 @@ def main():
     per_rank = None
     if distributed:
         # per-rank kernel time and the exposed part of the last exchange, gathered so that rank 0's line shows every rank
-        mine = torch.tensor([kernel_ms_avg, (ring.exposed_us() or -1.0) if has_reduction else -1.0], dtype=torch.float64, device="cuda")
-        rows = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+        mine = torch.tensor([kernel_ms_avg, (ring.exposed_us() or -1.0) if has_reduction else -1.0], dtype=torch.float64, device=ctl)
+        rows = [torch.zeros(2, dtype=torch.float64, device=ctl) for _ in range(world)]
         dist.all_gather(rows, mine)
         per_rank = {"kernel_ms_avg": [round(float(r[0]), 4) for r in rows],
                     "last_exchange_exposed_us": [round(float(r[1]), 1) if float(r[1]) >= 0 else None for r in rows]}
@@ -698,7 +709,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c3_elapsed = float(t.item())
         # the same self-check for the sharded 10^9-point cloud: global AABB == affine(union of the shards' source bounds), on every rank
@@ -816,6 +827,8 @@ def main():
             line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
             if collective_note:
                 line["config"]["collective_note"] = collective_note
+            if args.rehearse_on_one_gpu:
+                line["config"]["rehearsal"] = "every rank on GPU 0 over gloo: the N > 1 logic with real kernels; timings are meaningless"
             if per_rank is not None:
                 line["per_rank"] = per_rank
             if self_check is not None:

@@ -554,3 +554,28 @@ def test_single_process_two_devices_allreduce_multi_and_device_switch(hip):
     hip.set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     for o in out[1:]:
         assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse-on-one-gpu`: TWO ranks with real kernels on the one GPU of the box, talking over gloo -- the sharding by
+    index range, the per-step exchange path, the in-run self-check (all-reduced AABB == affine(union of the ranks' source bounds) on every
+    rank) and the sharded configs[3] leg; the global bounds equal those of ONE rank over the same global cloud.  (What it cannot exercise is
+    RCCL between two devices: pst_bounds_allreduce at N = 2 stays untested on hardware.)"""
+    import json
+    import subprocess
+    common = ["--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-north-star"]
+    one = _run_bench(*common, "--points", "10000000")
+    assert one.returncode == 0, one.stderr[-2000:]
+    want = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--points", "5000000", "--configs3-points", "30000001", *common]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["n_gpus"] == 2 and "rehearsal" in got["config"]
+    assert got["config"]["global_points"] == 10000000 and got["config"]["bounds"] == want["config"]["bounds"]
+    assert got["self_check"]["verified"] and got["self_check"]["ranks"] == 2 and got["self_check"]["comm_size"] == 2
+    assert len(got["per_rank"]["kernel_ms_avg"]) == 2
+    c3 = got["configs3_1e9"]
+    assert c3["global_points"] == 30000001 and c3["points_rank0"] == 15000001 and c3["self_check"]["verified"] and c3["self_check"]["ranks"] == 2
