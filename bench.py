@@ -665,9 +665,18 @@ def main():
             pa.calculate_bounds_async(src, src_rec.data_ptr())
         torch.cuda.synchronize()
         affine = args.workload == "convert_affine_bounds"
-        self_check = verify_global_bounds(src_rec, final, SCALE if affine else (1.0, 1.0, 1.0), OFFSET if affine else (0.0, 0.0, 0.0))
+        if os.environ.get("PASTURE_BENCH_FAULT") == str(rank):  # test hook: this rank holds a record that is off in the last bits
+            final = final.clone()
+            final[4] += 1e-9
+        # a failed check does not swallow the line: it is printed with "verified": false and the error, and THEN every rank exits non-zero
+        try:
+            self_check = verify_global_bounds(src_rec, final, SCALE if affine else (1.0, 1.0, 1.0), OFFSET if affine else (0.0, 0.0, 0.0))
+        except AssertionError as e:
+            self_check = {"verified": False, "ranks": world, "error": str(e)[:2000]}
         self_check["comm_size"] = transport.size() if transport is not None else world
-        assert self_check["comm_size"] == world, self_check
+        if self_check["comm_size"] != world:
+            self_check["verified"] = False
+            self_check.setdefault("error", f"pst_comm_size = {self_check['comm_size']}, expected {world}")
 
     if final is not None:
         rec = final
@@ -718,7 +727,10 @@ def main():
         if len(sh):
             pa.calculate_bounds_async(s_src, s_rec.data_ptr())
         torch.cuda.synchronize()
-        c3_check = _verify(s_rec, rec3, SCALE, OFFSET)
+        try:
+            c3_check = _verify(s_rec, rec3, SCALE, OFFSET)
+        except AssertionError as e:
+            c3_check = {"verified": False, "ranks": world, "error": str(e)[:2000]}
         configs3 = {"global_points": g3, "n_gpus": n_ranks_seen, "scaling": "strong", "steps": c3_steps,
                     "ms_per_step": round(c3_elapsed / c3_steps * 1e3, 4), "value": round(g3 * c3_steps / c3_elapsed / 1e6, 2), "unit": "Mpoints/s",
                     "aggregate_GBps": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9, 1),
@@ -842,11 +854,16 @@ def main():
             if cb is not None:
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
+    failed_check = (self_check is not None and not self_check["verified"]) or (configs3 is not None and not configs3["self_check"]["verified"])
+    if failed_check and rank == 0:
+        sys.stderr.write("bench.py: the in-run self-check of the sharded AABB FAILED (see self_check in the line above): exit 3\n")
     if distributed:
         dist.barrier()
         if transport is not None:
             transport.close()
         dist.destroy_process_group()
+    if failed_check:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -579,3 +579,19 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert len(got["per_rank"]["kernel_ms_avg"]) == 2
     c3 = got["configs3_1e9"]
     assert c3["global_points"] == 30000001 and c3["points_rank0"] == 15000001 and c3["self_check"]["verified"] and c3["self_check"]["ranks"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_failed_self_check_prints_the_line_and_exits_non_zero():
+    """A rank whose all-reduced record is off in the last bits (PASTURE_BENCH_FAULT): the JSON line still appears, with "verified": false and
+    the records of every rank, and every rank exits 3 -- loud, but the measurement is not lost."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PASTURE_BENCH_FAULT"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--points", "2000000", "--no-configs3", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-north-star"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode != 0 and "exitcode: 3" in r.stderr, (r.returncode, r.stderr[-2000:])  # (torch.distributed.run reports the ranks' exit 3 as its own 1)
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["self_check"]["verified"] is False and "self-check failed" in got["self_check"]["error"] and got["value"] > 0
