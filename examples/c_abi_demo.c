@@ -82,6 +82,29 @@ int main(void) {
     fprintf(stderr, "bounds mismatch: x [%.17g, %.17g] z [%.17g, %.17g]\n", mn[0], mx[0], mn[2], mx[2]);
     return 1;
   }
+  /* round 4: a slice is a buffer (SliceBuffer::slice, slice.rs:16-43); compute_centroid; a converting attribute view */
+  {
+    pst_buffer* half = NULL;
+    double hmn[3], hmx[3], c[3];
+    int hhas = 0;
+    CHECK(pst_buffer_slice(dst, N / 2, N - N / 2, &half));
+    CHECK(pst_calculate_bounds(half, hmn, hmx, &hhas));
+    if (!hhas || hmn[0] != ((double)(N / 2) * 0.001) + 500000.0 || hmx[0] != mx[0]) {
+      fprintf(stderr, "slice bounds mismatch: x [%.17g, %.17g]\n", hmn[0], hmx[0]);
+      return 1;
+    }
+    CHECK(pst_compute_centroid(dst, c));
+    const double cx = ((0.5 * last) * 0.001) + 500000.0;
+    if (c[0] < cx - 1e-6 || c[0] > cx + 1e-6) { fprintf(stderr, "centroid mismatch: %.17g\n", c[0]); return 1; }
+    pst_datatype f32 = {0};
+    f32.kind = PST_F32;
+    float* as_f32 = malloc(sizeof(float) * N);
+    CHECK(pst_buffer_read_attribute_converted(dst, "Intensity", &f32, 0, N, as_f32));  /* u16 -> f32, the Rust `as` table */
+    for (int i = 0; i < N; ++i)
+      if (as_f32[i] != (float)host[i].intensity) { fprintf(stderr, "converted view mismatch at %d\n", i); return 1; }
+    free(as_f32);
+    pst_buffer_destroy(half);
+  }
   printf("OK: %d points converted on the device, bounds x [%.3f, %.3f]\n", N, mn[0], mx[0]);
   pst_converter_destroy(conv);
   pst_buffer_destroy(src);
