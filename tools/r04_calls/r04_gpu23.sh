@@ -1,25 +1,33 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_jit.py tests/test_las_golden.py tests/test_las_encode.py -m gpu -x -q 2>&1 | grep -E "passed|failed|FAILED" | tail -3
-timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "las or LAS or raw" 2>&1 | grep -E "passed|failed|FAILED" | tail -3
-python - <<'PY'
-import ctypes, torch, sys, os
-sys.path.insert(0, os.getcwd())
-import pasture_amd as pa
-from pasture_amd import las, conversion as cv
-api = pa.product_api(); s = torch.cuda.current_stream(); api.set_stream(ctypes.c_void_p(s.cuda_stream))
-n = 50_000_000
-for f in (1, 3, 6, 7):
-    raw = las.point_layout_from_las_point_format(las.Format(f), True); typed = las.point_layout_from_las_point_format(las.Format(f), False)
-    src = pa.VectorBuffer.new_from_layout(raw); src.resize(n); src.synth_fill(1, 0)
-    dst = pa.VectorBuffer.new_from_layout(typed); dst.resize(n)
-    conv = las.get_default_las_converter(raw, typed, (0.001,)*3, (0.0,)*3)
-    for _ in range(2): conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(5): conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
-    e1.record(s); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    b = raw.size_of_point_entry() + typed.size_of_point_entry()
-    print(f"raw LAS-{f} -> typed records: {cv.last_plan_kinds(api)} {b * n / ms / 1e9 / 8000:.3f} of peak")
+# Where do the waves of the kernels that stay below 0.75 of peak spend their cycles?  One SQ pass per workload (counters only, with --kernel-trace).
+export TMPDIR=/tmp
+mkdir -p gpurun_out/r04
+for spec in "las0_encode:las" "columns_to_las0:convert" "filter_big_interleaved:filter" "filter_big_columnar:filter" "convert_affine_bounds:vec3f64_stream" "las0_to_columns:convert"; do
+  w=${spec%%:*}; kern=${spec##*:}
+  d=gpurun_out/prof_sq/$w; mkdir -p $d
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES -d $d -o bench -- \
+    python bench.py --no-cpu-baseline --no-north-star --workload $w --steps 3 --warmup 1 > $d/bench.log 2>&1
+  echo "$w rc=$?"
+  python - "$w" "$kern" "$d/bench_results.db" <<'PY'
+import json, sqlite3, sys
+w, kern, db = sys.argv[1:4]
+cur = sqlite3.connect(db).cursor()
+rows = list(cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name"))
+by = {}
+for name, counter, val, cnt in rows:
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+    by.setdefault(short, {"launches": cnt})[counter] = round(val)
+# the kernels with the most wave cycles first
+top = sorted(by.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:4]
+out = {"workload": w, "kernels": {k: v for k, v in top}}
+for k, v in top:
+    wc = v.get("SQ_WAVE_CYCLES", 0) or 1
+    v["frac_wait_any"] = round(v.get("SQ_WAIT_ANY", 0) / wc, 3)
+    v["frac_wait_inst_any"] = round(v.get("SQ_WAIT_INST_ANY", 0) / wc, 3)
+    v["frac_active_inst_any"] = round(v.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3)
+    v["frac_active_inst_valu"] = round(v.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3)
+print(json.dumps(out))
+open("gpurun_out/r04/sq_cycles.jsonl", "a").write(json.dumps(out) + "\n")
 PY
+  rm -rf $d
+done
