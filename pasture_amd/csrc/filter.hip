@@ -8,6 +8,8 @@
 //
 //   mask_count_kernel     one tile of the mask per block: number of non-zero bytes                (1 B/pt read)
 //   tile_scan_kernel      exclusive scan of the tile counts (one block; <= 10^5 values)           (negligible)
+//   filter_big_stream_kernel  (the bench layout's attribute sizes, either target kind) the columns are READ like a conversion reads them -- a
+//                         lane owns four consecutive points -- and selected points go to an LDS record tile / to LDS column spans at their rank
 //   filter_scatter_kernel per tile: selected local indices compacted into LDS (order preserved), then attribute by
 //                         attribute: gather from the source columns, store to the tile's contiguous output span —
 //                         columnar targets directly (coalesced, narrow values packed four/two per dword), interleaved
@@ -60,45 +62,57 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __res
 // (one 16-byte load), so 10^8 points (48,829 tiles) need 12 rounds of a 1024-thread scan (16 counts per thread and 3 rounds measured
 // slower: the 16 strided 8-byte stores per thread cost more than the saved rounds).
 constexpr uint32_t kScanPer = 4;
+// The counts of kScanAhead rounds are loaded before the first of them is scanned: a round's 16-byte load was the round's latency (12 dependent
+// rounds for 10^8 points: 28 us; with the loads of eight rounds in flight at once a round is shuffles, one barrier and the stores; sixteen
+// rounds ahead spill at the 128 registers a 1024-thread block has).
+constexpr uint32_t kScanAhead = 8;
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets,
                                                          unsigned long long* __restrict__ total_also) {  // total_also: a caller's word that receives the total too (or null)
   __shared__ unsigned long long wave_tot[2][16];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   unsigned long long carry = 0;
   uint32_t round = 0;
-  for (uint32_t base = 0; base < n_tiles; base += 1024u * kScanPer, ++round) {
-    const uint32_t i0 = base + threadIdx.x * kScanPer;
-    uint32_t c[kScanPer];
+  for (uint32_t base0 = 0; base0 < n_tiles; base0 += 1024u * kScanPer * kScanAhead) {
+    uint32_t c[kScanAhead][kScanPer];
 #pragma unroll
-    for (uint32_t k = 0; k < kScanPer; ++k) c[k] = 0;
-    if (i0 + kScanPer <= n_tiles) {
+    for (uint32_t a = 0; a < kScanAhead; ++a) {
+      const uint32_t i0 = base0 + a * 1024u * kScanPer + threadIdx.x * kScanPer;
 #pragma unroll
-      for (uint32_t q = 0; q < kScanPer / 4; ++q) {
-        const u32x4 v = load_un<u32x4>((cgptr_t)(counts + i0 + 4 * q));
-        c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+      for (uint32_t k = 0; k < kScanPer; ++k) c[a][k] = 0;
+      if (i0 + kScanPer <= n_tiles) {
+        const u32x4 v = load_un<u32x4>((cgptr_t)(counts + i0));
+        c[a][0] = v.x; c[a][1] = v.y; c[a][2] = v.z; c[a][3] = v.w;
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanPer; ++k) if (i0 + k < n_tiles) c[a][k] = counts[i0 + k];
       }
-    } else {
-#pragma unroll
-      for (uint32_t k = 0; k < kScanPer; ++k) if (i0 + k < n_tiles) c[k] = counts[i0 + k];
     }
-    unsigned long long v = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kScanPer; ++k) v += c[k];
-    unsigned long long incl = v;
+    for (uint32_t a = 0; a < kScanAhead; ++a) {
+      const uint32_t base = base0 + a * 1024u * kScanPer;
+      if (base < n_tiles) {  // (uniform)
+      const uint32_t i0 = base + threadIdx.x * kScanPer;
+      unsigned long long v = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t l = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), h = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
-      if ((int)lane >= off) incl += ((unsigned long long)h << 32) | l;
+      for (uint32_t k = 0; k < kScanPer; ++k) v += c[a][k];
+      unsigned long long incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t l = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), h = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+        if ((int)lane >= off) incl += ((unsigned long long)h << 32) | l;
+      }
+      unsigned long long (&tot)[16] = wave_tot[round & 1u];  // double-buffered: one barrier per round
+      ++round;
+      if (lane == 63) tot[wave] = incl;
+      __syncthreads();
+      unsigned long long before = carry + incl - v, all = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += tot[w]; all += tot[w]; }
+#pragma unroll
+      for (uint32_t k = 0; k < kScanPer; ++k) { if (i0 + k < n_tiles) offsets[i0 + k] = before; before += c[a][k]; }
+      carry += all;
+      }
     }
-    unsigned long long (&tot)[16] = wave_tot[round & 1u];  // double-buffered: one barrier per round
-    if (lane == 63) tot[wave] = incl;
-    __syncthreads();
-    unsigned long long before = carry + incl - v, all = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) { if (w < wave) before += tot[w]; all += tot[w]; }
-#pragma unroll
-    for (uint32_t k = 0; k < kScanPer; ++k) { if (i0 + k < n_tiles) offsets[i0 + k] = before; before += c[k]; }
-    carry += all;
   }
   if (threadIdx.x == 0) { offsets[n_tiles] = carry; if (total_also) *total_also = carry; }
 }
@@ -467,7 +481,18 @@ __global__ __launch_bounds__(kBlock) void filter_big_records_kernel(const Filter
 #define PST_FILTER_STREAM_CAP 1280  // (at density 0.5 a tile has 1024 +- 23 matches: 1024 sent half the tiles through a second round)
 #endif
 constexpr uint32_t kStreamThreads = 512, kStreamCap = PST_FILTER_STREAM_CAP;
-__global__ __launch_bounds__(kStreamThreads) void filter_big_records_stream_kernel(const FilterArgs a) {
+// DST_COLUMNS: the same read side and ranks for a columnar target of the same attribute sizes -- the LDS tile is then five column spans
+// (each with the 16-byte phase of its target span), a selected point's values go to index `rank` of every span with naturally aligned
+// LDS stores (no record image), and the spans leave one after the other with 16-byte stores.
+constexpr uint32_t kStreamColSize[5] = {8, 6, 24, 1, 2};
+__host__ __device__ constexpr uint32_t stream_col_region(int a) {  // LDS offset of column span a (multiples of 16; 16 bytes of slack for the phase)
+  uint32_t o = 0;
+  for (int i = 0; i < a; ++i) o += kStreamCap * kStreamColSize[i] + 16u;
+  return o;
+}
+static_assert(kStreamCap % 16 == 0, "column spans start on 16-byte boundaries");
+template <bool DST_COLUMNS, bool ALIGNED_IMAGES = false>
+__global__ __launch_bounds__(kStreamThreads) void filter_big_stream_kernel(const FilterArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   lptr_t lds = (lptr_t)lds_raw;
   __shared__ uint32_t wave_tot[kStreamThreads / 64];
@@ -549,28 +574,58 @@ __global__ __launch_bounds__(kStreamThreads) void filter_big_records_stream_kern
   };
   for (uint32_t base = 0; base < m; base += kStreamCap) {
     const uint32_t cm = (m - base) < kStreamCap ? (m - base) : kStreamCap;
-    const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
-    const uint32_t mis = (uint32_t)(ga & 15u);
-    uint32_t r = r0;
+    if constexpr (DST_COLUMNS) {
+      uint64_t ga[5];
+      uint32_t mis[5];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-      const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
-      if (on && r >= base && r < base + cm) {
-        pstlas::RecordImage<STRIDE> img;
-        img.put(0, 8, (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
-        img.put(8, 6, colour(i));
-        img.put(14, 8, (uint64_t)wp[6 * i] | ((uint64_t)wp[6 * i + 1] << 32));
-        img.put(22, 8, (uint64_t)wp[6 * i + 2] | ((uint64_t)wp[6 * i + 3] << 32));
-        img.put(30, 8, (uint64_t)wp[6 * i + 4] | ((uint64_t)wp[6 * i + 5] << 32));
-        img.put(38, 1, (wcl >> (8u * i)) & 0xFFu);
-        img.put(39, 2, (wi[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu);
-        img.store(lds + (mis + (r - base) * STRIDE));
+      for (int q = 0; q < 5; ++q) { ga[q] = a.attrs[q].dst + (out0 + base) * kStreamColSize[q]; mis[q] = (uint32_t)(ga[q] & 15u); }
+      uint32_t r = r0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+        if (on && r >= base && r < base + cm) {
+          const uint32_t j = r - base;
+          store_un<uint64_t>(lds + (stream_col_region(0) + mis[0] + j * 8u), (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
+          const uint64_t cv = colour(i);
+          store_un<uint32_t>(lds + (stream_col_region(1) + mis[1] + j * 6u), (uint32_t)cv);
+          store_un<uint16_t>(lds + (stream_col_region(1) + mis[1] + j * 6u + 4u), (uint16_t)(cv >> 32));
+#pragma unroll
+          for (uint32_t q = 0; q < 3; ++q)
+            store_un<uint64_t>(lds + (stream_col_region(2) + mis[2] + j * 24u + 8u * q), (uint64_t)wp[6 * i + 2 * q] | ((uint64_t)wp[6 * i + 2 * q + 1] << 32));
+          store_un<uint8_t>(lds + (stream_col_region(3) + mis[3] + j), (uint8_t)(wcl >> (8u * i)));
+          store_un<uint16_t>(lds + (stream_col_region(4) + mis[4] + j * 2u), (uint16_t)(wi[i >> 1] >> (16u * (i & 1u))));
+        }
+        r += on ? 1u : 0u;
       }
-      r += on ? 1u : 0u;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 5; ++q) tile_store<kStreamThreads>(lds + stream_col_region(q), as_global(ga[q] - mis[q]), mis[q], cm * kStreamColSize[q]);
+      if (base + kStreamCap < m) __syncthreads();
+    } else {
+      const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
+      const uint32_t mis = (uint32_t)(ga & 15u);
+      uint32_t r = r0;
+#pragma unroll
+      for (uint32_t i = 0; i < 4; ++i) {
+        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+        if (on && r >= base && r < base + cm) {
+          pstlas::RecordImage<STRIDE> img;
+          img.put(0, 8, (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
+          img.put(8, 6, colour(i));
+          img.put(14, 8, (uint64_t)wp[6 * i] | ((uint64_t)wp[6 * i + 1] << 32));
+          img.put(22, 8, (uint64_t)wp[6 * i + 2] | ((uint64_t)wp[6 * i + 3] << 32));
+          img.put(30, 8, (uint64_t)wp[6 * i + 4] | ((uint64_t)wp[6 * i + 5] << 32));
+          img.put(38, 1, (wcl >> (8u * i)) & 0xFFu);
+          img.put(39, 2, (wi[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu);
+          if constexpr (ALIGNED_IMAGES) img.store_aligned(lds + (mis + (r - base) * STRIDE));
+          else img.store(lds + (mis + (r - base) * STRIDE));
+        }
+        r += on ? 1u : 0u;
+      }
+      __syncthreads();
+      tile_store<kStreamThreads>(lds, as_global(ga - mis), mis, cm * STRIDE);
+      if (base + kStreamCap < m) __syncthreads();
     }
-    __syncthreads();
-    tile_store<kStreamThreads>(lds, as_global(ga - mis), mis, cm * STRIDE);
-    if (base + kStreamCap < m) __syncthreads();
   }
 }
 
@@ -663,6 +718,17 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
     static const bool static_plans = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
     // interleaved targets only: same-box A/B 0.6075 -> 0.6267 of peak; the columnar target LOST with constants (0.663 -> 0.626) and stays interpreted
     if (g == 0) reset_plan_kinds();
+    // columnar target of the bench layout's attribute sizes (round 4): the streaming read side with column spans in LDS; PST_FILTER_COLS_STREAM=0
+    // is the gather form (filter_scatter_kernel).  Same-box A/B, 10^8 points, density 0.5: 0.646 -> 0.710 of peak (1.235 -> 1.126 ms).
+    static const bool cols_stream = [] { const char* v = std::getenv("PST_FILTER_COLS_STREAM"); return !(v && *v == '0'); }();
+    if (static_plans && cols_stream && !dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, false)) {
+      note_plan_kind(PST_PLAN_STATIC);
+      const size_t lds_cs = stream_col_region(5);
+      if (lds_cs > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)filter_big_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cs);
+      hipLaunchKernelGGL((filter_big_stream_kernel<true, false>), dim3(n_tiles), dim3(kStreamThreads), lds_cs, stream, a);
+      continue;
+    }
     if (static_plans && dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, dst_aos)) {
       note_plan_kind(PST_PLAN_STATIC);
       // point-major record assembly (filter_big_records_kernel): same-box A/B against the granule-major constants 0.657 -> 0.673 of peak
@@ -670,7 +736,11 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
       static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 2; }();
       if (pm == 2) {  // streaming form (round 4): PST_FILTER_PM=1 is the gather form, 0 the granule-major constants
         const size_t lds_st = (size_t)kStreamCap * 41 + 64;
-        hipLaunchKernelGGL(filter_big_records_stream_kernel, dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
+        // record images written with naturally aligned LDS stores only (RecordImage::store_aligned): same-box A/B 0.690 -> 0.693 of peak -- the
+        // unaligned dword stores of a 41-byte record stride are NOT what holds this kernel's issue back; PST_FILTER_IMG_ALIGNED=0 is the plain form
+        static const bool aligned_images = [] { const char* v = std::getenv("PST_FILTER_IMG_ALIGNED"); return !(v && *v == '0'); }();
+        if (aligned_images) hipLaunchKernelGGL((filter_big_stream_kernel<false, true>), dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
+        else hipLaunchKernelGGL((filter_big_stream_kernel<false, false>), dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
       } else if (pm) {
         FilterArgs b = a;
         b.chunk = filter_chunk(dst_stride, 24L * 1024L);

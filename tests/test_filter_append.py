@@ -170,3 +170,22 @@ def test_filter_into_async_matches_the_synchronous_call(hip):
         tiny.resize(k - 1)
         with pytest.raises(PasturePanic, match="at least as large as the number of predicate matches"):
             src.filter_into_async(tiny, mask.data_ptr(), k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density", [0.5, 1.0, 0.02, 0.0])
+def test_filter_big_layout_takes_the_streaming_kernels(hip, density):
+    """CustomPointTypeBig columns (buffer_filter_bench.rs:71-74) into both target kinds run on the streaming compaction kernels (plan family
+    "static"): several tiles, a ragged last one, tiles with more matches than one LDS round holds (density 1.0), empty tiles (0.02, 0.0)."""
+    from pasture_amd import conversion as cv
+    layout = custom_point_type_big(hip)
+    n = 300_007
+    rec = random_records(layout, n, 21)
+    mask = np.random.default_rng(22).random(n) < density
+    src = HashMapBuffer.from_numpy(rec, layout)
+    for kind in (HashMapBuffer, VectorBuffer):
+        out = src.filter(kind, mask)
+        if mask.any():
+            assert cv.last_plan_kinds(hip) == ["static"], (kind.__name__, cv.last_plan_kinds(hip))
+        assert out.len() == int(mask.sum())
+        assert_same(out, rec[mask])

@@ -1,10 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04
-timeout 900 python bench.py --gpus 8 --rehearse-on-one-gpu --steps 5 --warmup 2 --no-cpu-baseline --no-north-star --points 12500000 --configs3-points 1000000000 2>gpurun_out/r04/rehearsal_8.err | tail -1 > gpurun_out/r04/r04_rehearsal_8ranks_one_gpu.json
-tail -3 gpurun_out/r04/rehearsal_8.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r04/r04_rehearsal_8ranks_one_gpu.json'))
-print(d['n_gpus'], d['config'].get('rehearsal'), d['self_check'], d['per_rank'])
-print(d['configs3_1e9']['self_check'], d['configs3_1e9']['points_rank0'], d['configs3_1e9']['bounds'])
-PY
+timeout 900 python -m pytest tests -m gpu -x -q -k "filter" 2>&1 | tail -2
+PST_FILTER_IMG_ALIGNED=1 timeout 900 python -m pytest tests -m gpu -x -q -k "filter" 2>&1 | tail -2
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2 3; do
+  for v in 0 1; do
+    PST_FILTER_IMG_ALIGNED=$v python bench.py --no-cpu-baseline --no-north-star --workload filter_big_interleaved --plan specialised --steps 20 --warmup 5 2>/dev/null | tail -1 | line "interleaved ALIGNED=$v"
+  done
+  for v in 0 1; do
+    PST_FILTER_COLS_STREAM=$v python bench.py --no-cpu-baseline --no-north-star --workload filter_big_columnar --plan specialised --steps 20 --warmup 5 2>/dev/null | tail -1 | line "columnar COLS_STREAM=$v"
+  done
+done

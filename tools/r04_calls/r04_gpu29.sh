@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-( time PST_JIT=sync timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_buffer_converter.py tests/test_las_golden.py tests/test_las_encode.py tests/test_slices_centroid_views.py tests/test_filter_append.py tests/test_jit.py -m gpu -q -x 2>&1 | grep -E "passed|failed|FAILED|Error" ) 2>&1 | tail -8
+export TMPDIR=/tmp
+d=gpurun_out/prof/scan; mkdir -p $d
+timeout 600 rocprofv3 --kernel-trace --stats -d $d -o bench -- python bench.py --no-cpu-baseline --no-north-star --workload filter_big_columnar --steps 10 --warmup 2 > $d/bench.log 2>&1
 python - <<'PY'
-import sys, os
-sys.path.insert(0, os.getcwd())
-import pasture_amd as pa
-from pasture_amd import conversion as cv
-print("jit stats of this process (none expected):", cv.jit_stats(pa.product_api()))
+import sqlite3
+cur = sqlite3.connect("gpurun_out/prof/scan/bench_results.db").cursor()
+for r in cur.execute("select name, average from top_kernels where name like '%tile_scan%' or name like '%mask_count%' or name like '%filter_big%'"): print(r)
 PY
-ls ~/.cache/pasture_amd 2>/dev/null | wc -l
+rm -rf gpurun_out/prof/scan
