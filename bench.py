@@ -61,6 +61,11 @@ WORKLOADS = {
     "filter_big_columnar": (63.5, "HashMapBuffer::filter_into, CustomPointTypeBig (41 B, 5 attrs) columnar -> columnar, random mask density 0.5 "
                                   "resident in HBM (2 mask reads + 41 R + 20.5 W per input point)"),
     "filter_big_interleaved": (63.5, "buffer_filter_bench: HashMapBuffer::filter_into, CustomPointTypeBig columnar -> VectorBuffer, density 0.5"),
+    "filter_las0_columnar": (54.5, "HashMapBuffer::filter_into, typed LAS-0 points (35 B, 10 attrs) columnar -> columnar, density 0.5 (2 mask reads + 35 R + 17.5 W); "
+                                   "config.plan says which kernel family ran (--plan interpreted = the gather kernels)"),
+    "filter_las0_interleaved": (54.5, "the same into a VectorBuffer of LasPointFormat0"),
+    "filter_las3_columnar": (75.5, "typed LAS-3 points (49 B, 12 attrs) columnar -> columnar, density 0.5: a layout without an in-tree kernel (run-time compiled)"),
+    "filter_las3_interleaved": (75.5, "the same into a VectorBuffer of LasPointFormat3"),
     "voxelgrid_xyz": (24, "voxelgrid_filter, columnar POSITION_3D, leaf 2.5 (about 15 points per voxel): keys + radix sort + run-length + "
                           "per-voxel sequential centroid sums (sort-bound; 24 B/pt is only the unavoidable read)"),
     "voxelgrid_xyz_async": (24, "the same through pst_voxelgrid_filter_async (round 4): planned once, then bounds + markers + keys + sort + run heads + "
@@ -438,8 +443,11 @@ def main():
 
         def step():
             las.encode_points(src, 0, (0.001, 0.001, 0.001), (0.0, 0.0, 0.0), dst)
-    elif args.workload.startswith("filter_big"):
-        big = pa.PointLayout.from_attributes_packed([A.GPS_TIME, A.COLOR_RGB, A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY.with_custom_datatype(T.I16)], 1)
+    elif args.workload.startswith("filter_"):
+        if args.workload.startswith("filter_big"):
+            big = pa.PointLayout.from_attributes_packed([A.GPS_TIME, A.COLOR_RGB, A.POSITION_3D, A.CLASSIFICATION, A.INTENSITY.with_custom_datatype(T.I16)], 1)
+        else:
+            big = las.point_layout_from_las_point_format(las.Format(int(args.workload[len("filter_las")])), False)
         src = pa.HashMapBuffer.new_from_layout(big)
         src.resize(n)
         src.synth_fill(SEED, first_index)
@@ -457,6 +465,11 @@ def main():
 
         def step():
             src.filter_into_async(dst, mask.data_ptr(), k, hits.data_ptr())
+
+        if args.plan != "interpreted":  # a layout without an in-tree streaming kernel: compiled now, before the timed region
+            cv.jit_set_mode("sync")
+            step()
+            cv.jit_set_mode("env")
 
         def after():
             assert int(hits.item()) == k, (int(hits.item()), k)

@@ -8,8 +8,9 @@
 //
 //   mask_count_kernel     one tile of the mask per block: number of non-zero bytes                (1 B/pt read)
 //   tile_scan_kernel      exclusive scan of the tile counts (one block; <= 10^5 values)           (negligible)
-//   filter_big_stream_kernel  (the bench layout's attribute sizes, either target kind) the columns are READ like a conversion reads them -- a
-//                         lane owns four consecutive points -- and selected points go to an LDS record tile / to LDS column spans at their rank
+//   filter_stream_body<P> (filter_stream.hpp; any layout of at most 64 bytes per point, either target kind) the columns are READ like a
+//                         conversion reads them -- a lane owns four consecutive points -- and selected points go to an LDS record tile / to LDS
+//                         column spans at their rank; P in-tree for the bench layout and typed LAS-0 points, otherwise compiled at run time
 //   filter_scatter_kernel per tile: selected local indices compacted into LDS (order preserved), then attribute by
 //                         attribute: gather from the source columns, store to the tile's contiguous output span —
 //                         columnar targets directly (coalesced, narrow values packed four/two per dword), interleaved
@@ -19,9 +20,14 @@
 #include "kernels.hpp"
 #include "las_device.hpp"
 #include "tile_io.hpp"
+#include "filter_stream.hpp"
 
 #include <algorithm>
 #include <cstdlib>
+#include <sstream>
+#include <string>
+
+#include "jit.hpp"
 
 using namespace pstd;
 
@@ -117,32 +123,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
   if (threadIdx.x == 0) { offsets[n_tiles] = carry; if (total_also) *total_also = carry; }
 }
 
-constexpr int kMaxFilterAttrs = 32;
-
-struct FilterAttr {
-  uint64_t src;         // address of the attribute of source point 0
-  uint64_t dst;         // columnar target: address of the attribute of target point 0; interleaved: unused
-  uint32_t src_stride;  // bytes between consecutive source points
-  uint32_t dst_off;     // interleaved target: offset inside the record
-  uint32_t unit;        // copy granule: largest of 16/8/4/2/1 dividing the attribute size
-  uint32_t cnt;         // granules per value
-};
-
-struct FilterArgs {
-  const uint8_t* mask;
-  const uint32_t* counts;
-  const unsigned long long* offsets;
-  uint64_t n;
-  uint64_t limit;       // never write target points >= limit (num_matches of the reference)
-  uint64_t dst_aos;     // interleaved target: address of record 0
-  uint32_t dst_stride;  // interleaved target: record size
-  uint32_t tile;
-  uint32_t n_attrs;
-  uint32_t dst_covered;  // interleaved target: attributes cover every byte of the record (no read-modify-write needed)
-  uint32_t chunk;        // interleaved target: records per LDS chunk (multiple of 16)
-  uint32_t reserved;
-  FilterAttr attrs[kMaxFilterAttrs];
-};
+using pstf::kMaxFilterAttrs;
+using pstf::FilterAttr;
+using pstf::FilterArgs;
 
 template <typename U>
 __device__ __forceinline__ void copy_granules(const FilterAttr& a, const uint16_t* sel, uint64_t first, uint64_t out0, uint32_t m, bool dst_aos, lptr_t lds,
@@ -212,10 +195,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DST_AOS 
   lptr_t lds = (lptr_t)lds_raw + ((a.tile * 2u + 15u) & ~15u);  // interleaved target: record tile
   __shared__ uint32_t wave_tot[kBlock / 64];
 
-  const uint64_t first = (uint64_t)blockIdx.x * a.tile;
+  const uint32_t tile_id = blockIdx.x + a.tile0;
+  const uint64_t first = (uint64_t)tile_id * a.tile;
   const uint32_t cnt = (uint32_t)((a.n - first) < a.tile ? (a.n - first) : a.tile);
-  const uint64_t out0 = a.offsets[blockIdx.x];
-  uint32_t m = a.counts[blockIdx.x];
+  const uint64_t out0 = a.offsets[tile_id];
+  uint32_t m = a.counts[tile_id];
   if (m == 0 || out0 >= a.limit) return;
 
   // ranks: lane t owns the PPL consecutive points t*PPL ..
@@ -471,164 +455,6 @@ __global__ __launch_bounds__(kBlock) void filter_big_records_kernel(const Filter
   }
 }
 
-// Streaming form for the same layout (round 4).  The gather above issues seven loads per SELECTED point at scattered indices -- but at the
-// densities a filter is used at, every cache line of the columns is touched anyway (density 0.5: every other point), so the columns can be READ
-// like a conversion reads them: a lane owns four consecutive points and fetches their 32 + 24 + 96 + 4 + 8 bytes with eleven vector loads
-// (lane-contiguous across the wave), all in flight before the ranks are known.  Selected points become 41-byte record images in registers and are
-// written to the LDS record tile at their rank; the tile leaves with 16-byte stores.  512 lanes x 4 points = the 2048-point tile of the count /
-// scan kernels; the record tile holds kStreamCap records, a tile with more matches takes another round over the same registers.
-#ifndef PST_FILTER_STREAM_CAP
-#define PST_FILTER_STREAM_CAP 1280  // (at density 0.5 a tile has 1024 +- 23 matches: 1024 sent half the tiles through a second round)
-#endif
-constexpr uint32_t kStreamThreads = 512, kStreamCap = PST_FILTER_STREAM_CAP;
-// DST_COLUMNS: the same read side and ranks for a columnar target of the same attribute sizes -- the LDS tile is then five column spans
-// (each with the 16-byte phase of its target span), a selected point's values go to index `rank` of every span with naturally aligned
-// LDS stores (no record image), and the spans leave one after the other with 16-byte stores.
-constexpr uint32_t kStreamColSize[5] = {8, 6, 24, 1, 2};
-__host__ __device__ constexpr uint32_t stream_col_region(int a) {  // LDS offset of column span a (multiples of 16; 16 bytes of slack for the phase)
-  uint32_t o = 0;
-  for (int i = 0; i < a; ++i) o += kStreamCap * kStreamColSize[i] + 16u;
-  return o;
-}
-static_assert(kStreamCap % 16 == 0, "column spans start on 16-byte boundaries");
-template <bool DST_COLUMNS, bool ALIGNED_IMAGES = false>
-__global__ __launch_bounds__(kStreamThreads) void filter_big_stream_kernel(const FilterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-  lptr_t lds = (lptr_t)lds_raw;
-  __shared__ uint32_t wave_tot[kStreamThreads / 64];
-  constexpr uint32_t STRIDE = 41;
-  const uint64_t first = (uint64_t)blockIdx.x * 2048u;
-  const uint32_t cnt = (uint32_t)((a.n - first) < 2048u ? (a.n - first) : 2048u);
-  const uint64_t out0 = a.offsets[blockIdx.x];
-  uint32_t m = a.counts[blockIdx.x];
-  if (m == 0 || out0 >= a.limit) return;
-  if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
-  const uint32_t p0 = threadIdx.x * 4u;
-  cgptr_t mp = (cgptr_t)((uint64_t)(uintptr_t)a.mask + first);
-  cgptr_t gps = (cgptr_t)as_global(a.attrs[0].src) + first * 8, col = (cgptr_t)as_global(a.attrs[1].src) + first * 6, pos = (cgptr_t)as_global(a.attrs[2].src) + first * 24,
-          cls = (cgptr_t)as_global(a.attrs[3].src) + first, inten = (cgptr_t)as_global(a.attrs[4].src) + first * 2;
-  // the lane's four points, as byte strings: gps 32 B, colour 24 B, position 96 B, classification 4 B, intensity 8 B
-  uint32_t wg[8], wc[6], wp[24], wcl = 0, wi[2] = {0, 0}, mw = 0;
-  if (p0 + 4u <= cnt) {
-    mw = load_un<uint32_t>(mp + p0);
-    const u32x4 g0 = load_un<u32x4>(gps + p0 * 8u), g1 = load_un<u32x4>(gps + p0 * 8u + 16);
-    const u32x4 c0 = load_un<u32x4>(col + p0 * 6u);
-    const uint64_t c1 = load_un<uint64_t>(col + p0 * 6u + 16);
-    u32x4 pv[6];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) pv[q] = load_un<u32x4>(pos + p0 * 24u + 16u * q);
-    wcl = load_un<uint32_t>(cls + p0);
-    const uint64_t iv = load_un<uint64_t>(inten + p0 * 2u);
-    wg[0] = g0.x; wg[1] = g0.y; wg[2] = g0.z; wg[3] = g0.w; wg[4] = g1.x; wg[5] = g1.y; wg[6] = g1.z; wg[7] = g1.w;
-    wc[0] = c0.x; wc[1] = c0.y; wc[2] = c0.z; wc[3] = c0.w; wc[4] = (uint32_t)c1; wc[5] = (uint32_t)(c1 >> 32);
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { wp[4 * q] = pv[q].x; wp[4 * q + 1] = pv[q].y; wp[4 * q + 2] = pv[q].z; wp[4 * q + 3] = pv[q].w; }
-    wi[0] = (uint32_t)iv; wi[1] = (uint32_t)(iv >> 32);
-  } else {  // the cloud's last, partly filled tile: point by point
-#pragma unroll
-    for (int q = 0; q < 8; ++q) wg[q] = 0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) wc[q] = 0;
-#pragma unroll
-    for (int q = 0; q < 24; ++q) wp[q] = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; ++i) {
-      if (p0 + i < cnt) {
-        const uint32_t pi = p0 + i;
-        mw |= (uint32_t)mp[pi] << (8u * i);
-        const uint64_t g = load_un<uint64_t>(gps + pi * 8u);
-        wg[2 * i] = (uint32_t)g; wg[2 * i + 1] = (uint32_t)(g >> 32);
-        const uint64_t c = (uint64_t)load_un<uint32_t>(col + pi * 6u) | ((uint64_t)load_un<uint16_t>(col + pi * 6u + 4) << 32);
-        // colour i occupies bytes [6 i, 6 i + 6) of the 24-byte string
-        const uint32_t bo = 6u * i, wi0 = bo >> 2, sh = (bo & 3u) * 8u;
-        wc[wi0] |= (uint32_t)(c << sh);
-        if (wi0 + 1 < 6) wc[wi0 + 1] |= (uint32_t)(sh ? (c >> (32u - sh)) : (c >> 32));
-#pragma unroll
-        for (uint32_t q = 0; q < 6; ++q) wp[6 * i + q] = load_un<uint32_t>(pos + pi * 24u + 4u * q);
-        wcl |= (uint32_t)load_un<uint8_t>(cls + pi) << (8u * i);
-        wi[i >> 1] |= (uint32_t)load_un<uint16_t>(inten + pi * 2u) << (16u * (i & 1u));
-      }
-    }
-  }
-  // ranks: matches before this lane's points, within the tile
-  uint32_t c = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < 4; ++i) c += ((mw >> (8u * i)) & 0xFFu) != 0u;
-  uint32_t incl = c;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-    if ((int)lane >= off) incl += o;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t r0 = incl - c;
-  for (uint32_t w = 0; w < wave; ++w) r0 += wave_tot[w];
-  // record images of the lane's four points (compile-time offsets into the byte strings)
-  auto colour = [&](uint32_t i) __attribute__((always_inline)) -> uint64_t {  // 6 bytes at byte 6 i of wc
-    const uint32_t bo = 6u * i, w0 = bo >> 2, sh = (bo & 3u) * 8u;
-    uint64_t v = (uint64_t)wc[w0] >> sh;
-    if (w0 + 1 < 6) v |= sh ? ((uint64_t)wc[w0 + 1] << (32u - sh)) : ((uint64_t)wc[w0 + 1] << 32);
-    return v & 0xFFFFFFFFFFFFull;
-  };
-  for (uint32_t base = 0; base < m; base += kStreamCap) {
-    const uint32_t cm = (m - base) < kStreamCap ? (m - base) : kStreamCap;
-    if constexpr (DST_COLUMNS) {
-      uint64_t ga[5];
-      uint32_t mis[5];
-#pragma unroll
-      for (int q = 0; q < 5; ++q) { ga[q] = a.attrs[q].dst + (out0 + base) * kStreamColSize[q]; mis[q] = (uint32_t)(ga[q] & 15u); }
-      uint32_t r = r0;
-#pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) {
-        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
-        if (on && r >= base && r < base + cm) {
-          const uint32_t j = r - base;
-          store_un<uint64_t>(lds + (stream_col_region(0) + mis[0] + j * 8u), (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
-          const uint64_t cv = colour(i);
-          store_un<uint32_t>(lds + (stream_col_region(1) + mis[1] + j * 6u), (uint32_t)cv);
-          store_un<uint16_t>(lds + (stream_col_region(1) + mis[1] + j * 6u + 4u), (uint16_t)(cv >> 32));
-#pragma unroll
-          for (uint32_t q = 0; q < 3; ++q)
-            store_un<uint64_t>(lds + (stream_col_region(2) + mis[2] + j * 24u + 8u * q), (uint64_t)wp[6 * i + 2 * q] | ((uint64_t)wp[6 * i + 2 * q + 1] << 32));
-          store_un<uint8_t>(lds + (stream_col_region(3) + mis[3] + j), (uint8_t)(wcl >> (8u * i)));
-          store_un<uint16_t>(lds + (stream_col_region(4) + mis[4] + j * 2u), (uint16_t)(wi[i >> 1] >> (16u * (i & 1u))));
-        }
-        r += on ? 1u : 0u;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 5; ++q) tile_store<kStreamThreads>(lds + stream_col_region(q), as_global(ga[q] - mis[q]), mis[q], cm * kStreamColSize[q]);
-      if (base + kStreamCap < m) __syncthreads();
-    } else {
-      const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
-      const uint32_t mis = (uint32_t)(ga & 15u);
-      uint32_t r = r0;
-#pragma unroll
-      for (uint32_t i = 0; i < 4; ++i) {
-        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
-        if (on && r >= base && r < base + cm) {
-          pstlas::RecordImage<STRIDE> img;
-          img.put(0, 8, (uint64_t)wg[2 * i] | ((uint64_t)wg[2 * i + 1] << 32));
-          img.put(8, 6, colour(i));
-          img.put(14, 8, (uint64_t)wp[6 * i] | ((uint64_t)wp[6 * i + 1] << 32));
-          img.put(22, 8, (uint64_t)wp[6 * i + 2] | ((uint64_t)wp[6 * i + 3] << 32));
-          img.put(30, 8, (uint64_t)wp[6 * i + 4] | ((uint64_t)wp[6 * i + 5] << 32));
-          img.put(38, 1, (wcl >> (8u * i)) & 0xFFu);
-          img.put(39, 2, (wi[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu);
-          if constexpr (ALIGNED_IMAGES) img.store_aligned(lds + (mis + (r - base) * STRIDE));
-          else img.store(lds + (mis + (r - base) * STRIDE));
-        }
-        r += on ? 1u : 0u;
-      }
-      __syncthreads();
-      tile_store<kStreamThreads>(lds, as_global(ga - mis), mis, cm * STRIDE);
-      if (base + kStreamCap < m) __syncthreads();
-    }
-  }
-}
-
 template <typename SP>
 static bool filter_plan_equals(const FilterArgs& a, bool dst_aos) {
   if (a.n_attrs != (uint32_t)SP::n || a.tile != 2048u) return false;
@@ -638,6 +464,133 @@ static bool filter_plan_equals(const FilterArgs& a, bool dst_aos) {
     if (a.attrs[i].src_stride != s.src_stride || a.attrs[i].unit != s.unit || a.attrs[i].cnt != s.cnt || (dst_aos && a.attrs[i].dst_off != s.dst_off)) return false;
   }
   return true;
+}
+
+
+// ---- plan-specialised streaming compaction (filter_stream.hpp): in-tree for typed LAS-0 points, run-time compiled for every other layout ------
+struct StreamSig {
+  int n = 0;
+  bool dst_columns = true;
+  uint32_t dst_stride = 0, cap = 0, total = 0;
+  uint32_t size[kMaxFilterAttrs] = {}, dst_off[kMaxFilterAttrs] = {};
+};
+// points per LDS round: about 52 KiB of values (three 512-lane blocks per CU), a multiple of 16
+__host__ __device__ constexpr uint32_t stream_cap_for(uint32_t total) {
+  uint32_t c = (52u * 1024u / (total ? total : 1u)) / 16u * 16u;
+  return c > 2048u ? 2048u : c;
+}
+// Can this launch take a streaming kernel?  Columnar source (every attribute contiguous), at most 64 bytes per point (the lane holds four points
+// in registers), packed records whose every byte is written / target columns that start on a multiple of their values' aligned piece.
+static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* sig) {
+  if (a.tile != pstf::kStreamTile || a.n_attrs == 0 || a.n_attrs > (uint32_t)kMaxFilterAttrs) return false;
+  sig->n = (int)a.n_attrs;
+  sig->dst_columns = !dst_aos;
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < a.n_attrs; ++i) {
+    const uint32_t size = a.attrs[i].unit * a.attrs[i].cnt;
+    if (size == 0 || a.attrs[i].src_stride != size) return false;
+    if (!dst_aos && a.attrs[i].dst % pstf::piece_of(size) != 0) return false;
+    sig->size[i] = size;
+    sig->dst_off[i] = dst_aos ? a.attrs[i].dst_off : 0u;
+    total += size;
+  }
+  if (total > 64u) return false;
+  if (dst_aos && (!a.dst_covered || a.dst_stride != total)) return false;
+  sig->dst_stride = dst_aos ? a.dst_stride : 0u;
+  sig->total = total;
+  sig->cap = stream_cap_for(total);
+  return true;
+}
+// the translation unit hipRTC compiles for `sig` (also the cache key)
+static std::string stream_source(const StreamSig& s) {
+  std::ostringstream o;
+  o << "#include \"filter_stream.hpp\"\n";
+  o << "struct PstFilterPlan {\n";
+  o << "  static constexpr int n = " << s.n << ";\n";
+  o << "  static constexpr bool dst_columns = " << (s.dst_columns ? "true" : "false") << ";\n";
+  o << "  static constexpr uint32_t dst_stride = " << s.dst_stride << ", cap = " << s.cap << ";\n";
+  o << "  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {";
+  for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.size[i];
+  o << "};\n    return t[k];\n  }\n";
+  o << "  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {";
+  for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.dst_off[i];
+  o << "};\n    return t[k];\n  }\n};\n";
+  o << "extern \"C\" __global__ __launch_bounds__(" << pstf::kStreamThreads << ") void pst_jit_filter(const pstf::FilterArgs a) {\n";
+  o << "  pstf::filter_stream_body<PstFilterPlan>(a);\n}\n";
+  return o.str();
+}
+
+// typed LAS-0 points (LasPointFormat0::layout(), las_types.rs: Position3D, Intensity, ReturnNumber, NumberOfReturns, ScanDirectionFlag,
+// EdgeOfFlightLine, Classification, ScanAngleRank, UserData, PointSourceID; 35 bytes packed): the cloud a pasture user filters most often
+template <bool COLUMNS>
+struct Las0StreamPlan {
+  static constexpr int n = 10;
+  static constexpr bool dst_columns = COLUMNS;
+  static constexpr uint32_t dst_stride = COLUMNS ? 0u : 35u, cap = stream_cap_for(35u);
+  __host__ __device__ static constexpr uint32_t size(int k) {
+    constexpr uint32_t t[n] = {24, 2, 1, 1, 1, 1, 1, 1, 1, 2};
+    return t[k];
+  }
+  __host__ __device__ static constexpr uint32_t dst_off(int k) {
+    constexpr uint32_t t[n] = {0, 24, 26, 27, 28, 29, 30, 31, 32, 33};
+    return COLUMNS ? 0u : t[k];
+  }
+};
+// CustomPointTypeBig (test_utils.rs:19-31; buffer_filter_bench.rs:71-74): GpsTime, ColorRGB, Position3D, Classification, Intensity (i16); 41 bytes
+template <bool COLUMNS>
+struct BigStreamPlan {
+  static constexpr int n = 5;
+  static constexpr bool dst_columns = COLUMNS;
+  static constexpr uint32_t dst_stride = COLUMNS ? 0u : 41u, cap = stream_cap_for(41u);
+  __host__ __device__ static constexpr uint32_t size(int k) {
+    constexpr uint32_t t[n] = {8, 6, 24, 1, 2};
+    return t[k];
+  }
+  __host__ __device__ static constexpr uint32_t dst_off(int k) {
+    constexpr uint32_t t[n] = {0, 8, 14, 38, 39};
+    return COLUMNS ? 0u : t[k];
+  }
+};
+template <typename P>
+__global__ __launch_bounds__(pstf::kStreamThreads) void filter_stream_static_kernel(const FilterArgs a) { pstf::filter_stream_body<P>(a); }
+
+template <typename P>
+static bool stream_sig_is(const StreamSig& s) {
+  if (s.n != P::n || s.dst_columns != P::dst_columns || s.dst_stride != P::dst_stride || s.cap != P::cap) return false;
+  for (int i = 0; i < P::n; ++i)
+    if (s.size[i] != P::size(i) || s.dst_off[i] != P::dst_off(i)) return false;
+  return true;
+}
+template <typename P>
+static void launch_stream_static(unsigned grid, hipStream_t stream, const FilterArgs& a) {
+  constexpr uint32_t lds = pstf::stream_lds_bytes<P>();
+  auto kfn = filter_stream_static_kernel<P>;
+  if (lds > 64u * 1024u) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(pstf::kStreamThreads), lds, stream, a);
+}
+// The full tiles of the launch through a streaming kernel, if one is at hand (in-tree, compiled, or PST_JIT=sync); returns the number of tiles it
+// covered (0: none -- the caller takes the gather kernel for everything) and the plan family.
+static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream_t stream, uint32_t* kind) {
+  static const bool enabled = [] { const char* v = std::getenv("PST_FILTER_STREAM"); return !(v && *v == '0'); }();
+  static const bool in_tree = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
+  const uint64_t n_full = a.n / pstf::kStreamTile;
+  StreamSig sig;
+  const pstjit::Mode mode = pstjit::mode();
+  if (!enabled || mode == pstjit::Mode::Off || n_full == 0 || n_full > (1ull << 30) || !stream_sig_from_args(a, dst_aos, &sig)) return 0;
+  if (in_tree && stream_sig_is<BigStreamPlan<true>>(sig)) { launch_stream_static<BigStreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+  if (in_tree && stream_sig_is<BigStreamPlan<false>>(sig)) { launch_stream_static<BigStreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+  if (in_tree && stream_sig_is<Las0StreamPlan<true>>(sig)) { launch_stream_static<Las0StreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+  if (in_tree && stream_sig_is<Las0StreamPlan<false>>(sig)) { launch_stream_static<Las0StreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+  const std::string source = stream_source(sig);
+  const uint32_t lds = sig.dst_columns ? sig.total * sig.cap + 16u * (uint32_t)sig.n : sig.cap * sig.dst_stride + 64u;
+  const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait : a.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
+  pstjit::Kernel k;
+  if (!pstjit::acquire_source(source, "pst_jit_filter", pstf::kStreamThreads, lds, pstf::kStreamTile, how, &k)) return 0;  // not ready (or failed): gather
+  FilterArgs b = a;
+  void* args[] = {(void*)&b};
+  if (hipModuleLaunchKernel(k.fn, (unsigned)n_full, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  *kind = PST_PLAN_JIT;
+  return (uint32_t)n_full;
 }
 
 }  // namespace
@@ -715,33 +668,37 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
       (void)hipFuncSetAttribute((const void*)filter_scatter_kernel<PPL, AOS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
     hipLaunchKernelGGL((filter_scatter_kernel<PPL, AOS>), dim3(n_tiles), dim3(kBlock), lds_bytes, stream, a);                          \
   }
-    static const bool static_plans = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
-    // interleaved targets only: same-box A/B 0.6075 -> 0.6267 of peak; the columnar target LOST with constants (0.663 -> 0.626) and stays interpreted
     if (g == 0) reset_plan_kinds();
-    // columnar target of the bench layout's attribute sizes (round 4): the streaming read side with column spans in LDS; PST_FILTER_COLS_STREAM=0
-    // is the gather form (filter_scatter_kernel).  Same-box A/B, 10^8 points, density 0.5: 0.646 -> 0.710 of peak (1.235 -> 1.126 ms).
-    static const bool cols_stream = [] { const char* v = std::getenv("PST_FILTER_COLS_STREAM"); return !(v && *v == '0'); }();
-    if (static_plans && cols_stream && !dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, false)) {
-      note_plan_kind(PST_PLAN_STATIC);
-      const size_t lds_cs = stream_col_region(5);
-      if (lds_cs > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)filter_big_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cs);
-      hipLaunchKernelGGL((filter_big_stream_kernel<true, false>), dim3(n_tiles), dim3(kStreamThreads), lds_cs, stream, a);
-      continue;
+    // 1. the plan-specialised streaming kernel over the full tiles (filter_stream.hpp: in-tree for the bench layout and typed LAS-0 points,
+    //    run-time compiled for every other layout whose points fit four to a lane), the gather kernel for the ragged last tile.
+    //    PST_JIT=0 / pst_jit_set_mode(0) switches every plan-specialised kernel off, the in-tree ones included (bench.py --plan interpreted).
+    if (n_attrs <= kMaxFilterAttrs) {
+      uint32_t kind = 0;
+      const uint32_t covered = launch_stream_tiles(a, dst_aos, stream, &kind);
+      if (covered) {
+        note_plan_kind(kind);
+        if ((uint64_t)covered * tile < n) {
+          FilterArgs b = a;
+          b.tile0 = covered;
+          if (dst_aos) {
+            if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)filter_scatter_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL((filter_scatter_kernel<8, true>), dim3(1), dim3(kBlock), lds_bytes, stream, b);
+          } else {
+            hipLaunchKernelGGL((filter_scatter_kernel<8, false>), dim3(1), dim3(kBlock), lds_bytes, stream, b);
+          }
+        }
+        continue;
+      }
     }
+    // 2. (PST_FILTER_STREAM=0 only: the A/B forms of rounds 2-3) the bench layout into records with compile-time attribute lists on the GATHER
+    //    side: point-major record assembly (filter_big_records_kernel: same-box A/B against the granule-major constants 0.657 -> 0.673 of peak,
+    //    0.680 with a 24 KiB record tile), PST_FILTER_PM=0 the granule-major constants; the columnar target LOST with constants and has none.
+    static const bool static_plans_env = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
+    const bool static_plans = static_plans_env && pstjit::mode() != pstjit::Mode::Off;
     if (static_plans && dst_aos && n_attrs <= kMaxFilterAttrs && filter_plan_equals<BigFilterPlan>(a, dst_aos)) {
       note_plan_kind(PST_PLAN_STATIC);
-      // point-major record assembly (filter_big_records_kernel): same-box A/B against the granule-major constants 0.657 -> 0.673 of peak
-      // (PST_FILTER_PM=0 switches back), 0.680 with a 24 KiB record tile (8 / 16 / 24 / 32 KiB: 0.671 / 0.674 / 0.680 / 0.676)
-      static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 2; }();
-      if (pm == 2) {  // streaming form (round 4): PST_FILTER_PM=1 is the gather form, 0 the granule-major constants
-        const size_t lds_st = (size_t)kStreamCap * 41 + 64;
-        // record images written with naturally aligned LDS stores only (RecordImage::store_aligned): same-box A/B 0.690 -> 0.693 of peak -- the
-        // unaligned dword stores of a 41-byte record stride are NOT what holds this kernel's issue back; PST_FILTER_IMG_ALIGNED=0 is the plain form
-        static const bool aligned_images = [] { const char* v = std::getenv("PST_FILTER_IMG_ALIGNED"); return !(v && *v == '0'); }();
-        if (aligned_images) hipLaunchKernelGGL((filter_big_stream_kernel<false, true>), dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
-        else hipLaunchKernelGGL((filter_big_stream_kernel<false, false>), dim3(n_tiles), dim3(kStreamThreads), lds_st, stream, a);
-      } else if (pm) {
+      static const int pm = [] { const char* v = std::getenv("PST_FILTER_PM"); return v && *v ? std::atoi(v) : 1; }();
+      if (pm) {
         FilterArgs b = a;
         b.chunk = filter_chunk(dst_stride, 24L * 1024L);
         const size_t lds_pm = (((size_t)tile * 2 + 15) & ~(size_t)15) + (size_t)b.chunk * dst_stride + 48;

@@ -1,0 +1,219 @@
+// Streaming compaction with the attribute list as a compile-time constant (gfx950): HashMapBuffer::filter_into (point_buffer.rs:1082-1136) for
+// ANY columnar source whose attributes sum to at most 64 bytes, into columns or into packed records.
+//
+// filter.hip's gather kernels issue one load per granule of every SELECTED point.  At the densities a filter runs at every cache line of the
+// source columns is touched anyway, so the columns can be read like a conversion reads them (jit_quad.hpp): a lane owns four consecutive points
+// and fetches their 4 x size bytes per attribute with 16-byte vector loads, all in flight before the ranks are known; selected points go to LDS
+// at their rank -- one span per target column (naturally aligned pieces), or a record tile (a record image in registers, shifted to the dword
+// grid of its slot) -- and leave with 16-byte stores.  `filter_stream_body<P>` is instantiated over a plan type P: in-tree for the layouts of the
+// reference's filter bench and of typed LAS-0 points (filter.hip), and from source text compiled by hipRTC at run time for every other layout
+// (jit.cpp).  The kernel covers FULL 2048-point tiles; the host sends the ragged last tile through the gather kernel.
+//
+// P:  static constexpr int n;                         // attributes
+//     static constexpr bool dst_columns;              // columnar target (else packed records whose every byte some attribute writes)
+//     static constexpr uint32_t dst_stride, cap;      // record size of an interleaved target; points per LDS round (multiple of 16)
+//     static constexpr uint32_t size(int k), dst_off(int k);
+#pragma once
+#include "jit_quad.hpp"
+
+namespace pstf {
+
+using namespace pstd;
+
+constexpr int kMaxFilterAttrs = 32;
+
+struct FilterAttr {
+  uint64_t src;         // address of the attribute of source point 0
+  uint64_t dst;         // columnar target: address of the attribute of target point 0; interleaved: unused
+  uint32_t src_stride;  // bytes between consecutive source points
+  uint32_t dst_off;     // interleaved target: offset inside the record
+  uint32_t unit;        // copy granule: largest of 16/8/4/2/1 dividing the attribute size
+  uint32_t cnt;         // granules per value
+};
+
+struct FilterArgs {
+  const uint8_t* mask;
+  const uint32_t* counts;
+  const unsigned long long* offsets;
+  uint64_t n;
+  uint64_t limit;       // never write target points >= limit (num_matches of the reference)
+  uint64_t dst_aos;     // interleaved target: address of record 0
+  uint32_t dst_stride;  // interleaved target: record size
+  uint32_t tile;
+  uint32_t n_attrs;
+  uint32_t dst_covered;  // interleaved target: attributes cover every byte of the record (no read-modify-write needed)
+  uint32_t chunk;        // interleaved target: records per LDS chunk (multiple of 16)
+  uint32_t tile0;        // the launch's block 0 is tile `tile0` (the ragged last tile after the streaming kernel took the full ones)
+  FilterAttr attrs[kMaxFilterAttrs];
+};
+
+constexpr uint32_t kStreamThreads = 512, kStreamTile = 2048;
+
+template <typename P>
+__host__ __device__ constexpr uint32_t words_before(int k) {  // a lane's four values of attribute j are size(j) dwords
+  uint32_t o = 0;
+  for (int j = 0; j < k; ++j) o += P::size(j);
+  return o;
+}
+template <typename P>
+__host__ __device__ constexpr uint32_t span_before(int k) {  // LDS offset of column span k (multiples of 16; 16 bytes of slack for the span's phase)
+  uint32_t o = 0;
+  for (int j = 0; j < k; ++j) o += P::cap * P::size(j) + 16u;
+  return o;
+}
+template <typename P>
+__host__ __device__ constexpr uint32_t stream_lds_bytes() { return P::dst_columns ? span_before<P>(P::n) : P::cap * P::dst_stride + 64u; }
+// the widest naturally aligned piece a value of `size` bytes splits into when its column starts on a multiple of that piece
+__host__ __device__ constexpr uint32_t piece_of(uint32_t size) { return size % 8u == 0 ? 8u : size % 4u == 0 ? 4u : size % 2u == 0 ? 2u : 1u; }
+
+template <uint32_t NB> struct PieceType;
+template <> struct PieceType<1> { typedef uint8_t type; };
+template <> struct PieceType<2> { typedef uint16_t type; };
+template <> struct PieceType<4> { typedef uint32_t type; };
+template <> struct PieceType<8> { typedef uint64_t type; };
+
+template <typename P>
+__device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
+  using pstq::static_for;
+  extern __shared__ __attribute__((aligned(16))) uint8_t pstf_lds[];
+  lptr_t lds = (lptr_t)pstf_lds;
+  __shared__ uint32_t wave_tot[kStreamThreads / 64];
+  constexpr int W = (int)words_before<P>(P::n);
+  static_assert(P::cap % 16u == 0 && P::cap >= 16u, "column spans start on 16-byte boundaries");
+  const uint32_t tile = blockIdx.x;
+  const uint64_t first = (uint64_t)tile * kStreamTile;
+  const uint64_t out0 = a.offsets[tile];
+  uint32_t m = a.counts[tile];
+  if (m == 0 || out0 >= a.limit) return;
+  if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
+  const uint32_t p0 = threadIdx.x * 4u;
+  const uint32_t mw = load_un<uint32_t>((cgptr_t)((uint64_t)(uintptr_t)a.mask + first) + p0);
+  uint32_t w[W];  // the lane's four points, attribute after attribute: 4 x size(k) bytes = size(k) dwords each
+  static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+    constexpr int k = decltype(K)::value;
+    constexpr uint32_t S = P::size(k);
+    pstq::load_words<S, false>((cgptr_t)as_global(a.attrs[k].src) + (first + p0) * S, w, words_before<P>(k));
+  });
+  // ranks: matches before this lane's points, within the tile
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) c += ((mw >> (8u * i)) & 0xFFu) != 0u;
+  uint32_t incl = c;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t r0 = incl - c;
+  for (uint32_t v = 0; v < wave; ++v) r0 += wave_tot[v];
+  for (uint32_t base = 0; base < m; base += P::cap) {
+    const uint32_t cm = (m - base) < P::cap ? (m - base) : P::cap;
+    if constexpr (P::dst_columns) {
+      uint64_t ga[P::n];
+      uint32_t mis[P::n];
+      static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        ga[k] = a.attrs[k].dst + (out0 + base) * P::size(k);
+        mis[k] = (uint32_t)(ga[k] & 15u);
+      });
+      uint32_t r = r0;
+      static_for<0, 4>([&](auto I) __attribute__((always_inline)) {
+        constexpr uint32_t i = (uint32_t) decltype(I)::value;
+        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+        if (on && r >= base && r < base + cm) {
+          const uint32_t j = r - base;
+          static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            constexpr uint32_t S = P::size(k), U = piece_of(S);
+            lptr_t q = lds + (span_before<P>(k) + mis[k] + j * S);
+            static_for<0, (int)(S / U)>([&](auto C) __attribute__((always_inline)) {
+              constexpr uint32_t cidx = (uint32_t) decltype(C)::value;
+              typedef typename PieceType<U>::type PT;
+              store_un<PT>(q + cidx * U, (PT)pstq::img_get<4u * words_before<P>(k) + i * S + cidx * U, U>(w));
+            });
+          });
+        }
+        r += on ? 1u : 0u;
+      });
+      __syncthreads();
+      if constexpr (P::n <= 6) {  // few, long spans: one after the other (same box, five spans: 0.706 against 0.695 of peak with the chunk list)
+        static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int k = decltype(K)::value;
+          tile_store<(int)kStreamThreads>(lds + span_before<P>(k), as_global(ga[k] - mis[k]), mis[k], cm * P::size(k));
+        });
+      } else {
+      // The spans leave as ONE list of 16-byte chunks spread over the block (a span of one-byte values is 64 chunks: a tile_store per span would
+      // keep 448 of 512 lanes idle, twelve times over for a LAS layout): chunk c belongs to the span whose chunk range holds it; chunks inside
+      // the span's bytes go out as 16-byte stores, the two ragged ends byte by byte, so that no byte outside the target range is written.
+      uint32_t pre[P::n + 1];
+      pre[0] = 0;
+      static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        pre[k + 1] = pre[k] + ((mis[k] + cm * P::size(k) + 15u) >> 4);
+      });
+      constexpr uint32_t kBatch = 4;
+      for (uint32_t c0 = threadIdx.x; c0 < pre[P::n]; c0 += kBatch * kStreamThreads) {
+        u32x4 v[kBatch];
+        uint64_t g[kBatch];
+        uint32_t lo[kBatch], b0[kBatch], b1[kBatch];  // LDS offset of the chunk, first and one-past-last valid byte inside it (16 = whole chunk)
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+          const uint32_t c = c0 + u * kStreamThreads;
+          uint32_t span_lds = 0, span_mis = 0, span_end = 0, span_c0 = 0;
+          uint64_t span_g = 0;
+          static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            if (c >= pre[k]) { span_lds = span_before<P>(k); span_mis = mis[k]; span_end = mis[k] + cm * P::size(k); span_c0 = pre[k]; span_g = ga[k] - mis[k]; }
+          });
+          const uint32_t off = (c - span_c0) << 4;
+          lo[u] = span_lds + off;
+          g[u] = span_g + off;
+          b0[u] = span_mis > off ? span_mis - off : 0u;
+          b1[u] = span_end - off < 16u ? span_end - off : 16u;
+          if (c >= pre[P::n]) b1[u] = 0u, b0[u] = 0u;
+          if (b1[u] > b0[u]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + lo[u]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kBatch; ++u) {
+          if (b0[u] == 0u && b1[u] == 16u) {
+            __builtin_nontemporal_store(v[u], reinterpret_cast<g4ptr_t>(as_global(g[u])));
+          } else {
+            for (uint32_t b = b0[u]; b < b1[u]; ++b) as_global(g[u])[b] = lds[lo[u] + b];
+          }
+        }
+      }
+      }
+      if (base + P::cap < m) __syncthreads();
+    } else {
+      constexpr uint32_t STRIDE = P::dst_stride;
+      const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
+      const uint32_t mis = (uint32_t)(ga & 15u);
+      uint32_t r = r0;
+      static_for<0, 4>([&](auto I) __attribute__((always_inline)) {
+        constexpr uint32_t i = (uint32_t) decltype(I)::value;
+        const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+        if (on && r >= base && r < base + cm) {
+          RecordImage<(int)STRIDE> img;
+          static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+            constexpr int k = decltype(K)::value;
+            constexpr uint32_t S = P::size(k);
+            static_for<0, (int)((S + 7u) / 8u)>([&](auto C) __attribute__((always_inline)) {
+              constexpr uint32_t o = 8u * (uint32_t) decltype(C)::value, nb = (S - o) < 8u ? (S - o) : 8u;
+              pstq::img_put<false, P::dst_off(k) + o, nb>(img.w, pstq::img_get<4u * words_before<P>(k) + i * S + o, nb>(w));
+            });
+          });
+          img.store_aligned(lds + (mis + (r - base) * STRIDE));
+        }
+        r += on ? 1u : 0u;
+      });
+      __syncthreads();
+      tile_store<(int)kStreamThreads>(lds, as_global(ga - mis), mis, cm * STRIDE);
+      if (base + P::cap < m) __syncthreads();
+    }
+  }
+}
+
+}  // namespace pstf

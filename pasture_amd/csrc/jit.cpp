@@ -181,7 +181,7 @@ std::string device_arch() {
 // ---- the cache --------------------------------------------------------------------------------------------------------------------
 struct Entry {
   enum State { Queued, Ready, Failed } state = Queued;
-  std::string source, error;
+  std::string source, error, entry_name = "pst_jit_convert";
   std::vector<char> code;
   std::map<int, std::pair<hipModule_t, hipFunction_t>> per_device;
   unsigned blk = 256;
@@ -439,6 +439,10 @@ std::vector<char> compile_source(const std::string& source, const std::string& a
 }
 
 bool acquire(const QuadSpec& spec, const std::string& src, Acquire how, Kernel* out, std::string* error) {
+  return acquire_source(src, "pst_jit_convert", (unsigned)spec.blk, spec.lds_bytes(), spec.tile(), how, out, error);
+}
+
+bool acquire_source(const std::string& src, const char* entry, unsigned blk, uint32_t lds_bytes, uint32_t tile, Acquire how, Kernel* out, std::string* error) {
   const bool wait = how == Acquire::Wait;
   Cache& c = cache();
   std::shared_ptr<Entry> e;
@@ -450,9 +454,10 @@ bool acquire(const QuadSpec& spec, const std::string& src, Acquire how, Kernel* 
       if (how == Acquire::IfReady) return false;
       e = std::make_shared<Entry>();
       e->source = src;
-      e->blk = (unsigned)spec.blk;
-      e->lds_bytes = spec.lds_bytes();
-      e->tile = spec.tile();
+      e->entry_name = entry;
+      e->blk = blk;
+      e->lds_bytes = lds_bytes;
+      e->tile = tile;
       c.by_source.emplace(src, e);
       if (wait) {
         compile_here = true;
@@ -491,7 +496,7 @@ bool acquire(const QuadSpec& spec, const std::string& src, Acquire how, Kernel* 
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     hipError_t err = hipModuleLoadData(&mod, e->code.data());
-    if (err == hipSuccess) err = hipModuleGetFunction(&fn, mod, "pst_jit_convert");
+    if (err == hipSuccess) err = hipModuleGetFunction(&fn, mod, e->entry_name.c_str());
     if (err != hipSuccess) {
       (void)hipGetLastError();
       e->state = Entry::Failed;

@@ -45,6 +45,11 @@ struct Kernel {
 enum class Acquire { IfReady, Enqueue, Wait };
 bool acquire(const QuadSpec& spec, const std::string& source, Acquire how, Kernel* out, std::string* error = nullptr);  // source = spec_source(spec)
 
+// The same cache for any other translation unit over the embedded device headers (filter_stream.hpp's compaction kernels): `entry` is the
+// extern "C" kernel of `source`; blk / lds_bytes / tile are handed back with the kernel.
+bool acquire_source(const std::string& source, const char* entry, unsigned blk, uint32_t lds_bytes, uint32_t tile, Acquire how, Kernel* out,
+                    std::string* error = nullptr);
+
 // Compile without touching a device (CPU test of the generator and of the headers under hipRTC): code object bytes, or empty + error.
 std::vector<char> compile_source(const std::string& source, const std::string& arch, std::string* error);
 

@@ -186,6 +186,32 @@ def test_bad_source_reports_the_compiler_log(hip):
     assert "error" in str(e.value)
 
 
+def _filter_plan_source(sizes, columns):
+    """The translation unit filter.hip writes for a compaction plan (stream_source): attribute sizes in layout order, packed record offsets."""
+    offs, o = [], 0
+    for s in sizes:
+        offs.append(0 if columns else o)
+        o += s
+    total = sum(sizes)
+    cap = min(2048, (52 * 1024 // total) // 16 * 16)
+    return ('#include "filter_stream.hpp"\nstruct PstFilterPlan {\n'
+            f'  static constexpr int n = {len(sizes)};\n  static constexpr bool dst_columns = {"true" if columns else "false"};\n'
+            f'  static constexpr uint32_t dst_stride = {0 if columns else total}, cap = {cap};\n'
+            '  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, sizes)) + '};\n    return t[k];\n  }\n'
+            '  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, offs)) + '};\n    return t[k];\n  }\n};\n'
+            'extern "C" __global__ __launch_bounds__(512) void pst_jit_filter(const pstf::FilterArgs a) {\n  pstf::filter_stream_body<PstFilterPlan>(a);\n}\n')
+
+
+@pytest.mark.parametrize("columns", [True, False])
+@pytest.mark.parametrize("sizes", [[24, 2, 1, 1, 1, 1, 1, 1, 1, 2, 8, 6], [8, 6, 24, 1, 2], [1], [3, 5, 12, 16, 7], [4] * 16, [24, 24, 16]])
+def test_compaction_plan_compiles_with_hiprtc(hip, sizes, columns):
+    """filter_stream.hpp under hipRTC (no device needed): the streaming compaction kernel for attribute lists of every granule class -- typed LAS-3
+    points, the bench layout, odd sizes, sixteen dwords, 64 bytes per point -- compiles for gfx950 without scratch memory."""
+    code = cv.jit_compile_source(_filter_plan_source(sizes, columns), api=hip)
+    assert code[:4] == b"\x7fELF"
+    assert _scratch_bytes(code) == 0, (sizes, columns)
+
+
 # ---- GPU -----------------------------------------------------------------------------------------------------------------------------------
 @pytest.fixture
 def jit_sync(hip):

@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
-run() { python bench.py --workload normals_knn16 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['ms_per_step'])"; }
-echo "default: $(run) $(run)"
-for m in 22 24 26 30 32 36; do echo "TAU_M=$m: $(PST_KNN_TAU_M=$m run)"; done
-for f in 32 40 56; do echo "FLUSH_AT=$f: $(PST_KNN_FLUSH_AT=$f run)"; done
-for rx in 3 5 6; do echo "RX=$rx: $(PST_KNN_RX=$rx run)"; done
-echo "default: $(run)"
+timeout 900 python -m pytest tests -m gpu -x -q -k "filter" 2>&1 | tail -3
+PST_JIT=sync timeout 900 python -m pytest tests -m gpu -x -q -k "filter" 2>&1 | tail -3
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2; do
+ for w in filter_las0_columnar filter_las0_interleaved filter_las3_columnar filter_las3_interleaved filter_big_columnar filter_big_interleaved; do
+  for plan in interpreted specialised; do
+    python bench.py --no-cpu-baseline --no-north-star --workload $w --plan $plan --steps 20 --warmup 5 2>gpurun_out/r04/err.txt | tail -1 | line "$w $plan" || tail -5 gpurun_out/r04/err.txt
+  done
+ done
+done

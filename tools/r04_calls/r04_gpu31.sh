@@ -1,2 +1,10 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_distributed_gloo.py -m gpu -x -q 2>&1 | grep -E "passed|failed|^E " | head -10
+mkdir -p gpurun_out/r04
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2; do
+ for w in filter_las0_columnar filter_las0_interleaved filter_las3_columnar filter_las3_interleaved filter_big_columnar filter_big_interleaved; do
+  for plan in interpreted specialised; do
+    python bench.py --no-cpu-baseline --no-north-star --workload $w --plan $plan --steps 20 --warmup 5 2>gpurun_out/r04/err.txt | tail -1 | line "$w $plan" || tail -5 gpurun_out/r04/err.txt
+  done
+ done
+done

@@ -1,2 +1,17 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_capi_symbols.py -m gpu -x -q 2>&1 | grep -E "passed|failed|^E " | head -8
+mkdir -p gpurun_out/r04
+timeout 900 python -m pytest tests -m gpu -x -q -k "filter" 2>&1 | tail -2
+PST_JIT=sync PST_FILTER_BIG=0 timeout 900 python -m pytest tests/test_filter_append.py tests/test_gpu_parity.py -m gpu -x -q -k "filter and not random" 2>&1 | tail -2
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2; do
+ for w in filter_las0_columnar filter_las3_columnar; do
+  for plan in interpreted specialised; do
+    python bench.py --no-cpu-baseline --no-north-star --workload $w --plan $plan --steps 20 --warmup 5 2>gpurun_out/r04/err.txt | tail -1 | line "$w $plan" || tail -5 gpurun_out/r04/err.txt
+  done
+ done
+ for w in filter_big_columnar filter_big_interleaved; do
+  for big in 1 0; do
+    PST_FILTER_BIG=$big python bench.py --no-cpu-baseline --no-north-star --workload $w --plan specialised --steps 20 --warmup 5 2>gpurun_out/r04/err.txt | tail -1 | line "$w PST_FILTER_BIG=$big" || tail -5 gpurun_out/r04/err.txt
+  done
+ done
+done

@@ -1,9 +1,12 @@
 cd $GRAFT_REPO_ROOT
-for wm in 8 4 16; do
-  for sd in 5 12 15 20; do
-    PST_JIT_WIDE_MIN=$wm timeout 600 python tools/exp_jit_layouts.py --seeds 1 --first-seed $sd --points 100000000 --steps 8 --skip-interp 2>/dev/null | grep '"pairing"' | python -c "
-import sys, json
-for l in sys.stdin:
-    d=json.loads(l); print('WIDE_MIN=$wm seed', d['seed'], d['pairing'], d['src_record'], d['dst_record'], d['jit_frac'])"
+mkdir -p gpurun_out/r04
+timeout 900 python -m pytest tests -m gpu -x -q -k "filter or static" 2>&1 | tail -15
+PST_JIT=sync timeout 900 python -m pytest tests/test_filter_append.py tests/test_gpu_parity.py -m gpu -x -q -k "filter and not random" 2>&1 | tail -15
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2; do
+ for w in filter_las0_columnar filter_las0_interleaved filter_las3_columnar filter_las3_interleaved filter_big_columnar filter_big_interleaved; do
+  for plan in interpreted specialised; do
+    python bench.py --no-cpu-baseline --no-north-star --workload $w --plan $plan --steps 20 --warmup 5 2>gpurun_out/r04/err.txt | tail -1 | line "$w $plan" || tail -5 gpurun_out/r04/err.txt
   done
+ done
 done
