@@ -146,44 +146,50 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
         });
       } else {
       // The spans leave as ONE list of 16-byte chunks spread over the block (a span of one-byte values is 64 chunks: a tile_store per span would
-      // keep 448 of 512 lanes idle, twelve times over for a LAS layout): chunk c belongs to the span whose chunk range holds it; chunks inside
-      // the span's bytes go out as 16-byte stores, the two ragged ends byte by byte, so that no byte outside the target range is written.
-      uint32_t pre[P::n + 1];
+      // keep 448 of 512 lanes idle, twelve times over for a LAS layout): chunk c belongs to the span whose range of WHOLE chunks holds it.  The
+      // ragged ends of every span (the bytes before its first and after its last whole chunk) go out byte by byte, one lane per byte -- 32
+      // lanes of the first wave per span --, so that no byte outside the target range is written.
+      uint32_t pre[P::n + 1], vf[P::n];
       pre[0] = 0;
       static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
-        pre[k + 1] = pre[k] + ((mis[k] + cm * P::size(k) + 15u) >> 4);
+        const uint32_t end = mis[k] + cm * P::size(k);
+        vf[k] = (mis[k] + 15u) >> 4;
+        const uint32_t vl = end >> 4;
+        pre[k + 1] = pre[k] + (vl > vf[k] ? vl - vf[k] : 0u);
       });
       constexpr uint32_t kBatch = 4;
       for (uint32_t c0 = threadIdx.x; c0 < pre[P::n]; c0 += kBatch * kStreamThreads) {
         u32x4 v[kBatch];
         uint64_t g[kBatch];
-        uint32_t lo[kBatch], b0[kBatch], b1[kBatch];  // LDS offset of the chunk, first and one-past-last valid byte inside it (16 = whole chunk)
 #pragma unroll
         for (uint32_t u = 0; u < kBatch; ++u) {
           const uint32_t c = c0 + u * kStreamThreads;
-          uint32_t span_lds = 0, span_mis = 0, span_end = 0, span_c0 = 0;
+          uint32_t span_lds = 0, span_c0 = 0;
           uint64_t span_g = 0;
           static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
             constexpr int k = decltype(K)::value;
-            if (c >= pre[k]) { span_lds = span_before<P>(k); span_mis = mis[k]; span_end = mis[k] + cm * P::size(k); span_c0 = pre[k]; span_g = ga[k] - mis[k]; }
+            if (c >= pre[k]) { span_lds = span_before<P>(k) + (vf[k] << 4); span_c0 = pre[k]; span_g = ga[k] - mis[k] + (vf[k] << 4); }
           });
           const uint32_t off = (c - span_c0) << 4;
-          lo[u] = span_lds + off;
           g[u] = span_g + off;
-          b0[u] = span_mis > off ? span_mis - off : 0u;
-          b1[u] = span_end - off < 16u ? span_end - off : 16u;
-          if (c >= pre[P::n]) b1[u] = 0u, b0[u] = 0u;
-          if (b1[u] > b0[u]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + lo[u]);
+          if (c < pre[P::n]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + (span_lds + off));
         }
 #pragma unroll
-        for (uint32_t u = 0; u < kBatch; ++u) {
-          if (b0[u] == 0u && b1[u] == 16u) {
-            __builtin_nontemporal_store(v[u], reinterpret_cast<g4ptr_t>(as_global(g[u])));
-          } else {
-            for (uint32_t b = b0[u]; b < b1[u]; ++b) as_global(g[u])[b] = lds[lo[u] + b];
-          }
-        }
+        for (uint32_t u = 0; u < kBatch; ++u)
+          if (c0 + u * kStreamThreads < pre[P::n]) __builtin_nontemporal_store(v[u], reinterpret_cast<g4ptr_t>(as_global(g[u])));
+      }
+      if (threadIdx.x < 32u) {
+        const uint32_t t = threadIdx.x & 15u;
+        static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+          constexpr int k = decltype(K)::value;
+          const uint32_t end = mis[k] + cm * P::size(k);
+          const uint32_t head_end = (vf[k] << 4) < end ? (vf[k] << 4) : end;              // bytes [mis, head_end)
+          const uint32_t tail_begin = ((end >> 4) << 4) > head_end ? ((end >> 4) << 4) : head_end;  // bytes [tail_begin, end)
+          const uint32_t b = threadIdx.x < 16u ? ((mis[k] >> 4) << 4) + t : tail_begin + t;
+          const bool mine = threadIdx.x < 16u ? (b >= mis[k] && b < head_end) : (b < end);
+          if (mine) as_global(ga[k] - mis[k])[b] = lds[span_before<P>(k) + b];
+        });
       }
       }
       if (base + P::cap < m) __syncthreads();
