@@ -267,6 +267,47 @@ def test_specialised_kernels_were_taken(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16 * FUZZ))
+def test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed):
+    """Differential fuzz of filter / filter_into with the streaming compaction kernel of every eligible layout compiled at run time (filter_stream.hpp;
+    PST_JIT=sync): random packed layouts of at most 64 bytes per point, both target kinds, full tiles on the compiled kernel and the ragged last tile
+    on the gather kernel; a hint below the number of matches truncates inside a tile.  Byte-identical to the oracle."""
+    rng = np.random.default_rng(77000 + seed)
+    ALL = [T.U8, T.I8, T.U16, T.I16, T.U32, T.F32, T.U64, T.F64, T.Vec3u8, T.Vec3u16, T.Vec3f32, T.Vec3f64, T.Vec4u8, T.ByteArray(5), T.ByteArray(16), T.ByteArray(7)]
+    attrs, total = [], 0
+    for i in range(int(rng.integers(1, 13))):
+        t = ALL[rng.integers(0, len(ALL))]
+        if total + t.size() > 64:
+            continue
+        attrs.append(PointAttributeDefinition(f"a{i}", t))
+        total += t.size()
+    n = int(rng.choice([2048, 2049, 10_000, 33_333, 70_001]))
+    density = float(rng.choice([0.03, 0.5, 0.5, 0.97, 1.0]))
+    mask = rng.random(n) < density
+    kind = "VH"[seed % 2]
+    k = int(mask.sum())
+    hint = k if rng.random() < 0.5 else max(0, k - int(rng.integers(1, 3000)))
+
+    def run(api):
+        layout = PointLayout.from_attributes_packed(attrs, 1, api=api)
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(seed, 5)
+        out = src.filter(BUFFER_KINDS[kind], mask)
+        kinds = cv.last_plan_kinds(api) if api is hip else None
+        short = BUFFER_KINDS[kind].new_from_layout(layout)
+        short.resize(k)
+        if hint == k:
+            assert src.filter_into(short, mask, hint) == k
+        return out.len(), out.get_point_range(range(0, out.len())).tobytes(), short.get_point_range(range(0, k)).tobytes() if hint == k else b"", kinds
+    hn, hb, hs, kinds = run(hip)
+    on, ob, os_, _ = run(oracle)
+    assert hn == on == k and hb == ob and hs == os_
+    if k:
+        assert kinds and kinds[0] in ("jit", "static"), kinds
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kinds", [("V", "H"), ("H", "V"), ("V", "V")])
 def test_las_reader_plan_into_a_custom_layout_specialised(hip, oracle, jit_sync, kinds):
     """The reader's "different layout" case (raw_readers.rs:820-905) with the affine position mapping and the bit fields of
