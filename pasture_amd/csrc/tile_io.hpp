@@ -70,6 +70,10 @@ struct RecordImage {
   // every phase go out as aligned b32 stores, the ragged head and tail as b16 / b8 pieces.  m = 1..4 bytes of dword 0 precede the record
   // (m = 4: the record starts on a dword boundary and dword 0 is not written at all).
   __device__ __forceinline__ void store_aligned(lptr_t p) const {
+    if constexpr (NB < 3) {  // (the head pieces below assume the record reaches the end of its first dword)
+      store(p);
+      return;
+    }
     typedef PST_AS_LDS uint8_t* p8;
     typedef PST_AS_LDS uint16_t* p16;
     typedef PST_AS_LDS uint32_t* p32;

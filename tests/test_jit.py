@@ -308,6 +308,59 @@ def test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["V", "H"])
+@pytest.mark.parametrize("types", [[T.U8], [T.U16], [T.Vec3u8], [T.U8, T.U8], [T.U32], [T.ByteArray(5)], [T.ByteArray(16), T.ByteArray(16), T.ByteArray(16), T.ByteArray(16)]])
+def test_specialised_compaction_of_tiny_and_largest_records(hip, oracle, jit_sync, types, kind):
+    """Records of one, two, three bytes (shorter than the dword grid a record image is shifted to) and of the 64-byte limit, sparse and dense masks."""
+    n = 70_001
+    for density in (0.03, 0.97):
+        mask = np.random.default_rng(len(types) + int(density * 100)).random(n) < density
+
+        def run(api):
+            layout = PointLayout.from_attributes_packed([PointAttributeDefinition(f"a{i}", t) for i, t in enumerate(types)], 1, api=api)
+            src = HashMapBuffer.new_from_layout(layout)
+            src.resize(n)
+            src.synth_fill(3, 5)
+            out = src.filter(BUFFER_KINDS[kind], mask)
+            kinds = cv.last_plan_kinds(api) if api is hip else None  # (before get_point_range: reading columns as records is a conversion)
+            return out.len(), out.get_point_range(range(0, out.len())).tobytes(), kinds
+        hn, hb, kinds = run(hip)
+        on, ob, _ = run(oracle)
+        assert hn == on and hb == ob, (types, density)
+        assert kinds[0] in ("jit", "static"), kinds
+
+
+@pytest.mark.gpu
+def test_compaction_kernel_arrives_in_the_background(hip):
+    """PST_JIT=async: a large filter of a layout without an in-tree kernel shows its plan to the compiler thread and runs on the gather kernels;
+    once the code object is there the same call takes the streaming kernel -- with identical bytes."""
+    cv.jit_set_mode("async", api=hip)
+    try:
+        n = (1 << 20) + 1234
+        layout = PointLayout.from_attributes_packed([A.POSITION_3D, PointAttributeDefinition("odd", T.ByteArray(7)), A.INTENSITY, A.GPS_TIME, A.CLASSIFICATION], 1, api=hip)
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(4321, 0)
+        mask = np.random.default_rng(8).random(n) < 0.5
+        first = src.filter(VectorBuffer, mask)
+        seen = [cv.last_plan_kinds(hip)]
+        deadline = time.time() + 60
+        while time.time() < deadline:
+            again = src.filter(VectorBuffer, mask)
+            seen.append(cv.last_plan_kinds(hip))
+            if "jit" in seen[-1]:
+                break
+            time.sleep(0.05)
+        assert "jit" in seen[-1], seen[-5:]
+        assert seen[0] == ["interpreted"] or "jit" in seen[0]  # (a warm disk cache may serve the very first call)
+        k = int(mask.sum())
+        assert first.len() == again.len() == k
+        assert first.get_point_range(range(0, k)).tobytes() == again.get_point_range(range(0, k)).tobytes()
+    finally:
+        cv.jit_set_mode("env", api=hip)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kinds", [("V", "H"), ("H", "V"), ("V", "V")])
 def test_las_reader_plan_into_a_custom_layout_specialised(hip, oracle, jit_sync, kinds):
     """The reader's "different layout" case (raw_readers.rs:820-905) with the affine position mapping and the bit fields of
