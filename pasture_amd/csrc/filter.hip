@@ -470,9 +470,9 @@ static bool filter_plan_equals(const FilterArgs& a, bool dst_aos) {
 // ---- plan-specialised streaming compaction (filter_stream.hpp): in-tree for typed LAS-0 points, run-time compiled for every other layout ------
 struct StreamSig {
   int n = 0;
-  bool dst_columns = true;
+  bool dst_columns = true, covered = true;
   uint32_t dst_stride = 0, cap = 0, total = 0;
-  uint32_t size[kMaxFilterAttrs] = {}, dst_off[kMaxFilterAttrs] = {};
+  uint32_t size[kMaxFilterAttrs] = {}, dst_off[kMaxFilterAttrs] = {}, piece[kMaxFilterAttrs] = {};
 };
 // points per LDS round: about 52 KiB of values (three 512-lane blocks per CU), a multiple of 16
 __host__ __device__ constexpr uint32_t stream_cap_for(uint32_t total) {
@@ -480,7 +480,12 @@ __host__ __device__ constexpr uint32_t stream_cap_for(uint32_t total) {
   return c > 2048u ? 2048u : c;
 }
 // Can this launch take a streaming kernel?  Columnar source (every attribute contiguous), at most 64 bytes per point (the lane holds four points
-// in registers), packed records whose every byte is written / target columns that start on a multiple of their values' aligned piece.
+// in registers), records of at most 128 bytes.  Values go to LDS in pieces as wide as the target's alignment allows.
+static uint32_t aligned_piece(uint32_t size, uint64_t a0, uint64_t a1 = 0, uint64_t a2 = 0) {
+  uint32_t p = pstf::piece_of(size);
+  while (p > 1u && (a0 % p != 0 || a1 % p != 0 || a2 % p != 0)) p >>= 1;
+  return p;
+}
 static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* sig) {
   if (a.tile != pstf::kStreamTile || a.n_attrs == 0 || a.n_attrs > (uint32_t)kMaxFilterAttrs) return false;
   sig->n = (int)a.n_attrs;
@@ -489,16 +494,21 @@ static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* s
   for (uint32_t i = 0; i < a.n_attrs; ++i) {
     const uint32_t size = a.attrs[i].unit * a.attrs[i].cnt;
     if (size == 0 || a.attrs[i].src_stride != size) return false;
-    if (!dst_aos && a.attrs[i].dst % pstf::piece_of(size) != 0) return false;
     sig->size[i] = size;
     sig->dst_off[i] = dst_aos ? a.attrs[i].dst_off : 0u;
     total += size;
   }
   if (total > 64u) return false;
-  if (dst_aos && (!a.dst_covered || a.dst_stride != total)) return false;
+  // records whose every byte is written are assembled as images; records with padding (or with attributes the source lacks) are staged from
+  // the target and only the attributes' bytes replaced
+  sig->covered = !dst_aos || (a.dst_covered && a.dst_stride == total);
+  if (dst_aos && a.dst_stride > 128u) return false;
+  for (uint32_t i = 0; i < a.n_attrs; ++i)
+    sig->piece[i] = !dst_aos ? aligned_piece(sig->size[i], a.attrs[i].dst)
+                    : sig->covered ? pstf::piece_of(sig->size[i]) : aligned_piece(sig->size[i], a.dst_aos, a.dst_stride, a.attrs[i].dst_off);
   sig->dst_stride = dst_aos ? a.dst_stride : 0u;
   sig->total = total;
-  sig->cap = stream_cap_for(total);
+  sig->cap = stream_cap_for(dst_aos ? a.dst_stride : total);
   return true;
 }
 // the translation unit hipRTC compiles for `sig` (also the cache key)
@@ -507,13 +517,16 @@ static std::string stream_source(const StreamSig& s) {
   o << "#include \"filter_stream.hpp\"\n";
   o << "struct PstFilterPlan {\n";
   o << "  static constexpr int n = " << s.n << ";\n";
-  o << "  static constexpr bool dst_columns = " << (s.dst_columns ? "true" : "false") << ";\n";
+  o << "  static constexpr bool dst_columns = " << (s.dst_columns ? "true" : "false") << ", covered = " << (s.covered ? "true" : "false") << ";\n";
   o << "  static constexpr uint32_t dst_stride = " << s.dst_stride << ", cap = " << s.cap << ";\n";
   o << "  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {";
   for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.size[i];
   o << "};\n    return t[k];\n  }\n";
   o << "  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {";
   for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.dst_off[i];
+  o << "};\n    return t[k];\n  }\n";
+  o << "  __host__ __device__ static constexpr uint32_t piece(int k) {\n    constexpr uint32_t t[n] = {";
+  for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.piece[i];
   o << "};\n    return t[k];\n  }\n};\n";
   o << "extern \"C\" __global__ __launch_bounds__(" << pstf::kStreamThreads << ") void pst_jit_filter(const pstf::FilterArgs a) {\n";
   o << "  pstf::filter_stream_body<PstFilterPlan>(a);\n}\n";
@@ -525,7 +538,7 @@ static std::string stream_source(const StreamSig& s) {
 template <bool COLUMNS>
 struct Las0StreamPlan {
   static constexpr int n = 10;
-  static constexpr bool dst_columns = COLUMNS;
+  static constexpr bool dst_columns = COLUMNS, covered = true;
   static constexpr uint32_t dst_stride = COLUMNS ? 0u : 35u, cap = stream_cap_for(35u);
   __host__ __device__ static constexpr uint32_t size(int k) {
     constexpr uint32_t t[n] = {24, 2, 1, 1, 1, 1, 1, 1, 1, 2};
@@ -535,12 +548,13 @@ struct Las0StreamPlan {
     constexpr uint32_t t[n] = {0, 24, 26, 27, 28, 29, 30, 31, 32, 33};
     return COLUMNS ? 0u : t[k];
   }
+  __host__ __device__ static constexpr uint32_t piece(int k) { return pstf::piece_of(size(k)); }
 };
 // CustomPointTypeBig (test_utils.rs:19-31; buffer_filter_bench.rs:71-74): GpsTime, ColorRGB, Position3D, Classification, Intensity (i16); 41 bytes
 template <bool COLUMNS>
 struct BigStreamPlan {
   static constexpr int n = 5;
-  static constexpr bool dst_columns = COLUMNS;
+  static constexpr bool dst_columns = COLUMNS, covered = true;
   static constexpr uint32_t dst_stride = COLUMNS ? 0u : 41u, cap = stream_cap_for(41u);
   __host__ __device__ static constexpr uint32_t size(int k) {
     constexpr uint32_t t[n] = {8, 6, 24, 1, 2};
@@ -550,15 +564,16 @@ struct BigStreamPlan {
     constexpr uint32_t t[n] = {0, 8, 14, 38, 39};
     return COLUMNS ? 0u : t[k];
   }
+  __host__ __device__ static constexpr uint32_t piece(int k) { return pstf::piece_of(size(k)); }
 };
 template <typename P>
 __global__ __launch_bounds__(pstf::kStreamThreads) void filter_stream_static_kernel(const FilterArgs a) { pstf::filter_stream_body<P>(a); }
 
 template <typename P>
 static bool stream_sig_is(const StreamSig& s) {
-  if (s.n != P::n || s.dst_columns != P::dst_columns || s.dst_stride != P::dst_stride || s.cap != P::cap) return false;
+  if (s.n != P::n || s.dst_columns != P::dst_columns || s.covered != P::covered || s.dst_stride != P::dst_stride || s.cap != P::cap) return false;
   for (int i = 0; i < P::n; ++i)
-    if (s.size[i] != P::size(i) || s.dst_off[i] != P::dst_off(i)) return false;
+    if (s.size[i] != P::size(i) || s.dst_off[i] != P::dst_off(i) || s.piece[i] != P::piece(i)) return false;
   return true;
 }
 template <typename P>

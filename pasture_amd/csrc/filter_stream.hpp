@@ -10,9 +10,13 @@
 // (jit.cpp).  The kernel covers FULL 2048-point tiles; the host sends the ragged last tile through the gather kernel.
 //
 // P:  static constexpr int n;                         // attributes
-//     static constexpr bool dst_columns;              // columnar target (else packed records whose every byte some attribute writes)
+//     static constexpr bool dst_columns;              // columnar target (else records)
+//     static constexpr bool covered;                  // record target: every byte of a record is written by some attribute (else the target span
+//                                                     // is read into the LDS tile first and only the attributes' bytes are replaced: padding survives)
 //     static constexpr uint32_t dst_stride, cap;      // record size of an interleaved target; points per LDS round (multiple of 16)
 //     static constexpr uint32_t size(int k), dst_off(int k);
+//     static constexpr uint32_t piece(int k);          // LDS store width of attribute k's values (8 / 4 / 2 / 1): divides the size and the
+//                                                     // alignment the host found for the target (column address; record base, stride, offset)
 #pragma once
 #include "jit_quad.hpp"
 
@@ -127,7 +131,7 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
           const uint32_t j = r - base;
           static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
             constexpr int k = decltype(K)::value;
-            constexpr uint32_t S = P::size(k), U = piece_of(S);
+            constexpr uint32_t S = P::size(k), U = P::piece(k);
             lptr_t q = lds + (span_before<P>(k) + mis[k] + j * S);
             static_for<0, (int)(S / U)>([&](auto C) __attribute__((always_inline)) {
               constexpr uint32_t cidx = (uint32_t) decltype(C)::value;
@@ -197,10 +201,29 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
       constexpr uint32_t STRIDE = P::dst_stride;
       const uint64_t ga = a.dst_aos + (out0 + base) * STRIDE;
       const uint32_t mis = (uint32_t)(ga & 15u);
+      if constexpr (!P::covered) {  // padding bytes (and attributes the source lacks) of the target records must survive
+        tile_load<(int)kStreamThreads>(lds, as_global(ga - mis), (mis + cm * STRIDE + 15u) & ~15u);
+        wait_tile_loads();
+        __syncthreads();
+      }
       uint32_t r = r0;
       static_for<0, 4>([&](auto I) __attribute__((always_inline)) {
         constexpr uint32_t i = (uint32_t) decltype(I)::value;
         const bool on = ((mw >> (8u * i)) & 0xFFu) != 0u;
+        if constexpr (!P::covered) {
+          if (on && r >= base && r < base + cm) {
+            lptr_t rec = lds + (mis + (r - base) * STRIDE);
+            static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+              constexpr int k = decltype(K)::value;
+              constexpr uint32_t S = P::size(k), U = P::piece(k);
+              static_for<0, (int)(S / U)>([&](auto C) __attribute__((always_inline)) {
+                constexpr uint32_t cidx = (uint32_t) decltype(C)::value;
+                typedef typename PieceType<U>::type PT;
+                store_un<PT>(rec + (P::dst_off(k) + cidx * U), (PT)pstq::img_get<4u * words_before<P>(k) + i * S + cidx * U, U>(w));
+              });
+            });
+          }
+        } else
         if (on && r >= base && r < base + cm) {
           RecordImage<(int)STRIDE> img;
           static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {

@@ -61,4 +61,19 @@ def test_deep_fuzz_specialised_conversions(hip, oracle, jit_sync, lo, hi):
             raise AssertionError(f"deep fuzz specialised conversions, seed {seed}: {e}") from e
 
 
+def _compaction_chunks():
+    first, last = 16 * tj.FUZZ, 16 * tj.FUZZ + 16 * DEEP
+    return [pytest.param(lo, min(last, lo + CHUNK), id=f"compaction-{lo}") for lo in range(first, last, CHUNK)]
+
+
+@pytest.mark.parametrize("lo,hi", _compaction_chunks())
+def test_deep_fuzz_specialised_compaction(hip, oracle, jit_sync, lo, hi):
+    """The run-time compiled streaming compaction kernels (filter_stream.hpp) on seeds beyond test_jit's own: byte-identical to the oracle."""
+    for seed in range(lo, hi):
+        try:
+            tj.test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed)
+        except AssertionError as e:
+            raise AssertionError(f"deep fuzz specialised compaction, seed {seed}: {e}") from e
+
+
 from test_jit import jit_sync  # noqa: E402,F401  (the fixture: PST_JIT=sync for the duration of a test)

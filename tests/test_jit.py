@@ -186,19 +186,27 @@ def test_bad_source_reports_the_compiler_log(hip):
     assert "error" in str(e.value)
 
 
-def _filter_plan_source(sizes, columns):
-    """The translation unit filter.hip writes for a compaction plan (stream_source): attribute sizes in layout order, packed record offsets."""
+def _filter_plan_source(sizes, columns, offsets=None, stride=None):
+    """The translation unit filter.hip writes for a compaction plan (stream_source): attribute sizes in layout order; packed record offsets unless
+    `offsets` / `stride` describe records with padding (then only the attributes' bytes of the staged target span are replaced)."""
     offs, o = [], 0
     for s in sizes:
         offs.append(0 if columns else o)
         o += s
     total = sum(sizes)
-    cap = min(2048, (52 * 1024 // total) // 16 * 16)
+    covered = offsets is None
+    if not covered:
+        offs = list(offsets)
+    stride = 0 if columns else (stride or total)
+    piece_of = lambda v: 8 if v % 8 == 0 else 4 if v % 4 == 0 else 2 if v % 2 == 0 else 1
+    pieces = [piece_of(z) if covered else min(piece_of(z), piece_of(o_) if o_ else 8) for z, o_ in zip(sizes, offs)]
+    cap = min(2048, (52 * 1024 // (stride or total)) // 16 * 16)
     return ('#include "filter_stream.hpp"\nstruct PstFilterPlan {\n'
-            f'  static constexpr int n = {len(sizes)};\n  static constexpr bool dst_columns = {"true" if columns else "false"};\n'
-            f'  static constexpr uint32_t dst_stride = {0 if columns else total}, cap = {cap};\n'
+            f'  static constexpr int n = {len(sizes)};\n  static constexpr bool dst_columns = {"true" if columns else "false"}, covered = {"true" if covered else "false"};\n'
+            f'  static constexpr uint32_t dst_stride = {stride}, cap = {cap};\n'
             '  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, sizes)) + '};\n    return t[k];\n  }\n'
-            '  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, offs)) + '};\n    return t[k];\n  }\n};\n'
+            '  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, offs)) + '};\n    return t[k];\n  }\n'
+            '  __host__ __device__ static constexpr uint32_t piece(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, pieces)) + '};\n    return t[k];\n  }\n};\n'
             'extern "C" __global__ __launch_bounds__(512) void pst_jit_filter(const pstf::FilterArgs a) {\n  pstf::filter_stream_body<PstFilterPlan>(a);\n}\n')
 
 
@@ -210,6 +218,13 @@ def test_compaction_plan_compiles_with_hiprtc(hip, sizes, columns):
     code = cv.jit_compile_source(_filter_plan_source(sizes, columns), api=hip)
     assert code[:4] == b"\x7fELF"
     assert _scratch_bytes(code) == 0, (sizes, columns)
+
+
+def test_compaction_plan_for_padded_records_compiles_with_hiprtc(hip):
+    """A repr(C) record {f64, u16, (2 bytes of padding), u32, u8, (7)} : 24 bytes, 15 of them written: the read-modify-write variant."""
+    code = cv.jit_compile_source(_filter_plan_source([8, 2, 4, 1], False, offsets=[0, 8, 12, 16], stride=24), api=hip)
+    assert code[:4] == b"\x7fELF"
+    assert _scratch_bytes(code) == 0
 
 
 # ---- GPU -----------------------------------------------------------------------------------------------------------------------------------
@@ -270,7 +285,7 @@ def test_specialised_kernels_were_taken(hip):
 @pytest.mark.parametrize("seed", range(16 * FUZZ))
 def test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed):
     """Differential fuzz of filter / filter_into with the streaming compaction kernel of every eligible layout compiled at run time (filter_stream.hpp;
-    PST_JIT=sync): random packed layouts of at most 64 bytes per point, both target kinds, full tiles on the compiled kernel and the ragged last tile
+    PST_JIT=sync): random packed (every third: repr(C), padded) layouts of at most 64 bytes per point, both target kinds, full tiles on the compiled kernel and the ragged last tile
     on the gather kernel; a hint below the number of matches truncates inside a tile.  Byte-identical to the oracle."""
     rng = np.random.default_rng(77000 + seed)
     ALL = [T.U8, T.I8, T.U16, T.I16, T.U32, T.F32, T.U64, T.F64, T.Vec3u8, T.Vec3u16, T.Vec3f32, T.Vec3f64, T.Vec4u8, T.ByteArray(5), T.ByteArray(16), T.ByteArray(7)]
@@ -289,7 +304,7 @@ def test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed):
     hint = k if rng.random() < 0.5 else max(0, k - int(rng.integers(1, 3000)))
 
     def run(api):
-        layout = PointLayout.from_attributes_packed(attrs, 1, api=api)
+        layout = PointLayout.from_attributes(attrs, api=api) if seed % 3 == 2 else PointLayout.from_attributes_packed(attrs, 1, api=api)
         src = HashMapBuffer.new_from_layout(layout)
         src.resize(n)
         src.synth_fill(seed, 5)
@@ -328,6 +343,36 @@ def test_specialised_compaction_of_tiny_and_largest_records(hip, oracle, jit_syn
         on, ob, _ = run(oracle)
         assert hn == on and hb == ob, (types, density)
         assert kinds[0] in ("jit", "static"), kinds
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density", [0.4, 1.0])
+def test_specialised_compaction_keeps_the_padding_of_repr_c_records(hip, jit_sync, density):
+    """filter_into a VectorBuffer of a repr(C) layout (padding between and after the attributes) on the compiled streaming kernel: the target's
+    padding bytes and the records beyond the matches keep what they held (the reference writes attribute bytes only, point_buffer.rs:1110-1131)."""
+    from harness import random_records
+    attrs = [PointAttributeDefinition("t", T.F64), PointAttributeDefinition("i", T.U16), PointAttributeDefinition("c", T.Vec3f32), PointAttributeDefinition("k", T.U8),
+             PointAttributeDefinition("p", T.Vec3f64), PointAttributeDefinition("b", T.ByteArray(5))]
+    layout = PointLayout.from_attributes(attrs, api=hip)
+    assert layout.size_of_point_entry() > sum(a.size() for a in layout.attributes())  # (there IS padding)
+    n = 70_001
+    rec = random_records(layout, n, 9)
+    mask = np.random.default_rng(3).random(n) < density
+    k = int(mask.sum())
+    src = HashMapBuffer.from_numpy(rec, layout)
+    dst = VectorBuffer.new_from_layout(layout)
+    dst.resize(k + 3)
+    raw = np.full((k + 3, layout.size_of_point_entry()), 0xAB, np.uint8)
+    dst.set_point_range(range(0, k + 3), raw.view(layout.numpy_record_dtype()).reshape(-1))
+    assert src.filter_into(dst, mask) == k
+    assert cv.last_plan_kinds(hip)[0] == "jit", cv.last_plan_kinds(hip)
+    got = np.ascontiguousarray(dst.get_point_range(range(0, k + 3))).view(np.uint8).reshape(k + 3, -1)
+    covered = np.zeros(layout.size_of_point_entry(), bool)
+    for a in layout.attributes():
+        covered[a.offset():a.offset() + a.size()] = True
+    assert (got[:, ~covered] == 0xAB).all() and (got[k:] == 0xAB).all()
+    exp = np.ascontiguousarray(rec[mask]).view(np.uint8).reshape(k, -1)
+    assert np.array_equal(got[:k][:, covered], exp[:, covered])
 
 
 @pytest.mark.gpu
