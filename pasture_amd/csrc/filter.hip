@@ -474,9 +474,13 @@ struct StreamSig {
   uint32_t dst_stride = 0, cap = 0, total = 0;
   uint32_t size[kMaxFilterAttrs] = {}, dst_off[kMaxFilterAttrs] = {}, piece[kMaxFilterAttrs] = {};
 };
-// points per LDS round: about 52 KiB of values (three 512-lane blocks per CU), a multiple of 16
+// points per LDS round: about 52 KiB of values (three 512-lane blocks per CU), a multiple of 16 -- but at least the 1088 matches a tile of a
+// half-dense mask has (1024 +- 23), as long as that stays below 72 KiB (two blocks per CU): a second round over a few records costs more than the
+// third block buys
 __host__ __device__ constexpr uint32_t stream_cap_for(uint32_t total) {
-  uint32_t c = (52u * 1024u / (total ? total : 1u)) / 16u * 16u;
+  const uint32_t t = total ? total : 1u;
+  uint32_t c = (52u * 1024u / t) / 16u * 16u;
+  if (c < 1088u && 1088u * t <= 72u * 1024u) c = 1088u;
   return c > 2048u ? 2048u : c;
 }
 // Can this launch take a streaming kernel?  Columnar source (every attribute contiguous), at most 64 bytes per point (the lane holds four points
@@ -503,6 +507,9 @@ static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* s
   // the target and only the attributes' bytes replaced
   sig->covered = !dst_aos || (a.dst_covered && a.dst_stride == total);
   if (dst_aos && a.dst_stride > 128u) return false;
+  // the staged form pays for the span it reads and for per-piece stores: measured (profiles/r04_ab_compaction_padded.txt) +17 % against the
+  // gather kernel for ten narrow attributes in a 40-byte record, -3 % for six wide ones in a 64-byte record -- taken below 4 bytes per attribute
+  if (dst_aos && !sig->covered && total > 4u * a.n_attrs) return false;
   for (uint32_t i = 0; i < a.n_attrs; ++i)
     sig->piece[i] = !dst_aos ? aligned_piece(sig->size[i], a.attrs[i].dst)
                     : sig->covered ? pstf::piece_of(sig->size[i]) : aligned_piece(sig->size[i], a.dst_aos, a.dst_stride, a.attrs[i].dst_off);
