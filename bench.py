@@ -78,6 +78,10 @@ WORKLOADS = {
     "normals_knn16_sheet": (44, "the same on a LiDAR-like sheet (a noisy 2-D manifold z = f(x, y) in a 3-D box, 23 % of the box occupied) with 0.001 % "
                                 "stray points far above and below it: measured scale, trimmed box, box search, exact search of the strays"),
 }
+# typed LAS points of the other formats (sizes of LasPointFormatN::layout(), las_types.rs): compaction at density 0.5 = 2 mask reads + S R + S/2 W
+for _f, _s in ((1, 43), (2, 41), (4, 72), (5, 78), (6, 46), (7, 52), (8, 54), (9, 75)):
+    for _t in ("columnar", "interleaved"):
+        WORKLOADS[f"filter_las{_f}_{_t}"] = (2 + 1.5 * _s, f"HashMapBuffer::filter_into, typed LAS-{_f} points ({_s} B) columnar -> {_t}, density 0.5")
 
 
 def parse():

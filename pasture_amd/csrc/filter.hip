@@ -483,8 +483,8 @@ __host__ __device__ constexpr uint32_t stream_cap_for(uint32_t total) {
   if (c < 1088u && 1088u * t <= 72u * 1024u) c = 1088u;
   return c > 2048u ? 2048u : c;
 }
-// Can this launch take a streaming kernel?  Columnar source (every attribute contiguous), at most 64 bytes per point (the lane holds four points
-// in registers), records of at most 128 bytes.  Values go to LDS in pieces as wide as the target's alignment allows.
+// Can this launch take a streaming kernel?  Columnar source (every attribute contiguous), at most 64 (columns) / 96 (records) bytes per point (the
+// lane holds four points in registers), records of at most 128 bytes.  Values go to LDS in pieces as wide as the target's alignment allows.
 static uint32_t aligned_piece(uint32_t size, uint64_t a0, uint64_t a1 = 0, uint64_t a2 = 0) {
   uint32_t p = pstf::piece_of(size);
   while (p > 1u && (a0 % p != 0 || a1 % p != 0 || a2 % p != 0)) p >>= 1;
@@ -502,7 +502,10 @@ static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* s
     sig->dst_off[i] = dst_aos ? a.attrs[i].dst_off : 0u;
     total += size;
   }
-  if (total > 64u) return false;
+  // bytes per point: 64 into columns (typed LAS-9, 75 bytes in 18 spans: 0.36 of peak against the gather kernel's 0.58 -- the span bookkeeping
+  // spills), 96 into records (LAS-9 0.43 -> 0.66, LAS-5 0.44 -> 0.67: every LAS point format fits); PST_FILTER_STREAM_MAX_BYTES overrides both
+  static const uint32_t max_env = [] { const char* v = std::getenv("PST_FILTER_STREAM_MAX_BYTES"); return v && *v ? (uint32_t)std::atoi(v) : 0u; }();
+  if (total > (max_env ? max_env : dst_aos ? 96u : 64u)) return false;
   // records whose every byte is written are assembled as images; records with padding (or with attributes the source lacks) are staged from
   // the target and only the attributes' bytes replaced
   sig->covered = !dst_aos || (a.dst_covered && a.dst_stride == total);

@@ -220,6 +220,15 @@ def test_compaction_plan_compiles_with_hiprtc(hip, sizes, columns):
     assert _scratch_bytes(code) == 0, (sizes, columns)
 
 
+def test_compaction_plan_for_the_largest_las_format_compiles_with_hiprtc(hip):
+    """Typed LAS-10 points (83 bytes, 20 attributes) into records: the largest plan the record side takes (96 bytes per point)."""
+    sizes = [a.size() for a in las.point_layout_from_las_point_format(las.Format(10), False, api=hip).attributes()]
+    assert sum(sizes) == 83
+    code = cv.jit_compile_source(_filter_plan_source(sizes, False), api=hip)
+    assert code[:4] == b"\x7fELF"
+    assert _scratch_bytes(code) == 0
+
+
 def test_compaction_plan_for_padded_records_compiles_with_hiprtc(hip):
     """A repr(C) record {f64, u16, (2 bytes of padding), u32, u8, (7)} : 24 bytes, 15 of them written: the read-modify-write variant."""
     code = cv.jit_compile_source(_filter_plan_source([8, 2, 4, 1], False, offsets=[0, 8, 12, 16], stride=24), api=hip)
@@ -324,9 +333,11 @@ def test_specialised_compaction_vs_oracle(hip, oracle, jit_sync, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["V", "H"])
-@pytest.mark.parametrize("types", [[T.U8], [T.U16], [T.Vec3u8], [T.U8, T.U8], [T.U32], [T.ByteArray(5)], [T.ByteArray(16), T.ByteArray(16), T.ByteArray(16), T.ByteArray(16)]])
+@pytest.mark.parametrize("types", [[T.U8], [T.U16], [T.Vec3u8], [T.U8, T.U8], [T.U32], [T.ByteArray(5)], [T.ByteArray(16), T.ByteArray(16), T.ByteArray(16), T.ByteArray(16)],
+                                   [T.ByteArray(16)] * 4 + [T.Vec3f64, T.U64]])
 def test_specialised_compaction_of_tiny_and_largest_records(hip, oracle, jit_sync, types, kind):
-    """Records of one, two, three bytes (shorter than the dword grid a record image is shifted to) and of the 64-byte limit, sparse and dense masks."""
+    """Records of one, two, three bytes (shorter than the dword grid a record image is shifted to), of the 64-byte limit of the column side and of the
+    96-byte limit of the record side, sparse and dense masks."""
     n = 70_001
     for density in (0.03, 0.97):
         mask = np.random.default_rng(len(types) + int(density * 100)).random(n) < density
@@ -342,7 +353,8 @@ def test_specialised_compaction_of_tiny_and_largest_records(hip, oracle, jit_syn
         hn, hb, kinds = run(hip)
         on, ob, _ = run(oracle)
         assert hn == on and hb == ob, (types, density)
-        assert kinds[0] in ("jit", "static"), kinds
+        if kind == "V" or sum(t.size() for t in types) <= 64:  # (96 bytes per point into records, 64 into columns)
+            assert kinds[0] in ("jit", "static"), kinds
 
 
 @pytest.mark.gpu

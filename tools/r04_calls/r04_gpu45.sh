@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['roofline']['frac'], d['config'].get('plan'))"; }
+for rep in 1 2; do for w in filter_las9_columnar filter_las9_interleaved; do
+  python bench.py --no-cpu-baseline --no-north-star --workload $w --plan interpreted --steps 20 --warmup 5 2>/dev/null | tail -1 | line "$w gather"
+  PST_FILTER_STREAM_MAX_BYTES=96 python bench.py --no-cpu-baseline --no-north-star --workload $w --plan specialised --steps 20 --warmup 5 2>/dev/null | tail -1 | line "$w stream96"
+done; done
