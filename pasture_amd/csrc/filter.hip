@@ -607,7 +607,7 @@ static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream
   if (in_tree && stream_sig_is<Las0StreamPlan<true>>(sig)) { launch_stream_static<Las0StreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
   if (in_tree && stream_sig_is<Las0StreamPlan<false>>(sig)) { launch_stream_static<Las0StreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
   const std::string source = stream_source(sig);
-  const uint32_t lds = sig.dst_columns ? sig.total * sig.cap + 16u * (uint32_t)sig.n : sig.cap * sig.dst_stride + 64u;
+  const uint32_t lds = sig.dst_columns ? sig.total * sig.cap + 32u * (uint32_t)sig.n : sig.cap * sig.dst_stride + 64u;  // (= stream_lds_bytes<P>())
   const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait : a.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;
   pstjit::Kernel k;
   if (!pstjit::acquire_source(source, "pst_jit_filter", pstf::kStreamThreads, lds, pstf::kStreamTile, how, &k)) return 0;  // not ready (or failed): gather

@@ -66,7 +66,9 @@ __host__ __device__ constexpr uint32_t span_before(int k) {  // LDS offset of co
   return o;
 }
 template <typename P>
-__host__ __device__ constexpr uint32_t stream_lds_bytes() { return P::dst_columns ? span_before<P>(P::n) : P::cap * P::dst_stride + 64u; }
+__host__ __device__ constexpr uint32_t stream_lds_bytes() {  // columns: the spans + one 16-byte descriptor per span (the chunk list's lookup table)
+  return P::dst_columns ? span_before<P>(P::n) + 16u * (uint32_t)P::n : P::cap * P::dst_stride + 64u;
+}
 // the widest naturally aligned piece a value of `size` bytes splits into when its column starts on a multiple of that piece
 __host__ __device__ constexpr uint32_t piece_of(uint32_t size) { return size % 8u == 0 ? 8u : size % 4u == 0 ? 4u : size % 2u == 0 ? 2u : 1u; }
 
@@ -86,8 +88,12 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
   static_assert(P::cap % 16u == 0 && P::cap >= 16u, "column spans start on 16-byte boundaries");
   const uint32_t tile = blockIdx.x;
   const uint64_t first = (uint64_t)tile * kStreamTile;
-  const uint64_t out0 = a.offsets[tile];
-  uint32_t m = a.counts[tile];
+  // block-uniform by construction: on the scalar unit, so that everything derived from them (span addresses, phases, chunk ranges, the round
+  // loop) stays in scalar registers
+  const unsigned long long out0_v = a.offsets[tile];
+  const uint64_t out0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(out0_v >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)out0_v);
+  uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.counts[tile]);
   if (m == 0 || out0 >= a.limit) return;
   if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
   const uint32_t p0 = threadIdx.x * 4u;
@@ -142,6 +148,28 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
         }
         r += on ? 1u : 0u;
       });
+      // chunk list (below): span k's whole chunks are the list entries [pre[k], pre[k + 1]); entry c of span k lies at LDS byte A_k + 16 c and goes
+      // to address B_k + 16 c -- lane k leaves {A_k, B_k} in a table behind the spans, so that a lane finds its span by counting and one LDS read
+      uint32_t pre[P::n + 1], vf[P::n];
+      pre[0] = 0;
+      static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        const uint32_t end = mis[k] + cm * P::size(k);
+        vf[k] = (mis[k] + 15u) >> 4;
+        const uint32_t vl = end >> 4;
+        pre[k + 1] = pre[k] + (vl > vf[k] ? vl - vf[k] : 0u);
+        if constexpr (P::n > 6) {
+          if (threadIdx.x == (uint32_t)k) {
+            const uint64_t bk = ga[k] - mis[k] + (uint64_t)(vf[k] << 4) - ((uint64_t)pre[k] << 4);
+            u32x4 d;
+            d.x = span_before<P>(k) + (vf[k] << 4) - (pre[k] << 4);
+            d.y = (uint32_t)bk;
+            d.z = (uint32_t)(bk >> 32);
+            d.w = 0;
+            *reinterpret_cast<l4ptr_t>(lds + (span_before<P>(P::n) + 16u * (uint32_t)k)) = d;
+          }
+        }
+      });
       __syncthreads();
       if constexpr (P::n <= 6) {  // few, long spans: one after the other (same box, five spans: 0.706 against 0.695 of peak with the chunk list)
         static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
@@ -153,15 +181,6 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
       // keep 448 of 512 lanes idle, twelve times over for a LAS layout): chunk c belongs to the span whose range of WHOLE chunks holds it.  The
       // ragged ends of every span (the bytes before its first and after its last whole chunk) go out byte by byte, one lane per byte -- 32
       // lanes of the first wave per span --, so that no byte outside the target range is written.
-      uint32_t pre[P::n + 1], vf[P::n];
-      pre[0] = 0;
-      static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
-        constexpr int k = decltype(K)::value;
-        const uint32_t end = mis[k] + cm * P::size(k);
-        vf[k] = (mis[k] + 15u) >> 4;
-        const uint32_t vl = end >> 4;
-        pre[k + 1] = pre[k] + (vl > vf[k] ? vl - vf[k] : 0u);
-      });
       constexpr uint32_t kBatch = 4;
       for (uint32_t c0 = threadIdx.x; c0 < pre[P::n]; c0 += kBatch * kStreamThreads) {
         u32x4 v[kBatch];
@@ -169,15 +188,11 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
 #pragma unroll
         for (uint32_t u = 0; u < kBatch; ++u) {
           const uint32_t c = c0 + u * kStreamThreads;
-          uint32_t span_lds = 0, span_c0 = 0;
-          uint64_t span_g = 0;
-          static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
-            constexpr int k = decltype(K)::value;
-            if (c >= pre[k]) { span_lds = span_before<P>(k) + (vf[k] << 4); span_c0 = pre[k]; span_g = ga[k] - mis[k] + (vf[k] << 4); }
-          });
-          const uint32_t off = (c - span_c0) << 4;
-          g[u] = span_g + off;
-          if (c < pre[P::n]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + (span_lds + off));
+          uint32_t k = 0;
+          static_for<1, P::n>([&](auto K) __attribute__((always_inline)) { k += c >= pre[decltype(K)::value] ? 1u : 0u; });
+          const u32x4 d = *reinterpret_cast<cl4ptr_t>(lds + (span_before<P>(P::n) + 16u * k));
+          g[u] = (((uint64_t)d.z << 32) | d.y) + ((uint64_t)c << 4);
+          if (c < pre[P::n]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + (d.x + (c << 4)));
         }
 #pragma unroll
         for (uint32_t u = 0; u < kBatch; ++u)
