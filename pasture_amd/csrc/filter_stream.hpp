@@ -158,27 +158,19 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
         vf[k] = (mis[k] + 15u) >> 4;
         const uint32_t vl = end >> 4;
         pre[k + 1] = pre[k] + (vl > vf[k] ? vl - vf[k] : 0u);
-        if constexpr (P::n > 6) {
-          if (threadIdx.x == (uint32_t)k) {
-            const uint64_t bk = ga[k] - mis[k] + (uint64_t)(vf[k] << 4) - ((uint64_t)pre[k] << 4);
-            u32x4 d;
-            d.x = span_before<P>(k) + (vf[k] << 4) - (pre[k] << 4);
-            d.y = (uint32_t)bk;
-            d.z = (uint32_t)(bk >> 32);
-            d.w = 0;
-            *reinterpret_cast<l4ptr_t>(lds + (span_before<P>(P::n) + 16u * (uint32_t)k)) = d;
-          }
+        if (threadIdx.x == (uint32_t)k) {
+          const uint64_t bk = ga[k] - mis[k] + (uint64_t)(vf[k] << 4) - ((uint64_t)pre[k] << 4);
+          u32x4 d;
+          d.x = span_before<P>(k) + (vf[k] << 4) - (pre[k] << 4);
+          d.y = (uint32_t)bk;
+          d.z = (uint32_t)(bk >> 32);
+          d.w = 0;
+          *reinterpret_cast<l4ptr_t>(lds + (span_before<P>(P::n) + 16u * (uint32_t)k)) = d;
         }
       });
       __syncthreads();
-      if constexpr (P::n <= 6) {  // few, long spans: one after the other (same box, five spans: 0.706 against 0.695 of peak with the chunk list)
-        static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
-          constexpr int k = decltype(K)::value;
-          tile_store<(int)kStreamThreads>(lds + span_before<P>(k), as_global(ga[k] - mis[k]), mis[k], cm * P::size(k));
-        });
-      } else {
       // The spans leave as ONE list of 16-byte chunks spread over the block (a span of one-byte values is 64 chunks: a tile_store per span would
-      // keep 448 of 512 lanes idle, twelve times over for a LAS layout): chunk c belongs to the span whose range of WHOLE chunks holds it.  The
+      // keep 448 of 512 lanes idle, twelve times over for a LAS layout; even the bench layout's five long spans gain 2 % from the list).  The
       // ragged ends of every span (the bytes before its first and after its last whole chunk) go out byte by byte, one lane per byte -- 32
       // lanes of the first wave per span --, so that no byte outside the target range is written.
       constexpr uint32_t kBatch = 4;
@@ -209,7 +201,6 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
           const bool mine = threadIdx.x < 16u ? (b >= mis[k] && b < head_end) : (b < end);
           if (mine) as_global(ga[k] - mis[k])[b] = lds[span_before<P>(k) + b];
         });
-      }
       }
       if (base + P::cap < m) __syncthreads();
     } else {
