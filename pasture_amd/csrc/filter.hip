@@ -543,23 +543,24 @@ static std::string stream_source(const StreamSig& s) {
   return o.str();
 }
 
-// typed LAS-0 points (LasPointFormat0::layout(), las_types.rs: Position3D, Intensity, ReturnNumber, NumberOfReturns, ScanDirectionFlag,
-// EdgeOfFlightLine, Classification, ScanAngleRank, UserData, PointSourceID; 35 bytes packed): the cloud a pasture user filters most often
-template <bool COLUMNS>
-struct Las0StreamPlan {
-  static constexpr int n = 10;
+// typed LAS points (LasPointFormatN::layout(), las_types.rs: packed in field order; sizes from las_device.hpp): the clouds a pasture user filters
+// most often -- formats 0-3 (LAS 1.2) and 6-8 (LAS 1.4) in-tree, the waveform formats through the run-time compiler
+template <int FORMAT, bool COLUMNS>
+struct LasStreamPlan {
+  static constexpr pstlas::Fmt F = pstlas::fmt_of(FORMAT);
+  __host__ __device__ static constexpr int slots() {
+    int k = 0;
+    while (pstlas::typed_slot_offset(F, k) < pstlas::typed_size(F)) ++k;
+    return k;
+  }
+  static constexpr int n = slots();
   static constexpr bool dst_columns = COLUMNS, covered = true;
-  static constexpr uint32_t dst_stride = COLUMNS ? 0u : 35u, cap = stream_cap_for(35u);
-  __host__ __device__ static constexpr uint32_t size(int k) {
-    constexpr uint32_t t[n] = {24, 2, 1, 1, 1, 1, 1, 1, 1, 2};
-    return t[k];
-  }
-  __host__ __device__ static constexpr uint32_t dst_off(int k) {
-    constexpr uint32_t t[n] = {0, 24, 26, 27, 28, 29, 30, 31, 32, 33};
-    return COLUMNS ? 0u : t[k];
-  }
+  static constexpr uint32_t dst_stride = COLUMNS ? 0u : pstlas::typed_size(F), cap = stream_cap_for(pstlas::typed_size(F));
+  __host__ __device__ static constexpr uint32_t size(int k) { return pstlas::typed_slot_offset(F, k + 1) - pstlas::typed_slot_offset(F, k); }
+  __host__ __device__ static constexpr uint32_t dst_off(int k) { return COLUMNS ? 0u : pstlas::typed_slot_offset(F, k); }
   __host__ __device__ static constexpr uint32_t piece(int k) { return pstf::piece_of(size(k)); }
 };
+static_assert(LasStreamPlan<0, false>::n == 10 && LasStreamPlan<0, false>::dst_stride == 35 && LasStreamPlan<3, true>::n == 12 && LasStreamPlan<8, false>::dst_stride == 54, "typed LAS layouts");
 // CustomPointTypeBig (test_utils.rs:19-31; buffer_filter_bench.rs:71-74): GpsTime, ColorRGB, Position3D, Classification, Intensity (i16); 41 bytes
 template <bool COLUMNS>
 struct BigStreamPlan {
@@ -604,8 +605,11 @@ static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream
   if (!enabled || mode == pstjit::Mode::Off || n_full == 0 || n_full > (1ull << 30) || !stream_sig_from_args(a, dst_aos, &sig)) return 0;
   if (in_tree && stream_sig_is<BigStreamPlan<true>>(sig)) { launch_stream_static<BigStreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
   if (in_tree && stream_sig_is<BigStreamPlan<false>>(sig)) { launch_stream_static<BigStreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
-  if (in_tree && stream_sig_is<Las0StreamPlan<true>>(sig)) { launch_stream_static<Las0StreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
-  if (in_tree && stream_sig_is<Las0StreamPlan<false>>(sig)) { launch_stream_static<Las0StreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+#define PST_TRY_LAS(FMT)                                                                                                                   \
+  if (in_tree && stream_sig_is<LasStreamPlan<FMT, true>>(sig)) { launch_stream_static<LasStreamPlan<FMT, true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }   \
+  if (in_tree && stream_sig_is<LasStreamPlan<FMT, false>>(sig)) { launch_stream_static<LasStreamPlan<FMT, false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
+  PST_TRY_LAS(0) PST_TRY_LAS(1) PST_TRY_LAS(2) PST_TRY_LAS(3) PST_TRY_LAS(6) PST_TRY_LAS(7) PST_TRY_LAS(8)
+#undef PST_TRY_LAS
   const std::string source = stream_source(sig);
   const uint32_t lds = sig.dst_columns ? sig.total * sig.cap + 32u * (uint32_t)sig.n : sig.cap * sig.dst_stride + 64u;  // (= stream_lds_bytes<P>())
   const pstjit::Acquire how = mode == pstjit::Mode::Sync ? pstjit::Acquire::Wait : a.n >= pstjit::min_points() ? pstjit::Acquire::Enqueue : pstjit::Acquire::IfReady;

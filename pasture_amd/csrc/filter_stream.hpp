@@ -101,8 +101,8 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
   uint32_t w[W];  // the lane's four points, attribute after attribute: 4 x size(k) bytes = size(k) dwords each
   static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
     constexpr int k = decltype(K)::value;
-    constexpr uint32_t S = P::size(k);
-    pstq::load_words<S, false>((cgptr_t)as_global(a.attrs[k].src) + (first + p0) * S, w, words_before<P>(k));
+    constexpr uint32_t S = P::size(k), WB = words_before<P>(k);  // (constexpr locals: a plan's functions may be loops the optimiser would not fold)
+    pstq::load_words<S, false>((cgptr_t)as_global(a.attrs[k].src) + (first + p0) * S, w, WB);
   });
   // ranks: matches before this lane's points, within the tile
   uint32_t c = 0;
@@ -126,7 +126,8 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
       uint32_t mis[P::n];
       static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
-        ga[k] = a.attrs[k].dst + (out0 + base) * P::size(k);
+        constexpr uint32_t S = P::size(k);
+        ga[k] = a.attrs[k].dst + (out0 + base) * S;
         mis[k] = (uint32_t)(ga[k] & 15u);
       });
       uint32_t r = r0;
@@ -137,8 +138,8 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
           const uint32_t j = r - base;
           static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
             constexpr int k = decltype(K)::value;
-            constexpr uint32_t S = P::size(k), U = P::piece(k);
-            lptr_t q = lds + (span_before<P>(k) + mis[k] + j * S);
+            constexpr uint32_t S = P::size(k), U = P::piece(k), SB = span_before<P>(k);
+            lptr_t q = lds + (SB + mis[k] + j * S);
             static_for<0, (int)(S / U)>([&](auto C) __attribute__((always_inline)) {
               constexpr uint32_t cidx = (uint32_t) decltype(C)::value;
               typedef typename PieceType<U>::type PT;
@@ -154,18 +155,19 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
       pre[0] = 0;
       static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
-        const uint32_t end = mis[k] + cm * P::size(k);
+        constexpr uint32_t S = P::size(k), SB = span_before<P>(k), TB = span_before<P>(P::n);
+        const uint32_t end = mis[k] + cm * S;
         vf[k] = (mis[k] + 15u) >> 4;
         const uint32_t vl = end >> 4;
         pre[k + 1] = pre[k] + (vl > vf[k] ? vl - vf[k] : 0u);
         if (threadIdx.x == (uint32_t)k) {
           const uint64_t bk = ga[k] - mis[k] + (uint64_t)(vf[k] << 4) - ((uint64_t)pre[k] << 4);
           u32x4 d;
-          d.x = span_before<P>(k) + (vf[k] << 4) - (pre[k] << 4);
+          d.x = SB + (vf[k] << 4) - (pre[k] << 4);
           d.y = (uint32_t)bk;
           d.z = (uint32_t)(bk >> 32);
           d.w = 0;
-          *reinterpret_cast<l4ptr_t>(lds + (span_before<P>(P::n) + 16u * (uint32_t)k)) = d;
+          *reinterpret_cast<l4ptr_t>(lds + (TB + 16u * (uint32_t)k)) = d;
         }
       });
       __syncthreads();
@@ -182,7 +184,8 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
           const uint32_t c = c0 + u * kStreamThreads;
           uint32_t k = 0;
           static_for<1, P::n>([&](auto K) __attribute__((always_inline)) { k += c >= pre[decltype(K)::value] ? 1u : 0u; });
-          const u32x4 d = *reinterpret_cast<cl4ptr_t>(lds + (span_before<P>(P::n) + 16u * k));
+          constexpr uint32_t TB = span_before<P>(P::n);
+          const u32x4 d = *reinterpret_cast<cl4ptr_t>(lds + (TB + 16u * k));
           g[u] = (((uint64_t)d.z << 32) | d.y) + ((uint64_t)c << 4);
           if (c < pre[P::n]) v[u] = *reinterpret_cast<cl4ptr_t>(lds + (d.x + (c << 4)));
         }
@@ -194,12 +197,13 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
         const uint32_t t = threadIdx.x & 15u;
         static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
           constexpr int k = decltype(K)::value;
-          const uint32_t end = mis[k] + cm * P::size(k);
+          constexpr uint32_t S = P::size(k), SB = span_before<P>(k);
+          const uint32_t end = mis[k] + cm * S;
           const uint32_t head_end = (vf[k] << 4) < end ? (vf[k] << 4) : end;              // bytes [mis, head_end)
           const uint32_t tail_begin = ((end >> 4) << 4) > head_end ? ((end >> 4) << 4) : head_end;  // bytes [tail_begin, end)
           const uint32_t b = threadIdx.x < 16u ? ((mis[k] >> 4) << 4) + t : tail_begin + t;
           const bool mine = threadIdx.x < 16u ? (b >= mis[k] && b < head_end) : (b < end);
-          if (mine) as_global(ga[k] - mis[k])[b] = lds[span_before<P>(k) + b];
+          if (mine) as_global(ga[k] - mis[k])[b] = lds[SB + b];
         });
       }
       if (base + P::cap < m) __syncthreads();
@@ -225,7 +229,8 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
               static_for<0, (int)(S / U)>([&](auto C) __attribute__((always_inline)) {
                 constexpr uint32_t cidx = (uint32_t) decltype(C)::value;
                 typedef typename PieceType<U>::type PT;
-                store_un<PT>(rec + (P::dst_off(k) + cidx * U), (PT)pstq::img_get<4u * words_before<P>(k) + i * S + cidx * U, U>(w));
+                constexpr uint32_t DO = P::dst_off(k);
+                store_un<PT>(rec + (DO + cidx * U), (PT)pstq::img_get<4u * words_before<P>(k) + i * S + cidx * U, U>(w));
               });
             });
           }

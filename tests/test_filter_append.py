@@ -189,3 +189,28 @@ def test_filter_big_layout_takes_the_streaming_kernels(hip, density):
             assert cv.last_plan_kinds(hip) == ["static"], (kind.__name__, cv.last_plan_kinds(hip))
         assert out.len() == int(mask.sum())
         assert_same(out, rec[mask])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_kind", ["V", "H"])
+@pytest.mark.parametrize("fmt", [0, 1, 2, 3, 6, 7, 8])
+def test_filter_typed_las_points_takes_the_in_tree_streaming_kernels(hip, oracle, fmt, out_kind):
+    """Typed LAS points of the formats without waveform packets (LasPointFormatN::layout(), las_types.rs) are compacted by kernels instantiated in the
+    library (no run-time compilation): byte-identical to the oracle, plan family "static"."""
+    from pasture_amd import conversion as cv
+    from pasture_amd import las
+    n = 70_001
+    mask = np.random.default_rng(fmt).random(n) < 0.5
+
+    def run(api):
+        layout = las.point_layout_from_las_point_format(las.Format(fmt), False, api=api)
+        src = HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(40 + fmt, 0)
+        out = src.filter(BUFFER_KINDS[out_kind], mask)
+        kinds = cv.last_plan_kinds(api) if api is hip else None
+        return out.len(), out.get_point_range(range(0, out.len())).tobytes(), kinds
+    hn, hb, kinds = run(hip)
+    on, ob, _ = run(oracle)
+    assert hn == on == int(mask.sum()) and hb == ob
+    assert kinds == ["static"], kinds

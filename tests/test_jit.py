@@ -120,6 +120,24 @@ def _scratch_bytes(code: bytes) -> int:
     return {0xcc: lambda: b[1], 0xcd: lambda: int.from_bytes(b[1:3], "big"), 0xce: lambda: int.from_bytes(b[1:5], "big")}[b[0]]()
 
 
+def test_in_tree_plan_kernels_use_no_scratch_memory():
+    """The plan-specialised kernels instantiated in the library (conversions: convert_static.hip, compactions: filter.hip) keep their register images
+    in registers: .private_segment_fixed_size == 0 for every one of them, read from the metadata of the built library.  (A plan type whose
+    constants the optimiser does not fold compiles, passes every parity test -- and runs a hundred times slower.)"""
+    from pasture_amd import _capi
+    data = open(_capi.LIB_PATH, "rb").read()
+    key = b".private_segment_fixed_size"
+    seen = {}
+    for family in (b"filter_stream_static_kernel", b"quad_convert_static_kernel"):
+        for m in re.finditer(rb"\.name[\xa0-\xbf\xd9\xda].?.?(_Z[0-9A-Za-z_]*" + family + rb"[0-9A-Za-z_]*)", data):
+            j = data.find(key, m.end())
+            assert 0 <= j - m.end() <= 4, "metadata layout changed"
+            seen[m.group(1)] = _scratch_bytes(data[j:j + len(key) + 8])
+    assert sum(1 for k in seen if b"filter_stream_static_kernel" in k) >= 16 and sum(1 for k in seen if b"quad_convert_static_kernel" in k) >= 19, len(seen)
+    bad = {k.decode(): v for k, v in seen.items() if v != 0}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_generated_plans_compile_under_hiprtc(hip, seed):
     """Host logic only: random converters -> the translation unit jit.cpp would hand to hipRTC -> compiled for gfx950 against the embedded
