@@ -45,6 +45,23 @@ __global__ __launch_bounds__(kBlock) void mask_count_kernel(const uint8_t* __res
                                                             uint32_t* __restrict__ counts) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+  if (tile == 2048u && (uint64_t)(wave + 1u) * kCountTilesPerWave * 2048u <= n) {
+    // four whole 2048-byte tiles: all eight 16-byte loads of the lane in flight before the first count (23.1 -> 20.2 us per 10^8 mask bytes)
+    cgptr_t m = (cgptr_t)((uint64_t)(uintptr_t)mask + (uint64_t)wave * kCountTilesPerWave * 2048u);
+    u32x4 v[2 * kCountTilesPerWave];
+#pragma unroll
+    for (uint32_t q = 0; q < 2 * kCountTilesPerWave; ++q) v[q] = load_un<u32x4>(m + 1024u * q + 16u * lane);
+#pragma unroll
+    for (uint32_t u = 0; u < kCountTilesPerWave; ++u) {
+      uint32_t c = 0;
+#pragma unroll
+      for (uint32_t h = 0; h < 2; ++h) { const u32x4 x = v[2 * u + h]; c += nonzero_bytes(x.x) + nonzero_bytes(x.y) + nonzero_bytes(x.z) + nonzero_bytes(x.w); }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+      if (lane == 0) counts[wave * kCountTilesPerWave + u] = c;
+    }
+    return;
+  }
   for (uint32_t u = 0; u < kCountTilesPerWave; ++u) {
     const uint32_t t = wave * kCountTilesPerWave + u;
     if (t >= n_tiles) return;
@@ -121,6 +138,43 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const uint32_t* __restr
     }
   }
   if (threadIdx.x == 0) { offsets[n_tiles] = carry; if (total_also) *total_also = carry; }
+}
+
+// The same scan by MANY blocks without any hand-over between them: block b owns the 1024 tile counts [1024 b, 1024 b + 1024) and finds its own base
+// by summing every count before them (the last block of a 10^8-point call reads 48 k counts = 190 KiB from L2; all blocks together 4.6 MB) -- no
+// flags, no atomics, no ordering assumption, and the 12 dependent rounds of the one-block scan (24.5 us) become one block-wide reduction and one
+// block-wide scan per block, all blocks at once.  The work grows with the square of the tile count: taken up to 2^19 tiles (10^9 points).
+constexpr uint32_t kScanBlockTiles = 1024;
+__global__ __launch_bounds__(kScanBlockTiles) void tile_scan_blocks_kernel(const uint32_t* __restrict__ counts, uint32_t n_tiles, unsigned long long* __restrict__ offsets,
+                                                                           unsigned long long* __restrict__ total_also) {
+  __shared__ unsigned long long before_tot[16], own_tot[16];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * kScanBlockTiles;
+  unsigned long long s = 0;
+  for (uint32_t i = threadIdx.x * 4u; i < first; i += kScanBlockTiles * 4u) {  // (first is a multiple of 1024: whole 16-byte groups)
+    const u32x4 v = load_un<u32x4>((cgptr_t)(counts + i));
+    s += (unsigned long long)v.x + v.y + v.z + v.w;
+  }
+  const uint32_t t = first + threadIdx.x;
+  const uint32_t c = t < n_tiles ? counts[t] : 0u;
+  uint32_t incl = c;  // (a block's own counts sum to at most 1024 x 2048 points)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+    if ((int)lane >= off) incl += o;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t l = (uint32_t)__shfl_xor((int)(uint32_t)s, off, 64), h = (uint32_t)__shfl_xor((int)(uint32_t)(s >> 32), off, 64);
+    s += ((unsigned long long)h << 32) | l;
+  }
+  if (lane == 63) { own_tot[wave] = incl; before_tot[wave] = s; }
+  __syncthreads();
+  unsigned long long base = 0, own_before = 0, own_all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; ++w) { base += before_tot[w]; if (w < wave) own_before += own_tot[w]; own_all += own_tot[w]; }
+  if (t < n_tiles) offsets[t] = base + own_before + incl - c;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { offsets[n_tiles] = base + own_all; if (total_also) *total_also = base + own_all; }
 }
 
 using pstf::kMaxFilterAttrs;
@@ -655,7 +709,12 @@ void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uin
   uint32_t* counts = (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
   const uint32_t tiles_per_block = (kBlock / 64) * kCountTilesPerWave;
   hipLaunchKernelGGL(mask_count_kernel, dim3((n_tiles + tiles_per_block - 1) / tiles_per_block), dim3(kBlock), 0, stream, mask_dev, n, tile, n_tiles, counts);
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)counts, n_tiles, offsets, total_also);
+  static const bool scan_blocks = [] { const char* v = std::getenv("PST_FILTER_SCAN_BLOCKS"); return !(v && *v == '0'); }();  // (0: the one-block scan, the A/B)
+  if (scan_blocks && n_tiles > kScanBlockTiles && n_tiles <= (1u << 19))
+    hipLaunchKernelGGL(tile_scan_blocks_kernel, dim3((n_tiles + kScanBlockTiles - 1) / kScanBlockTiles), dim3(kScanBlockTiles), 0, stream, (const uint32_t*)counts, n_tiles,
+                       offsets, total_also);
+  else
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, (const uint32_t*)counts, n_tiles, offsets, total_also);
   *out_total_dev = offsets + n_tiles;
 }
 
