@@ -556,6 +556,18 @@ def test_single_process_two_devices_allreduce_multi_and_device_switch(hip):
         assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
 
 
+def _run_ranks(cmd, env, as_expected):
+    """A multi-rank bench.py run under torch.distributed.run.  One full GPU suite in five saw one of these runs fail without the failure showing again
+    in eight repetitions (rendezvous over 127.0.0.1 between freshly spawned processes): an unexpected outcome is reported on stderr and the run
+    repeated ONCE, so that the suite's `-x` does not end on it; a real defect fails both times."""
+    import subprocess
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    if not as_expected(r):
+        sys.stderr.write(f"[test_distributed_gloo] unexpected outcome of {' '.join(cmd[1:])}: rc={r.returncode}\n{r.stderr[-3000:]}\n-- repeating once --\n")
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    return r
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsed_on_one_gpu():
     """`bench.py --gpus 2 --rehearse-on-one-gpu`: TWO ranks with real kernels on the one GPU of the box, talking over gloo -- the sharding by
@@ -570,7 +582,7 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     want = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--points", "5000000", "--configs3-points", "30000001", *common]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    r = _run_ranks(cmd, env, lambda r: r.returncode == 0)
     assert r.returncode == 0, r.stderr[-3000:]
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert got["n_gpus"] == 2 and "rehearsal" in got["config"]
@@ -591,7 +603,7 @@ def test_bench_failed_self_check_prints_the_line_and_exits_non_zero():
     env["PASTURE_BENCH_FAULT"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--points", "2000000", "--no-configs3", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-north-star"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    r = _run_ranks(cmd, env, lambda r: r.returncode != 0 and "exitcode: 3" in r.stderr)
     assert r.returncode != 0 and "exitcode: 3" in r.stderr, (r.returncode, r.stderr[-2000:])  # (torch.distributed.run reports the ranks' exit 3 as its own 1)
     got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert got["self_check"]["verified"] is False and "self-check failed" in got["self_check"]["error"] and got["value"] > 0
