@@ -17,9 +17,10 @@ for seed in ${RANDOM_SEEDS:-1 4 7}; do
     done
   done
 done
-for w in filter_big_columnar filter_big_interleaved; do
-  PST_STATIC_PLANS=0 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out
-  python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out
+for w in filter_big_columnar filter_big_interleaved filter_las0_columnar filter_las0_interleaved filter_las3_columnar filter_las3_interleaved filter_las9_interleaved; do
+  for plan in interpreted specialised; do   # (interpreted = the gather kernels; specialised = the streaming kernels, in-tree or compiled before the timed region)
+    python bench.py --workload $w --plan $plan --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 >> $out
+  done
 done
 if [ -z "${GENERIC_ONLY:-}" ]; then
 for w in convert_affine_bounds bounds las0_encode voxelgrid_xyz voxelgrid_xyz_async narrow_f64_f32 normals_knn16 normals_knn16_async normals_knn16_sheet; do
