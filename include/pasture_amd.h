@@ -146,11 +146,18 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
  * slice: calculate_bounds(&buf.slice(a..b)), the chunked minmax_attribute of pasture-tools/src/bin/info.rs:66-78, transform_attribute on
  * slice_mut, compute_normals, conversions from / into it.  A range outside the parent is PST_ERR_RANGE (the slice's index assertions
  * :52-75); a slice cannot be resized (PST_ERR_UNSUPPORTED: it is not an OwningBuffer).  It borrows the parent's memory: destroy it
- * before the parent is resized or destroyed (what the borrow checker enforces in Rust). */
+ * before the parent is resized or destroyed (what the borrow checker enforces in Rust).  The library checks what the borrow checker would:
+ * every owning buffer carries a storage epoch that its resize and destroy bump, and any later use of a slice cut before that (or of a slice
+ * of such a slice) is PST_ERR_INVALID_ARGUMENT -- never a read of freed device memory.  (pst_buffer_destroy of the stale slice itself
+ * still succeeds.  Slices of caller-owned external memory are not tracked: that memory's lifetime is the caller's.) */
 int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_buffer** out);
 int pst_buffer_destroy(pst_buffer* b);
 int pst_buffer_len(const pst_buffer* b, size_t* out);                 /* BorrowedBuffer::len :29 */
 int pst_buffer_resize(pst_buffer* b, size_t count);                   /* OwningBuffer::resize :263 — new points zero-filled */
+/* BorrowedMutBuffer::swap (point_buffer.rs:229; VectorBuffer :770-783, HashMapBuffer :1276-1292, ExternalMemoryBuffer :1591-1612): exchanges two
+ * points in place, on the current stream (three small device copies per record / per column through the library's scratch).  Either index out of
+ * bounds -> PST_ERR_RANGE (the reference's assert!); equal indices return at once.  Not a bulk path: a per-point device round trip. */
+int pst_buffer_swap(pst_buffer* b, size_t from_index, size_t to_index);
 int pst_buffer_is_columnar(const pst_buffer* b, int* out);            /* as_columnar / as_interleaved probes :143-151 */
 int pst_buffer_layout(const pst_buffer* b, pst_layout** out_clone);   /* point_layout() :33 (returns a clone) */
 int pst_buffer_points_ptr(const pst_buffer* b, void** out);           /* get_point_range_ref(0..len).as_ptr() :524-526 */

@@ -1,5 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see pasture_oracle.hpp header).  C API over the CPU restatement.
 #include "oracle_capi.h"
+#include <algorithm>
 
 #include <chrono>
 #include <string>
@@ -121,6 +122,28 @@ int orc_buffer_create(const orc_layout* l, uint32_t storage, uint32_t, orc_buffe
 int orc_buffer_destroy(orc_buffer* b) { delete b; return OK; }
 int orc_buffer_len(const orc_buffer* b, size_t* out) { ORC_TRY *need(out, "out") = need(b, "buffer")->b->len(); ORC_CATCH }
 int orc_buffer_resize(orc_buffer* b, size_t count) { ORC_TRY need(b, "buffer")->b->resize(count); ORC_CATCH }
+// BorrowedMutBuffer::swap -- point_buffer.rs:229; VectorBuffer :770-783 (the two records), HashMapBuffer :1276-1292 (per attribute storage),
+// ExternalMemoryBuffer :1591-1612.  Panics (assert!) when either index is out of bounds; equal indices return at once.
+int orc_buffer_swap(orc_buffer* b_, size_t from_index, size_t to_index) {
+  ORC_TRY
+  Buffer& b = *need(b_, "buffer")->b;
+  if (!(from_index < b.len())) throw Panic(ERR_RANGE, "assertion failed: from_index < self.len()");
+  if (!(to_index < b.len())) throw Panic(ERR_RANGE, "assertion failed: to_index < self.len()");
+  if (from_index == to_index) return 0;
+  if (InterleavedBuffer* ib = b.as_interleaved()) {
+    const size_t size_of_point = b.point_layout().size_of_point_entry();
+    uint8_t* base = ib->get_point_range_mut({0, b.len()});
+    std::swap_ranges(base + from_index * size_of_point, base + (from_index + 1) * size_of_point, base + to_index * size_of_point);
+  } else {
+    ColumnarBuffer* cb = b.as_columnar();
+    for (const AttributeMember& m : b.point_layout().attributes) {
+      const size_t sz = (size_t)m.def.size();
+      uint8_t* col = cb->get_attribute_range_mut(m.def, {0, b.len()});
+      std::swap_ranges(col + from_index * sz, col + (from_index + 1) * sz, col + to_index * sz);
+    }
+  }
+  ORC_CATCH
+}
 int orc_buffer_is_columnar(const orc_buffer* b, int* out) { ORC_TRY *need(out, "out") = need(b, "buffer")->b->as_columnar() != nullptr; ORC_CATCH }
 int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone) { ORC_TRY *need(out_clone, "out") = new orc_layout{need(b, "buffer")->b->point_layout()}; ORC_CATCH }
 

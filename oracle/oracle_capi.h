@@ -72,6 +72,7 @@ int orc_buffer_create(const orc_layout* l, uint32_t storage, uint32_t memkind, o
 int orc_buffer_destroy(orc_buffer* b);
 int orc_buffer_len(const orc_buffer* b, size_t* out);
 int orc_buffer_resize(orc_buffer* b, size_t count);
+int orc_buffer_swap(orc_buffer* b, size_t from_index, size_t to_index);  /* BorrowedMutBuffer::swap, point_buffer.rs:229, :770-783, :1276-1292 */
 int orc_buffer_is_columnar(const orc_buffer* b, int* out);
 int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone);
 int orc_buffer_write_points(orc_buffer* b, size_t first, size_t count, const void* src);

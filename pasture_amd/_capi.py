@@ -96,6 +96,7 @@ _SHARED_SIGNATURES = {
     "buffer_destroy": [_P],
     "buffer_len": [_P, C.POINTER(_SZ)],
     "buffer_resize": [_P, _SZ],
+    "buffer_swap": [_P, _SZ, _SZ],
     "buffer_is_columnar": [_P, C.POINTER(C.c_int)],
     "buffer_layout": [_P, _PP],
     "buffer_write_points": [_P, _SZ, _SZ, _P],

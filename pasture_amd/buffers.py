@@ -156,6 +156,9 @@ class _Buffer:
         cdt = dt.to_c()
         self.api.buffer_write_attribute(self._h, attribute.name().encode(), C.byref(cdt), first, count, arr.ctypes.data_as(C.c_void_p))
 
+    def swap(self, from_index: int, to_index: int) -> None:  # BorrowedMutBuffer::swap :229 (panics when an index is out of bounds)
+        self.api.buffer_swap(self._h, from_index, to_index)
+
     # OwningBuffer --------------------------------------------------------------------------------------
     def resize(self, count: int) -> None:  # :263 (new points zero-filled)
         self.api.buffer_resize(self._h, count)

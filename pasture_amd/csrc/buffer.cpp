@@ -196,6 +196,15 @@ PlanEntry identity_entry(const Member& src, const Member& dst) {
   return e;
 }
 
+void check_live(const pst_buffer& b) {
+  if (b.is_slice && b.epoch && b.epoch->load(std::memory_order_acquire) != b.epoch_cut)
+    throw Error(PST_ERR_INVALID_ARGUMENT, "this slice outlived its parent's storage: the parent buffer was resized or destroyed after the slice was cut "
+                                          "(a slice borrows the parent's memory, slice.rs:16-43)");
+}
+void bump_epoch(pst_buffer& b) {
+  if (b.owns && b.epoch) b.epoch->fetch_add(1, std::memory_order_acq_rel);
+}
+
 static void check_range(const pst_buffer& b, size_t first, size_t count) {
   if (first + count < first || first + count > b.len)
     throw Error(PST_ERR_RANGE, "range end index " + std::to_string(first + count) + " out of range for buffer of length " + std::to_string(b.len));
@@ -213,6 +222,7 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
     if (count != b.len) throw Error(PST_ERR_UNSUPPORTED, "ExternalMemoryBuffer is not an OwningBuffer: it cannot be resized");
     return;
   }
+  if (count != b.len) bump_epoch(b);  // Vec::resize needs &mut: no slice of this buffer can be alive in the reference
   hipStream_t s = current_stream();
   if (count > b.capacity) {
     // pool allocations are stream-ordered (hipMallocAsync / hipFreeAsync on the current stream): copy and free need no host round trip
@@ -255,6 +265,7 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
 
 pst_buffer::~pst_buffer() {
   if (owns) {
+    pst::bump_epoch(*this);
     pst::dev_free(data, memkind);
     for (auto* c : columns) pst::dev_free(c, memkind);
   }
@@ -336,6 +347,10 @@ int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_b
   b->owns = false;
   b->memkind = parent->memkind;
   b->len = b->capacity = count;
+  b->is_slice = true;
+  if (parent->owns && !parent->epoch) parent->epoch = std::make_shared<std::atomic<uint64_t>>(0);
+  b->epoch = parent->epoch;  // a slice of a slice watches the same owning ancestor; a slice of external memory watches nothing
+  b->epoch_cut = parent->is_slice ? parent->epoch_cut : (parent->epoch ? parent->epoch->load(std::memory_order_acquire) : 0);
   if (parent->columnar) {
     for (size_t a = 0; a < parent->layout.members.size(); ++a)
       b->columns.push_back(parent->columns[a] ? parent->columns[a] + first * parent->layout.members[a].size : nullptr);
@@ -348,6 +363,32 @@ int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_b
 int pst_buffer_destroy(pst_buffer* b) { delete b; return PST_OK; }
 int pst_buffer_len(const pst_buffer* b, size_t* out) { PST_API_BEGIN *not_null(out, "out") = not_null(b, "buffer")->len; PST_API_END }
 int pst_buffer_resize(pst_buffer* b, size_t count) { PST_API_BEGIN resize_buffer(*not_null(b, "buffer"), count, true); PST_API_END }
+int pst_buffer_swap(pst_buffer* b, size_t from_index, size_t to_index) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  if (!(from_index < b->len)) throw Error(PST_ERR_RANGE, "assertion failed: from_index < self.len()");
+  if (!(to_index < b->len)) throw Error(PST_ERR_RANGE, "assertion failed: to_index < self.len()");
+  if (from_index == to_index) return PST_OK;
+  ensure_device();
+  hipStream_t s = current_stream();
+  uint8_t* tmp = workspace().dev;  // Workspace::kWorkspaceBytes (1 MiB) of per-thread device scratch; stream order makes the three copies a swap
+  auto swap_bytes = [&](uint8_t* base, size_t size) {
+    if (!size) return;
+    if (size > Workspace::kWorkspaceBytes) throw Error(PST_ERR_UNSUPPORTED, "pst_buffer_swap: values wider than 1 MiB are not supported");
+    uint8_t *a = base + from_index * size, *c = base + to_index * size;
+    const hipMemcpyKind kind = b->memkind == PST_MEM_PINNED_HOST ? hipMemcpyDefault : hipMemcpyDeviceToDevice;
+    PST_HIP_CHECK(hipMemcpyAsync(tmp, a, size, kind, s));
+    PST_HIP_CHECK(hipMemcpyAsync(a, c, size, kind, s));
+    PST_HIP_CHECK(hipMemcpyAsync(c, tmp, size, kind, s));
+  };
+  if (b->columnar) {
+    for (size_t a = 0; a < b->columns.size(); ++a) swap_bytes(b->columns[a], b->layout.members[a].size);
+  } else {
+    swap_bytes(b->data, b->layout.size);
+  }
+  stream_sync(s);
+  PST_API_END
+}
 int pst_buffer_is_columnar(const pst_buffer* b, int* out) { PST_API_BEGIN *not_null(out, "out") = not_null(b, "buffer")->columnar; PST_API_END }
 int pst_buffer_layout(const pst_buffer* b, pst_layout** out_clone) { PST_API_BEGIN *not_null(out_clone, "out") = new pst_layout{not_null(b, "buffer")->layout}; PST_API_END }
 int pst_buffer_points_ptr(const pst_buffer* b, void** out) {

@@ -81,6 +81,9 @@ struct KnnPlan;
 KnnPlan* knn_plan_create(const KnnPlanRecord& rec, bool packed_source, hipStream_t stream);
 void knn_plan_free(KnnPlan* p);
 const KnnPlanRecord& knn_plan_record(const KnnPlan* p);
+// a plan made on a packed, 8-byte aligned Vec3f64 array searches its source in place and has no staging copy: it replays packed sources only;
+// a plan made on any other storage owns a staging copy and replays both
+bool knn_plan_accepts(const KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride);
 bool run_normals_replay(KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride, double* out_normals_dev, double* out_curv_dev, uint32_t* out_knn_u32_dev,
                         uint64_t normal_attr, uint64_t normal_stride, uint64_t curv_attr, uint64_t curv_stride, unsigned long long* status2, hipStream_t stream);
 

@@ -1682,6 +1682,9 @@ KnnPlan* knn_plan_create(const KnnPlanRecord& rec, bool packed_source, hipStream
   return p.release();
 }
 void knn_plan_free(KnnPlan* p) { delete p; }
+bool knn_plan_accepts(const KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride) {
+  return (pos_stride == 24 && ((uintptr_t)pos_base & 7u) == 0) || p->xyz_own.p != nullptr;
+}
 const KnnPlanRecord& knn_plan_record(const KnnPlan* p) { return p->rec; }
 
 bool run_normals_replay(KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride, double* out_normals_dev, double* out_curv_dev, uint32_t* out_knn_u32_dev,
@@ -1693,8 +1696,12 @@ bool run_normals_replay(KnnPlan* p, const uint8_t* pos_base, uint64_t pos_stride
   const GridParams& g = r.g;
   const unsigned cus = (unsigned)device_cus(), sgrid = p->sgrid;
   RCK(hipMemsetAsync(p->counters.p, 0, 128, stream));
+  // packed or not is a property of THIS call's buffer, not of the one the plan was made on (another cloud of the same length may sit in a
+  // VectorBuffer): a plan made on a packed column has no staging copy and takes packed sources only (knn_plan_accepts)
+  const bool packed_now = pos_stride == 24 && ((uintptr_t)pos_base & 7u) == 0;
+  if (!packed_now && !p->xyz_own.p) return false;
   const double* src = (const double*)pos_base;
-  if (!p->packed_source) {
+  if (!packed_now) {
     hipLaunchKernelGGL(gather_positions_kernel, dim3(sgrid), dim3(kBlock), 0, stream, pos_base, pos_stride, n, p->xyz_own.as<double>(), p->partials.as<double>());
     src = p->xyz_own.as<double>();
   }

@@ -177,6 +177,9 @@ int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, 
   const NormalTargets t = resolve_normal_targets(*b, plan->k, *dst);
   const pstk::KnnPlanRecord& r = pstk::knn_plan_record(plan->plan);
   if (b->len != r.n) throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made for " + std::to_string(r.n) + " points, the buffer holds " + std::to_string(b->len));
+  if (!pstk::knn_plan_accepts(plan->plan, (const uint8_t*)(uintptr_t)t.base, t.stride))
+    throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made on a packed Vec3f64 position array (searched in place, no staging copy); this buffer stores "
+                                          "Position3D with stride " + std::to_string(t.stride) + " -- make the plan on a buffer with this storage");
   ensure_device();
   int dev = 0;
   PST_HIP_CHECK(hipGetDevice(&dev));

@@ -1,5 +1,7 @@
 // Internal host runtime declarations: device buffers, per-thread workspace, plan execution.
 #pragma once
+#include <atomic>
+#include <memory>
 #include <vector>
 
 #include "core.hpp"
@@ -20,6 +22,13 @@ struct pst_buffer {
   size_t capacity = 0;  // points
   uint8_t* data = nullptr;         // interleaved storage
   std::vector<uint8_t*> columns;   // columnar storage, layout order
+  // Slices borrow the parent's storage (slice.rs:16-43; Rust's borrow checker keeps the parent untouched while one lives).  The C ABI has no
+  // borrow checker, so an owning buffer carries a storage epoch -- bumped whenever its storage moves, shrinks, grows or dies -- and a slice
+  // remembers the epoch it was cut at: any use of a slice whose parent has been resized or destroyed since is PST_ERR_INVALID_ARGUMENT
+  // instead of a read of freed device memory.
+  mutable std::shared_ptr<std::atomic<uint64_t>> epoch;  // owning buffers: their own, made when the first slice is cut; slices: the owning ancestor's; external memory: none
+  uint64_t epoch_cut = 0;                        // slices: the ancestor's epoch when the slice was cut
+  bool is_slice = false;
   ~pst_buffer();
 };
 
@@ -43,6 +52,20 @@ void dev_free(uint8_t* p, uint32_t memkind);
 // no-throw forms on an explicit stream (stream-ordered pool, or hipMalloc / hipFree without pool support or with PST_NO_POOL)
 hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s);
 void dev_free_stream(void* p, hipStream_t s);
+
+// every API entry takes its buffers through not_null(b, "..."): this overload is where a stale slice is caught
+void check_live(const pst_buffer& b);
+inline const pst_buffer* not_null(const pst_buffer* p, const char* what) {
+  if (!p) throw Error(PST_ERR_INVALID_ARGUMENT, std::string(what) + " must not be NULL");
+  check_live(*p);
+  return p;
+}
+inline pst_buffer* not_null(pst_buffer* p, const char* what) {
+  if (!p) throw Error(PST_ERR_INVALID_ARGUMENT, std::string(what) + " must not be NULL");
+  check_live(*p);
+  return p;
+}
+void bump_epoch(pst_buffer& b);  // the storage of an owning buffer is about to move or die
 
 // address helpers
 inline uint64_t aos_addr(const pst_buffer& b, size_t point) { return (uint64_t)(uintptr_t)b.data + (uint64_t)point * b.layout.size; }

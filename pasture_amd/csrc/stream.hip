@@ -17,8 +17,12 @@
 // Reduction: wave64 shuffle -> LDS across the 4 waves -> one {min xyz, max xyz} record per block -> a one-block
 // finalize kernel.  Seeds are +/-f64::MAX like the reference; fmin/fmax never let a NaN win, exactly like the
 // reference's strict `<` / `>` compares.  HBM-bound: no MFMA, no LDS staging needed.
+//
+// Since round 5 the kernel in THIS file serves the read-only modes (AABB, AABB of the transformed values) as a persistent grid; every mode that
+// writes runs the one-tile-per-block body of stream_tile.hpp (rotated accumulators, LDS block fold, few bytes in flight per CU).
 #include "device_common.hpp"
 #include "kernels.hpp"
+#include "stream_tile.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -310,36 +314,54 @@ __global__ __launch_bounds__(kBlock) void centroid_kernel(const ReduceParams p) 
 
 namespace pstk {
 
-// Launch geometry (measured on MI355X, tools/tune_stream*.hip, 10^8 points, random data):
-//  * read-only AABB: persistent grid of 4 blocks per CU, 6 loads in flight per lane  -> ~7.1 TB/s (8 blocks/CU: 6.0 TB/s)
-//  * any mode that writes: ONE tile per block (non-persistent)                       -> ~5.9 TB/s (persistent: 5.45 TB/s);
-//    staggered block start times keep reads and writes interleaved at the memory controllers.
-constexpr int kStreamLoads = 6;  // re-checked under XCD-aware numbering: 3 loads 4.9 TB/s, 6 and 12 equal (6.1-6.2), 9 slightly lower
+// Launch geometry (measured on MI355X; tools/tune_stream*.hip, profiles/r05_stream_sweeps.txt; 10^8 and 10^9 points, random data):
+//  * read-only AABB: the round 1-4 kernel as a persistent grid of 4 blocks per CU, 6 loads in flight per lane -> 7.05-7.1 TB/s; the one-tile-
+//    per-block body reaches 7.2 but pays it back in the fold of its 10^5 records.
+//  * any mode that writes: the round-5 body (stream_tile.hpp), ONE tile per block, and -- the finding of round 5 -- FEW BYTES IN FLIGHT:
+//    the rate peaks at about 48 KiB of loads in flight per CU (24 KiB without the reduction tail) and falls off on both sides; the round 1-4
+//    launch kept 8 blocks x 6 loads x 256 lanes = 192 KiB per CU in flight.  Same box, 10^8 points, fused convert + affine + AABB:
+//    8 blocks/CU x K=6 x 256 lanes 5.93 TB/s | 4 x K=3 x 256 6.47 | 2 x K=3 x 512 6.73 (10^9 points: 6.55 -> 7.03).  The blocks resident per CU
+//    are capped through the dynamic LDS size of the launch.
+constexpr int kStreamLoads = 6;  // read-only persistent kernel
 constexpr int kStreamTileVec = kStreamLoads * kBlock;
 int stream_grid() { return device_cus() * 4; }
 int reduce_grid() { return device_cus() * 8; }
 size_t minmax_partials_bytes() { return (size_t)(reduce_grid() + kFoldBlocks) * 6 * sizeof(double); }
 
 static bool stream_xcd_aware() {
-  static const bool on = [] { const char* v = std::getenv("PST_STREAM_XCD"); return !(v && *v == '0'); }();  // on by default: +2-5 % on the fused convert + AABB (same-box A/B)
+  static const bool on = [] { const char* v = std::getenv("PST_STREAM_XCD"); return !(v && *v == '0'); }();  // on by default: each XCD streams one contiguous eighth
   return on;
 }
-// PST_STREAM_XCD_BLOCK = B: the XCD-aware numbering deals runs of B tiles (24 KiB each) to the XCDs round-robin instead of giving each XCD one
-// contiguous eighth of the stream.  Why it matters: with eighths, the eight XCDs' streams are n/8 points apart, and the rate depends on that
-// DISTANCE (same box: 6.06 TB/s at 10^8 points, 6.71 at 5 10^8, 6.05 at 6 10^8, 6.58 at 10^9 -- the streams' relative position in the HBM
-// channel / bank interleave), not on the buffers' base alignment (profiles/r04_ab_placement.txt).  Runs keep the streams a fixed distance apart.
-static uint64_t stream_xcd_block() {
-  static const uint64_t b = [] { const char* v = std::getenv("PST_STREAM_XCD_BLOCK"); return v && *v ? (uint64_t)std::strtoull(v, nullptr, 10) : 0ull; }();
-  return b;
+// shape of the writing modes: loads per lane, threads per block, blocks resident per CU
+struct StreamShape { int loads, block, resident; };
+static StreamShape stream_shape(unsigned mode) {
+  StreamShape s = (mode & 4u) ? StreamShape{3, 512, 2} : StreamShape{3, 256, 2};
+  static const int cap = [] { const char* v = std::getenv("PST_STREAM_RESIDENT"); return v && *v ? std::atoi(v) : 0; }();  // same-box A/Bs
+  if (cap > 0) s.resident = cap;
+  return s;
+}
+static unsigned lds_per_cu() {
+  static const unsigned v = [] {
+    int dev = 0, bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || bytes <= 0) bytes = 64 * 1024;
+    return (unsigned)bytes;
+  }();
+  return v;
+}
+// dynamic LDS of one block: the reduction rows (modes with bounds), padded so that at most `resident` blocks fit one CU
+static unsigned stream_lds_bytes(const StreamShape& s, bool bounds) {
+  const unsigned need = bounds ? 6u * (unsigned)(s.block + 8) * 8u : 0u;
+  if (s.resident >= 8) return need;
+  return std::min(64u * 1024u, std::max(need, lds_per_cu() / (unsigned)(s.resident + 1) + 64u));
 }
 static uint64_t stream_launch_grid(uint64_t n_points, unsigned mode) {
   const uint64_t n_vec = (3 * n_points) / 2;
-  const uint64_t n_tiles = std::max<uint64_t>(1, (n_vec + kStreamTileVec - 1) / kStreamTileVec);
   if (mode & 2u) {
-    if (!stream_xcd_aware()) return n_tiles;
-    const uint64_t b = stream_xcd_block();
-    return b ? 8 * b * ((n_tiles + 8 * b - 1) / (8 * b)) : 8 * ((n_tiles + 7) / 8);
+    const StreamShape s = stream_shape(mode);
+    const uint64_t tile_vec = (uint64_t)s.loads * s.block;
+    return 8 * ((std::max<uint64_t>(1, (n_vec + tile_vec - 1) / tile_vec) + 7) / 8);
   }
+  const uint64_t n_tiles = std::max<uint64_t>(1, (n_vec + kStreamTileVec - 1) / kStreamTileVec);
   return std::min<uint64_t>(n_tiles, (uint64_t)stream_grid());
 }
 size_t stream_partials_bytes(uint64_t n_points, unsigned mode) {
@@ -349,31 +371,46 @@ size_t stream_partials_bytes(uint64_t n_points, unsigned mode) {
 void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, const double scale[3], const double offset[3], unsigned mode,
                            double* partials, double* out6, hipStream_t stream) {
   const bool write = mode & 2u, bounds = mode & 4u;
-  StreamParams p{};
-  p.src = src;
-  p.dst = write ? dst : const_cast<double*>(src);
-  p.n_doubles = 3 * n_points;
+  const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
   // 16-byte vectors: src and dst must share their alignment phase — the host only takes this path when
   // (src - dst) % 16 == 0 (converter.cpp), so only the phase of src matters.
-  p.vec_first = (((uintptr_t)src & 15u) != 0 && p.n_doubles > 0) ? 1 : 0;
-  p.n_vec = (p.n_doubles - p.vec_first) / 2;
-  for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
-  p.partials = partials;
-  const unsigned grid = (unsigned)stream_launch_grid(n_points, mode);
-  p.xcd_chunk = (write && stream_xcd_aware()) ? grid / 8u : 0u;  // the read-only persistent grid loses 1.5 % with it
-  p.xcd_block = p.xcd_chunk ? (uint32_t)stream_xcd_block() : 0u;
-#define PST_STREAM(A, W, B) \
-  hipLaunchKernelGGL((vec3f64_stream_kernel<A, W, B, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p)
-  switch (mode & 7u) {
-    case 1: case 0: break;  // nothing to do (affine without a sink is meaningless)
-    case 2: PST_STREAM(false, true, false); break;
-    case 3: PST_STREAM(true, true, false); break;
-    case 4: PST_STREAM(false, false, true); break;
-    case 5: PST_STREAM(true, false, true); break;
-    case 6: PST_STREAM(false, true, true); break;
-    case 7: PST_STREAM(true, true, true); break;
+  const uint64_t n_doubles = 3 * n_points;
+  const uint32_t vec_first = (((uintptr_t)src & 15u) != 0 && n_doubles > 0) ? 1 : 0;
+  if (write) {
+    Stream2Params p{};
+    p.src = src;
+    p.dst = dst;
+    p.n_doubles = n_doubles;
+    p.vec_first = vec_first;
+    p.n_vec = (n_doubles - vec_first) / 2;
+    for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
+    p.partials = partials;
+    p.xcd_stride = grid / 8u;
+    p.plain = stream_xcd_aware() ? 0u : 1u;
+    const StreamShape s = stream_shape(mode);
+    const unsigned lds = stream_lds_bytes(s, bounds);
+#define PST_STREAM2(A, B, K, BLK) hipLaunchKernelGGL((vec3f64_stream2_kernel<A, true, B, K, BLK>), dim3(grid), dim3(BLK), lds, stream, p)
+    switch (mode & 7u) {
+      case 2: PST_STREAM2(false, false, 3, 256); break;
+      case 3: PST_STREAM2(true, false, 3, 256); break;
+      case 6: PST_STREAM2(false, true, 3, 512); break;
+      case 7: PST_STREAM2(true, true, 3, 512); break;
+    }
+#undef PST_STREAM2
+  } else if (bounds) {
+    StreamParams p{};
+    p.src = src;
+    p.dst = const_cast<double*>(src);
+    p.n_doubles = n_doubles;
+    p.vec_first = vec_first;
+    p.n_vec = (n_doubles - vec_first) / 2;
+    for (int c = 0; c < 3; ++c) { p.scale[c] = scale ? scale[c] : 1.0; p.offset[c] = offset ? offset[c] : 0.0; }
+    p.partials = partials;
+    p.xcd_chunk = 0u;  // the read-only persistent grid loses 1.5 % with the XCD-aware numbering
+    p.xcd_block = 0u;
+    if (mode & 1u) hipLaunchKernelGGL((vec3f64_stream_kernel<true, false, true, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    else hipLaunchKernelGGL((vec3f64_stream_kernel<false, false, true, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
   }
-#undef PST_STREAM
   if (bounds) launch_finalize<double, 3>(partials, grid, out6, kF64Max, -kF64Max, stream);
 }
 

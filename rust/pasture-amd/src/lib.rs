@@ -125,7 +125,8 @@ macro_rules! device_buffer {
                 let dt = datatype_to_c(attribute.datatype());
                 check(pst_buffer_write_attribute(self.handle, name.as_ptr(), &dt, point_range.start, point_range.len(), attribute_data.as_ptr().cast()))
             }
-            fn swap(&mut self, _from_index: usize, _to_index: usize) { unimplemented!("per-point swap is not a bulk path") }
+            // point_buffer.rs:229; panics like the reference's assert! when an index is out of bounds (PST_ERR_RANGE -> panic in `check`)
+            fn swap(&mut self, from_index: usize, to_index: usize) { check(unsafe { pst_buffer_swap(self.handle, from_index, to_index) }) }
         }
         impl<'a> OwningBuffer<'a> for $name {
             unsafe fn push_points(&mut self, point_bytes: &[u8]) {

@@ -67,6 +67,66 @@ def test_slice_panics(api, kind):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("packed", [False, True])
+def test_swap_exchanges_two_points_and_panics_out_of_bounds(api, kind, packed):
+    """BorrowedMutBuffer::swap, point_buffer.rs:229 (VectorBuffer :770-783, HashMapBuffer :1276-1292): expectations are numpy swaps."""
+    n = 257
+    buf, cols = cloud(api, kind, n, packed=packed)
+    expect = {k: v.copy() for k, v in cols.items()}
+    for i, j in [(0, n - 1), (5, 5), (17, 18), (n - 1, 100), (100, 0)]:
+        buf.swap(i, j)
+        for v in expect.values():
+            v[[i, j]] = v[[j, i]]
+    for a in (A.POSITION_3D, A.INTENSITY, A.GPS_TIME, A.CLASSIFICATION):
+        assert np.array_equal(buf.view_attribute(a), expect[a.name()])
+    view = buf.slice(range(10, 20))  # swap through a slice_mut exchanges points of the parent
+    view.swap(0, 9)
+    for v in expect.values():
+        v[[10, 19]] = v[[19, 10]]
+    assert np.array_equal(buf.view_attribute(A.POSITION_3D), expect["Position3D"])
+    for i, j in [(n, 0), (0, n), (n + 5, n + 5)]:
+        with pytest.raises(PasturePanic) as e:
+            buf.swap(i, j)
+        assert e.value.code == 3
+    with pytest.raises(PasturePanic):
+        view.swap(0, 10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_stale_slice_is_an_error_not_a_read_of_freed_memory(hip, kind):
+    """What Rust's borrow checker forbids (slice.rs:16-43: the slice borrows the parent) the C ABI has to catch at run time: a slice cut before
+    its parent was resized or destroyed fails with PST_ERR_INVALID_ARGUMENT on every later use; a slice cut afterwards works."""
+    buf, cols = cloud(hip, kind, 5000)
+    s = buf.slice(range(1000, 3000))
+    ss = s.slice(range(10, 20))
+    assert np.array_equal(s.view_attribute(A.INTENSITY), cols["Intensity"][1000:3000])
+    buf.resize(5000)  # same length: nothing moves, the slices stay valid
+    assert np.array_equal(ss.view_attribute(A.INTENSITY), cols["Intensity"][1010:1020])
+    buf.resize(200_000)  # the storage is reallocated
+    for stale in (s, ss):
+        for use in (lambda v: v.view_attribute(A.INTENSITY), lambda v: calculate_bounds(v), lambda v: v.slice(range(0, 5)), lambda v: len(v)):
+            with pytest.raises(PastureError) as e:
+                use(stale)
+            assert e.value.code == 1 and "slice" in str(e.value)
+    fresh = buf.slice(range(1000, 3000))
+    assert np.array_equal(fresh.view_attribute(A.INTENSITY), cols["Intensity"][1000:3000])
+    buf.resize(100)  # shrinking needs &mut too
+    with pytest.raises(PastureError) as e:
+        fresh.view_attribute(A.INTENSITY)
+    assert e.value.code == 1
+    # destroying the parent while a view is alive (the Python mirror keeps the parent alive for its views; the C ABI does not)
+    raw_parent, _ = cloud(hip, kind, 300)
+    view = raw_parent.slice(range(0, 100))
+    view._keepalive = None
+    hip.buffer_destroy(raw_parent._h)
+    raw_parent._h = None
+    with pytest.raises(PastureError) as e:
+        calculate_bounds(view)
+    assert e.value.code == 1
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_bounds_of_slices_and_chunked_minmax(api, kind):
     """calculate_bounds(&buf.slice(a..b)) and the chunked min-max of pasture-tools/src/bin/info.rs:66-78 (per-chunk minmax_attribute folded
     with infimum / supremum) equal the whole-buffer answers."""
