@@ -112,6 +112,8 @@ def parse():
                    help="generic conversion workloads: auto / specialised = the plan-specialised kernel (in-tree instantiation or hipRTC, compiled before the "
                         "timed region with pst_converter_prepare); interpreted = the generic tile kernels interpreting the mapping list (PST_JIT=0)")
     p.add_argument("--layout-seed", type=int, default=0, help="randomlayout_* workloads: which random layout pair")
+    p.add_argument("--no-extra-legs", action="store_true",
+                   help="skip the configs[2] (LAS-0 records -> 10 columns) and configs[4] (kNN(16) normals) legs appended at N=1 to the default workload's line")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-points", type=int, default=100_000_000, help="CPU baseline sample (default: the whole 10^8-point workload, ~10 s of CPU work)")
     return p.parse_args()
@@ -144,7 +146,175 @@ def _native_oracle():
     return None, None
 
 
-def cpu_baseline(workload, sample_points):
+def _torch_bytes(ptr, nbytes):
+    """A uint8 torch view of `nbytes` of device memory at `ptr` (no copy)."""
+    import torch
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    return torch.as_tensor(_Mem(), device="cuda")
+
+
+def leg_configs2(pa, las, cv, torch, stream, n, seed):
+    """BASELINE.json configs[2]: n typed LAS-0 points (35 B, 10 attributes, packed) VectorBuffer -> HashMapBuffer of 10 columns, 70 B/point,
+    HIP events around each of 10 steps.  Returns (report, sample): sample = the first 10^5 points of every column as bytes, for the oracle check."""
+    src_layout = las.point_layout_from_las_point_format(las.Format(0), False)
+    src = pa.VectorBuffer.new_from_layout(src_layout)
+    src.resize(n)
+    src.synth_fill(seed, 0)
+    dst = pa.HashMapBuffer.new_from_layout(src_layout)
+    dst.resize(n)
+    conv = pa.BufferLayoutConverter.for_layouts(src_layout, src_layout)
+    plan = cv.PLAN_NAMES[conv.prepare(type(src), type(dst), False)]
+    steps = 10
+    for _ in range(2):
+        conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in ev:
+        e0.record(stream)
+        conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+        e1.record(stream)
+    torch.cuda.synchronize()
+    kinds = cv.last_plan_kinds()
+    ms_all = [a.elapsed_time(b) for a, b in ev]
+    ms = sum(ms_all) / steps
+    gbs = 70 * n / (ms * 1e-3) / 1e9
+    m = min(n, 100_000)
+    sample = {a.name(): dst.get_attribute_range(a.attribute_definition(), range(0, m)).tobytes() for a in src_layout.attributes()}
+    report = {"points": n, "steps": steps, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(ms_all), 4), "value": round(n / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s",
+              "algorithmic_bytes_per_point": 70, "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "plan": kinds, "plan_prepared": plan,
+              "note": "BASELINE.json configs[2]: typed LAS-0 records (35 B, 10 attributes) VectorBuffer -> 10 columns HashMapBuffer, 35 R + 35 W per point; HIP events "
+                      "around each of 10 steps after the timed region of the headline"}
+    return report, {"points": m, "seed": seed, "columns": sample}
+
+
+def leg_configs4(pa, torch, stream, n, seed, n_queries=48):
+    """BASELINE.json configs[4]: kNN(k = 16) normal estimation over n uniform points, NORMAL (Vec3f32) + Curvature (F64) written to columns.
+    Timed: the synchronous call (wall clock around call + synchronize) and the planned stream-ordered form (HIP events).  Then, outside the timing:
+    the raw f64 results + neighbour lists once more (pst_compute_normals_device), `n_queries` sampled neighbour lists against a brute force over all
+    n points on the device, and the columns against the f64 results narrowed with `as`.  Returns (report, sample for the oracle's plane fit)."""
+    from pasture_amd.algorithms import NormalsPlan, compute_normals_device, compute_normals_into
+    from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, attributes as A
+    k = 16
+    layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+    src = pa.HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(seed, 0)
+    curv_def = PointAttributeDefinition("Curvature", T.F64)
+    dst = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.NORMAL, curv_def]))
+    dst.resize(n)
+    compute_normals_into(src, k, dst)  # warm-up: scratch allocation, measurement passes
+    torch.cuda.synchronize()
+    sync_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        compute_normals_into(src, k, dst)
+        torch.cuda.synchronize()
+        sync_ms.append((time.perf_counter() - t0) * 1e3)
+    plan_ms, plan_status = None, None
+    try:
+        nplan = NormalsPlan(src, k, dst)
+        nst = torch.zeros(2, dtype=torch.int64, device="cuda")
+        nplan.compute_into_async(src, dst, nst.data_ptr())
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for e0, e1 in ev:
+            e0.record(stream)
+            nplan.compute_into_async(src, dst, nst.data_ptr())
+            e1.record(stream)
+        torch.cuda.synchronize()
+        plan_ms = [a.elapsed_time(b) for a, b in ev]
+        plan_status = nst.tolist()
+        nplan.destroy()
+    except Exception as e:  # noqa: BLE001  (no plan for this cloud: the line says so)
+        plan_status = f"{type(e).__name__}: {e}"[:300]
+    # -- checks, outside the timing
+    normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    curv = torch.empty(n, dtype=torch.float64, device="cuda")
+    knn = torch.empty((n, k), dtype=torch.int32, device="cuda")  # uint32 bit patterns; n < 2^31
+    compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
+    pts = _torch_bytes(src.column_ptr(A.POSITION_3D), n * 24).view(torch.float64).view(n, 3)
+    n32 = _torch_bytes(dst.column_ptr(A.NORMAL), n * 12).view(torch.float32).view(n, 3)
+    c64 = _torch_bytes(dst.column_ptr(curv_def), n * 8).view(torch.float64)
+    columns_equal = bool(torch.equal(n32, normals.to(torch.float32))) and bool(torch.equal(c64, curv))
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    queries = torch.randint(0, n, (n_queries,), generator=g).tolist()
+    lists_exact, fits = 0, []
+    for q in queries:
+        d = ((pts - pts[q]) ** 2).sum(dim=1)
+        dist, _want = torch.topk(d, k, largest=False, sorted=True)
+        got = knn[q].long()
+        dg = ((pts[got] - pts[q]) ** 2).sum(dim=1)
+        lists_exact += int(bool((dg == dist).all()) and int(got[0]) == q)
+        fits.append({"query": q, "neighbours": pts[got].cpu().numpy(), "normal": normals[q].cpu().numpy(), "curvature": float(curv[q])})
+        del d
+    med = statistics.median(sync_ms)
+    report = {"points": n, "k": k, "ms_per_call": round(med, 3), "ms_per_call_all": [round(x, 3) for x in sync_ms], "value": round(n / (med * 1e-3) / 1e6, 2), "unit": "Mpoints/s",
+              "ms_per_call_planned": round(sum(plan_ms) / len(plan_ms), 3) if plan_ms else None, "planned_status": plan_status,
+              "algorithmic_bytes_per_point": 44, "frac_of_hbm_lower_bound": round(44 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "checks": {"columns_equal_f64_results_narrowed": columns_equal, "neighbour_lists_checked": n_queries, "neighbour_lists_exact": lists_exact},
+              "note": "BASELINE.json configs[4]: uniform cloud, k = 16, NORMAL (Vec3f32) + Curvature (F64) columns; ms_per_call = median wall time of 3 synchronous "
+                      "pst_compute_normals_into calls (index build, sort, searches, fits; host round trips included), ms_per_call_planned = HIP events around the "
+                      "stream-ordered replay; the call is bound by its vector instructions, not by HBM (bound_valu)"}
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get("normals_knn16")
+        if v and v.get("points") == n:
+            issue_rate = 256 * 4 * 2.4e9 / 4.0
+            bound_ms = v["valu_wave_instructions_per_launch"] / issue_rate * 1e3
+            report["bound_valu"] = {"kernel": v["kernel"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"], "bound_ms": round(bound_ms, 3),
+                                    "frac_of_call": round(bound_ms / med, 4),
+                                    "source": f"profiles/knn_valu.json (round {v.get('round')}: rocprofv3 --pmc SQ_INSTS_VALU pass); NOT measured in this run"}
+    except Exception:
+        pass
+    return report, {"k": k, "fits": fits}
+
+
+def oracle_spot_checks(lib_path, checks):
+    """The oracle (test infrastructure) as the checker of the extra legs' samples -- called from the cpu_baseline leg only."""
+    import numpy as np
+    import pasture_amd as pa
+    from pasture_amd import las
+    from pasture_amd._capi import CApi
+    from pasture_amd.algorithms import compute_normals
+    from pasture_amd.layout import attributes as A
+    orc = CApi(ctypes.CDLL(lib_path), "orc", product=False)
+    out = {}
+    c2 = checks.get("configs2")
+    if c2:
+        layout = las.point_layout_from_las_point_format(las.Format(0), False, api=orc)
+        src = pa.VectorBuffer.new_from_layout(layout)
+        src.resize(c2["points"])
+        src.synth_fill(c2["seed"], 0)
+        conv = pa.BufferLayoutConverter.for_layouts(layout, layout)
+        cols = conv.convert(src, pa.HashMapBuffer)
+        bad = [a.name() for a in layout.attributes()
+               if cols.get_attribute_range(a.attribute_definition(), range(0, c2["points"])).tobytes() != c2["columns"][a.name()]]
+        out["configs2"] = {"verified": not bad, "points_compared": c2["points"], "columns_compared": len(c2["columns"]), "columns_differing": bad,
+                           "how": "the first points of the GPU's 10 columns, byte for byte against the oracle's conversion of the same synthetic records"}
+    c4 = checks.get("configs4")
+    if c4:
+        k, worst_n, worst_c, failed = c4["k"], 0.0, 0.0, 0
+        for f in c4["fits"]:
+            ob = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.POSITION_3D], api=orc))
+            ob.resize(k)
+            ob.set_attribute_range(A.POSITION_3D, range(0, k), f["neighbours"])
+            on, oc = compute_normals(ob, k)  # the 16 neighbours in ascending distance as a 16-point cloud: the fit of point 0 is the full computation's
+            nerr = float(np.linalg.norm(f["normal"] - on[0]) / max(np.linalg.norm(on[0]), 1e-300))
+            dev = f["neighbours"] - f["neighbours"].mean(axis=0)
+            floor = max(1e-12, 1e-13 * float(np.abs(dev.T @ dev).max()))  # the window of tests/test_gpu_parity.py::_compare_normals
+            cdiff = abs(f["curvature"] - float(oc[0]))
+            worst_n, worst_c = max(worst_n, nerr), max(worst_c, cdiff)
+            failed += int(nerr > 1e-9 or cdiff > 1e-9 * abs(float(oc[0])) + floor)
+        out["configs4"] = {"verified": failed == 0, "fits_compared": len(c4["fits"]), "fits_outside_window": failed, "worst_rel_normal_diff": worst_n,
+                           "worst_abs_curvature_diff": worst_c,
+                           "how": "the oracle's plane fit of the GPU's own neighbour lists (16-point clouds, k = 16) against the GPU's f64 normals (1e-9 relative) "
+                                  "and curvatures (1e-9 relative + the documented floor)"}
+    return out
+
+
+def cpu_baseline(workload, sample_points, checks=None):
     """Oracle timed on one pinned host core.  Only the checker lives under oracle/; it is never the thing shipped."""
     lib_path, flags = _native_oracle()
     if lib_path is None:
@@ -187,6 +357,13 @@ def cpu_baseline(workload, sample_points):
         if lib.orc_bench_config1(1_000_000, reps1, SEED, secs1, bounds) == 0:
             out["config0_1e6_aos_to_soa_plus_bounds_Mpoints_per_s"] = round(1.0 / statistics.median(list(secs1)), 3)
         out["wall_s"] = round(time.time() - t0, 2)
+        if checks:
+            t1 = time.time()
+            try:
+                out["spot_checks"] = oracle_spot_checks(lib_path, checks)
+            except Exception as e:  # noqa: BLE001
+                out["spot_checks"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            out["spot_checks_wall_s"] = round(time.time() - t1, 2)
         try:
             with open("/proc/cpuinfo") as f:
                 models = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
@@ -758,6 +935,24 @@ def main():
                             "one AABB all-reduce per step; wall time between barriers, max over ranks"}
         del s_src, s_dst
 
+    # BASELINE.json configs[2] and configs[4] made driver-visible (N = 1, default workload): measured after the timed region, never folded into `value`
+    extra_legs, extra_checks = {}, {}
+    if world == 1 and args.workload == "convert_affine_bounds" and not args.global_points and not args.no_extra_legs:
+        del src, dst
+        try:
+            rep, smp = leg_configs2(pa, las, cv, torch, stream, n, SEED)
+            extra_legs["configs2_las0_to_columns"], extra_checks["configs2"] = rep, smp
+        except Exception as e:  # noqa: BLE001  (a failed leg is reported, it does not take the headline with it)
+            extra_legs["configs2_las0_to_columns"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        try:
+            rep, smp = leg_configs4(pa, torch, stream, n, SEED)
+            extra_legs["configs4_knn16"], extra_checks["configs4"] = rep, smp
+            from pasture_amd.algorithms import release_scratch
+            release_scratch()
+        except Exception as e:  # noqa: BLE001
+            extra_legs["configs4_knn16"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        src = dst = None
+
     # north_star size made driver-visible: the same fused convert + AABB over 10^9 points (24 GB in, 24 GB out) on ONE GPU, measured in this
     # run after the timed region (N = 1, default workload only); reported beside the headline, never folded into `value`
     north_star = None
@@ -766,7 +961,7 @@ def main():
         nn = args.north_star_points
         free_b, _total_b = torch.cuda.mem_get_info()
         if free_b > 2 * 24 * nn + (8 << 30):
-            del src, dst
+            src = dst = None
             big_src = pa.HashMapBuffer.new_from_layout(layout)
             big_src.resize(nn)
             big_src.synth_fill(SEED, 0)
@@ -867,10 +1062,24 @@ def main():
             line["configs3_1e9"] = configs3
         if north_star is not None:
             line["north_star_1e9"] = north_star
+        for name, rep in extra_legs.items():
+            line[name] = rep
         if world == 1 and not args.no_cpu_baseline and args.workload == "convert_affine_bounds":
-            cb = cpu_baseline(args.workload, args.cpu_sample_points)
+            cb = cpu_baseline(args.workload, args.cpu_sample_points, extra_checks)
             if cb is not None:
                 line["cpu_baseline"] = cb
+                # the headline's own check: the AABB of the 10^8 converted points on the GPU == the oracle's over the same synthetic points, digit for digit
+                if args.cpu_sample_points == n and not args.global_points:
+                    gpu_b = [float(x) for x in result[0]] + [float(x) for x in result[1]] if result else None
+                    line["verified"] = bool(gpu_b is not None and gpu_b == [float(x) for x in cb["bounds"]])
+                    line["verification"] = "config.bounds (GPU, fused convert + AABB of the timed steps) == cpu_baseline.bounds (oracle, same 10^8 synthetic points), all six doubles"
+                sc = cb.get("spot_checks") if isinstance(cb.get("spot_checks"), dict) else {}
+                if "configs2" in sc and "configs2_las0_to_columns" in line:
+                    line["configs2_las0_to_columns"]["verified"] = bool(sc["configs2"].get("verified"))
+                if "configs4" in sc and "configs4_knn16" in line:
+                    ck = line["configs4_knn16"].get("checks", {})
+                    line["configs4_knn16"]["verified"] = bool(sc["configs4"].get("verified")) and bool(ck.get("columns_equal_f64_results_narrowed")) \
+                        and ck.get("neighbour_lists_exact") == ck.get("neighbour_lists_checked")
         print(json.dumps(line), flush=True)
     failed_check = (self_check is not None and not self_check["verified"]) or (configs3 is not None and not configs3["self_check"]["verified"])
     if failed_check and rank == 0:

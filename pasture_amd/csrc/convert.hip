@@ -170,7 +170,7 @@ static bool launch_specialised(const ConvertPlan& plan, bool src_aos, bool dst_a
     note_plan_kind(PST_PLAN_STATIC);
   } else {
     void* args[] = {(void*)&h, (void*)&entries};
-    if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) return false;
+    if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, lds_with_resident_cap(k.lds_bytes, kResidentQuad), stream, args, nullptr) != hipSuccess) return false;
     note_plan_kind(PST_PLAN_JIT);
   }
   if (n_records) *n_records = grid;

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(P::blk) void quad_convert_static_kernel(const Conve
 
 template <typename P>
 void launch_plan(unsigned grid, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries) {
-  constexpr uint32_t lds = pstq::quad_lds_bytes<P>();
+  const uint32_t lds = pstk::lds_with_resident_cap(pstq::quad_lds_bytes<P>(), pstk::kResidentQuad);
   auto kfn = quad_convert_static_kernel<P>;
   if (lds > 64u * 1024u) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(P::blk), lds, stream, h, entries);

@@ -643,7 +643,7 @@ static bool stream_sig_is(const StreamSig& s) {
 }
 template <typename P>
 static void launch_stream_static(unsigned grid, hipStream_t stream, const FilterArgs& a) {
-  constexpr uint32_t lds = pstf::stream_lds_bytes<P>();
+  const uint32_t lds = pstk::lds_with_resident_cap(pstf::stream_lds_bytes<P>(), pstk::kResidentFilterStream);
   auto kfn = filter_stream_static_kernel<P>;
   if (lds > 64u * 1024u) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(pstf::kStreamThreads), lds, stream, a);
@@ -671,7 +671,7 @@ static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream
   if (!pstjit::acquire_source(source, "pst_jit_filter", pstf::kStreamThreads, lds, pstf::kStreamTile, how, &k)) return 0;  // not ready (or failed): gather
   FilterArgs b = a;
   void* args[] = {(void*)&b};
-  if (hipModuleLaunchKernel(k.fn, (unsigned)n_full, 1, 1, k.blk, 1, 1, k.lds_bytes, stream, args, nullptr) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipModuleLaunchKernel(k.fn, (unsigned)n_full, 1, 1, k.blk, 1, 1, pstk::lds_with_resident_cap(k.lds_bytes, pstk::kResidentFilterStream), stream, args, nullptr) != hipSuccess) { (void)hipGetLastError(); return 0; }
   *kind = PST_PLAN_JIT;
   return (uint32_t)n_full;
 }

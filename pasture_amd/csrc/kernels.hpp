@@ -28,6 +28,14 @@ size_t bounds_partials_bytes(unsigned n_records);
 // fold n_records per-block {min xyz, max xyz} records into out6
 void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream);
 int device_cus();
+// Dynamic LDS bytes of a launch that needs `lds_bytes` and wants at most `resident` workgroups per CU (0 = whatever fits): the memory side of
+// MI355X saturates with FEW bytes in flight per CU and loses throughput beyond that (profiles/r05_stream_sweeps.txt), so the streaming kernels
+// cap their residency by asking for more LDS than they use.  PST_RESIDENT=<n> overrides every family's cap (same-box A/Bs; 0 = no cap).
+// Never more than 64 KiB (no per-kernel attribute needed): caps below 2 are not expressible this way.
+uint32_t lds_with_resident_cap(size_t lds_bytes, int resident);
+constexpr int kResidentQuad = 0;          // plan-specialised conversion kernels (one-wave workgroups, 256-point tiles)
+constexpr int kResidentFilterStream = 0;  // plan-specialised streaming compaction
+constexpr int kResidentColumn = 0;        // columnar -> columnar conversion of one attribute (columns.hip)
 
 // K1/K2 fast path: columnar Vec3f64 stream. mode bits: 1 = affine, 2 = write dst, 4 = bounds.
 // partials must hold stream_partials_bytes(); out6 receives {min xyz, max xyz} when bounds are requested.

@@ -24,6 +24,8 @@ using namespace pstlas;
 namespace {
 
 constexpr uint32_t kQuadTile = 4 * kBlock;
+// workgroups resident per CU (kernels.hpp lds_with_resident_cap; 0 = whatever fits)
+constexpr int kResidentDecode = 0, kResidentDecodeAos = 0;
 
 struct DecodeArgs {
   uint64_t src;                  // address of raw record 0 of the source range
@@ -333,7 +335,7 @@ bool launch_las_decode(int format, uint64_t src, uint64_t n, const uint64_t* dst
   for (int c = 0; c < 3; ++c) { a.scale[c] = scale[c]; a.offset[c] = offset[c]; }
   a.partial_bounds = partials;
   const unsigned grid = las_decode_grid(n);
-  const size_t lds_bytes = (size_t)kQuadTile * raw_size(fmt_of(format)) + 64;
+  const size_t lds_bytes = lds_with_resident_cap((size_t)kQuadTile * raw_size(fmt_of(format)) + 64, kResidentDecode);
 #define PST_DEC(N)                                                                                                                          \
   case N: {                                                                                                                                 \
     static const hipError_t attr = hipFuncSetAttribute((const void*)las_decode_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
@@ -370,7 +372,7 @@ bool launch_las_decode_aos(int format, uint64_t src, uint64_t dst, uint64_t n, c
   a.tile = las_decode_aos_tile(format);
   const unsigned grid = las_decode_aos_grid(format, n);
   const Fmt f = fmt_of(format);
-  const size_t lds_bytes = (((size_t)a.tile * raw_size(f) + 32 + 15) & ~(size_t)15) + (size_t)a.tile * typed_size(f) + 64;
+  const size_t lds_bytes = lds_with_resident_cap((((size_t)a.tile * raw_size(f) + 32 + 15) & ~(size_t)15) + (size_t)a.tile * typed_size(f) + 64, kResidentDecodeAos);
 #define PST_DEC(N)                                                                                                                              \
   case N: {                                                                                                                                     \
     static const hipError_t attr = hipFuncSetAttribute((const void*)las_decode_aos_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \

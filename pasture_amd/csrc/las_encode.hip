@@ -151,6 +151,7 @@ __device__ __forceinline__ void encode_point(const EncodeArgs& a, const Src& src
 }
 
 constexpr uint32_t kQuadTile = 4 * kBlock;  // points per tile of the columnar path
+constexpr int kResidentEncode = 0;  // workgroups resident per CU (kernels.hpp lds_with_resident_cap; 0 = whatever fits)
 
 // One full tile of kQuadTile points starting at `first`; records staged at lds + mis.
 template <int FORMAT>
@@ -394,7 +395,7 @@ bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* at
   unsigned long long* pc = (unsigned long long*)(workspace + (size_t)(kMaxGrid + kFoldGrid) * 6 * sizeof(double));
   a.partial_bounds = pb;
   a.partial_counts = pc;
-  const size_t lds_bytes = (((size_t)a.tile * rs + 16 + 15) & ~(size_t)15) + (mode == MODE_STAGED ? (size_t)a.tile * ts + 48 : 16);
+  const size_t lds_bytes = lds_with_resident_cap((((size_t)a.tile * rs + 16 + 15) & ~(size_t)15) + (mode == MODE_STAGED ? (size_t)a.tile * ts + 48 : 16), kResidentEncode);
 #define PST_ENC_MODE(N, M)                                                                                                         \
   {                                                                                                                                 \
     static const hipError_t attr = hipFuncSetAttribute((const void*)las_encode_kernel<N, M>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \

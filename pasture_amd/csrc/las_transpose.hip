@@ -17,6 +17,7 @@ using namespace pstlas;
 namespace {
 
 constexpr uint32_t kQuadTile = 4 * kBlock;
+constexpr int kResidentTranspose = 0;  // workgroups resident per CU (kernels.hpp lds_with_resident_cap; 0 = whatever fits)
 
 struct TransposeArgs {
   uint64_t aos;                // address of typed record 0 of the range
@@ -287,7 +288,7 @@ bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint6
   a.n = n;
   for (int i = 0; i < n_cols && i < kMaxAttrs; ++i) a.col[i] = cols[i];
   const unsigned grid = las_transpose_grid(n);
-  const size_t lds_bytes = (size_t)kQuadTile * typed_size(fmt_of(format)) + 64;
+  const size_t lds_bytes = lds_with_resident_cap((size_t)kQuadTile * typed_size(fmt_of(format)) + 64, kResidentTranspose);
 #define PST_TR(N)                                                                                                                                   \
   case N: {                                                                                                                                         \
     if (to_records) {                                                                                                                               \

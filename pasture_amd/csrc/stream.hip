@@ -340,7 +340,15 @@ static StreamShape stream_shape(unsigned mode) {
   if (cap > 0) s.resident = cap;
   return s;
 }
-static unsigned lds_per_cu() {
+unsigned lds_per_cu();
+uint32_t lds_with_resident_cap(size_t lds_bytes, int resident) {
+  static const int forced = [] { const char* v = std::getenv("PST_RESIDENT"); return v && *v ? std::atoi(v) : -1; }();
+  if (forced >= 0) resident = forced;
+  if (resident <= 0 || resident >= 32) return (uint32_t)lds_bytes;
+  const size_t want = lds_per_cu() / (unsigned)(resident + 1) + 64u;
+  return (uint32_t)std::max(lds_bytes, std::min<size_t>(want, 64u * 1024u));
+}
+unsigned lds_per_cu() {
   static const unsigned v = [] {
     int dev = 0, bytes = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || bytes <= 0) bytes = 64 * 1024;
