@@ -504,6 +504,17 @@ int orc_compute_normals(const orc_buffer* b, size_t k, double* out_normals, doub
   ORC_CATCH
 }
 
+// test infrastructure: the reference's plane fit (normal_estimation.rs:111-123, 240-305, 429-467) of neighbour lists given by the caller
+int orc_fit_neighbourhoods(const double* points_xyz, size_t n_points, const int64_t* knn, size_t n_queries, size_t k, double* out_normals, double* out_curvature) {
+  ORC_TRY
+  need(points_xyz, "points");
+  need(knn, "knn");
+  for (size_t i = 0; i < n_queries * k; ++i)
+    if (knn[i] >= (int64_t)n_points) throw Panic(ERR_RANGE, "neighbour index out of range");
+  fit_neighbourhoods(reinterpret_cast<const double (*)[3]>(points_xyz), n_queries, knn, k, need(out_normals, "out_normals"), need(out_curvature, "out_curvature"));
+  ORC_CATCH
+}
+
 // ---- LAS writer: write_points_default_layout, pasture-io/src/las/raw_writers.rs:203-363 ---------------------------------
 
 int orc_voxelgrid_filter(const orc_buffer* buffer, double leafsize_x, double leafsize_y, double leafsize_z, orc_buffer* filtered) {

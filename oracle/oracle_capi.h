@@ -72,6 +72,8 @@ int orc_buffer_create(const orc_layout* l, uint32_t storage, uint32_t memkind, o
 int orc_buffer_destroy(orc_buffer* b);
 int orc_buffer_len(const orc_buffer* b, size_t* out);
 int orc_buffer_resize(orc_buffer* b, size_t count);
+/* test infrastructure: the reference's per-point plane fit for neighbour lists given by the caller (points [n_points][3] f64, knn [n_queries][k] int64, < 0 ends a list) */
+int orc_fit_neighbourhoods(const double* points_xyz, size_t n_points, const int64_t* knn, size_t n_queries, size_t k, double* out_normals, double* out_curvature);
 int orc_buffer_swap(orc_buffer* b, size_t from_index, size_t to_index);  /* BorrowedMutBuffer::swap, point_buffer.rs:229, :770-783, :1276-1292 */
 int orc_buffer_is_columnar(const orc_buffer* b, int* out);
 int orc_buffer_layout(const orc_buffer* b, orc_layout** out_clone);

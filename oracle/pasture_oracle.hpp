@@ -1430,6 +1430,26 @@ inline void compute_normals(const Buffer& point_cloud, size_t k_nn, double* out_
   }
 }
 
+// The per-point step of compute_normals (:108-123) for neighbour lists GIVEN by the caller instead of found by the kd-tree: the positions of
+// knn[i][0 .. k) (in that order; an index < 0 ends the list) go through compute_covariance_matrix + solve_plane_parameter exactly as above.
+// Test infrastructure for clouds with exact distance ties (quantised LAS coordinates), where the un-vendored kd-tree crate's tie order is
+// unpinned: the GPU's own lists, once verified as exact k-nearest sets, pin the FIT of every query.
+inline void fit_neighbourhoods(const double (*pts)[3], size_t n_queries, const int64_t* knn, size_t k, double* out_normals, double* out_curvature) {
+  std::vector<std::array<double, 3>> nb;
+  for (size_t i = 0; i < n_queries; ++i) {
+    nb.clear();
+    for (size_t j = 0; j < k && knn[i * k + j] >= 0; ++j) {
+      const double* p = pts[knn[i * k + j]];
+      nb.push_back({p[0], p[1], p[2]});
+    }
+    Mat3 cov;
+    if (!compute_covariance_matrix(reinterpret_cast<const double (*)[3]>(nb.data()), nb.size(), cov))
+      throw Panic(ERR_NOT_ENOUGH_NEIGHBOURS,
+                  "The number of valid (finite and non-NaN values) points in a k nearest neighborhood is not enough to span a plane!");
+    solve_plane_parameter(cov, out_normals + 3 * i, out_curvature[i]);
+  }
+}
+
 // ----------------------------------------------------------------------------------
 // Synthetic inputs — SURVEY.md §8(d): u = splitmix64(seed ^ (3*i + c)), f = (u >> 11) * 2^-53
 // ----------------------------------------------------------------------------------

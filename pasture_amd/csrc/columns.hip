@@ -142,7 +142,7 @@ unsigned column_grid(uint64_t total) {
 template <typename S, typename D>
 unsigned launch_typed(const ColumnArgs& a, bool launch, hipStream_t stream) {
   const unsigned grid = column_grid<S, D>(a.total);
-  if (launch) hipLaunchKernelGGL((column_convert_kernel<S, D>), dim3(grid), dim3(kBlock), pstk::lds_with_resident_cap(0, pstk::kResidentColumn), stream, a);
+  if (launch) hipLaunchKernelGGL((column_convert_kernel<S, D>), dim3(grid), dim3(kBlock), pstk::lds_with_resident_cap(0, sizeof(S) >= sizeof(D) ? pstk::kResidentColumn : 0), stream, a);
   return grid;
 }
 

@@ -1,0 +1,350 @@
+// Device expressions: user-written transformations and predicates compiled at run time (hipRTC) into the library's kernels.
+//
+// What they stand in for.  The reference takes ANY closure where this library used to take a closed descriptor set:
+//   * BufferLayoutConverter::set_custom_mapping_with_transformation<T, F: Fn(T) -> T>      buffer_conversion.rs:13-36, 194-234
+//   * BorrowedMutBufferExt::transform_attribute<T, F: Fn(usize, T) -> T>                    point_buffer.rs:391-404
+//   * HashMapBuffer::filter / filter_into<F: Fn(usize) -> bool>                             point_buffer.rs:1064-1136
+// A Rust closure cannot cross a C ABI into a GPU kernel; its SOURCE TEXT can.  An expression is C++ expression syntax over a fixed set of
+// names; the library wraps it into a kernel (below), compiles it through the same hipRTC pipeline as the plan-specialised conversion kernels
+// (jit.cpp: cached in memory per source text and on disk per source hash, compiled with -ffp-contract=off so that `v * s + o` keeps its two
+// roundings) and launches it.  A syntax error is PST_ERR_UNSUPPORTED_TRANSFORM with the compiler's log as the message.
+//
+// Transformation expressions (mapping transformations and transform_attribute).  The closure's argument type T is the attribute's datatype
+// (the SOURCE attribute's when apply_to_source, the TARGET's otherwise -- buffer_conversion.rs:209-213).  Names:
+//     v          this component of the value, of T's component type (the value itself for scalar attributes)
+//     x, y, z    the three components of a Vec3 value (scalar attributes: x = y = z = v)
+//     c          the component being computed: 0, 1, 2 (int)
+//     i          the point's index in the buffer the call was made on (uint64_t): the `usize` of transform_attribute's closure
+//     p0 .. p3   caller-provided device arrays of double (what a closure would capture): `p0[3 * i + c]`
+// One expression is evaluated per component; a Vec3 attribute may give three, separated by `;` (x ; y ; z).  The result is converted to T's
+// component type with Rust `as` (so integer attributes saturate / truncate as `as` does); the usual C++ arithmetic conversions apply INSIDE
+// the expression (a u16 times 2.0 is a double).  <cmath> functions of the HIP device runtime are available (sqrt, fabs, floor, fmin, ...).
+//
+// Predicate expressions (filter).  Names: every attribute of the buffer's layout whose name is a C identifier -- scalars as values of their
+// type, Vec3 attributes as structs with .x .y .z --, plus i and p0 .. p3: `Classification == 2 && Position3D.z < 120.0`.
+#include <cctype>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jit.hpp"
+#include "runtime.hpp"
+
+using namespace pst;
+
+namespace pstexpr {
+
+static const char* ct_name(uint32_t ct) {
+  static const char* names[10] = {"uint8_t", "int8_t", "uint16_t", "int16_t", "uint32_t", "int32_t", "uint64_t", "int64_t", "float", "double"};
+  return ct < 10 ? names[ct] : "uint8_t";
+}
+
+// split at top-level ';' (none inside parentheses / brackets)
+static std::vector<std::string> split_components(const std::string& expr) {
+  std::vector<std::string> out;
+  std::string cur;
+  int depth = 0;
+  for (char ch : expr) {
+    if (ch == '(' || ch == '[') ++depth;
+    if (ch == ')' || ch == ']') --depth;
+    if (ch == ';' && depth == 0) { out.push_back(cur); cur.clear(); }
+    else cur += ch;
+  }
+  out.push_back(cur);
+  auto blank = [](const std::string& s) { for (char c : s) if (!std::isspace((unsigned char)c)) return false; return true; };
+  if (out.size() > 1 && blank(out.back())) out.pop_back();  // a trailing ';'
+  for (const std::string& s : out)
+    if (blank(s)) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression: an empty component expression");
+  return out;
+}
+
+static void check_text(const char* expr) {
+  if (!expr || !*expr) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression must not be empty");
+  if (std::strlen(expr) > 4096) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression longer than 4096 characters");
+  // the text is pasted into a function body: keep it an EXPRESSION (no statements, no preprocessor, no string / character literals)
+  for (const char* p = expr; *p; ++p)
+    if (*p == '{' || *p == '}' || *p == '#' || *p == '"' || *p == '\'' || *p == '\\' || *p == '\n' || *p == '\r')
+      throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string("expression: character '") + *p + "' is not allowed (an expression, not statements)");
+}
+
+struct MapSpec {
+  uint32_t src_ct = 9, dst_ct = 9, ncomp = 1;
+  bool pre = false;  // the expression sees the SOURCE value (apply_to_source), the conversion follows; otherwise the converted value
+  std::string expr;
+};
+
+// The translation unit of one mapping / transform_attribute kernel.
+std::string map_source(const MapSpec& s) {
+  std::vector<std::string> comps = split_components(s.expr);
+  if (comps.size() != 1 && comps.size() != s.ncomp)
+    throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression: " + std::to_string(comps.size()) + " component expressions for a value of " + std::to_string(s.ncomp) +
+                                                   " component(s): give one, or one per component separated by ';'");
+  std::string t = "// pasture_amd device expression (expr.cpp): one mapping, strided source and target\n#include \"device_common.hpp\"\nusing namespace pstd;\n";
+  t += std::string("typedef ") + ct_name(s.src_ct) + " TS;\ntypedef " + ct_name(s.dst_ct) + " TD;\ntypedef " + (s.pre ? "TS" : "TD") + " TI;\n";
+  t += "#define PST_NC " + std::to_string(s.ncomp) + "\n#define PST_PRE " + (s.pre ? "1" : "0") + "\n";
+  for (uint32_t c = 0; c < s.ncomp; ++c) {
+    t += "__device__ __forceinline__ TI pst_expr_" + std::to_string(c) +
+         "(const TI v, const TI x, const TI y, const TI z, const int c, const uint64_t i, const double* __restrict__ p0, const double* __restrict__ p1, "
+         "const double* __restrict__ p2, const double* __restrict__ p3) {\n  (void)v; (void)x; (void)y; (void)z; (void)c; (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n"
+         "  return rust_as<TI>(\n" + comps[comps.size() == 1 ? 0 : c] + "\n  );\n}\n";
+  }
+  t += R"(extern "C" __global__ __launch_bounds__(256) void pst_jit_expr_map(uint64_t src, uint64_t sstride, uint64_t dst, uint64_t dstride, uint64_t n, uint64_t first,
+                                                                     const double* p0, const double* p1, const double* p2, const double* p3) {
+  for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256u) {
+    const uint64_t i = first + e;
+    TI in[3];
+#pragma unroll
+    for (int c = 0; c < PST_NC; ++c) {
+      const TS s = load_un<TS>((cgptr_t)as_global(src) + e * sstride + c * sizeof(TS));
+      if (PST_PRE) in[c] = (TI)s; else in[c] = (TI)rust_as<TD>(s);
+    }
+#pragma unroll
+    for (int c = PST_NC; c < 3; ++c) in[c] = in[0];
+    TI r[3];
+)";
+  for (uint32_t c = 0; c < s.ncomp; ++c)
+    t += "    r[" + std::to_string(c) + "] = pst_expr_" + std::to_string(c) + "(in[" + std::to_string(c) + "], in[0], in[1], in[2], " + std::to_string(c) + ", i, p0, p1, p2, p3);\n";
+  t += R"(#pragma unroll
+    for (int c = 0; c < PST_NC; ++c) store_un<TD>(as_global(dst) + e * dstride + c * sizeof(TD), rust_as<TD>(r[c]));
+  }
+}
+)";
+  return t;
+}
+
+struct PredAttr {
+  std::string name;
+  uint32_t ct = 0, ncomp = 1;
+  uint64_t base = 0, stride = 0;
+};
+constexpr size_t kMaxPredAttrs = 16;
+struct PredArgs { uint64_t base[kMaxPredAttrs], stride[kMaxPredAttrs]; };
+
+static bool is_identifier(const std::string& s) {
+  if (s.empty() || !(std::isalpha((unsigned char)s[0]) || s[0] == '_')) return false;
+  for (char c : s) if (!(std::isalnum((unsigned char)c) || c == '_')) return false;
+  return true;
+}
+// identifiers of `expr` (tokens that start with a letter or '_' and are not preceded by '.': member names like `.x` are not attribute names)
+static std::vector<std::string> identifiers(const std::string& expr) {
+  std::vector<std::string> out;
+  for (size_t p = 0; p < expr.size();) {
+    const unsigned char ch = (unsigned char)expr[p];
+    if (std::isalpha(ch) || ch == '_') {
+      size_t q = p;
+      while (q < expr.size() && (std::isalnum((unsigned char)expr[q]) || expr[q] == '_')) ++q;
+      size_t b = p;
+      while (b > 0 && std::isspace((unsigned char)expr[b - 1])) --b;
+      if (!(b > 0 && expr[b - 1] == '.')) out.push_back(expr.substr(p, q - p));
+      p = q;
+    } else if (std::isdigit(ch)) {  // a number (and its suffix / exponent letters)
+      while (p < expr.size() && (std::isalnum((unsigned char)expr[p]) || expr[p] == '.')) ++p;
+    } else {
+      ++p;
+    }
+  }
+  return out;
+}
+
+std::string pred_source(const std::vector<PredAttr>& attrs, const std::string& expr) {
+  std::string t = "// pasture_amd device expression (expr.cpp): filter predicate -> byte mask\n#include \"device_common.hpp\"\nusing namespace pstd;\n";
+  t += "template <typename T> struct PstV3 { T x, y, z; };\nstruct PstPredArgs { uint64_t base[" + std::to_string(kMaxPredAttrs) + "], stride[" + std::to_string(kMaxPredAttrs) + "]; };\n";
+  std::string params, args;
+  for (size_t a = 0; a < attrs.size(); ++a) {
+    const std::string ty = attrs[a].ncomp == 3 ? std::string("PstV3<") + ct_name(attrs[a].ct) + ">" : std::string(ct_name(attrs[a].ct));
+    params += "const " + ty + " " + attrs[a].name + ", ";
+  }
+  t += "__device__ __forceinline__ bool pst_pred(" + params +
+       "const uint64_t i, const double* __restrict__ p0, const double* __restrict__ p1, const double* __restrict__ p2, const double* __restrict__ p3) {\n"
+       "  (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n  return (bool)(\n" + expr + "\n  );\n}\n";
+  t += "extern \"C\" __global__ __launch_bounds__(256) void pst_jit_expr_pred(const PstPredArgs a, uint64_t n, uint64_t first, uint8_t* __restrict__ mask,\n"
+       "                                                                      const double* p0, const double* p1, const double* p2, const double* p3) {\n"
+       "  for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256u) {\n";
+  for (size_t a = 0; a < attrs.size(); ++a) {
+    const std::string T = ct_name(attrs[a].ct), A = std::to_string(a), q = "(cgptr_t)as_global(a.base[" + A + "]) + e * a.stride[" + A + "]";
+    if (attrs[a].ncomp == 3)
+      t += "    const PstV3<" + T + "> v" + A + " = {load_un<" + T + ">(" + q + "), load_un<" + T + ">(" + q + " + sizeof(" + T + ")), load_un<" + T + ">(" + q + " + 2 * sizeof(" + T + "))};\n";
+    else
+      t += "    const " + T + " v" + A + " = load_un<" + T + ">(" + q + ");\n";
+    args += "v" + A + ", ";
+  }
+  t += "    mask[e] = pst_pred(" + args + "first + e, p0, p1, p2, p3) ? (uint8_t)1 : (uint8_t)0;\n  }\n}\n";
+  return t;
+}
+
+static pstjit::Kernel compile(const std::string& source, const char* entry, const char* what) {
+  if (pstjit::mode() == pstjit::Mode::Off)
+    throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string(what) + ": device expressions need the run-time compiler (PST_JIT=0 switches it off)");
+  pstjit::Kernel k;
+  std::string error;
+  if (!pstjit::acquire_source(source, entry, 256, 0, 0, pstjit::Acquire::Wait, &k, &error))
+    throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string(what) + ": the expression does not compile:\n" + error);
+  return k;
+}
+static unsigned grid_for(uint64_t n) {
+  const uint64_t blocks = (n + 255) / 256;
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(blocks, (uint64_t)pstk::device_cus() * 16));
+}
+static void fill_params(const double* const* device_params, size_t n_params, const double* p[4]) {
+  if (n_params > 4) throw Error(PST_ERR_INVALID_ARGUMENT, "at most 4 parameter arrays (p0 .. p3)");
+  for (size_t a = 0; a < 4; ++a) p[a] = a < n_params ? not_null(device_params, "device_params")[a] : nullptr;
+}
+
+void launch_map(const MapSpec& s, uint64_t src, uint64_t sstride, uint64_t dst, uint64_t dstride, uint64_t n, uint64_t first_index, const double* const p[4], hipStream_t stream) {
+  const pstjit::Kernel k = compile(map_source(s), "pst_jit_expr_map", "transformation expression");
+  if (n == 0) return;
+  const double *p0 = p ? p[0] : nullptr, *p1 = p ? p[1] : nullptr, *p2 = p ? p[2] : nullptr, *p3 = p ? p[3] : nullptr;
+  void* args[] = {&src, &sstride, &dst, &dstride, &n, &first_index, &p0, &p1, &p2, &p3};
+  if (hipModuleLaunchKernel(k.fn, grid_for(n), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+    throw Error(PST_ERR_HIP, std::string("expression kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+  pstk::note_plan_kind(PST_PLAN_JIT);
+}
+
+void launch_pred(const std::vector<PredAttr>& attrs, const std::string& expr, uint64_t n, uint64_t first_index, uint8_t* mask_dev, const double* const p[4], hipStream_t stream) {
+  const pstjit::Kernel k = compile(pred_source(attrs, expr), "pst_jit_expr_pred", "predicate expression");
+  if (n == 0) return;
+  PredArgs a{};
+  for (size_t i = 0; i < attrs.size(); ++i) { a.base[i] = attrs[i].base; a.stride[i] = attrs[i].stride; }
+  const double *p0 = p ? p[0] : nullptr, *p1 = p ? p[1] : nullptr, *p2 = p ? p[2] : nullptr, *p3 = p ? p[3] : nullptr;
+  void* args[] = {&a, &n, &first_index, &mask_dev, &p0, &p1, &p2, &p3};
+  if (hipModuleLaunchKernel(k.fn, grid_for(n), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+    throw Error(PST_ERR_HIP, std::string("predicate kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+}
+
+// the attributes of `layout` an expression names (C identifiers only; scalars and Vec3)
+std::vector<PredAttr> referenced_attributes(const Layout& layout, const std::string& expr) {
+  std::vector<PredAttr> out;
+  const std::vector<std::string> ids = identifiers(expr);
+  for (const Member& m : layout.members) {
+    if (!is_identifier(m.def.name)) continue;
+    bool used = false;
+    for (const std::string& id : ids) used = used || id == m.def.name;
+    if (!used) continue;
+    if (!(m.def.datatype.is_scalar() || m.def.datatype.is_vec3()))
+      throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression: attribute " + m.def.name + " of datatype " + m.def.datatype.display() + " cannot be named (scalars and Vec3 only)");
+    PredAttr a;
+    a.name = m.def.name;
+    a.ct = (uint32_t)m.def.datatype.comp_type();
+    a.ncomp = m.def.datatype.num_components();
+    out.push_back(a);
+    if (out.size() > kMaxPredAttrs) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression names more than 16 attributes");
+  }
+  return out;
+}
+
+MapSpec map_spec(const DataType& src, const DataType& dst, bool pre, const char* expr) {
+  check_text(expr);
+  if (!((src.is_scalar() && dst.is_scalar()) || (src.is_vec3() && dst.is_vec3())))
+    throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "transformation expression: scalar and Vec3 attributes only (" + src.display() + " -> " + dst.display() + ")");
+  MapSpec s;
+  s.src_ct = (uint32_t)src.comp_type();
+  s.dst_ct = (uint32_t)dst.comp_type();
+  s.ncomp = src.num_components();
+  s.pre = pre;
+  s.expr = expr;
+  return s;
+}
+
+}  // namespace pstexpr
+
+namespace pst {
+// converter.cpp: a mapping whose transformation is an expression (one strided launch per such mapping)
+void launch_expression_mapping(const DataType& src_dt, const DataType& dst_dt, bool apply_to_source, const std::string& expr, uint64_t src, uint64_t sstride, uint64_t dst,
+                               uint64_t dstride, uint64_t n, uint64_t first_index, hipStream_t stream) {
+  const pstexpr::MapSpec s = pstexpr::map_spec(src_dt, dst_dt, apply_to_source, expr.c_str());
+  pstexpr::launch_map(s, src, sstride, dst, dstride, n, first_index, nullptr, stream);
+}
+void validate_expression_mapping(const DataType& src_dt, const DataType& dst_dt, bool apply_to_source, const char* expr) {
+  (void)pstexpr::map_source(pstexpr::map_spec(src_dt, dst_dt, apply_to_source, expr));  // shape errors now; syntax errors at the first conversion
+}
+}  // namespace pst
+
+namespace {
+struct TempDev {
+  uint8_t* p = nullptr;
+  explicit TempDev(size_t bytes) { p = bytes ? dev_alloc(bytes, PST_MEM_DEVICE) : nullptr; }
+  ~TempDev() { dev_free(p, PST_MEM_DEVICE); }
+};
+void copy_out(const std::string& text, char* buf, size_t cap, size_t* needed) {
+  if (needed) *needed = text.size() + 1;
+  if (buf && cap) {
+    const size_t m = std::min(cap - 1, text.size());
+    std::memcpy(buf, text.data(), m);
+    buf[m] = 0;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// transform_attribute(attribute, |index, value| expr), point_buffer.rs:391-404, in place on the current stream
+int pst_transform_attribute_expr(pst_buffer* b, const char* name, const pst_datatype* dt, const char* expr, const double* const* device_params, size_t n_params) {
+  PST_API_BEGIN
+  not_null(b, "buffer");
+  AttributeDef def{not_null(name, "name"), DataType::from_c(dt)};
+  const int slot = b->layout.index_of(def);
+  if (slot < 0) throw Error(PST_ERR_MISSING_ATTRIBUTE, "Attribute not found in PointLayout of buffer");
+  const pstexpr::MapSpec s = pstexpr::map_spec(def.datatype, def.datatype, false, not_null(expr, "expr"));
+  const double* p[4];
+  pstexpr::fill_params(device_params, n_params, p);
+  ensure_device();
+  hipStream_t st = current_stream();
+  pstk::reset_plan_kinds();
+  const Member& m = b->layout.members[(size_t)slot];
+  const uint64_t base = b->columnar ? col_addr(*b, (size_t)slot, 0) : aos_addr(*b, 0) + m.offset;
+  const uint64_t stride = b->columnar ? m.size : b->layout.size;
+  pstexpr::launch_map(s, base, stride, base, stride, b->len, 0, p, st);
+  stream_sync(st);
+  PST_API_END
+}
+
+int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, pst_buffer** out);
+
+// HashMapBuffer::filter(|index| expr) -> a new buffer of `out_storage` (point_buffer.rs:1064-1075): the predicate is evaluated on the device
+// into a byte mask, which the compaction kernels then take like a caller-provided device mask
+int pst_buffer_filter_expr(const pst_buffer* src, const char* expr, const double* const* device_params, size_t n_params, uint32_t out_storage, pst_buffer** out) {
+  PST_API_BEGIN
+  not_null(src, "src");
+  not_null(out, "out");
+  pstexpr::check_text(not_null(expr, "expr"));
+  if (!src->columnar) throw Error(PST_ERR_INVALID_ARGUMENT, "filter is defined on HashMapBuffer (point_buffer.rs:1064)");
+  std::vector<pstexpr::PredAttr> attrs = pstexpr::referenced_attributes(src->layout, expr);
+  for (pstexpr::PredAttr& a : attrs) {
+    const Member* m = src->layout.find_by_name(a.name);
+    const size_t slot = (size_t)(m - src->layout.members.data());
+    a.base = col_addr(*src, slot, 0);
+    a.stride = m->size;
+  }
+  const double* p[4];
+  pstexpr::fill_params(device_params, n_params, p);
+  ensure_device();
+  hipStream_t st = current_stream();
+  TempDev mask(src->len);
+  pstexpr::launch_pred(attrs, expr, src->len, 0, mask.p, p, st);
+  static uint8_t empty_mask = 0;
+  const int rc = pst_buffer_filter(src, src->len ? mask.p : &empty_mask, PST_MEM_DEVICE, out_storage, out);
+  stream_sync(st);  // the mask is freed on return
+  if (rc != PST_OK) return rc;
+  PST_API_END
+}
+
+// The translation units the two kinds of expression become (tests compile them without a device through pst_jit_compile_source; also what a
+// maintainer reads when a compile error points into generated code).  kind 0: transformation (source / target datatype, apply_to_source),
+// kind 1: predicate over `layout` (datatypes ignored).  Returns the text's size in *needed (terminator included).
+int pst_expr_source(int kind, const pst_layout* layout, const pst_datatype* src_dt, const pst_datatype* dst_dt, int apply_to_source, const char* expr, char* buf,
+                    size_t cap, size_t* needed) {
+  PST_API_BEGIN
+  pstexpr::check_text(not_null(expr, "expr"));
+  std::string text;
+  if (kind == 0) {
+    text = pstexpr::map_source(pstexpr::map_spec(DataType::from_c(not_null(src_dt, "src_dt")), DataType::from_c(not_null(dst_dt, "dst_dt")), apply_to_source != 0, expr));
+  } else if (kind == 1) {
+    text = pstexpr::pred_source(pstexpr::referenced_attributes(not_null(layout, "layout")->l, expr), expr);
+  } else {
+    throw Error(PST_ERR_INVALID_ARGUMENT, "pst_expr_source: kind must be 0 (transformation) or 1 (predicate)");
+  }
+  copy_out(text, buf, cap, needed);
+  PST_API_END
+}
+
+}  // extern "C"

@@ -1444,7 +1444,7 @@ long long run_normals(const uint8_t* pos_base, uint64_t pos_stride, uint64_t n, 
           rec_tiled = true; rec_list = list_ptr != nullptr; rec_n_list = n_list; rec_n_fb = n_fb; rec_shape = shape; rec_g = g; rec_cells = cells; rec_nf = nf;
           mark("box-search");
           if (debug)
-            fprintf(stderr, "[pst knn] n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u kernel=%c threads=%u cap=%u fallback=%u\n", (unsigned long long)n,
+            fprintf(stderr, "[pst knn] fit=%s n=%llu nf=%llu cells=%llu dim=%ux%ux%u h=%g box=%ux%ux%u kernel=%c threads=%u cap=%u fallback=%u\n", shape.fit_seq ? "reference-order" : "one-pass+guard", (unsigned long long)n,
                     (unsigned long long)nf, (unsigned long long)cells, g.dim[0], g.dim[1], g.dim[2], g.h, shape.bx, shape.by, shape.bz, shape.tag, shape.threads,
                     shape.cap, n_fb);
           if (n_fb) {

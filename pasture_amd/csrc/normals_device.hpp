@@ -91,8 +91,27 @@ struct Fit { double nx, ny, nz, curvature; int ok; };
 
 // Everything of the fit behind the covariance matrix (upper triangle, NOT divided by the count): eigen_3x3 :429-453 with solve_polynomial
 // :328-392, get_largest_eigen_vector :395-426, solve_plane_parameter :456-467.
-__device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, double c02, double c11, double c12, double c22) {
+//
+// `ill` (optional): set when the reference's solver AMPLIFIES last-bit differences of the covariance beyond the parity window, i.e. when a
+// covariance that is not the reference's own sequence of operations (plane_fit_pivot) must not be trusted for this neighbourhood:
+//   * the two SMALLEST roots of the characteristic cubic nearly coincide (prolate / collinear neighbourhoods: half_beta >= 0 and
+//     -q <= 1e-2 |alpha/3|^3, i.e. |sin 3 theta| <= 0.1): the trigonometric form takes the square root of the discriminant q, an error
+//     delta in q becomes delta / (2 sqrt(-q)) in the roots -- beyond the threshold a factor > 5 on the ~1e-15 relative difference between two
+//     valid summation orders, against a window of 1e-13 x scale (measured, 4 10^6 uniform points, k = 16, worst curvature difference to the
+//     reference-order instance: 3.6e-10 unguarded, 5.2e-11 with the threshold at 1e-4 -- amplification ~50 just outside it).  (The other double root, theta = pi / 3, is harmless: the smallest root is the
+//     simple one there and its derivative with respect to theta vanishes.)
+//   * all three roots nearly coincide (isotropic neighbourhoods, e.g. a lattice point with its six face neighbours): |alpha/3| <= 1e-5 (k2/3)^2;
+//     rho = sqrt(-alpha/3) then turns a relative 1e-16 into 1e-8.
+//   * the matrix is nearly of rank one (collinear points): every cross product of two rows is a difference of nearly equal products, and the
+//     normal -- the largest of them -- carries a relative error of ~1e-16 / (lambda_1 / lambda_2); flagged when its norm in the scaled
+//     matrix is below 1e-4.
+//   * two of the three cross products have norms within 1e-6 of each other: "the first maximum wins" (:395-426) is then decided by last bits,
+//     and on exactly planar neighbourhoods the candidates are parallel but may point in opposite directions (found by the round-5 structured
+//     volume test on a quantised plane: normal = -oracle's).
+// A flagged lane re-runs the fit in the reference's order of operations (knn_tile2_kernel).
+__device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, double c02, double c11, double c12, double c22, bool* ill = nullptr) {
   Fit f{0, 0, 0, 0, 1};
+  bool flagged = false;
   const double c10 = c01, c20 = c02, c21 = c12;
   // eigen_3x3 :429-453
   double scale = __builtin_fabs(c00);  // covariance_matrix.abs().max(), column-major order
@@ -128,6 +147,8 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
       const double half_beta = 0.5 * (k0 + k2_third * (2.0 * k2_third * k2_third - k1));
       double q = half_beta * half_beta + alpha_third * alpha_third * alpha_third;
       if (q > 0.0) q = 0.0;
+      const double a3 = -alpha_third;
+      flagged = (half_beta >= 0.0 && -q <= 1e-2 * (a3 * a3 * a3)) || a3 <= 1e-5 * (k2_third * k2_third);
       const double rho = __builtin_sqrt(-alpha_third);
       const double theta = ::atan2(__builtin_sqrt(-q), half_beta) * one_third;
       const double ct = ::cos(theta), st = ::sin(theta);
@@ -154,7 +175,13 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
   f.nx = a0; f.ny = a1; f.nz = a2;
   double best = na;
   if (nb > best) { f.nx = b0; f.ny = b1; f.nz = b2; best = nb; }
-  if (nd > best) { f.nx = d0; f.ny = d1; f.nz = d2; }
+  if (nd > best) { f.nx = d0; f.ny = d1; f.nz = d2; best = nd; }
+  if (ill) {
+    // ... and the winner among the three cross products must be the reference's: with two norms within 1e-6 of each other (exact ties on
+    // lattices and quantised planes, where the candidates are parallel and may point in OPPOSITE directions) last bits decide it
+    const double lo = __builtin_fmin(na, __builtin_fmin(nb, nd)), mid = (na + nb + nd) - best - lo;
+    *ill = flagged || !(best >= 1e-4) || (best - mid) <= 1e-6 * best;
+  }
   // solve_plane_parameter :456-467
   const double eigen_sum = c00 + c11 + c22;
   f.curvature = eigen_sum != 0.0 ? __builtin_fabs(eigen_value / eigen_sum) : 0.0;
@@ -224,7 +251,7 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
 // to ~1e-14 relative, inside the north star's 1e-9; PST_KNN_FIT=seq selects the reference-order instance for bit comparison.
 // Finite coordinates only (the grid searches never see another kind).
 template <int KMAX, typename GetPoint>
-__device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py, double pz, GetPoint&& get) {
+__device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py, double pz, GetPoint&& get, bool* ill = nullptr) {
   double sx = 0, sy = 0, sz = 0, mxx = 0, mxy = 0, mxz = 0, myy = 0, myz = 0, mzz = 0;
 #pragma unroll
   for (int t = 0; t < KMAX; ++t) {
@@ -236,11 +263,11 @@ __device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py,
       myy = __builtin_fma(uy, uy, myy); myz = __builtin_fma(uy, uz, myz); mzz = __builtin_fma(uz, uz, mzz);
     }
   }
-  if (m < 3) { Fit f{0, 0, 0, 0, 0}; return f; }  // Err(...) :293-295 -> unwrap panic :471
+  if (m < 3) { Fit f{0, 0, 0, 0, 0}; if (ill) *ill = false; return f; }  // Err(...) :293-295 -> unwrap panic :471
   const double inv = 1.0 / (double)m;
   const double tx = sx * inv, ty = sy * inv, tz = sz * inv;  // centroid - pivot
   return fit_from_covariance(__builtin_fma(-sx, tx, mxx), __builtin_fma(-sx, ty, mxy), __builtin_fma(-sx, tz, mxz),
-                             __builtin_fma(-sy, ty, myy), __builtin_fma(-sy, tz, myz), __builtin_fma(-sz, tz, mzz));
+                             __builtin_fma(-sy, ty, myy), __builtin_fma(-sy, tz, myz), __builtin_fma(-sz, tz, mzz), ill);
 }
 
 // The fit as a WAVE-LEVEL operation (BASELINE.json configs[4]: "per-point 3x3 covariance wavefront reduction") for kernels that spend a whole

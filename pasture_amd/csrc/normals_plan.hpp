@@ -32,6 +32,7 @@ struct KnnTuning {
   int reorder_unroll = 2;      // PST_REORDER_UNROLL: points per lane in flight in the permutation kernel (1 / 2 / 4)
   int fit = -1;                // PST_KNN_FIT=seq|pivot: the box search's plane fit in the reference's order of operations (two passes) / in one pass about the query; default (-1): by cloud --
                                // one pass for clouds that fill their box, the reference's order for surfaces and strips (near-planar neighbourhoods: see normals_device.hpp)
+  bool fit_guard = true;       // PST_KNN_FIT_GUARD=0: the one-pass fit never falls back to the reference's order for ill-conditioned neighbourhoods (tests that the guard is what keeps them in the window)
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
   unsigned ablate = 0;         // PST_KNN_ABLATE (tuning only)
   unsigned flush_at = 48;      // PST_KNN_FLUSH_AT
@@ -55,6 +56,7 @@ struct KnnTuning {
     if (const char* e = std::getenv("PST_KNN_VAR")) t.variant = *e;
     if (const char* e = std::getenv("PST_KNN_FIT")) t.fit = e[0] == 's' ? 1 : (e[0] == 'p' ? 0 : -1);
     t.sort_fallback = !off("PST_KNN_SORT_FALLBACK");
+    t.fit_guard = !off("PST_KNN_FIT_GUARD");
     if (const char* e = std::getenv("PST_REORDER_UNROLL")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) t.reorder_unroll = v; }
     if (const char* e = std::getenv("PST_KNN_TILE")) {
       unsigned x = 0, y = 0, z = 0;

@@ -74,6 +74,7 @@ struct TileArgs {
   const uint32_t* box_list;    // the boxes to search (null: all n_boxes of them, box = workgroup id); n_boxes = its length then
   const uint32_t* n_boxes_dev; // stream-ordered replay of a plan: the list's length lives on the device (n_boxes = the capacity the grid was sized for)
   uint32_t flush_at;           // PST_KNN_FLUSH_AT, default 48
+  uint32_t fit_guard;          // 1 (default): a lane whose neighbourhood is ill-conditioned repeats the one-pass fit in the reference's order (PST_KNN_FIT_GUARD=0: never)
   uint32_t ablate;             // tuning only (PST_KNN_ABLATE): 1 = no insertion, 2 = no plane fit, 4 = no scan, 8 = nothing queued, 16 = no copy, 32 = no records, 64 = empty kernel
 };
 
@@ -949,12 +950,27 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       if constexpr (FIT == 1) {
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
+        bool ill = false;
         if (!(a.ablate & 2u)) f = plane_fit_pivot<K>(m, qx, qy, qz, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
           uint32_t pl = 0;
 #pragma unroll
           for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = nb[u];
           exact_xyz(pl, x, y, z);
-        });
+        }, &ill);
+        // Conditioning is a property of the NEIGHBOURHOOD, not of the cloud (round-4 review): where the reference's solver amplifies last-bit
+        // differences of the covariance (fit_from_covariance: `ill`), this lane repeats the fit in the reference's own order of operations --
+        // centroid, then moments, the neighbours gathered again for each pass.  Rare in volume-filling clouds (about one query in 300, one wave in
+        // five); on walls, wires and lattices inside such clouds it is what keeps curvature and normal inside the parity window.
+        ill = ill && a.fit_guard;
+        PST_KNN_STAT(if (ill) atomicAdd(a.dbg + 6, 1ull);)
+        if (__builtin_amdgcn_ballot_w64(ill)) {
+          if (ill) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
+            uint32_t pl = 0;
+#pragma unroll
+            for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = nb[u];
+            exact_xyz(pl, x, y, z);
+          });
+        }
       } else if constexpr (!P3LDS && K <= 16) {
         // f64 coordinates from global memory: every neighbour is fetched ONCE (the plane fit walks the neighbours twice, and a gather of
         // 64 scattered 24-byte points keeps the texture path busy for ~64 cycles whether it hits the cache or not)
@@ -1327,6 +1343,7 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
   a.n_boxes_dev = box_list ? n_list_dev : nullptr;
   a.k = k; a.nf = nf; a.out = out; a.fb_list = fb_list; a.fb_count = fb_count;
   a.ablate = knn_tuning().ablate;
+  a.fit_guard = knn_tuning().fit_guard ? 1u : 0u;
   a.flush_at = knn_tuning().flush_at;
   // A-priori bound on the squared k-th distance: the grid's cell edge h was chosen as the radius of the sphere expected to hold about
   // 1.75 k points (normals.hip), and candidates beyond tau0 = h^2 (less a few ulps for the packed keys) are not even queued.  Without

@@ -412,6 +412,43 @@ def _cov_scales(pts, knn):
     return np.abs(cov).reshape(len(pts), 9).max(axis=1)
 
 
+def _oracle_fit_of_lists(oracle, pts, knn):
+    """The oracle's plane fit (normal_estimation.rs:111-123, 240-305, 429-467) of GIVEN neighbour lists -- `knn` [q][k] int64 indices into
+    `pts` [n][3] f64, in list order: normals [q][3], curvature [q].  With exact distance ties (quantised coordinates) the tie ORDER of the
+    un-vendored kd-tree crate is unpinned, so the oracle's own lists cannot be compared index by index; the GPU's lists, once checked to be
+    exact k-nearest sets in ascending distance, pin the FIT of every query instead (round-4 review, item 1b)."""
+    import ctypes
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    knn = np.ascontiguousarray(knn, dtype=np.int64)
+    q, k = knn.shape
+    on, oc = np.zeros((q, 3)), np.zeros(q)
+    fn = oracle.lib.orc_fit_neighbourhoods
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    rc = fn(pts.ctypes.data, len(pts), knn.ctypes.data, q, k, on.ctypes.data, oc.ctypes.data)
+    assert rc == 0, f"orc_fit_neighbourhoods: status {rc}"
+    return on, oc
+
+
+def _assert_fits_match_oracle(oracle, pts, knn, hn, hc, what, chunk=200_000):
+    """Every query's normal / curvature against the oracle's fit of the SAME neighbour list, inside the windows of _compare_normals."""
+    n_bad = n_cbad = 0
+    worst = None
+    for first in range(0, len(knn), chunk):
+        kk = knn[first:first + chunk]
+        on, oc = _oracle_fit_of_lists(oracle, pts, kk)
+        nb = pts[kk]
+        d = nb - nb.mean(axis=1, keepdims=True)
+        scales = np.abs(np.einsum("nki,nkj->nij", d, d)).reshape(len(kk), 9).max(axis=1)
+        bad, cbad = _compare_normals(hn[first:first + chunk], hc[first:first + chunk], on, oc, scales=scales)
+        if (bad.any() or cbad.any()) and worst is None:
+            i = int(np.flatnonzero(bad | cbad)[0])
+            worst = f"query {first + i}: normal {hn[first + i].tolist()} vs oracle {on[i].tolist()}, curvature {float(hc[first + i])!r} vs {float(oc[i])!r}, scale {scales[i]:.3e}"
+        n_bad += int(bad.sum())
+        n_cbad += int(cbad.sum())
+    assert n_bad == 0 and n_cbad == 0, f"{what}: {n_bad} normals / {n_cbad} curvatures of {len(knn)} outside the window; first: {worst}"
+
+
 def _compare_normals(hn, hc, on, oc, rel=1e-9, scales=None):
     """<= 1e-9 relative (BASELINE.json).  Documented tie window: the normal is the largest of three cross products
     (normal_estimation.rs:395-426); when two candidates have norms within 1e-9 of each other the winner may differ."""
@@ -936,7 +973,7 @@ def test_every_instance_of_the_box_kernel_vs_oracle(hip, oracle, monkeypatch, va
 
 
 @pytest.mark.parametrize("n_side,k", [(48, 16), (40, 8), (36, 27)])
-def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
+def test_knn_on_quantised_coordinates_with_exact_ties(hip, oracle, n_side, k):
     """LAS coordinates are integers times a scale: equal distances are the rule, not the exception.  On a jittered-then-quantised lattice
     (every point has 6 neighbours at exactly the same distance, 12 at the next, ...) the tie ORDER is unpinned (kd-tree crate), but the
     multiset of neighbour distances is not: every list must hold the k smallest distances in ascending order, start with the point itself
@@ -957,7 +994,8 @@ def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
     buf.set_attribute_range(A.POSITION_3D, range(0, n), pts)
     knn = torch.empty((n, k), dtype=torch.int32, device="cuda")
     curv = torch.empty(n, dtype=torch.float64, device="cuda")
-    compute_normals_device(buf, k, 0, curv.data_ptr(), knn.data_ptr())
+    normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    compute_normals_device(buf, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
     tp = torch.as_tensor(pts, device="cuda")
     kk = knn.long()
     assert bool((kk[:, 0] == torch.arange(n, device="cuda")).all())
@@ -970,6 +1008,92 @@ def test_knn_on_quantised_coordinates_with_exact_ties(hip, n_side, k):
         want = torch.topk(d, k, dim=1, largest=False, sorted=True).values
         assert torch.equal(got[first:first + 8192], want), "neighbour distances differ from the brute-force k smallest"
     assert bool(torch.isfinite(curv).all())
+    # the lists are exact k-nearest sets in ascending distance: they pin the fit of EVERY query (lattice neighbourhoods are the isotropic /
+    # exactly planar ones where the reference's cubic solver is at its worst)
+    _assert_fits_match_oracle(oracle, pts, kk.cpu().numpy(), normals.cpu().numpy(), curv.cpu().numpy(), f"quantised lattice {n_side}^3, k = {k}")
+
+
+def _structured_volume(n, seed, quantise=None):
+    """A cloud that FILLS its box (96 % uniform in [0, 100)^3: it takes the box search and, by default, the one-pass plane fit) with the structures
+    of a building scan inside it, each dense enough that the neighbourhoods of its points lie inside it: an axis-aligned floor patch (exactly
+    planar), a tilted wall (planar up to rounding), axis-aligned / tilted / slightly noisy wires (exactly and nearly collinear), a cubic
+    lattice (isotropic neighbourhoods, exact distance ties), a few tight clusters.  quantise = a LAS scale: every coordinate becomes an integer
+    multiple of it (duplicates dropped)."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    r = lambda *shape: torch.rand(*shape, device="cuda", dtype=torch.float64, generator=g)
+    f64 = lambda *v: torch.tensor(v, device="cuda", dtype=torch.float64)
+    col = lambda m, v: torch.full((m, 1), v, device="cuda", dtype=torch.float64)
+    parts = []
+    m = int(n * 0.015)
+    parts.append(torch.cat([r(m, 2) * 18.0 + 20.0, col(m, 40.0)], dim=1))                                         # floor patch, z = 40 exactly
+    m = int(n * 0.010)
+    uv = r(m, 2) * 15.0
+    parts.append(f64(60.0, 10.0, 5.0) + uv[:, :1] * f64(0.6, 0.8, 0.0) + uv[:, 1:] * f64(-0.16, 0.12, 0.9797958971132712))  # tilted wall
+    m = int(n * 0.0015)
+    parts.append(torch.cat([r(m, 1) * 10.0 + 10.0, col(m, 77.0), col(m, 13.5)], dim=1))                           # wires along x and z: exactly collinear
+    parts.append(torch.cat([col(m, 5.25), col(m, 91.0), r(m, 1) * 10.0 + 20.0], dim=1))
+    parts.append(f64(15.0, 15.0, 80.0) + r(m, 1) * 10.0 * f64(0.48, 0.6, 0.64))                                   # a tilted wire: collinear up to rounding
+    parts.append(f64(90.0, 20.0, 20.0) + r(m, 1) * 10.0 * f64(-0.7071067811865476, 0.7071067811865476, 0.0) + (r(m, 3) - 0.5) * 2e-6)  # ... with micrometre noise
+    side = max(2, int(round((n * 0.005) ** (1.0 / 3.0))))
+    ax = torch.arange(side, device="cuda", dtype=torch.float64) * 0.25
+    parts.append(torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).reshape(-1, 3) + f64(30.0, 60.0, 62.0))  # lattice
+    for c in range(4):
+        parts.append(r(1, 3) * 80.0 + 10.0 + torch.randn(int(n * 0.0005), 3, device="cuda", dtype=torch.float64, generator=g) * 0.05)
+    parts.append(r(n - sum(len(p) for p in parts), 3) * 100.0)
+    pts = torch.cat(parts)
+    if quantise:
+        pts = torch.unique(torch.round(pts / quantise), dim=0) * quantise
+    return pts[torch.randperm(len(pts), device="cuda", generator=g)].contiguous()
+
+
+@pytest.mark.parametrize("fit", ["default", "pivot"])
+@pytest.mark.parametrize("quantise", [None, 0.001])
+@pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8, 16])
+def test_structured_volume_every_fit_against_the_oracle(hip, oracle, k, quantise, fit):
+    """Round-4 review, item 1: conditioning is a property of the NEIGHBOURHOOD, and the one-pass plane fit used to be chosen per CLOUD.  A cloud that
+    fills its box with exactly planar, collinear and lattice structure inside it (_structured_volume), continuous and quantised to a LAS
+    scale, k = 3 ... 8 and 16, through the box search under the default dispatch AND with the one-pass fit forced (PST_KNN_FIT=pivot: what a
+    volume-filling cloud takes): neighbour lists checked on the device (ascending distance, no repeats, a sample against brute force), then
+    normal and curvature of EVERY query against the oracle's fit of the same list.  What keeps the one-pass instance inside the window here is
+    the per-query guard (fit_from_covariance `ill`: the lane repeats the fit in the reference's order); PST_KNN_FIT_GUARD=0 shows the cases."""
+    import torch
+    from pasture_amd.algorithms import compute_normals_device, reload_tuning
+    from pasture_amd.buffers import ExternalColumnsBuffer
+    pts = _structured_volume(1_200_000, 100 + k, quantise)
+    n = pts.shape[0]
+    assert n >= 1 << 20  # the box search takes clouds of 2^20 points and more
+    try:
+        if fit != "default":
+            _os.environ["PST_KNN_FIT"] = fit
+            reload_tuning(hip)
+        src = ExternalColumnsBuffer([pts], PointLayout.from_attributes([A.POSITION_3D], api=hip), n)
+        normals = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+        curv = torch.empty(n, dtype=torch.float64, device="cuda")
+        knn = torch.empty((n, k), dtype=torch.int32, device="cuda")
+        compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
+    finally:
+        _os.environ.pop("PST_KNN_FIT", None)
+        reload_tuning(hip)
+    kk = knn.long()
+    assert bool(((kk >= 0) & (kk < n)).all())
+    # squared distances in the reference's order of operations, (dx dx + dy dy) + dz dz with every product and sum rounded on its own: on
+    # quantised coordinates neighbours tie to within an ulp, and a reduction that adds in another order ranks them differently
+    def dist2(a, b):
+        e = a - b
+        return (e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1]) + e[..., 2] * e[..., 2]
+    d = dist2(pts[kk.reshape(-1)].view(n, k, 3), pts[:, None, :])
+    assert bool((d[:, 0] == 0).all()) and bool((d[:, 1:] >= d[:, :-1]).all())
+    srt = kk.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "a neighbour is listed twice"
+    gq = torch.Generator(device="cpu")
+    gq.manual_seed(k)
+    for q in torch.randint(0, n, (384,), generator=gq).tolist():
+        want = torch.topk(dist2(pts, pts[q]), k, largest=False, sorted=True).values
+        assert torch.equal(d[q], want), f"query {q}: neighbour distances differ from the brute-force k smallest"
+    _assert_fits_match_oracle(oracle, pts.cpu().numpy(), kk.cpu().numpy(), normals.cpu().numpy(), curv.cpu().numpy(),
+                              f"structured volume, k = {k}, quantise = {quantise}, fit = {fit}")
 
 
 # ---- buffer kinds of the boundary: external memory, pinned host memory, explicit stream --------------------------
