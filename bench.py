@@ -400,8 +400,11 @@ def self_launch(args):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}; refusing to run fewer ranks "
                              f"than asked (no silent 1-GPU run)\n")
             sys.exit(2)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own agent picks AND HOLDS the rendezvous port.  (Choosing a free port here and passing --master-port left a
+    # window of seconds -- python start-up, import torch -- in which any outgoing connection of the box could take that port as its source port:
+    # the one unexplained multi-rank failure in five full suites of round 4.)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
     sys.exit(subprocess.call(cmd, env=env))
@@ -888,7 +891,7 @@ def main():
         from pasture_amd.distributed import shard_range
         g3 = args.configs3_points
         sh = shard_range(g3, rank, world)
-        del src, dst
+        src = dst = None
         s_src = pa.HashMapBuffer.new_from_layout(layout)
         s_src.resize(len(sh))
         s_src.synth_fill(SEED, sh.start)
@@ -906,9 +909,16 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
+        # per-rank HIP events around each step's conversion launch (north_star-style): the first hardware run separates kernel time from
+        # exchange / launch time without a second run -- wall time between the barriers minus the slowest rank's kernel time is what the 48-byte
+        # all-reduce and the launch path cost
+        c3_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(c3_steps)]
         t3 = time.perf_counter()
-        for _ in range(c3_steps):
-            c3_step()
+        for e0, e1 in c3_ev:
+            e0.record(stream)
+            conv.convert_into_with_bounds_async(s_src, s_dst, ring3.current().data_ptr())
+            e1.record(stream)
+            ring3.submit()
         rec3 = ring3.finish()
         torch.cuda.synchronize()
         dist.barrier()
@@ -916,6 +926,10 @@ def main():
         t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c3_elapsed = float(t.item())
+        c3_kernel = [a.elapsed_time(b) for a, b in c3_ev]
+        mine3 = torch.tensor([sum(c3_kernel) / len(c3_kernel), min(c3_kernel), float(len(sh))], dtype=torch.float64, device=ctl)
+        rows3 = [torch.zeros(3, dtype=torch.float64, device=ctl) for _ in range(world)]
+        dist.all_gather(rows3, mine3)
         # the same self-check for the sharded 10^9-point cloud: global AABB == affine(union of the shards' source bounds), on every rank
         from pasture_amd.distributed import F64_MAX as _F64_MAX, verify_global_bounds as _verify
         s_rec = torch.tensor([_F64_MAX] * 3 + [-_F64_MAX] * 3, dtype=torch.float64, device="cuda")
@@ -931,14 +945,17 @@ def main():
                     "aggregate_GBps": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9, 1),
                     "frac_of_aggregate_peak": round(bytes_per_point * g3 * c3_steps / c3_elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
                     "points_rank0": len(sh), "bounds": bounds_from_record(rec3.cpu()), "self_check": c3_check,
+                    "per_rank": {"points": [int(r[2]) for r in rows3], "kernel_ms_avg": [round(float(r[0]), 4) for r in rows3], "kernel_ms_min": [round(float(r[1]), 4) for r in rows3],
+                                 "kernel_frac_of_peak": [round(bytes_per_point * float(r[2]) / (float(r[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if float(r[0]) > 0 else None for r in rows3]},
+                    "exchange_and_launch_ms_per_step": round(c3_elapsed / c3_steps * 1e3 - max(float(r[0]) for r in rows3), 4),
                     "note": "BASELINE.json configs[3]: ONE cloud sharded by index range, rank r owns [r*ceil(G/N), min(G,(r+1)*ceil(G/N))); "
                             "one AABB all-reduce per step; wall time between barriers, max over ranks"}
         del s_src, s_dst
 
     # BASELINE.json configs[2] and configs[4] made driver-visible (N = 1, default workload): measured after the timed region, never folded into `value`
     extra_legs, extra_checks = {}, {}
-    if world == 1 and args.workload == "convert_affine_bounds" and not args.global_points and not args.no_extra_legs:
-        del src, dst
+    if world == 1 and not distributed and args.workload == "convert_affine_bounds" and not args.global_points and not args.no_extra_legs:
+        src = dst = None
         try:
             rep, smp = leg_configs2(pa, las, cv, torch, stream, n, SEED)
             extra_legs["configs2_las0_to_columns"], extra_checks["configs2"] = rep, smp

@@ -197,6 +197,34 @@ int pst_buffer_filter_into_async(const pst_buffer* src, pst_buffer* dst, const u
 /* HashMapBuffer::filter::<B, _> (point_buffer.rs:1064-1076): new buffer of out_storage holding exactly the matching points */
 int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_memkind, uint32_t out_storage, pst_buffer** out);
 
+/* ---- device expressions: user-written closures as source text (round 5) -----------------------------------------------------------------
+ * The reference takes ANY closure: Fn(T) -> T transformations (buffer_conversion.rs:13-36, 194-234), transform_attribute's Fn(usize, T) -> T
+ * (point_buffer.rs:391-404) and filter's Fn(usize) -> bool (point_buffer.rs:1064-1136).  A closure cannot cross a C ABI into a kernel; its
+ * source text can.  An expression is C++ EXPRESSION syntax (no statements, no braces, no string literals) over these names, compiled at run
+ * time with hipRTC (cached per text; -ffp-contract=off: `v * s + o` keeps its two roundings) and run as a device function:
+ *   transformations:  v = this component of the value (of T's component type; the value itself for scalars),  x y z = the components of a
+ *                     Vec3 value,  c = the component being computed (0 1 2),  i = the point's index (the closure's usize),  p0 .. p3 = device
+ *                     arrays of double given with the call (what a closure would capture).  One expression serves every component; a Vec3
+ *                     attribute may give three, `x-expr ; y-expr ; z-expr`.  The result is converted to T's component type with Rust `as`.
+ *   predicates:       every attribute of the buffer's layout whose name is a C identifier -- scalars by value, Vec3 as .x .y .z --, i, p0 .. p3:
+ *                     "Classification == 2 && Position3D.z < 120.0".
+ * Scalar and Vec3 attributes only.  A text that does not compile is PST_ERR_UNSUPPORTED_TRANSFORM with the compiler's log in pst_last_error;
+ * PST_JIT=0 (no run-time compiler) makes every expression PST_ERR_UNSUPPORTED_TRANSFORM.  The closed descriptors (pst_transform) remain the
+ * fast path for the in-tree callers' closures; an expression mapping is its own strided launch. */
+/* BufferLayoutConverter::set_custom_mapping_with_transformation (buffer_conversion.rs:194-234) with the closure as an expression; T = the
+ * source attribute's datatype when apply_to_source (the conversion follows), the target's otherwise (the conversion precedes) :209-213 */
+int pst_converter_set_custom_mapping_with_expression(pst_converter* c, const char* from_name, const pst_datatype* from_dt, const char* to_name,
+                                                     const pst_datatype* to_dt, const char* expr, int apply_to_source);
+/* BorrowedMutBufferExt::transform_attribute(attribute, |index, value| expr), point_buffer.rs:391-404, in place; device_params = up to four
+ * device arrays of double the expression names p0 .. p3 (NULL / 0 for none) */
+int pst_transform_attribute_expr(pst_buffer* b, const char* name, const pst_datatype* dt, const char* expr, const double* const* device_params, size_t n_params);
+/* HashMapBuffer::filter(|index| expr) -> new buffer of out_storage holding exactly the matching points (point_buffer.rs:1064-1076) */
+int pst_buffer_filter_expr(const pst_buffer* src, const char* expr, const double* const* device_params, size_t n_params, uint32_t out_storage, pst_buffer** out);
+/* the translation unit an expression becomes (kind 0: transformation between src_dt / dst_dt; kind 1: predicate over `layout`): what a compile
+ * error's line numbers refer to, and what the CPU tests hand to pst_jit_compile_source.  *needed = its size, terminator included. */
+int pst_expr_source(int kind, const pst_layout* layout, const pst_datatype* src_dt, const pst_datatype* dst_dt, int apply_to_source, const char* expr, char* buf,
+                    size_t cap, size_t* needed);
+
 /* RawPointConverter::{from_to, convert}, pasture-core/src/layout/conversion/attribute_conversion.rs:62-109 — the point-major variant:
  * one `as` converter per attribute present in BOTH layouts (matched by name, in the order of `from`) whose datatypes differ.
  * Attributes with equal datatypes get no converter and are SKIPPED, not copied (:73-90); an impossible pair is the panic of :267-269

@@ -171,6 +171,10 @@ _PRODUCT_SIGNATURES = {
     "jit_compile_source": [C.c_char_p, _P, _SZ, C.POINTER(_SZ), C.c_char_p, _SZ],
     "jit_get_stats": [C.POINTER(JitStatsStruct)],
     "jit_set_mode": [C.c_int],
+    "converter_set_custom_mapping_with_expression": [_P, C.c_char_p, _DT, C.c_char_p, _DT, C.c_char_p, C.c_int],
+    "transform_attribute_expr": [_P, C.c_char_p, _DT, C.c_char_p, _PP, _SZ],
+    "buffer_filter_expr": [_P, C.c_char_p, _PP, _SZ, C.c_uint32, _PP],
+    "expr_source": [C.c_int, _P, _DT, _DT, C.c_int, C.c_char_p, C.c_char_p, _SZ, C.POINTER(_SZ)],
 }
 
 PRODUCT_SYMBOLS = ["last_error"] + list(_SHARED_SIGNATURES) + list(_PRODUCT_SIGNATURES)

@@ -71,6 +71,15 @@ def transform_attribute(buffer: _Buffer, attribute: PointAttributeDefinition, tr
     buffer.api.transform_attribute(buffer._h, attribute.name().encode(), C.byref(cdt), C.byref(x))
 
 
+def transform_attribute_expr(buffer: _Buffer, attribute: PointAttributeDefinition, expression: str, device_params=()) -> None:
+    """transform_attribute(attribute, |index, value| expression), point_buffer.rs:391-404: a device expression over v, x y z, c, i (the
+    closure's index) and p0 .. p3 = `device_params` (addresses of device arrays of double: what the closure would capture)."""
+    cdt = attribute.datatype().to_c()
+    arr = (C.c_void_p * max(1, len(device_params)))(*[C.c_void_p(int(p)) for p in device_params])
+    buffer.api.transform_attribute_expr(buffer._h, attribute.name().encode(), C.byref(cdt), expression.encode(), C.cast(arr, C.POINTER(C.c_void_p)) if device_params else None,
+                                        len(device_params))
+
+
 def compute_normals(point_cloud: _Buffer, k_nn: int, return_knn: bool = False):
     """Vec<(Vector3<f64>, f64)> as (normals (n,3) f64, curvature (n,) f64[, knn indices (n,k) int64])."""
     n = point_cloud.len()

@@ -189,6 +189,15 @@ class _Buffer:
         self.api.buffer_filter(self._h, ptr, kind, out_buffer_type._storage, C.byref(h))
         return out_buffer_type(h.value, self.api)
 
+    def filter_expr(self, out_buffer_type, expression: str, device_params=()):
+        """HashMapBuffer::filter(|index| expression) with the predicate as a device expression over the layout's attribute names (scalars by
+        value, Vec3 as .x .y .z), i and p0 .. p3: "Classification == 2 && Position3D.z < 120.0"."""
+        h = C.c_void_p()
+        arr = (C.c_void_p * max(1, len(device_params)))(*[C.c_void_p(int(p)) for p in device_params])
+        self.api.buffer_filter_expr(self._h, expression.encode(), C.cast(arr, C.POINTER(C.c_void_p)) if device_params else None, len(device_params),
+                                    out_buffer_type._storage, C.byref(h))
+        return out_buffer_type(h.value, self.api)
+
     def filter_into(self, buffer: "_Buffer", predicate, num_matches_hint: Optional[int] = None) -> int:  # :1082-1136
         ptr, kind, keep = self._mask_arg(predicate, self.len())
         n = C.c_size_t()

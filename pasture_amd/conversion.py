@@ -103,6 +103,20 @@ def jit_compile_source(source: str, api=None) -> bytes:
     return code.raw[:n.value]
 
 
+def expr_source(kind: str, expression: str, layout: PointLayout = None, src_datatype=None, dst_datatype=None, apply_to_source: bool = False, api=None) -> str:
+    """The translation unit a device expression becomes (kind "transform" between the two datatypes, or "predicate" over `layout`)."""
+    api = api or (layout.api if layout is not None else _capi.product_api())
+    n = C.c_size_t()
+    sd = src_datatype.to_c() if src_datatype is not None else None
+    dd = dst_datatype.to_c() if dst_datatype is not None else None
+    args = (0 if kind == "transform" else 1, layout._h if layout is not None else None, C.byref(sd) if sd is not None else None,
+            C.byref(dd) if dd is not None else None, 1 if apply_to_source else 0, expression.encode())
+    api.expr_source(*args, None, 0, C.byref(n))
+    buf = C.create_string_buffer(n.value)
+    api.expr_source(*args, buf, n.value, C.byref(n))
+    return buf.value.decode()
+
+
 class RawPointConverter:
     """attribute_conversion.rs:62-109 — the point-major converter: `from_to` collects one `as` converter per attribute present in both
     layouts whose datatypes differ (equal datatypes: no converter, the attribute is SKIPPED, not copied); `convert` runs them on
@@ -174,6 +188,15 @@ class BufferLayoutConverter:
         self.api.converter_set_custom_mapping_with_transformation(self._h, from_attribute.name().encode(), C.byref(f),
                                                                   to_attribute.name().encode(), C.byref(t), C.byref(x),
                                                                   1 if apply_to_source_attribute else 0)
+
+    def set_custom_mapping_with_expression(self, from_attribute: PointAttributeDefinition, to_attribute: PointAttributeDefinition,
+                                           expression: str, apply_to_source_attribute: bool) -> None:
+        """set_custom_mapping_with_transformation (:194-234) with the closure as a DEVICE EXPRESSION (include/pasture_amd.h, "device
+        expressions"): C++ expression text over v (this component), x y z (the Vec3's components), c (component index), i (point index),
+        compiled at run time; T is the source datatype when apply_to_source_attribute, the target's otherwise."""
+        f, t = from_attribute.datatype().to_c(), to_attribute.datatype().to_c()
+        self.api.converter_set_custom_mapping_with_expression(self._h, from_attribute.name().encode(), C.byref(f), to_attribute.name().encode(), C.byref(t),
+                                                              expression.encode(), 1 if apply_to_source_attribute else 0)
 
     def mappings(self) -> List[MappingInfo]:
         n = C.c_size_t()

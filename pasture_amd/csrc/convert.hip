@@ -20,7 +20,12 @@
 #include "convert_kernels.hpp"
 #include "jit.hpp"
 
+#include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace pstk {
 
@@ -30,16 +35,20 @@ void launch_convert_tile_tf(unsigned grid, size_t lds_bytes, hipStream_t stream,
 void launch_convert_tile_ft(unsigned grid, size_t lds_bytes, hipStream_t stream, const ConvertHeader& h, const PlanEntry* entries);
 bool launch_convert_static(const std::string& source, uint32_t* tile, bool tile_only, unsigned grid, const ConvertHeader& h, const PlanEntry* entries, hipStream_t stream);
 
+// (per device: pst_set_device may move a thread to a GPU with another CU count)
 int device_cus() {
-  static int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
-    }
-    return n;
-  }();
-  return cus;
+  static std::mutex mu;
+  static std::map<int, int> by_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = by_device.find(dev);
+  if (it != by_device.end()) return it->second;
+  int n = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+  by_device[dev] = n;
+  return n;
 }
 
 static long env_long(const char* name, long dflt) {
@@ -52,10 +61,15 @@ static long env_long(const char* name, long dflt) {
 // common single-stream case and 256 launches deep otherwise.
 static const PlanEntry* upload_entries(const ConvertPlan& plan, hipStream_t stream) {
   constexpr int kSlots = 256;
-  static uint8_t* ring = nullptr;
-  static unsigned next = 0;
+  struct Ring { uint8_t* base = nullptr; unsigned next = 0; };
+  static std::map<int, Ring> rings;  // one ring per device: a kernel on device 1 cannot read plan entries that live in device 0's memory
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Ring& r = rings[dev];
+  uint8_t*& ring = r.base;
+  unsigned& next = r.next;
   constexpr size_t kSlotBytes = sizeof(plan.e) + sizeof(plan.masks);  // entries immediately followed by the wave masks
   static_assert(offsetof(ConvertPlan, masks) == offsetof(ConvertPlan, e) + sizeof(plan.e), "masks must follow the entries");
   if (!ring) {
@@ -101,6 +115,17 @@ static thread_local uint32_t t_plan_kinds = 0;
 void reset_plan_kinds() { t_plan_kinds = 0; }
 void note_plan_kind(uint32_t kind) { t_plan_kinds |= 1u << kind; }
 uint32_t plan_kinds() { return t_plan_kinds; }
+void note_slow_family(const char* what, uint64_t n_points, const char* why) {
+  static const bool quiet = [] { const char* v = std::getenv("PST_QUIET"); return v && *v && *v != '0'; }();
+  if (quiet || n_points < ((uint64_t)1 << 20)) return;
+  static std::mutex mu;
+  static std::set<std::string> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!seen.insert(std::string(what) + '|' + why).second) return;
+  fprintf(stderr, "pasture_amd: note: %s of %llu points ran on a fall-back kernel family (%s); pst_last_plan_kinds reports the family of every call, "
+                  "pst_converter_prepare compiles the plan-specialised kernel ahead of the first call, PST_QUIET=1 silences this note (printed once)\n",
+          what, (unsigned long long)n_points, why);
+}
 
 // the same plan for the points [first, n) of its range
 static ConvertPlan plan_tail(const ConvertPlan& plan, bool src_aos, bool dst_aos, uint64_t first) {
@@ -125,12 +150,21 @@ static bool launch_interpreted(const ConvertPlan& plan, bool src_aos, bool dst_a
     const size_t lds_bytes = tile_lds_bytes(h, src_aos, dst_aos);
     // 256-thread blocks: 512 / 1024 measured 15-60 % slower (per-wave interpretation cost is amortised over fewer points)
     note_plan_kind(PST_PLAN_INTERPRETED);
+    {
+      pstjit::QuadSpec spec;
+      const char* why = pstjit::mode() == pstjit::Mode::Off ? "the run-time compiler is switched off: PST_JIT=0"
+                        : !pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec) ? "this plan has no specialised form: more than 24 mappings, records beyond 224 bytes per point pair, or unaligned record bases"
+                        : pstjit::mode() == pstjit::Mode::Async ? "its specialised kernel is still compiling in the background: later calls take it"
+                                                                : "its specialised kernel failed to compile";
+      note_slow_family("a conversion", h.n, why);
+    }
     if (src_aos && dst_aos) launch_convert_tile_tt(grid, lds_bytes, stream, h, entries);
     else if (src_aos) launch_convert_tile_tf(grid, lds_bytes, stream, h, entries);
     else launch_convert_tile_ft(grid, lds_bytes, stream, h, entries);
     return hipGetLastError() == hipSuccess;
   }
   note_plan_kind(PST_PLAN_DIRECT);
+  if (src_aos || dst_aos) note_slow_family("a conversion", h.n, "records too large for an LDS tile: strided accesses without staging");
   if (src_aos && dst_aos) hipLaunchKernelGGL((convert_direct_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (src_aos) hipLaunchKernelGGL((convert_direct_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, h, entries);
   else if (dst_aos) hipLaunchKernelGGL((convert_direct_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, h, entries);

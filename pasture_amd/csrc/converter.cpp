@@ -37,7 +37,12 @@ struct Mapping {
   bool has_converter = false;
   std::optional<XfDesc> xf;
   bool apply_to_source = false;
+  std::string expr;  // a device expression instead of a descriptor (expr.cpp): this mapping is its own strided launch
 };
+// expr.cpp
+void launch_expression_mapping(const DataType& src_dt, const DataType& dst_dt, bool apply_to_source, const std::string& expr, uint64_t src, uint64_t sstride, uint64_t dst,
+                               uint64_t dstride, uint64_t n, uint64_t first_index, hipStream_t stream);
+void validate_expression_mapping(const DataType& src_dt, const DataType& dst_dt, bool apply_to_source, const char* expr);
 
 static Mapping make_default_mapping(const Member& from, const Member& to) {  // :368-396
   Mapping m;
@@ -242,7 +247,7 @@ static bool match_identity_records(const pst_converter& c) {
   std::vector<uint8_t> seen(c.to.members.size(), 0);
   for (const Mapping& m : c.mappings) {
     const int tslot = c.to.index_of(m.target.def), sslot = c.from.index_of(m.source.def);
-    if (tslot < 0 || tslot != sslot || seen[(size_t)tslot] || m.xf || m.has_converter) return false;
+    if (tslot < 0 || tslot != sslot || seen[(size_t)tslot] || m.xf || m.has_converter || !m.expr.empty()) return false;
     seen[(size_t)tslot] = 1;
     covered += m.target.size;
   }
@@ -266,7 +271,7 @@ static int match_las_decode_plan(const pst_converter& c) {
   std::vector<uint8_t> seen(c.to.members.size(), 0);
   for (const Mapping& m : c.mappings) {
     const int tslot = c.to.index_of(m.target.def);
-    if (tslot < 0 || seen[(size_t)tslot]) return -1;
+    if (tslot < 0 || seen[(size_t)tslot] || !m.expr.empty()) return -1;
     seen[(size_t)tslot] = 1;
     const std::string& tn = m.target.def.name;
     if (tn == "Position3D") {
@@ -284,7 +289,7 @@ static int match_las_decode_plan(const pst_converter& c) {
         return -1;
       continue;
     }
-    if (m.source.def.name != tn || m.xf || m.has_converter) return -1;  // plain copy of the same-named attribute
+    if (m.source.def.name != tn || m.xf || m.has_converter || !m.expr.empty()) return -1;  // plain copy of the same-named attribute
   }
   return format;
 }
@@ -384,6 +389,14 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
       if (src.columnar) e.src_col = col_addr(src, (size_t)sslot, s0);
       if (dst.columnar) e.dst_col = col_addr(dst, (size_t)tslot, t0);
+      if (!m.expr.empty()) {
+        // a user-written transformation (expr.cpp): this mapping is its own strided launch, whatever the storage pairing; the index the
+        // expression sees is the point's index in the SOURCE buffer
+        launch_expression_mapping(m.source.def.datatype, m.target.def.datatype, m.apply_to_source, m.expr,
+                                  src.columnar ? e.src_col : aos_addr(src, s0) + m.source.offset, src.columnar ? m.source.size : c.from.size,
+                                  dst.columnar ? e.dst_col : aos_addr(dst, t0) + m.target.offset, dst.columnar ? m.target.size : c.to.size, n, s0, stream);
+        continue;
+      }
       if (src.columnar && dst.columnar) {
         const bool same_type = !m.has_converter;
         const bool vec3f64 = m.source.def.datatype.kind == PST_VEC3F64;
@@ -454,6 +467,7 @@ static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool
   std::vector<PlanEntry> generic;
   bool bounds_done = false;
   for (const Mapping& m : c.mappings) {
+    if (!m.expr.empty()) continue;  // (its own launch, compiled at the first conversion)
     PlanEntry e = entry_from_mapping(m);
     const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
     if (src_columnar) e.src_col = 0x100000ull * (uint64_t)(sslot + 1);
@@ -593,6 +607,27 @@ int pst_converter_set_custom_mapping_with_transformation(pst_converter* c, const
   Mapping m = make_default_mapping(*fm, *tm);
   validate_transform(x);
   m.xf = x;
+  m.apply_to_source = apply_to_source != 0;
+  install_mapping(*c, std::move(m), ta);
+  PST_API_END
+}
+// set_custom_mapping_with_transformation with the closure given as a device expression (expr.cpp: names v, x, y, z, c, i; C++ expression
+// syntax; the result converted to T with Rust `as`).  T is the source attribute's datatype when apply_to_source, the target's otherwise
+// (buffer_conversion.rs:209-213) -- there is no separate T to mismatch.  Shape errors (components, datatype kinds) are reported here, syntax
+// errors by the first conversion (PST_ERR_UNSUPPORTED_TRANSFORM with the compiler's log).
+int pst_converter_set_custom_mapping_with_expression(pst_converter* c, const char* from_name, const pst_datatype* from_dt, const char* to_name,
+                                                     const pst_datatype* to_dt, const char* expr, int apply_to_source) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  not_null(expr, "expr");
+  const AttributeDef fa = def_from(from_name, from_dt), ta = def_from(to_name, to_dt);
+  const Member* fm = c->from.find(fa);
+  if (!fm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "from_attribute not found in source PointLayout");
+  const Member* tm = c->to.find(ta);
+  if (!tm) throw Error(PST_ERR_MISSING_ATTRIBUTE, "to_attribute not found in target PointLayout");
+  Mapping m = make_default_mapping(*fm, *tm);
+  validate_expression_mapping(fm->def.datatype, tm->def.datatype, apply_to_source != 0, expr);
+  m.expr = expr;
   m.apply_to_source = apply_to_source != 0;
   install_mapping(*c, std::move(m), ta);
   PST_API_END

@@ -797,6 +797,10 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
       continue;
     }
     note_plan_kind(PST_PLAN_INTERPRETED);
+    note_slow_family("a compaction (filter)", n, pstjit::mode() == pstjit::Mode::Off ? "the run-time compiler is switched off: PST_JIT=0"
+                                                 : n_attrs > kMaxFilterAttrs ? "more attributes than one streaming launch takes"
+                                                 : pstjit::mode() == pstjit::Mode::Async ? "no streaming kernel for this layout yet (compiling in the background, or points beyond 64 / 96 bytes): the gather kernels"
+                                                                                         : "no streaming kernel for this layout (points beyond 64 / 96 bytes, or padded records with wide attributes): the gather kernels");
     switch (tile / kBlock) {
       case 8: if (dst_aos) PST_FILTER(8, true) else PST_FILTER(8, false) break;
       case 4: if (dst_aos) PST_FILTER(4, true) else PST_FILTER(4, false) break;

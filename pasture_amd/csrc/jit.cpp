@@ -28,6 +28,7 @@
 #include <mutex>
 #include <sstream>
 #include <thread>
+#include <unordered_map>
 
 #include "jit_embedded.inc"  // kJitHeaderNames / kJitHeaderTexts / kJitHeaderCount: the device headers as text (tools/embed_headers.py)
 
@@ -182,6 +183,9 @@ std::string device_arch() {
 struct Entry {
   enum State { Queued, Ready, Failed } state = Queued;
   std::string source, error, entry_name = "pst_jit_convert";
+  std::string arch;       // the architecture of the device the REQUESTING thread was on (the compiler thread's current device is another matter)
+  std::string disk_path;  // where the code object was read from (a stale or damaged file is deleted and compiled again, once)
+  bool retried = false;
   std::vector<char> code;
   std::map<int, std::pair<hipModule_t, hipFunction_t>> per_device;
   unsigned blk = 256;
@@ -194,6 +198,8 @@ struct Cache {
   std::map<std::string, std::shared_ptr<Entry>> by_source;
   std::deque<std::shared_ptr<Entry>> queue;
   bool worker_started = false;
+  int compiling = 0;       // compilations in flight (the exit handler waits for them: hipRTC's libraries must not be torn down under a compile)
+  bool stopping = false;   // set at exit: the worker takes nothing more from the queue
   Stats st;
 };
 Cache& cache() {
@@ -203,7 +209,11 @@ Cache& cache() {
 
 void compile_entry(const std::shared_ptr<Entry>& e) {
   Cache& c = cache();
-  const std::string arch = device_arch();
+  const std::string arch = e->arch.empty() ? device_arch() : e->arch;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.compiling++;
+  }
   std::string err;
   std::vector<char> code;
   bool from_disk = false;
@@ -211,7 +221,7 @@ void compile_entry(const std::shared_ptr<Entry>& e) {
   std::string path;
   if (!dir.empty()) {
     path = dir + "/" + hash_hex(toolchain_salt() + arch + e->source) + ".hsaco";
-    code = read_file(path);
+    if (!e->retried) code = read_file(path);
     from_disk = !code.empty();
   }
   const auto t0 = std::chrono::steady_clock::now();
@@ -221,6 +231,8 @@ void compile_entry(const std::shared_ptr<Entry>& e) {
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::lock_guard<std::mutex> lock(c.mu);
+  c.compiling--;
+  e->disk_path = from_disk ? path : std::string();
   if (code.empty()) {
     e->state = Entry::Failed;
     e->error = err;
@@ -242,7 +254,8 @@ void worker_main() {
     std::shared_ptr<Entry> e;
     {
       std::unique_lock<std::mutex> lock(c.mu);
-      c.cv.wait(lock, [&] { return !c.queue.empty(); });
+      c.cv.wait(lock, [&] { return !c.queue.empty() || c.stopping; });
+      if (c.stopping) return;
       e = c.queue.front();
       c.queue.pop_front();
     }
@@ -442,23 +455,40 @@ bool acquire(const QuadSpec& spec, const std::string& src, Acquire how, Kernel* 
   return acquire_source(src, "pst_jit_convert", (unsigned)spec.blk, spec.lds_bytes(), spec.tile(), how, out, error);
 }
 
+// process exit: stop the compiler thread at its next wake-up and give a compilation in flight time to finish -- hipRTC's libraries (comgr,
+// LLVM) run static destructors at exit, and a detached thread inside hiprtcCompileProgram at that moment races them
+static void drain_at_exit() {
+  Cache& c = cache();
+  std::unique_lock<std::mutex> lock(c.mu);
+  c.stopping = true;
+  c.queue.clear();
+  c.cv.notify_all();
+  c.cv.wait_for(lock, std::chrono::seconds(30), [&] { return c.compiling == 0; });
+}
+
 bool acquire_source(const std::string& src, const char* entry, unsigned blk, uint32_t lds_bytes, uint32_t tile, Acquire how, Kernel* out, std::string* error) {
   const bool wait = how == Acquire::Wait;
   Cache& c = cache();
   std::shared_ptr<Entry> e;
   bool compile_here = false;
+  // entries are per (architecture, source): the requesting thread's device decides the architecture, not the compiler thread's
+  const std::string arch = device_arch();
+  const std::string key = arch + '\n' + src;
   {
     std::unique_lock<std::mutex> lock(c.mu);
-    auto it = c.by_source.find(src);
+    static bool at_exit = false;
+    if (!at_exit) { at_exit = true; std::atexit(drain_at_exit); }
+    auto it = c.by_source.find(key);
     if (it == c.by_source.end()) {
       if (how == Acquire::IfReady) return false;
       e = std::make_shared<Entry>();
+      e->arch = arch;
       e->source = src;
       e->entry_name = entry;
       e->blk = blk;
       e->lds_bytes = lds_bytes;
       e->tile = tile;
-      c.by_source.emplace(src, e);
+      c.by_source.emplace(key, e);
       if (wait) {
         compile_here = true;
       } else {
@@ -484,7 +514,7 @@ bool acquire_source(const std::string& src, const char* entry, unsigned blk, uin
     }
   }
   if (compile_here) compile_entry(e);
-  std::lock_guard<std::mutex> lock(c.mu);
+  std::unique_lock<std::mutex> lock(c.mu);
   if (e->state != Entry::Ready) {
     if (error) *error = e->error;
     return false;
@@ -497,6 +527,25 @@ bool acquire_source(const std::string& src, const char* entry, unsigned blk, uin
     hipFunction_t fn = nullptr;
     hipError_t err = hipModuleLoadData(&mod, e->code.data());
     if (err == hipSuccess) err = hipModuleGetFunction(&fn, mod, e->entry_name.c_str());
+    if (err != hipSuccess) {
+      (void)hipGetLastError();
+      if (!e->disk_path.empty() && !e->retried) {
+        // a code object from the disk cache that does not load (damaged file, another toolchain's leftovers): delete it and compile again, once
+        (void)unlink(e->disk_path.c_str());
+        e->retried = true;
+        e->state = Entry::Queued;
+        e->code.clear();
+        const std::shared_ptr<Entry> again = e;
+        lock.unlock();
+        compile_entry(again);
+        lock.lock();
+        if (e->state == Entry::Ready) {
+          mod = nullptr; fn = nullptr;
+          err = hipModuleLoadData(&mod, e->code.data());
+          if (err == hipSuccess) err = hipModuleGetFunction(&fn, mod, e->entry_name.c_str());
+        }
+      }
+    }
     if (err != hipSuccess) {
       (void)hipGetLastError();
       e->state = Entry::Failed;

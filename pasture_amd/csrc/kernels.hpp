@@ -21,6 +21,10 @@ unsigned convert_max_records(const ConvertPlan& plan, bool src_aos, bool dst_aos
 void reset_plan_kinds();
 void note_plan_kind(uint32_t kind);
 uint32_t plan_kinds();
+// One note on stderr per process and `what` when a call of 2^20 points or more ends on a fall-back kernel family (the interpreter, the gather
+// kernels): those run at 0.26-0.70 of peak where the plan-specialised families reach 0.75-0.84, and a caller who never asks
+// pst_last_plan_kinds would not know.  PST_QUIET=1 silences it.
+void note_slow_family(const char* what, uint64_t n_points, const char* why);
 // compile (or fetch) the plan-specialised kernel this plan would take (jit.cpp); false + message when it cannot have one
 bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error, bool* in_tree = nullptr);
 bool convert_specialised_ready(const ConvertPlan& plan, bool src_aos, bool dst_aos);

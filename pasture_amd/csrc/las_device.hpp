@@ -94,37 +94,6 @@ struct RecTail {
     if (NB - 4 * k >= 2) { store_un<uint16_t>(p + 4 * k, (uint16_t)w[k]); if (NB - 4 * k == 3) store_un<uint8_t>(p + 4 * k + 2, (uint8_t)(w[k] >> 16)); }
     else if (NB - 4 * k == 1) store_un<uint8_t>(p + 4 * k, (uint8_t)w[k]);
   }
-  // The same bytes with naturally aligned LDS stores only (device_common.hpp: an LDS access that is not naturally aligned stalls the pipe):
-  // the image is shifted in registers to the dword grid of its target (v_alignbyte with the lane's own phase), the dwords that are covered for
-  // every phase go out as aligned b32 stores, the ragged head and tail as b16 / b8 pieces.  m = 1..4 bytes of dword 0 precede the record
-  // (m = 4: the record starts on a dword boundary and dword 0 is not written at all).
-  __device__ __forceinline__ void store_aligned(lptr_t p) const {
-    typedef PST_AS_LDS uint8_t* p8;
-    typedef PST_AS_LDS uint16_t* p16;
-    typedef PST_AS_LDS uint32_t* p32;
-    constexpr int NW = (NB + 3) / 4 + 1;      // dwords of w (the last one is zero padding)
-    constexpr int NO = (NB + 7) / 4;          // dwords of the shifted image: bytes [0, 4 NO) hold the record at [m, m + NB)
-    constexpr int KF = (NB - 3) / 4;          // dwords 1 .. KF are covered whatever the phase
-    const uint32_t ph = (uint32_t)(uintptr_t)p & 3u, m = ph ? ph : 4u;
-    lptr_t pa = p - m;
-    const uint32_t sh = 4u - m;               // out[k] = bytes [4 k - m, 4 k - m + 4) of the record
-    uint32_t o[NO];
-#pragma unroll
-    for (int k = 0; k < NO; ++k) o[k] = __builtin_amdgcn_alignbyte(k < NW ? w[k] : 0u, (k >= 1 && k - 1 < NW) ? w[k - 1] : 0u, sh);
-    if (m & 1u) *(p8)(pa + m) = (uint8_t)(o[0] >> (8u * m));
-    if (m <= 2u) *(p16)(pa + 2) = (uint16_t)(o[0] >> 16);
-#pragma unroll
-    for (int k = 1; k <= KF; ++k) *(p32)(pa + 4 * k) = o[k];
-#pragma unroll
-    for (int k = KF + 1; k < NO; ++k) {
-      const int c = (int)m + NB - 4 * k;      // record bytes in dword k
-      if (c >= 4) *(p32)(pa + 4 * k) = o[k];
-      else if (c > 0) {
-        if (c & 2) *(p16)(pa + 4 * k) = (uint16_t)o[k];
-        if (c & 1) *(p8)(pa + 4 * k + (c & 2)) = (uint8_t)(o[k] >> (8 * (c & 2)));
-      }
-    }
-  }
 };
 
 // N bytes at an arbitrarily aligned LDS address as aligned dwords re-aligned in registers (r[0] = bytes 0..3, ...)

@@ -89,16 +89,78 @@ struct KBest {
 // ---- plane fit, normal_estimation.rs:198-467, on neighbours visited in ascending-distance order ------------------
 struct Fit { double nx, ny, nz, curvature; int ok; };
 
+// cos(theta) and sin(theta) for theta = atan2(s, b) / 3 with s >= 0 -- the angle of the reference's trigonometric cubic solver
+// (normal_estimation.rs:364-371: `theta = f64::atan2(f64::sqrt(-q), half_beta) * one_third`, then cos / sin of it).  The device libm's atan2, cos
+// and sin are general-purpose (quadrant logic, huge-argument reduction, table constants): about 450 vector instructions per query, a twelfth of
+// the box search's budget.  Here the ranges are known -- phi = atan2(s, b) in [0, pi], theta in [0, pi / 3] -- so: ONE division
+// (u = num / den, or (num - den) / (num + den) above tan(pi / 8)), an odd polynomial for atan on |u| <= tan(pi / 8) (degree 11 in u^2, fitted
+// at Chebyshev nodes against 50-digit references: 2.2e-16 relative), and the Taylor polynomials of cos and sin on [0, pi / 3] (nine terms:
+// 1.1e-16 absolute / 2.1e-16 relative) -- each within an ulp or two of the correctly rounded value, like the functions they replace; the
+// results enter the eigenvalue exactly as before.  PST_FIT_LIBM_TRIG (compile time) restores the libm calls for an A/B.
+__device__ __forceinline__ void cos_sin_third_angle(double s, double b, double& ct, double& st) {
+#ifdef PST_FIT_LIBM_TRIG
+  const double theta = ::atan2(s, b) * (1.0 / 3.0);
+  ct = ::cos(theta); st = ::sin(theta);
+#else
+  const double ab = __builtin_fabs(b);
+  const bool swap = s > ab;                                 // the larger one is the denominator: t = num / den in [0, 1]
+  const double num = swap ? ab : s, den = swap ? s : ab;
+  const bool hi = num > 0.41421356237309503 * den;          // t > tan(pi / 8): atan(t) = pi / 4 + atan((t - 1) / (t + 1))
+  const double un = hi ? num - den : num, ud = hi ? num + den : den;
+  const double u = ud > 0.0 ? un / ud : 0.0;                // (s = b = 0: phi = 0 or pi by the sign of b, below)
+  const double z = u * u;
+  double p = 0.011133722158619984;
+  p = __builtin_fma(p, z, -0.029802426579855917);
+  p = __builtin_fma(p, z, 0.043605084067176156);
+  p = __builtin_fma(p, z, -0.05187003409810214);
+  p = __builtin_fma(p, z, 0.058727581474367595);
+  p = __builtin_fma(p, z, -0.06665857298205219);
+  p = __builtin_fma(p, z, 0.07692262470384811);
+  p = __builtin_fma(p, z, -0.09090907471736968);
+  p = __builtin_fma(p, z, 0.11111111076292801);
+  p = __builtin_fma(p, z, -0.14285714285314552);
+  p = __builtin_fma(p, z, 0.1999999999999803);
+  p = __builtin_fma(p, z, -0.3333333333333335);
+  double a = __builtin_fma(u * z, p, u);                    // atan(u)
+  if (hi) a += 0.7853981633974483;                          // + pi / 4
+  double phi = swap ? 1.5707963267948966 - a : a;           // atan2(s, |b|)
+  if (__builtin_signbit(b)) phi = 3.141592653589793 - phi;  // atan2(s, b), b < 0 (and atan2(0, -0) = pi)
+  const double theta = phi * (1.0 / 3.0);
+  const double w = theta * theta;
+  double c = 1.0 / 6402373705728000.0;                      // cos: 1 + w (-1/2! + w (1/4! - ... + w / 18!))
+  c = __builtin_fma(c, w, -1.0 / 20922789888000.0);
+  c = __builtin_fma(c, w, 1.0 / 87178291200.0);
+  c = __builtin_fma(c, w, -1.0 / 479001600.0);
+  c = __builtin_fma(c, w, 1.0 / 3628800.0);
+  c = __builtin_fma(c, w, -1.0 / 40320.0);
+  c = __builtin_fma(c, w, 1.0 / 720.0);
+  c = __builtin_fma(c, w, -1.0 / 24.0);
+  c = __builtin_fma(c, w, 0.5);
+  ct = __builtin_fma(-w, c, 1.0);
+  double q = -1.0 / 121645100408832000.0;                   // sin: theta + theta w (-1/3! + w (1/5! - ... - w / 19!))
+  q = __builtin_fma(q, w, 1.0 / 355687428096000.0);
+  q = __builtin_fma(q, w, -1.0 / 1307674368000.0);
+  q = __builtin_fma(q, w, 1.0 / 6227020800.0);
+  q = __builtin_fma(q, w, -1.0 / 39916800.0);
+  q = __builtin_fma(q, w, 1.0 / 362880.0);
+  q = __builtin_fma(q, w, -1.0 / 5040.0);
+  q = __builtin_fma(q, w, 1.0 / 120.0);
+  q = __builtin_fma(q, w, -1.0 / 6.0);
+  st = __builtin_fma(theta * w, q, theta);
+#endif
+}
+
 // Everything of the fit behind the covariance matrix (upper triangle, NOT divided by the count): eigen_3x3 :429-453 with solve_polynomial
 // :328-392, get_largest_eigen_vector :395-426, solve_plane_parameter :456-467.
 //
 // `ill` (optional): set when the reference's solver AMPLIFIES last-bit differences of the covariance beyond the parity window, i.e. when a
 // covariance that is not the reference's own sequence of operations (plane_fit_pivot) must not be trusted for this neighbourhood:
 //   * the two SMALLEST roots of the characteristic cubic nearly coincide (prolate / collinear neighbourhoods: half_beta >= 0 and
-//     -q <= 1e-2 |alpha/3|^3, i.e. |sin 3 theta| <= 0.1): the trigonometric form takes the square root of the discriminant q, an error
-//     delta in q becomes delta / (2 sqrt(-q)) in the roots -- beyond the threshold a factor > 5 on the ~1e-15 relative difference between two
-//     valid summation orders, against a window of 1e-13 x scale (measured, 4 10^6 uniform points, k = 16, worst curvature difference to the
-//     reference-order instance: 3.6e-10 unguarded, 5.2e-11 with the threshold at 1e-4 -- amplification ~50 just outside it).  (The other double root, theta = pi / 3, is harmless: the smallest root is the
+//     -q <= 1e-3 |alpha/3|^3, i.e. |sin 3 theta| <= 0.03): the trigonometric form takes the square root of the discriminant q, an error
+//     delta in q becomes delta / (2 sqrt(-q)) in the roots -- beyond the threshold a factor > 16 on the ~1e-15 relative difference between two
+//     valid summation orders, against a window of 1e-13 x scale.  The threshold is a price list (4 10^6 uniform points, k = 16): 1e-4 flags
+//     0.004 % of the queries, 1e-2 0.4 % -- and each flagged query costs an exact search (10^8 points: +2.6 % of the call at 1e-2,
+//     profiles/r05_abab.txt).  (The other double root, theta = pi / 3, is harmless: the smallest root is the
 //     simple one there and its derivative with respect to theta vanishes.)
 //   * all three roots nearly coincide (isotropic neighbourhoods, e.g. a lattice point with its six face neighbours): |alpha/3| <= 1e-5 (k2/3)^2;
 //     rho = sqrt(-alpha/3) then turns a relative 1e-16 into 1e-8.
@@ -108,7 +170,7 @@ struct Fit { double nx, ny, nz, curvature; int ok; };
 //   * two of the three cross products have norms within 1e-6 of each other: "the first maximum wins" (:395-426) is then decided by last bits,
 //     and on exactly planar neighbourhoods the candidates are parallel but may point in opposite directions (found by the round-5 structured
 //     volume test on a quantised plane: normal = -oracle's).
-// A flagged lane re-runs the fit in the reference's order of operations (knn_tile2_kernel).
+// A flagged query is handed to the exact search behind the box search, whose fit adds in the reference's order of operations (knn_tile2_kernel).
 __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, double c02, double c11, double c12, double c22, bool* ill = nullptr) {
   Fit f{0, 0, 0, 0, 1};
   bool flagged = false;
@@ -148,10 +210,10 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
       double q = half_beta * half_beta + alpha_third * alpha_third * alpha_third;
       if (q > 0.0) q = 0.0;
       const double a3 = -alpha_third;
-      flagged = (half_beta >= 0.0 && -q <= 1e-2 * (a3 * a3 * a3)) || a3 <= 1e-5 * (k2_third * k2_third);
+      flagged = (half_beta >= 0.0 && -q <= 1e-3 * (a3 * a3 * a3)) || a3 <= 1e-5 * (k2_third * k2_third);
       const double rho = __builtin_sqrt(-alpha_third);
-      const double theta = ::atan2(__builtin_sqrt(-q), half_beta) * one_third;
-      const double ct = ::cos(theta), st = ::sin(theta);
+      double ct, st;
+      cos_sin_third_angle(__builtin_sqrt(-q), half_beta, ct, st);
       double a = k2_third + 2.0 * rho * ct;
       double b = k2_third - rho * (ct + sqrt_3 * st);
       double c = k2_third - rho * (ct - sqrt_3 * st);

@@ -947,6 +947,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         }
       }
       Fit f{0, 0, 0, 0, 1};
+      bool handed = false;
       if constexpr (FIT == 1) {
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
@@ -958,19 +959,15 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           exact_xyz(pl, x, y, z);
         }, &ill);
         // Conditioning is a property of the NEIGHBOURHOOD, not of the cloud (round-4 review): where the reference's solver amplifies last-bit
-        // differences of the covariance (fit_from_covariance: `ill`), this lane repeats the fit in the reference's own order of operations --
-        // centroid, then moments, the neighbours gathered again for each pass.  Rare in volume-filling clouds (about one query in 300, one wave in
-        // five); on walls, wires and lattices inside such clouds it is what keeps curvature and normal inside the parity window.
+        // differences of the covariance (fit_from_covariance: `ill`), the one-pass result is not written; the query is handed to the exact
+        // search behind this kernel, whose fit adds in the reference's own order of operations -- centroid, then moments.  Rare in
+        // volume-filling clouds (4 queries in 1000 at k = 16); on wires, lattices and quantised planes inside such clouds it is what keeps
+        // curvature and normal inside the parity window.  (Repeating the fit HERE, in the lane, cost 5.5 % of the call at 10^8 points: one ill lane
+        // makes its whole wave walk two dependent gathers of k neighbours; handed back, the same queries cost the exact search a quarter more
+        // work -- profiles/r05_abab.txt.)
         ill = ill && a.fit_guard;
         PST_KNN_STAT(if (ill) atomicAdd(a.dbg + 6, 1ull);)
-        if (__builtin_amdgcn_ballot_w64(ill)) {
-          if (ill) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
-            uint32_t pl = 0;
-#pragma unroll
-            for (int u = 0; u < K; ++u) if ((uint32_t)u == t) pl = nb[u];
-            exact_xyz(pl, x, y, z);
-          });
-        }
+        if (ill) { a.fb_list[atomicAdd(a.fb_count, 1u)] = j; handed = true; }
       } else if constexpr (!P3LDS && K <= 16) {
         // f64 coordinates from global memory: every neighbour is fetched ONCE (the plane fit walks the neighbours twice, and a gather of
         // 64 scattered 24-byte points keeps the texture path busy for ~64 cycles whether it hits the cache or not)
@@ -992,7 +989,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           exact_xyz(pl, x, y, z);
         });
       }
-      write_record(a.out, orig, f);
+      if (!handed) write_record(a.out, orig, f);
     }
     PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
   }
@@ -1424,9 +1421,9 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
                 t.tag, 100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot, 100.0 * h[13] / tot,
                 100.0 * (tot - (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13])) / tot, tot / 1000.0 / (double)(h[2] ? h[2] : 1));
       }
-      fprintf(stderr, "[pst knn tile2 %c] query waves %llu: scan steps %.1f, insertion steps %.1f per wave; slots tested %.1f, queued %.1f per query; %.4f %% failed the proof; eps %.2f\n",
+      fprintf(stderr, "[pst knn tile2 %c] query waves %llu: scan steps %.1f, insertion steps %.1f per wave; slots tested %.1f, queued %.1f per query; %.4f %% failed the proof; %.4f %% handed to the exact search by the fit's conditioning guard; eps %.2f\n",
               t.tag, h[2], (double)h[0] / (double)(h[2] ? h[2] : 1), (double)h[1] / (double)(h[2] ? h[2] : 1), (double)h[3] / (double)nf, (double)h[4] / (double)nf,
-              100.0 * (double)h[5] / (double)nf, eps);
+              100.0 * (double)h[5] / (double)nf, 100.0 * (double)h[6] / (double)nf, eps);
     }
 #endif
     return;

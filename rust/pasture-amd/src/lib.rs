@@ -185,6 +185,15 @@ impl DeviceBufferLayoutConverter {
         check(unsafe { pst_converter_set_custom_mapping_with_transformation(self.handle, fname.as_ptr(), &datatype_to_c(from.datatype()), tname.as_ptr(),
                                                                            &datatype_to_c(to.datatype()), &xf, apply_to_source_attribute as c_int) })
     }
+    /// The same with the closure as a DEVICE EXPRESSION (include/pasture_amd.h, "device expressions"): what `F: Fn(T) -> T` is in
+    /// buffer_conversion.rs:194-234, given as C++ expression text over `v`, `x y z`, `c`, `i` and compiled at run time.  A text that does not
+    /// compile panics at the first conversion with the compiler's log (PST_ERR_UNSUPPORTED_TRANSFORM).
+    pub fn set_custom_mapping_with_expression(&mut self, from: &PointAttributeDefinition, to: &PointAttributeDefinition, expression: &str,
+                                              apply_to_source_attribute: bool) {
+        let (fname, tname, text) = (CString::new(from.name()).unwrap(), CString::new(to.name()).unwrap(), CString::new(expression).unwrap());
+        check(unsafe { pst_converter_set_custom_mapping_with_expression(self.handle, fname.as_ptr(), &datatype_to_c(from.datatype()), tname.as_ptr(),
+                                                                       &datatype_to_c(to.datatype()), text.as_ptr(), apply_to_source_attribute as c_int) })
+    }
     pub fn convert_into(&self, source: &impl DeviceBuffer, target: &mut impl DeviceBuffer, n: usize) { self.convert_into_range(source, 0..n, target, 0..n) }
     pub fn convert_into_range(&self, source: &impl DeviceBuffer, source_range: Range<usize>, target: &mut impl DeviceBuffer, target_range: Range<usize>) {
         check(unsafe { pst_converter_convert_into_range(self.handle, source.handle(), source_range.start, source_range.end, target.handle(),
@@ -278,6 +287,29 @@ impl DeviceHashMapBuffer {
     /// `device_mask` must point to `self.len()` bytes of device memory that stay valid until the stream has run the call.
     pub unsafe fn filter_into_async(&self, buffer: &mut impl DeviceBuffer, device_mask: *const u8, num_matches: usize, device_count_out: *mut u64) {
         check(pst_buffer_filter_into_async(self.raw(), buffer.handle(), device_mask, num_matches, device_count_out))
+    }
+}
+
+/// BorrowedMutBufferExt::transform_attribute (point_buffer.rs:391-404) with `|index, value| expression` as a device expression; `device_params`
+/// (at most four device arrays of f64) are what the closure would capture: `p0[3 * i + c]`.
+///
+/// # Safety
+/// Every pointer of `device_params` must be device memory valid for the indices the expression uses.
+pub unsafe fn transform_attribute_expr(buffer: &mut impl DeviceBuffer, attribute: &PointAttributeDefinition, expression: &str, device_params: &[*const f64]) {
+    let (name, text) = (CString::new(attribute.name()).unwrap(), CString::new(expression).unwrap());
+    check(pst_transform_attribute_expr(buffer.handle(), name.as_ptr(), &datatype_to_c(attribute.datatype()), text.as_ptr(),
+                                       if device_params.is_empty() { std::ptr::null() } else { device_params.as_ptr() }, device_params.len()))
+}
+
+impl DeviceHashMapBuffer {
+    /// HashMapBuffer::filter (point_buffer.rs:1064-1076) with the predicate as a device expression over the layout's attribute names:
+    /// `buffer.filter_expr::<DeviceVectorBuffer>("Classification == 2 && Position3D.z < 120.0")`.  Returns the raw handle of the new buffer's
+    /// storage kind `out_storage` (PST_STORAGE_*); wrap it with the matching Device*Buffer.
+    pub fn filter_expr_raw(&self, expression: &str, out_storage: u32) -> *mut pst_buffer {
+        let text = CString::new(expression).unwrap();
+        let mut out: *mut pst_buffer = std::ptr::null_mut();
+        check(unsafe { pst_buffer_filter_expr(self.raw(), text.as_ptr(), std::ptr::null(), 0, out_storage, &mut out) });
+        out
     }
 }
 

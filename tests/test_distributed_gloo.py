@@ -549,22 +549,40 @@ def test_single_process_two_devices_allreduce_multi_and_device_switch(hip):
         buf.set_attribute_range(A.POSITION_3D, range(0, len(pts)), pts)
         out.append(compute_normals(buf, 16, return_knn=True))
         del buf
+        # a conversion on each device too (round-4 advice: the plan-entry ring and the CU count used to be process-wide, allocated on the first
+        # device): interleaved LAS-0 records -> columns through the interpreter and through the plan-specialised kernels
+        from pasture_amd import conversion as cv, las
+        from pasture_amd.buffers import VectorBuffer
+        lay = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+        rec = VectorBuffer.new_from_layout(lay)
+        rec.resize(200_000)
+        rec.synth_fill(7, 0)
+        conv = cv.BufferLayoutConverter.for_layouts(lay, lay)
+        cols = []
+        for mode in ("off", "sync"):
+            cv.jit_set_mode(mode)
+            got = conv.convert(rec, HashMapBuffer)
+            cols.append([got.view_attribute(a.attribute_definition()).tobytes() for a in lay.attributes()])
+        cv.jit_set_mode("env")
+        assert cols[0] == cols[1]
+        out[-1] = out[-1] + (cols[0],)
     hip.set_device(0)
     torch.cuda.set_device(0)
     hip.set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
     for o in out[1:]:
         assert np.array_equal(o[2], out[0][2]) and np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+        assert o[3] == out[0][3]
 
 
 def _run_ranks(cmd, env, as_expected):
-    """A multi-rank bench.py run under torch.distributed.run.  One full GPU suite in five saw one of these runs fail without the failure showing again
-    in eight repetitions (rendezvous over 127.0.0.1 between freshly spawned processes): an unexpected outcome is reported on stderr and the run
-    repeated ONCE, so that the suite's `-x` does not end on it; a real defect fails both times."""
+    """A multi-rank bench.py run.  Round 4 repeated such a run once on an unexpected outcome (one unexplained failure in five full suites); the
+    cause found in round 5 is the launcher's port: bench.py chose a free port, closed it and handed it to torch.distributed.run seconds later
+    -- any outgoing connection of the box could take it in between.  bench.py now starts its ranks with --standalone (the agent picks and holds
+    the port), and the run is made ONCE."""
     import subprocess
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     if not as_expected(r):
-        sys.stderr.write(f"[test_distributed_gloo] unexpected outcome of {' '.join(cmd[1:])}: rc={r.returncode}\n{r.stderr[-3000:]}\n-- repeating once --\n")
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        sys.stderr.write(f"[test_distributed_gloo] unexpected outcome of {' '.join(cmd[1:])}: rc={r.returncode}\n{r.stderr[-3000:]}\n")
     return r
 
 

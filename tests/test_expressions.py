@@ -1,0 +1,286 @@
+"""Device expressions (include/pasture_amd.h "device expressions", pasture_amd/csrc/expr.cpp): user-written closures as source text.
+
+What the reference takes as closures -- Fn(T) -> T transformations (buffer_conversion.rs:13-36, 194-234), transform_attribute's
+Fn(usize, T) -> T (point_buffer.rs:391-404), filter's Fn(usize) -> bool (point_buffer.rs:1064-1136) -- the library takes as C++ expression
+text and compiles with hipRTC.  CPU suite: the generated translation units compile for gfx950 (no device), shape errors are reported.
+GPU suite: the reference's own scenarios (`+ 42.0` before and after the conversion, buffer_conversion.rs:764-846; positions overwritten by
+index, point_buffer.rs:2007-2043) with numpy expectations, and a differential suite against the SAME text compiled by g++ (tests/expr_twin.py),
+bit for bit, over datatypes, storage pairings, apply_to_source, parameters and slices."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import expr_twin
+from harness import BUFFER_KINDS, PAIRINGS, custom_point_type_big, make_buffer, random_records
+from pasture_amd import conversion as cv, las
+from pasture_amd._capi import PastureError
+from pasture_amd.algorithms import transform_attribute_expr
+from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+from pasture_amd.conversion import BufferLayoutConverter
+from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+
+SCALARS = {"u8": T.U8, "i8": T.I8, "u16": T.U16, "i16": T.I16, "u32": T.U32, "i32": T.I32, "u64": T.U64, "i64": T.I64, "f32": T.F32, "f64": T.F64}
+VEC3 = {"u8": T.Vec3u8, "u16": T.Vec3u16, "i32": T.Vec3i32, "f32": T.Vec3f32, "f64": T.Vec3f64}
+
+# expression texts: (text, works on integer T, works on float T).  No libm functions whose last bit differs between libraries (sin, exp, pow):
+# arithmetic, sqrt, floor / fabs / fmin / fmax, comparisons, casts, bit operations.
+EXPRS = [
+    ("v + 42.0", True, True),
+    ("v * 0.001 + 500000.0", True, True),
+    ("(v > x ? v : x) - z * 0.5", True, True),
+    ("sqrt(fabs((double)v)) + (double)c", True, True),
+    ("floor((double)v / 3.0) + (double)(i % 7)", True, True),
+    ("fmin((double)x, fmax((double)y, (double)z)) * 2.0 - 1.0", True, True),
+    ("p0[i % 13] * (double)v + p1[c]", True, True),
+    ("c == 0 ? y : (c == 1 ? z : x)", True, True),
+    ("(v ^ (v >> 1)) + 3", True, False),
+    ("(uint32_t)v * 2654435761u + (uint32_t)i", True, False),
+    ("v == v ? -v : 0.0", False, True),
+    ("x * 2.0 ; y - z ; (double)c + floor((double)z)", True, True),
+]
+
+
+# ---- CPU suite: generator + headers under hipRTC, shape errors ---------------------------------------------------------------------------
+@pytest.mark.parametrize("text,ints,floats", EXPRS)
+def test_transformation_sources_compile_with_hiprtc(hip, text, ints, floats):
+    for name, dt in list(SCALARS.items()) + [("v" + k, v) for k, v in VEC3.items()]:
+        is_float = name.endswith("f32") or name.endswith("f64")
+        if (is_float and not floats) or (not is_float and not ints) or (";" in text and not name.startswith("v")):
+            continue
+        for pre in (False, True):
+            src = cv.expr_source("transform", text, src_datatype=dt, dst_datatype=dt, apply_to_source=pre, api=hip)
+            assert "pst_jit_expr_map" in src and text.split(";")[0].strip() in src
+            if name in ("u8", "f64", "vf64", "vu16", "i64"):  # (a compile takes ~0.3 s: a spread of types, not all of them)
+                assert cv.jit_compile_source(src, api=hip)[:4] == b"\x7fELF"
+
+
+def test_predicate_source_names_only_the_referenced_attributes(hip):
+    layout = las.point_layout_from_las_point_format(las.Format(3), False, api=hip)
+    src = cv.expr_source("predicate", "Classification == 2 && Position3D.z < 120.0 && (i & 1) == 0 && p0[i] > 0.5", layout=layout, api=hip)
+    assert "const PstV3<double> Position3D, const uint8_t Classification, const uint64_t i" in src
+    assert "Intensity" not in src and "ColorRGB" not in src
+    assert cv.jit_compile_source(src, api=hip)[:4] == b"\x7fELF"
+    src = cv.expr_source("predicate", "ColorRGB.x > ColorRGB.y || GpsTime < 1e5", layout=layout, api=hip)
+    assert "const double GpsTime, const PstV3<uint16_t> ColorRGB" in src
+
+
+def test_expression_shape_errors(hip):
+    for bad in ("", "v; }", "v + 1 # x", 'v + "a"', "v;\nw", "x ; y"):  # statements / preprocessor / strings / two components for a Vec3
+        with pytest.raises(PastureError) as e:
+            cv.expr_source("transform", bad, src_datatype=T.Vec3f64, dst_datatype=T.Vec3f64, api=hip)
+        assert e.value.code == 7, bad
+    with pytest.raises(PastureError) as e:  # scalar <-> Vec3 has no conversion, Vec4u8 no components the expression could name
+        cv.expr_source("transform", "v", src_datatype=T.Vec4u8, dst_datatype=T.Vec4u8, api=hip)
+    assert e.value.code == 7
+    layout = PointLayout.from_attributes([A.POSITION_3D, A.INTENSITY], api=hip)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    with pytest.raises(PastureError) as e:
+        conv.set_custom_mapping_with_expression(A.INTENSITY, A.INTENSITY, "v ; v", False)
+    assert e.value.code == 7
+    with pytest.raises(PastureError) as e:  # attribute lookups keep the reference's panics
+        conv.set_custom_mapping_with_expression(A.CLASSIFICATION, A.INTENSITY, "v", False)
+    assert e.value.code == 4
+    with pytest.raises(PastureError) as e:
+        cv.jit_compile_source(cv.expr_source("transform", "v +* 2", src_datatype=T.F64, dst_datatype=T.F64, api=hip), api=hip)
+    assert "error" in str(e.value)
+
+
+def test_twin_semantics_are_rust_as():
+    """The g++ twin itself against numpy on the documented rules: the result is converted to T with Rust `as`."""
+    f = expr_twin.map_twin("u16", "u8", 1, True, "v * 2.0 + 0.5")  # T = u16: 400.5 -> 400; then u16 -> u8 truncates: 144
+    assert f(np.array([0, 1, 200, 40000], dtype=np.uint16)).tolist() == [0, 2, 144, 255 & 65535 & 0xFF]
+    g = expr_twin.map_twin("f64", "i8", 1, False, "v * 1000.0")  # T = i8 (post): f64 -> i8 saturates first, then the product saturates again
+    assert g(np.array([0.5, -3.0, 1e9, np.nan])).tolist() == [0, -128, 127, 0]
+    h = expr_twin.map_twin("f64", "f64", 3, False, "x + y + z ; (double)i ; (double)c")
+    assert h(np.arange(6.0).reshape(2, 3), first=10).tolist() == [[3.0, 10.0, 2.0], [12.0, 11.0, 2.0]]
+
+
+# ---- GPU suite -----------------------------------------------------------------------------------------------------------------------------
+def _device_array(values):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(values, dtype=np.float64), device="cuda")
+    return t, t.data_ptr()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_kind,dst_kind", PAIRINGS)
+@pytest.mark.parametrize("apply_to_source", [False, True])
+def test_reference_plus_42_scenarios_through_the_expression_path(hip, src_kind, dst_kind, apply_to_source):
+    """buffer_converter_transformed_{target,source}_attribute_generic, buffer_conversion.rs:764-846: CustomPointTypeBig -> [POSITION_3D] with
+    `|p| p.add_scalar(42.0)`, for the reference's four buffer pairings; expected = the closure applied to the source positions."""
+    big = custom_point_type_big(hip)
+    rec = random_records(big, 16, 5)
+    src = make_buffer(src_kind, big, rec)
+    custom = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    conv = BufferLayoutConverter.for_layouts_with_default(big, custom)
+    conv.set_custom_mapping_with_expression(A.POSITION_3D, A.POSITION_3D, "v + 42.0", apply_to_source)
+    out = conv.convert(src, BUFFER_KINDS[dst_kind])
+    assert out.point_layout() == custom
+    assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"] + 42.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["V", "H"])
+def test_reference_transform_attribute_by_index(hip, kind):
+    """test_transform_attribute_generic, point_buffer.rs:2007-2043: positions overwritten with `overwrite_data[index].position` -- the closure
+    captures an array and uses its index argument: p0[3 * i + c]."""
+    big = custom_point_type_big(hip)
+    test_data, overwrite = random_records(big, 16, 1), random_records(big, 16, 2)
+    buf = make_buffer(kind, big, test_data)
+    keep, ptr = _device_array(overwrite["Position3D"])
+    transform_attribute_expr(buf, A.POSITION_3D, "p0[3 * i + c]", [ptr])
+    assert np.array_equal(buf.view_attribute(A.POSITION_3D), overwrite["Position3D"])
+    for a in big.attributes():  # nothing else moved
+        if a.name() != "Position3D":
+            assert np.array_equal(buf.view_attribute(a.attribute_definition()), test_data[a.name()])
+    del keep
+
+
+def _values(ct, n, ncomp, rng):
+    npdt = expr_twin._NP[ct]
+    shape = (n, ncomp) if ncomp > 1 else (n,)
+    if npdt in (np.float32, np.float64):
+        v = (rng.random(shape) - 0.3) * 1000.0
+        v.reshape(-1)[:: 97] = np.nan  # NaN -> 0 and friends
+        v.reshape(-1)[1:: 89] = 1e300 if npdt is np.float64 else 3e38
+        return v.astype(npdt)
+    info = np.iinfo(npdt)
+    return rng.integers(info.min, info.max, size=shape, dtype=npdt, endpoint=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(EXPRS)))
+@pytest.mark.parametrize("kind", ["V", "H"])
+def test_transform_attribute_expressions_against_the_gxx_twin(hip, case, kind):
+    """Every expression text on every scalar / Vec3 datatype it applies to, in place on interleaved (packed: odd offsets) and columnar
+    buffers, 5 003 points (ragged against every block size), parameters and the point index included: bit for bit against the g++ twin."""
+    text, ints, floats = EXPRS[case]
+    rng = np.random.default_rng(100 + case)
+    n = 5003
+    p0, p1 = rng.random(13) * 10.0, rng.random(3) - 0.5
+    k0, ptr0 = _device_array(p0)
+    k1, ptr1 = _device_array(p1)
+    for name, dt, ncomp in [(k, v, 1) for k, v in SCALARS.items()] + [(k, v, 3) for k, v in VEC3.items()]:
+        is_float = name in ("f32", "f64")
+        if (is_float and not floats) or (not is_float and not ints) or (";" in text and ncomp == 1):
+            continue
+        attr = PointAttributeDefinition("Value", dt)
+        layout = PointLayout.from_attributes_packed([A.CLASSIFICATION, attr, A.INTENSITY], 1, api=hip)
+        vals = _values(name, n, ncomp, rng)
+        buf = BUFFER_KINDS[kind].new_from_layout(layout)
+        buf.resize(n)
+        buf.set_attribute_range(attr, range(0, n), vals)
+        transform_attribute_expr(buf, attr, text, [ptr0, ptr1])
+        want = expr_twin.map_twin(name, name, ncomp, False, text)(vals, 0, [p0, p1])
+        got = buf.view_attribute(attr)
+        assert got.tobytes() == want.tobytes(), f"{text!r} on {'Vec3' if ncomp == 3 else ''}{name}: {np.flatnonzero((got != want).reshape(n, -1).any(axis=1))[:5]}"
+        # a slice_mut sees its OWN indices (the closure's index is the index in the buffer the call is made on)
+        view = buf.slice(range(1000, 1100))
+        before = view.view_attribute(attr)
+        transform_attribute_expr(view, attr, text, [ptr0, ptr1])
+        assert view.view_attribute(attr).tobytes() == expr_twin.map_twin(name, name, ncomp, False, text)(before, 0, [p0, p1]).tobytes()
+    del k0, k1
+
+
+CONVERSIONS = [("u8", "f64", 1), ("f64", "u8", 1), ("i32", "f32", 3), ("f64", "f32", 3), ("u16", "i32", 3), ("f32", "i16", 1), ("i64", "u16", 1), ("f64", "f64", 3), ("u32", "u32", 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_kind,dst_kind", PAIRINGS)
+@pytest.mark.parametrize("apply_to_source", [False, True])
+def test_mapping_expressions_with_conversion_against_the_gxx_twin(hip, src_kind, dst_kind, apply_to_source):
+    """set_custom_mapping_with_expression between DIFFERENT datatypes: T is the source datatype before the `as` conversion (apply_to_source) or
+    the target datatype after it; four storage pairings, packed layouts with other attributes around the mapped one, a sub-range conversion
+    (the index the expression sees is the point's index in the source buffer)."""
+    rng = np.random.default_rng(7 + apply_to_source)
+    n = 4099
+    for s_ct, d_ct, ncomp in CONVERSIONS:
+        s_dt = (VEC3 if ncomp == 3 else SCALARS)[s_ct]
+        d_dt = (VEC3 if ncomp == 3 else SCALARS)[d_ct]
+        is_float_T = (s_ct if apply_to_source else d_ct) in ("f32", "f64")
+        for text, ints, floats in EXPRS[:6] + EXPRS[7:8]:
+            if (is_float_T and not floats) or (not is_float_T and not ints):
+                continue
+            sa, da = PointAttributeDefinition("Value", s_dt), PointAttributeDefinition("Value", d_dt)
+            sl = PointLayout.from_attributes_packed([A.CLASSIFICATION, sa, A.GPS_TIME], 1, api=hip)
+            dl = PointLayout.from_attributes_packed([A.GPS_TIME, da, A.CLASSIFICATION], 1, api=hip)
+            vals = _values(s_ct, n, ncomp, rng)
+            src = BUFFER_KINDS[src_kind].new_from_layout(sl)
+            src.resize(n)
+            src.set_attribute_range(sa, range(0, n), vals)
+            gps = rng.random(n)
+            src.set_attribute_range(A.GPS_TIME, range(0, n), gps)
+            conv = BufferLayoutConverter.for_layouts(sl, dl)
+            conv.set_custom_mapping_with_expression(sa, da, text, apply_to_source)
+            out = conv.convert(src, BUFFER_KINDS[dst_kind])
+            twin = expr_twin.map_twin(s_ct, d_ct, ncomp, apply_to_source, text)
+            assert out.view_attribute(da).tobytes() == twin(vals, 0).tobytes(), (text, s_ct, d_ct, apply_to_source)
+            assert np.array_equal(out.view_attribute(A.GPS_TIME), gps)  # the other mappings went through the regular plan
+            part = BUFFER_KINDS[dst_kind].new_from_layout(dl)
+            part.resize(500)
+            conv.convert_into_range(src, range(1234, 1734), part, range(0, 500))
+            assert part.view_attribute(da).tobytes() == twin(vals[1234:1734], 1234).tobytes()
+
+
+PREDICATES = [
+    "Classification == 2 && Position3D.z < 50.0",
+    "(Intensity & 1) == 0 || GpsTime > 0.75",
+    "Position3D.x * Position3D.x + Position3D.y * Position3D.y < 250000.0",
+    "i % 3 == 0",
+    "p0[Classification] > 0.5 && ColorRGB.x >= ColorRGB.z",
+    "true",
+    "ReturnNumber > NumberOfReturns",
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(PREDICATES)))
+@pytest.mark.parametrize("out_kind", ["V", "H"])
+def test_filter_expressions_against_the_gxx_twin_and_the_mask_path(hip, case, out_kind):
+    """HashMapBuffer::filter with the predicate as an expression over attribute names: the selected points equal (a) numpy selection with the
+    g++ twin's mask and (b) the library's own mask-based filter given that mask, attribute by attribute."""
+    text = PREDICATES[case]
+    layout = las.point_layout_from_las_point_format(las.Format(3), False, api=hip)  # typed LAS-3: Position3D, flags, GpsTime, ColorRGB, ...
+    n = 20_011
+    rec = random_records(layout, n, 40 + case)
+    rec["Position3D"] = np.random.default_rng(case).random((n, 3)) * np.array([1000.0, 1000.0, 100.0])
+    rec["ReturnNumber"] %= 8
+    rec["NumberOfReturns"] %= 8
+    src = make_buffer("H", layout, rec)
+    p0 = np.random.default_rng(9).random(256)
+    keep, ptr = _device_array(p0)
+    out = src.filter_expr(BUFFER_KINDS[out_kind], text, [ptr])
+    attrs = [(a.name(), {v: k for k, v in SCALARS.items()}.get(a.datatype()) or {v: k for k, v in VEC3.items()}.get(a.datatype()), a.datatype().num_components())
+             for a in layout.attributes() if a.name() in text]
+    mask = expr_twin.pred_twin(attrs, text)({name: rec[name] for name, _, _ in attrs}, n, 0, [p0])
+    assert out.len() == int(mask.sum()) and 0 < out.len() <= n
+    ref = src.filter(BUFFER_KINDS[out_kind], mask)
+    for a in layout.attributes():
+        d = a.attribute_definition()
+        assert np.array_equal(out.view_attribute(d), rec[a.name()][mask.astype(bool)])
+        assert out.view_attribute(d).tobytes() == ref.view_attribute(d).tobytes()
+    del keep
+
+
+@pytest.mark.gpu
+def test_expression_errors_at_run_time(hip):
+    layout = PointLayout.from_attributes([A.POSITION_3D, A.CLASSIFICATION], api=hip)
+    buf = HashMapBuffer.new_from_layout(layout)
+    buf.resize(100)
+    with pytest.raises(PastureError) as e:  # a text that does not compile: the compiler's log is the message
+        transform_attribute_expr(buf, A.POSITION_3D, "v +* nothing")
+    assert e.value.code == 7 and "error" in str(e.value)
+    with pytest.raises(PastureError) as e:
+        buf.filter_expr(HashMapBuffer, "NoSuchAttribute > 1")
+    assert e.value.code == 7 and "NoSuchAttribute" in str(e.value)
+    with pytest.raises(PastureError) as e:  # the attribute lookup keeps the reference's panic
+        transform_attribute_expr(buf, A.INTENSITY, "v")
+    assert e.value.code == 4
+    vec = VectorBuffer.new_from_layout(layout)
+    with pytest.raises(PastureError) as e:  # filter is defined on HashMapBuffer (point_buffer.rs:1064)
+        vec.filter_expr(HashMapBuffer, "Classification == 1")
+    assert e.value.code == 1
+    empty = HashMapBuffer.new_from_layout(layout)
+    assert empty.filter_expr(VectorBuffer, "Classification == 1").len() == 0
+    transform_attribute_expr(empty, A.POSITION_3D, "v + 1.0")  # no points: still compiles the text, launches nothing

@@ -45,13 +45,21 @@ for name, pts in (("structured volume", gp._structured_volume(1_200_000, 105, No
             os.environ.pop("PST_KNN_DEBUG", None)
         gn, gc, gk = run(pts, k, {"PST_KNN_FIT": "pivot"})
         un, uc, uk = run(pts, k, {"PST_KNN_FIT": "pivot", "PST_KNN_FIT_GUARD": "0"})
-        assert torch.equal(sk, gk) and torch.equal(sk, uk)
+        # (a query the guard hands to the exact search gets its list from THAT kernel: the same distances, possibly another order among exact ties)
+        same = (sk == gk).all(dim=1) & (sk == uk).all(dim=1)
         changed = ((gn != un).any(dim=1) | (gc != uc)).sum().item()
         same_as_seq = ((gn == sn).all(dim=1) & (gc == sc)).sum().item()
+        # the parity window of tests/test_gpu_parity.py::_compare_normals per query: 1e-9 |c| + max(1e-12, 1e-13 scale), scale = max |entry| of the covariance
+        nb = pts[sk.long().reshape(-1)].view(pts.shape[0], k, 3)
+        d = nb - nb.mean(dim=1, keepdim=True)
+        scale = torch.einsum("nki,nkj->nij", d, d).abs().reshape(-1, 9).max(dim=1).values
+        window = 1e-9 * sc.abs() + torch.clamp(1e-13 * scale, min=1e-12)
+        del nb, d
 
         def worst(n_, c_):
-            rn = ((n_ - sn).norm(dim=1) / sn.norm(dim=1).clamp_min(1e-300)).max().item()
-            ac = (c_ - sc).abs().max().item()
-            return rn, ac
-        print(f"{name}, n = {pts.shape[0]}, k = {k}: guard changed {changed} queries; guarded == reference-order bit for bit on {same_as_seq}; "
-              f"worst vs reference-order (rel. normal, abs. curvature): guarded {worst(gn, gc)}, unguarded {worst(un, uc)}", flush=True)
+            rn = ((n_ - sn).norm(dim=1) / sn.norm(dim=1).clamp_min(1e-300))[same].max().item()
+            ratio = ((c_ - sc).abs() / window)[same]
+            i = int(ratio.argmax())
+            return f"rel. normal {rn:.2e}, curvature difference / window {ratio[i].item():.3f} (|diff| {(c_ - sc).abs()[same][i].item():.2e}, scale {scale[same][i].item():.3g}, curvature {sc[same][i].item():.3g})"
+        print(f"{name}, n = {pts.shape[0]}, k = {k}: lists identical on {int(same.sum())}; guard changed {changed} queries; guarded == reference-order bit for bit on {same_as_seq}\n"
+              f"    guarded   vs reference-order: {worst(gn, gc)}\n    unguarded vs reference-order: {worst(un, uc)}", flush=True)

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 | cut -c1-1500
+python tools/abab.py --workload normals_knn16 --steps 6 --a "PST_KNN_FIT_GUARD=0" --b "" --out gpurun_out/r05/abab_3.txt
+timeout 900 python tools/exp_knn_guard.py > gpurun_out/r05/knn_guard.txt 2>&1; grep -E "^structured|^uniform" gpurun_out/r05/knn_guard.txt | cut -c1-500
+cp gpurun_out/curvature_floor_use.json gpurun_out/r05/ 2>/dev/null; cat gpurun_out/curvature_floor_use.json 2>/dev/null
