@@ -21,6 +21,9 @@
 #include "tile_io.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 using namespace pstd;
 using namespace pstlas;
@@ -35,12 +38,39 @@ struct EncodeArgs {
   uint64_t dst;                     // address of raw record 0 of the target range
   uint64_t n;
   double scale[3], offset[3];
+  double rscale[3];                 // RN(1 / scale[c]) when fast_div (host: launch_las_encode)
+  uint32_t fast_div;                // 1: every scale passes quotient_by_reciprocal's preconditions; 0: the IEEE division instruction sequence
   double seed_min[3], seed_max[3];  // the header's current bounds (raw_writers.rs:136-141: f64::MAX / f64::MIN initially)
   double* partial_bounds;           // [grid][6]
   unsigned long long* partial_counts;  // [grid][kReturnSlots]
   uint32_t max_return;              // 5 (legacy header) or 15 (large_file) — raw_writers.rs:221-225
   uint32_t tile;                    // points per tile (multiple of kBlock)
 };
+
+// a / b for a divisor that is the same for every point, WITHOUT the division sequence (v_div_scale, the quarter-rate v_rcp_f64, six fused
+// multiply-adds, v_div_fmas, v_div_fixup: a third of this kernel's vector instructions, round-4 review item 7) and still the CORRECTLY ROUNDED
+// quotient, which the record needs bit for bit: LAS positions are multiples of the scale, so (p - offset) / scale sits within an ulp of an integer
+// for nearly every point and the truncation of write_helpers.rs:15-17 sees the last bit.
+//   y = RN(1 / b) (host, one IEEE division);  q0 = RN(a y)  -- relative error <= 2^-52 (1 + 2^-53), up to two ulps;
+//   r0 = RN(a - b q0), q1 = RN(q0 + r0 y)  -- q0 + r0 y = a/b + (a/b - q0)(b y - 1) (+ the rounding of r0, itself <= 2^-53 |r0|): within
+//   2^-104 |a/b| of the quotient before the rounding, so q1 is a FAITHFUL rounding of a/b (one of the two doubles next to it);
+//   r1 = a - b q1 is then exact (the residual of a faithful quotient is representable) and q2 = RN(q1 + r1 y) is RN(a / b): Markstein's division theorem
+//   (P. Markstein, "Computation of elementary functions on the IBM RISC System/6000 processor", IBM J. Res. Dev. 34, 1990 -- the correction step
+//   every fused-multiply-add division ends with), which needs y = RN(1 / b); divisors whose significand is all ones (where 1 / b rounds worst) are
+//   left to the division sequence as well.
+// Preconditions checked on the host (fast_div): b finite, normal, 2^-400 <= |b| <= 2^400, significand not all ones.  Per value: |q0| < 2^62 and
+// |a| >= 2^-500 or the plain quotient is taken (overflow, infinities and NaN propagate through a y exactly as through a / b as far as the checked
+// narrowing can tell: +-inf and NaN stay what they are, and a quotient that large is out of the i32 range either way; a tiny |a| gives |a / b| < 1/2
+// in both forms = the integer 0, but its residuals could underflow, so it does not take the correction steps).  Five full-rate instructions.
+// tests/test_gpu_las_encode.py::test_reciprocal_division_is_the_ieee_quotient compares both forms of this kernel over adversarial and random inputs.
+__device__ __forceinline__ double quotient_by_reciprocal(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r0 = __builtin_fma(-q0, b, a);
+  const double q1 = __builtin_fma(r0, y, q0);
+  const double r1 = __builtin_fma(-q1, b, a);
+  const double q2 = __builtin_fma(r1, y, q1);
+  return (__builtin_fabs(q0) < 0x1p62 && __builtin_fabs(a) >= 0x1p-500) ? q2 : q0;
+}
 
 // Where one point's typed attributes are read from: HBM at any per-attribute stride, or a record staged in LDS.
 struct GlobalSrc {
@@ -92,7 +122,8 @@ __device__ __forceinline__ void encode_point(const EncodeArgs& a, const Src& src
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double w = src.template get<double>(s, 8 * c);
-      const double local = (w - a.offset[c]) / a.scale[c];  // two roundings, like the Rust expression
+      const double num = w - a.offset[c];  // two roundings, like the Rust expression
+      const double local = a.fast_div ? quotient_by_reciprocal(num, a.scale[c], a.rscale[c]) : num / a.scale[c];
       // `as i64` saturates and maps NaN to 0; try_into::<i32>() then fails outside [i32::MIN, i32::MAX]
       const long long t = rust_as<long long, double>(local);
       if (t > 2147483647ll || t < -2147483648ll) bad = true;
@@ -200,11 +231,12 @@ __device__ __forceinline__ void encode_quad_tile(const EncodeArgs& a, uint64_t f
   // scale/offset are kept "rotated by c0" and indexed with compile-time r; the rotation is undone once at the end.
   {
     const uint32_t d0 = 2u * tid, q0 = d0 / 3u, c0 = d0 - 3u * q0;
-    double sc_r[3], of_r[3], rmn[3], rmx[3];
+    double sc_r[3], rc_r[3], of_r[3], rmn[3], rmx[3];
 #pragma unroll
     for (uint32_t r = 0; r < 3; ++r) {
       const uint32_t c = c0 + r >= 3u ? c0 + r - 3u : c0 + r;
       sc_r[r] = pick3(c, a.scale[0], a.scale[1], a.scale[2]);
+      rc_r[r] = pick3(c, a.rscale[0], a.rscale[1], a.rscale[2]);
       of_r[r] = pick3(c, a.offset[0], a.offset[1], a.offset[2]);
       rmn[r] = pick3(c, mn[0], mn[1], mn[2]);
       rmx[r] = pick3(c, mx[0], mx[1], mx[2]);
@@ -217,7 +249,8 @@ __device__ __forceinline__ void encode_quad_tile(const EncodeArgs& a, uint64_t f
         const uint32_t k = 512u * j + e, A = k / 3u, r = k % 3u;  // compile-time
         const uint64_t bits = (uint64_t)(e ? pc[j].z : pc[j].x) | ((uint64_t)(e ? pc[j].w : pc[j].y) << 32);
         const double w = __builtin_bit_cast(double, bits);
-        const double local = (w - of_r[r]) / sc_r[r];
+        const double num = w - of_r[r];
+        const double local = a.fast_div ? quotient_by_reciprocal(num, sc_r[r], rc_r[r]) : num / sc_r[r];
         if (local >= 2147483648.0 || local <= -2147483649.0) bad = true;  // == (local as i64) does not fit an i32 (NaN -> 0 fits)
         const int32_t v = rust_as<int32_t, double>(local);
         const bool wrap = c0 + r >= 3u;
@@ -366,6 +399,10 @@ uint32_t las_raw_record_size(int format) { return raw_size(fmt_of(format)); }
 // attr_base / attr_stride: typed attributes in LasPointFormatN field order.  out_bounds (6 doubles) and out_counts (16 u64)
 // are device-accessible.  workspace must hold las_encode_workspace_bytes().
 constexpr uint32_t kMaxGrid = 16384, kFoldGrid = 64;
+static bool las_encode_fast_div_allowed() {  // PST_LAS_EXACT_DIV=1: the division instruction sequence for every launch (A/B, and the parity test's other side)
+  const char* e = std::getenv("PST_LAS_EXACT_DIV");
+  return !(e && e[0] == '1');
+}
 size_t las_encode_workspace_bytes() { return (size_t)(kMaxGrid + kFoldGrid) * (6 * sizeof(double) + kReturnSlots * sizeof(unsigned long long)); }
 
 bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* attr_stride, const uint32_t* attr_size, int n_attrs, bool interleaved,
@@ -382,6 +419,13 @@ bool launch_las_encode(int format, const uint64_t* attr_base, const uint32_t* at
   a.n = n;
   for (int c = 0; c < 3; ++c) { a.scale[c] = scale[c]; a.offset[c] = offset[c]; a.seed_min[c] = bounds_in[c]; a.seed_max[c] = bounds_in[3 + c]; }
   a.max_return = max_return;
+  a.fast_div = las_encode_fast_div_allowed() ? 1u : 0u;
+  for (int c = 0; c < 3; ++c) {
+    uint64_t bits; std::memcpy(&bits, &scale[c], 8);
+    const double m = std::fabs(scale[c]);
+    if (!(std::isfinite(m) && m >= 0x1p-400 && m <= 0x1p400) || (bits & 0xFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFull) a.fast_div = 0;
+    a.rscale[c] = 1.0 / scale[c];
+  }
   const uint32_t rs = las_raw_record_size(format);
   const uint32_t ts = attr_stride[0];
   // columnar sources: tiles of kQuadTile points (four per lane); interleaved: source + records in <= 48 KiB; otherwise ~32 KiB of records

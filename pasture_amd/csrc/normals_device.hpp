@@ -171,6 +171,14 @@ __device__ __forceinline__ void cos_sin_third_angle(double s, double b, double& 
 //     and on exactly planar neighbourhoods the candidates are parallel but may point in opposite directions (found by the round-5 structured
 //     volume test on a quantised plane: normal = -oracle's).
 // A flagged query is handed to the exact search behind the box search, whose fit adds in the reference's order of operations (knn_tile2_kernel).
+//
+// FAST (the one-pass fit of the box search only; every exact search keeps the reference's sequence): the parts of the solver whose rounding does NOT
+// feed the amplifying steps are taken in a cheaper form -- the nine entries are scaled by ONE reciprocal (1 / scale, then six products) instead of six
+// IEEE divisions, and the three cross products are ranked by their SQUARED norms (three f64 square roots less).  Both change the scaled entries / the
+// ranking by a few 1e-16 relative, the size of the difference between the two summation orders this instance already carries; a ranking that close is
+// flagged by the tie test below (in squared norms: 2e-6) and handed to the exact search, like every other neighbourhood where last bits decide.
+// 542 -> 430 vector instructions for the fit (round 5).
+template <bool FAST = false>
 __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, double c02, double c11, double c12, double c22, bool* ill = nullptr) {
   Fit f{0, 0, 0, 0, 1};
   bool flagged = false;
@@ -182,8 +190,14 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const double v = __builtin_fabs(a[q]); if (v > scale) scale = v; }
   }
-  const double s00 = c00 / scale, s01 = c01 / scale, s02 = c02 / scale, s10 = c10 / scale, s11 = c11 / scale, s12 = c12 / scale,
-               s20 = c20 / scale, s21 = c21 / scale, s22 = c22 / scale;
+  double s00, s01, s02, s11, s12, s22;
+  if constexpr (FAST) {
+    const double inv = 1.0 / scale;
+    s00 = c00 * inv; s01 = c01 * inv; s02 = c02 * inv; s11 = c11 * inv; s12 = c12 * inv; s22 = c22 * inv;
+  } else {
+    s00 = c00 / scale; s01 = c01 / scale; s02 = c02 / scale; s11 = c11 / scale; s12 = c12 / scale; s22 = c22 / scale;
+  }
+  const double s10 = s01, s20 = s02, s21 = s12;
   // solve_polynomial on the UNSCALED matrix :328-392
   double ev0, ev1, ev2;
   {
@@ -232,8 +246,8 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
   const double a0 = s01 * s12 - s02 * s11, a1 = s02 * s10 - s00 * s12, a2 = s00 * s11 - s01 * s10;
   const double b0 = s01 * s22 - s02 * s21, b1 = s02 * s20 - s00 * s22, b2 = s00 * s21 - s01 * s20;
   const double d0 = s11 * s22 - s12 * s21, d1 = s12 * s20 - s10 * s22, d2 = s10 * s21 - s11 * s20;
-  const double na = __builtin_sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = __builtin_sqrt(b0 * b0 + b1 * b1 + b2 * b2),
-               nd = __builtin_sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  double na = a0 * a0 + a1 * a1 + a2 * a2, nb = b0 * b0 + b1 * b1 + b2 * b2, nd = d0 * d0 + d1 * d1 + d2 * d2;  // FAST: squared norms throughout
+  if constexpr (!FAST) { na = __builtin_sqrt(na); nb = __builtin_sqrt(nb); nd = __builtin_sqrt(nd); }
   f.nx = a0; f.ny = a1; f.nz = a2;
   double best = na;
   if (nb > best) { f.nx = b0; f.ny = b1; f.nz = b2; best = nb; }
@@ -242,7 +256,7 @@ __device__ __forceinline__ Fit fit_from_covariance(double c00, double c01, doubl
     // ... and the winner among the three cross products must be the reference's: with two norms within 1e-6 of each other (exact ties on
     // lattices and quantised planes, where the candidates are parallel and may point in OPPOSITE directions) last bits decide it
     const double lo = __builtin_fmin(na, __builtin_fmin(nb, nd)), mid = (na + nb + nd) - best - lo;
-    *ill = flagged || !(best >= 1e-4) || (best - mid) <= 1e-6 * best;
+    *ill = flagged || !(best >= (FAST ? 1e-8 : 1e-4)) || (best - mid) <= (FAST ? 2e-6 : 1e-6) * best;
   }
   // solve_plane_parameter :456-467
   const double eigen_sum = c00 + c11 + c22;
@@ -328,7 +342,12 @@ __device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py,
   if (m < 3) { Fit f{0, 0, 0, 0, 0}; if (ill) *ill = false; return f; }  // Err(...) :293-295 -> unwrap panic :471
   const double inv = 1.0 / (double)m;
   const double tx = sx * inv, ty = sy * inv, tz = sz * inv;  // centroid - pivot
-  return fit_from_covariance(__builtin_fma(-sx, tx, mxx), __builtin_fma(-sx, ty, mxy), __builtin_fma(-sx, tz, mxz),
+#ifdef PST_FIT_NO_FAST  // (A/B builds: tools/build_variant_lib.sh)
+  constexpr bool kFast = false;
+#else
+  constexpr bool kFast = true;
+#endif
+  return fit_from_covariance<kFast>(__builtin_fma(-sx, tx, mxx), __builtin_fma(-sx, ty, mxy), __builtin_fma(-sx, tz, mxz),
                              __builtin_fma(-sy, ty, myy), __builtin_fma(-sy, tz, myz), __builtin_fma(-sz, tz, mzz), ill);
 }
 

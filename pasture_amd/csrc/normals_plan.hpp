@@ -30,7 +30,7 @@ struct KnnTuning {
   char variant = '\0';         // PST_KNN_VAR: '1', 'B', 'D', 'G'
   bool sort_fallback = true;   // PST_KNN_SORT_FALLBACK=0: the exact fallback search takes its queries in the order the box kernel's workgroups finished
   int reorder_unroll = 2;      // PST_REORDER_UNROLL: points per lane in flight in the permutation kernel (1 / 2 / 4)
-  int fit = -1;                // PST_KNN_FIT=seq|pivot: the box search's plane fit in the reference's order of operations (two passes) / in one pass about the query; default (-1): by cloud --
+  int fit = -1;                // PST_KNN_FIT=seq|pivot|rows (rows: the cross-lane covariance, sixteen lanes per query -- a measured alternative, normals_tile.hip FIT 2): the box search's plane fit in the reference's order of operations (two passes) / in one pass about the query; default (-1): by cloud --
                                // one pass for clouds that fill their box, the reference's order for surfaces and strips (near-planar neighbourhoods: see normals_device.hpp)
   bool fit_guard = true;       // PST_KNN_FIT_GUARD=0: the one-pass fit never falls back to the reference's order for ill-conditioned neighbourhoods (tests that the guard is what keeps them in the window)
   unsigned tile[3] = {0, 0, 0};  // PST_KNN_TILE=bx,by,bz
@@ -54,7 +54,7 @@ struct KnnTuning {
     if (const char* e = std::getenv("PST_KNN_DENSE")) t.dense = *e == '0' ? 0 : 1;
     t.direct_out = !off("PST_KNN_DIRECT"); t.box_list = !off("PST_KNN_BOX_LIST"); t.rounds = !off("PST_KNN_ROUNDS"); t.side_stream = !off("PST_KNN_SIDE_STREAM"); t.occupancy_all = num("PST_KNN_OCC_ALL") != 0.0;
     if (const char* e = std::getenv("PST_KNN_VAR")) t.variant = *e;
-    if (const char* e = std::getenv("PST_KNN_FIT")) t.fit = e[0] == 's' ? 1 : (e[0] == 'p' ? 0 : -1);
+    if (const char* e = std::getenv("PST_KNN_FIT")) t.fit = e[0] == 's' ? 1 : (e[0] == 'p' ? 0 : (e[0] == 'r' ? 2 : -1));
     t.sort_fallback = !off("PST_KNN_SORT_FALLBACK");
     t.fit_guard = !off("PST_KNN_FIT_GUARD");
     if (const char* e = std::getenv("PST_REORDER_UNROLL")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) t.reorder_unroll = v; }

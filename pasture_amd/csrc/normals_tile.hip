@@ -519,6 +519,24 @@ struct KBestU32 {
   }
 };
 
+// ---- FIT 2: the nine pivot moments of a query, reduced across the sixteen lanes of a DPP row --------------------------------------------------
+// v += row_ror(v, 8), 4, 2, 1: after four rotations every lane of the row holds the sum of all sixteen (each lane in its own order of additions;
+// the owner keeps its own).  A 64-bit value moves as two v_mov_b32 dpp (gfx950 has no 64-bit DPP rotation): 3 instructions per stage and sum.
+template <int CTRL>
+__device__ __forceinline__ double row_ror_f64(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += row_ror_f64<0x128>(v);  // row_ror:8
+  v += row_ror_f64<0x124>(v);  // row_ror:4
+  v += row_ror_f64<0x122>(v);  // row_ror:2
+  v += row_ror_f64<0x121>(v);  // row_ror:1
+  return v;
+}
+
 struct Tile2Args {
   TileArgs t;
   double s;        // f32 coordinates are (x - c) * s
@@ -530,7 +548,10 @@ struct Tile2Args {
   uint32_t f_max;  // the k-th entry's bin must lie below this one: upper edge + eps < tau0 * s2
 };
 
-// FIT: 1 = the plane fit in ONE pass about the query (plane_fit_pivot: 12 running sums, every neighbour fetched once and not kept);
+// FIT: 2 = the covariance as a CROSS-LANE reduction (BASELINE.json's "per-point 3x3 covariance wavefront reduction", taken literally: sixteen lanes per
+//          query, one neighbour each, the nine sums folded across the row with DPP rotations) -- built to be MEASURED against FIT 1 (round-4 review,
+//          row NS-1; PST_KNN_FIT=rows, k <= 16, no neighbour lists, unrotated grids); see rows16_moments below for the count and the result;
+//      1 = the plane fit in ONE pass about the query (plane_fit_pivot: 12 running sums, every neighbour fetched once and not kept);
 //      0 = the reference's order of operations (plane_fit: centroid, then moments -- the 16 neighbours are held across the two passes, which
 //          at 128 registers means scratch memory; kept for bit comparison and the A/B, PST_KNN_FIT=seq)
 template <int K, int THREADS, int CAP, bool P3LDS, int BATCH, int WPE, bool WITH_KNN, bool ROT, int FIT>
@@ -899,6 +920,10 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       // the neighbours' LDS slots, in list order (a separate array: the key registers are not written outside the insertion rounds)
 #pragma unroll
       for (int t = 0; t < K; ++t) nb[t] = best.key[t] & SLOT_MASK;
+      if (a.ablate) {  // (tuning runs: every query counts as done, whatever its list holds -- empty entries must still be staged slots)
+#pragma unroll
+        for (int t = 0; t < K; ++t) nb[t] = nb[t] < total ? nb[t] : 0u;
+      }
       if (__builtin_amdgcn_ballot_w64(amb != 0u)) {  // rare: about one wave in five settles one pair
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
@@ -927,6 +952,36 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     //  waited for at the loop's head, and this one comes from HBM)
     const uint32_t orig = active && done ? a.out.sidx[j] : 0u;
     PST_KNN_STAT(const long long t_fit = clock64(); if (lane == 0) atomicAdd(a.dbg + 12, (unsigned long long)(t_fit - t_proof));)
+    // FIT 2: sixteen rounds; in round r the sixteen lanes of row g serve the query of lane 16 g + r (same row: the owner keeps its own lane's
+    // totals), lane t of the row fetching neighbour t.  The lists cross the lanes through the candidate queue's LDS (free after the search).
+    // Per round: 1 LDS read + 1 ds_bpermute (the owner's slot) + 2 gathers of 24 bytes + 3 subtractions + 6 products + 6 selects (lanes t >= m)
+    // + 9 sums x 4 stages x 3 instructions + 18 selects (the owner keeps) ~ 150 wave instructions, x 16 rounds = 2400 per 64 queries, against
+    // ~320 for the sixteen iterations of the one-lane loop it replaces (12 f64 operations + the gather per neighbour, all 64 lanes busy).
+    double rows_s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (FIT == 2) {
+      static_assert(K <= 16 && kQ >= K, "one DPP row per query");
+#pragma unroll
+      for (int t = 0; t < K; ++t) qbuf[t * THREADS + tid] = (uint16_t)nb[t];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t tl = lane & 15u, row0 = tid & ~15u;
+      const bool use = tl < m;
+#pragma unroll 1
+      for (uint32_t r = 0; r < 16u; ++r) {
+        const uint32_t owner = row0 + r;  // thread index of the query this row serves
+        const uint32_t ns = qbuf[(tl < (uint32_t)K ? tl : 0u) * THREADS + owner];
+        const uint32_t qs = (uint32_t)__shfl((int)slot, (int)((lane & ~15u) + r), 64);
+        double qx, qy, qz, x, y, z;
+        exact_xyz(qs, qx, qy, qz);
+        exact_xyz(use && ns < total ? ns : qs, x, y, z);  // (an unfinished query's list holds empty entries: any staged point will do, its sums are not used)
+        const double ux = use ? x - qx : 0.0, uy = use ? y - qy : 0.0, uz = use ? z - qz : 0.0;
+        const double v[9] = {row16_sum(ux), row16_sum(uy), row16_sum(uz), row16_sum(ux * ux), row16_sum(ux * uy), row16_sum(ux * uz),
+                             row16_sum(uy * uy), row16_sum(uy * uz), row16_sum(uz * uz)};
+        const bool mine = tl == r;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) rows_s[c] = mine ? v[c] : rows_s[c];
+      }
+    }
     if (active && done && !(a.ablate & 32u)) {
       if constexpr (WITH_KNN) {
         for (uint32_t t = 0; t < a.k; ++t) {
@@ -948,7 +1003,18 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       }
       Fit f{0, 0, 0, 0, 1};
       bool handed = false;
-      if constexpr (FIT == 1) {
+      if constexpr (FIT == 2) {
+        bool ill = false;
+        if (m < 3) f.ok = 0;
+        else if (!(a.ablate & 2u)) {
+          const double inv = 1.0 / (double)m;
+          const double tx = rows_s[0] * inv, ty = rows_s[1] * inv, tz = rows_s[2] * inv;
+          f = fit_from_covariance<true>(__builtin_fma(-rows_s[0], tx, rows_s[3]), __builtin_fma(-rows_s[0], ty, rows_s[4]), __builtin_fma(-rows_s[0], tz, rows_s[5]),
+                                        __builtin_fma(-rows_s[1], ty, rows_s[6]), __builtin_fma(-rows_s[1], tz, rows_s[7]), __builtin_fma(-rows_s[2], tz, rows_s[8]), &ill);
+        }
+        ill = ill && a.fit_guard;
+        if (ill) { a.fb_list[atomicAdd(a.fb_count, 1u)] = j; handed = true; }
+      } else if constexpr (FIT == 1) {
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
         bool ill = false;
@@ -1398,11 +1464,13 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
     } while (0)
 #define PST_TILE2_K(TT, CC, P3, BB, WW)                                                                                        \
     do {                                                                                                                       \
-      if (fit_seq) { if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 0); else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 0); }   \
+      if (fit_rows) hipLaunchKernelGGL((knn_tile2_kernel<16, TT, CC, P3, BB, WW, false, false, 2>), dim3(grid), dim3(TT), 0, stream, b);                 \
+      else if (fit_seq) { if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 0); else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 0); }   \
       else if (k <= 8) PST_TILE2_LAUNCH(8, TT, CC, P3, BB, WW, 1);                                                             \
       else PST_TILE2_LAUNCH(16, TT, CC, P3, BB, WW, 1);                                                                        \
     } while (0)
     const bool fit_seq = t.fit_seq;
+    const bool fit_rows = knn_tuning().fit == 2 && !fit_seq && !knn && !g.rotated;  // (PST_KNN_FIT=rows: the measured alternative, not a default)
     switch (t.tag) {
       case 'D': PST_TILE2_K(512, 3000, false, 4, 4); break;
       case 'G': PST_TILE2_K(256, 1536, false, 4, 4); break;

@@ -2130,6 +2130,39 @@ def test_compute_normals_into_async_is_graph_capturable(hip):
         assert np.max(np.abs(gn.astype(np.float64) - wn)) <= 1e-6 * np.max(np.abs(wn)) and np.all(np.abs(gc - wc) <= 1e-12 * np.maximum(1.0, np.abs(wc)))
 
 
+def test_cross_lane_covariance_agrees_with_the_one_lane_fit(hip):
+    """BASELINE.json configs[4] names a "per-point 3x3 covariance wavefront reduction".  The box search fits one query per LANE (64 queries per wave,
+    every lane busy: the cheaper form on a kernel bound by its instruction count); the cross-lane form -- sixteen lanes per query, DPP row rotations
+    (knn_tile2_kernel FIT 2, PST_KNN_FIT=rows) -- exists to be measured against it (profiles/r05_abab.txt) and must give the same fits: 4 10^6 uniform
+    points, k = 16 and k = 9 (lanes t >= k idle), normals and curvature of every query within 1e-9 relative."""
+    import torch
+    from pasture_amd.algorithms import compute_normals_device, reload_tuning
+    n = 1 << 22
+    src = HashMapBuffer.new_from_layout(PointLayout.from_attributes([A.POSITION_3D], api=hip))
+    src.resize(n)
+    src.synth_fill(78, 0)
+    for k in (16, 9):
+        res = {}
+        try:
+            for fit in ("pivot", "rows"):
+                _os.environ["PST_KNN_FIT"] = fit
+                reload_tuning(hip)
+                nrm = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+                cur = torch.zeros(n, dtype=torch.float64, device="cuda")
+                compute_normals_device(src, k, nrm.data_ptr(), cur.data_ptr(), 0)  # (no neighbour lists: the instance FIT 2 is built for)
+                torch.cuda.synchronize()
+                res[fit] = (nrm, cur)
+        finally:
+            _os.environ.pop("PST_KNN_FIT", None)
+            reload_tuning(hip)
+        (pn, pc), (rn, rc) = res["pivot"], res["rows"]
+        assert bool((pn.norm(dim=1) > 0).all()) and bool((rn.norm(dim=1) > 0).all())
+        rel_n = ((pn - rn).norm(dim=1) / pn.norm(dim=1).clamp_min(1e-300)).max().item()
+        rel_c = ((pc - rc).abs() / pc.abs().clamp_min(1e-300)).max().item()
+        print(f"cross-lane against one-lane covariance, k = {k}, {n} queries: worst relative difference normals {rel_n:.2e}, curvature {rel_c:.2e}")
+        assert rel_n <= 1e-9 and rel_c <= 1e-9, (k, rel_n, rel_c)
+
+
 def test_one_pass_fit_agrees_with_the_reference_order_fit(hip):
     """The box search's two plane fits on the same neighbour lists, 2 10^7 uniform points (a cloud that fills its box takes the one-pass fit by
     default): normals and curvature of EVERY query within 1e-9 relative of the instance that adds in the reference's order (PST_KNN_FIT=seq),

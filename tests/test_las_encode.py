@@ -239,3 +239,57 @@ def test_write_points_custom_layout(api, fmt, src_kind):
     d = BUFFER_KINDS[src_kind].from_numpy(exp, typed)
     _, counts2 = las.write_points(d, fmt, scale, offset, dst)
     assert counts2[:7] == [int((exp[A.RETURN_NUMBER.name()] == r).sum()) for r in range(1, 8)]
+
+
+_DIV_SCALES = [
+    ((0.001, 0.01, 0.1), (500000.0, 5400000.0, 100.0)),
+    ((1.0 / 3.0, 0.0254, 1e-7), (0.0, -12.5, 1e-3)),
+    ((0.125, 3.0, 7.0), (1.0, 2.0, 3.0)),
+    ((0.0009765625 * float(np.nextafter(2.0, 0.0)), 1e-3, 1e-2), (0.0, 0.0, 0.0)),  # a significand of all ones: the division sequence
+    ((-0.01, 2.5e-4, 1.0), (3.0, 3.0, 3.0)),                                            # a negative scale divides like any other
+    ((1e-200, 0.3, 1e150), (0.0, 0.5, 0.0)),                                            # outside the reciprocal form's window
+    ("random", (123.456, -7.0, 0.0)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(_DIV_SCALES)))
+@pytest.mark.parametrize("src_kind", ["V", "H"])
+def test_reciprocal_division_is_the_ieee_quotient(api, case, src_kind, monkeypatch):
+    """write_helpers.rs:15-17: `((p - offset) / scale) as i64` truncates the IEEE quotient.  The HIP encoder forms it from a host-side
+    reciprocal and two fused correction steps (las_encode.hip quotient_by_reciprocal); positions ON the LAS grid sit within an ulp of an
+    integer quotient, where the last bit decides the record.  Adversarial inputs: grid points k * scale + offset over the whole i32 range and
+    their neighbours a few ulps away, against numpy's IEEE division; the HIP path runs both forms (PST_LAS_EXACT_DIV=1 = the division
+    instruction sequence) and both must give these bytes."""
+    typed, raw = layouts(0, api)
+    n = 200_000 + 37
+    rng = np.random.default_rng(1000 + case)
+    scale, offset = _DIV_SCALES[case]
+    if scale == "random":
+        scale = tuple(float(v) for v in rng.uniform(1e-4, 10.0, size=3))
+    rec = random_typed(typed, n, 50 + case)
+    k = np.empty((n, 3), dtype=np.int64)
+    k[: n // 2] = rng.integers(-(2**31) + 8, 2**31 - 8, size=(n // 2, 3))
+    k[n // 2:] = rng.integers(-100000, 100000, size=(n - n // 2, 3))
+    s, o = np.asarray(scale), np.asarray(offset)
+    with np.errstate(over="ignore"):
+        p = k.astype(np.float64) * s + o
+    for step in range(3):  # every fourth point 1, 2, 3 ulps up / down
+        up = np.nextafter(p, np.inf)
+        down = np.nextafter(p, -np.inf)
+        sel = rng.integers(0, 4, size=p.shape)
+        p = np.where(sel == 0, up, np.where(sel == 1, down, p))
+    with np.errstate(over="ignore", invalid="ignore"):
+        local = (p - o) / s
+    ok = np.isfinite(local) & (np.abs(local) < 2147483000.0)
+    p = np.where(ok, p, o)  # (in range only: numpy_encode has no checked narrowing)
+    rec[A.POSITION_3D.name()] = p
+    want = numpy_encode(rec, 0, scale, offset)
+    src = BUFFER_KINDS[src_kind].from_numpy(rec, typed)
+    for exact in ("0", "1"):
+        monkeypatch.setenv("PST_LAS_EXACT_DIV", exact)
+        dst = VectorBuffer.new_from_layout(raw)
+        dst.resize(n)
+        las.encode_points(src, 0, scale, offset, dst)
+        got = raw_bytes(dst)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (exact, bad[:5], p[bad[:5]], got[bad[:5], :12].view("<i4"), want[bad[:5], :12].view("<i4"))
