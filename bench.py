@@ -155,6 +155,20 @@ def _torch_bytes(ptr, nbytes):
     return torch.as_tensor(_Mem(), device="cuda")
 
 
+def _family_report(conv, dst_type, with_bounds):
+    """What the converter measured on this device for plans two kernel families can serve (pst_converter_family_choice): the first call of
+    >= 2^22 points times the LAS-format kernels against the plan-specialised one and keeps the faster -- the choice config.plan then shows."""
+    try:
+        choice, ms = conv.family_choice(dst_type, with_bounds)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    names = {-1: "not measured", 0: "las", 1: "plan-specialised", 2: "one family only"}
+    rep = {"choice": names.get(choice, str(choice))}
+    if choice in (0, 1):
+        rep["ms_per_pass"] = {"las": round(ms[0], 4), "plan-specialised": round(ms[1], 4)}
+    return rep
+
+
 def leg_configs2(pa, las, cv, torch, stream, n, seed):
     """BASELINE.json configs[2]: n typed LAS-0 points (35 B, 10 attributes, packed) VectorBuffer -> HashMapBuffer of 10 columns, 70 B/point,
     HIP events around each of 10 steps.  Returns (report, sample): sample = the first 10^5 points of every column as bytes, for the oracle check."""
@@ -177,13 +191,14 @@ def leg_configs2(pa, las, cv, torch, stream, n, seed):
         e1.record(stream)
     torch.cuda.synchronize()
     kinds = cv.last_plan_kinds()
+    family = _family_report(conv, type(dst), False)
     ms_all = [a.elapsed_time(b) for a, b in ev]
     ms = sum(ms_all) / steps
     gbs = 70 * n / (ms * 1e-3) / 1e9
     m = min(n, 100_000)
     sample = {a.name(): dst.get_attribute_range(a.attribute_definition(), range(0, m)).tobytes() for a in src_layout.attributes()}
     report = {"points": n, "steps": steps, "ms_per_step": round(ms, 4), "ms_per_step_min": round(min(ms_all), 4), "value": round(n / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s",
-              "algorithmic_bytes_per_point": 70, "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "plan": kinds, "plan_prepared": plan,
+              "algorithmic_bytes_per_point": 70, "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "plan": kinds, "plan_prepared": plan, "family_measured": family,
               "note": "BASELINE.json configs[2]: typed LAS-0 records (35 B, 10 attributes) VectorBuffer -> 10 columns HashMapBuffer, 35 R + 35 W per point; HIP events "
                       "around each of 10 steps after the timed region of the headline"}
     return report, {"points": m, "seed": seed, "columns": sample}
@@ -840,6 +855,10 @@ def main():
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
     # which kernel families the last step's conversion / compaction call launched, as the library reports it (pst_last_plan_kinds)
     plan_kinds = cv.last_plan_kinds() if (conv is not None or args.workload.startswith("filter_")) else None
+    family_rep = None
+    _src, _dst = locals().get("src"), locals().get("dst")
+    if conv is not None and _dst is not None and getattr(_src, "_storage", None) == pa.VectorBuffer._storage and hasattr(conv, "family_choice"):
+        family_rep = _family_report(conv, type(_dst), has_reduction)
     if after is not None:
         after()  # (a workload's own check of what its stream-ordered steps left behind; outside the timed region)
     per_rank = None
@@ -1038,7 +1057,8 @@ def main():
                        "layout": "columnar Vec3f64" if args.workload in ("convert_affine_bounds", "bounds", "narrow_f64_f32", "normals_knn16", "normals_knn16_sheet") else "LAS format 0",
                        "parallelism": (f"index-range shard x{world} of one {global_points}-point cloud (configs[3]), one all-reduce of the 6-f64 AABB" if args.global_points
                                        else f"index-range shard x{world}, one all-reduce of the 6-f64 AABB") if distributed else "1 GPU",
-                       "seed": SEED, "bounds": result, "plan": plan_kinds, "plan_requested": args.plan},
+                       "seed": SEED, "bounds": result, "plan": plan_kinds, "plan_requested": args.plan,
+                       **({"family_measured": family_rep} if family_rep is not None else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_point": bytes_per_point, "kernel_ms_avg": round(kernel_ms_avg, 4),

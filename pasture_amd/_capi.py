@@ -167,6 +167,7 @@ _PRODUCT_SIGNATURES = {
     "bounds_allreduce_multi": [_P, _PP, _PP],
     "last_plan_kinds": [C.POINTER(C.c_uint32)],
     "converter_prepare": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)],
+    "converter_family_choice": [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     "converter_jit_source": [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _SZ, C.POINTER(_SZ)],
     "jit_compile_source": [C.c_char_p, _P, _SZ, C.POINTER(_SZ), C.c_char_p, _SZ],
     "jit_get_stats": [C.POINTER(JitStatsStruct)],

@@ -232,6 +232,14 @@ class BufferLayoutConverter:
                                    1 if target_type._storage == HashMapBuffer._storage else 0, 1 if with_bounds else 0, C.byref(kind))
         return kind.value
 
+    def family_choice(self, target_type: Type[_Buffer], with_bounds: bool = False):
+        """Which of the two kernel families that can serve an interleaved LAS-shaped plan this converter measured to be the faster one on this
+        device (first conversion of at least 2^22 points): (choice, (ms LAS family, ms plan-specialised)); choice -1 = not measured yet,
+        0 = LAS family, 1 = plan-specialised, 2 = the plan has one family only."""
+        choice, ms = C.c_int(), (C.c_float * 2)()
+        self.api.converter_family_choice(self._h, 1 if target_type._storage == HashMapBuffer._storage else 0, 1 if with_bounds else 0, C.byref(choice), ms)
+        return choice.value, (ms[0], ms[1])
+
     def jit_source(self, source_type: Type[_Buffer], target_type: Type[_Buffer], with_bounds: bool = False) -> str:
         """The translation unit the run-time compiler is handed for this converter and storage pairing ('' if another family serves it)."""
         need = C.c_size_t()

@@ -85,6 +85,12 @@ struct pst_converter {
   // (atomics: two threads may share one converter, each on its own stream; both compute the same value, either store wins)
   mutable std::atomic<int> las_decode_format{-2};
   mutable std::atomic<int> identity_records{-2};
+  // Which kernel family a conversion of LAS-shaped interleaved records takes when TWO are at hand -- the format-specialised LAS kernels
+  // (las_transpose.hip / las_decode.hip) or the plan-specialised quad kernel (convert_static.hip / hipRTC) -- is MEASURED, once per converter and
+  // target storage, on the first call of at least 2^22 points (convert_range: family_autotune): the two trade places from box to box by +-5 %
+  // (round-4 review, item 6).  [dst columnar][with bounds]: -1 not measured, 0 = LAS family, 1 = plan-specialised, 2 = nothing to choose.
+  mutable std::atomic<int> family_choice[2][2] = {{{-1}, {-1}}, {{-1}, {-1}}};
+  mutable std::atomic<float> family_ms[2][2][2] = {};  // [dst columnar][with bounds][family]: what the measurement saw (pst_converter_family_choice)
   mutable std::atomic<int> las_typed_format{-2};  // -2 not examined, -1 no, 0..10: identity plan over LasPointFormatN::layout() (las_transpose.hip)  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
 };
 
@@ -231,16 +237,17 @@ static std::vector<PlanEntry> interleaved_source_entries(const pst_converter& c,
   }
   return out;
 }
+// force_family: -1 = by the converter's measured choice (default: plan-specialised), 0 = the LAS family, 1 = plan-specialised if at hand
 static bool las_plan_prefers_generic(const pst_converter& c, const pst_buffer& src, size_t s0, const pst_buffer& dst, size_t t0, uint64_t n, int pos_slot,
-                                     bool with_bounds) {
+                                     bool with_bounds, int force_family) {
   static const bool on = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();  // the A/B switch
-  if (!on || src.columnar) return false;
+  if (!on || src.columnar || force_family == 0) return false;
+  if (force_family < 0 && c.family_choice[dst.columnar ? 1 : 0][with_bounds ? 1 : 0] == 0) return false;
   const std::vector<PlanEntry> entries = interleaved_source_entries(c, &dst, t0, dst.columnar, pos_slot, with_bounds);
   if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES) return false;
   return specialised_kernel_ready(true, aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar, dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, entries,
                                   with_bounds);
 }
-
 static bool match_identity_records(const pst_converter& c) {
   if (!(c.from == c.to) || c.mappings.size() != c.to.members.size()) return false;
   uint64_t covered = 0;
@@ -294,11 +301,60 @@ static int match_las_decode_plan(const pst_converter& c) {
   return format;
 }
 
+static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1, double* bounds_out6, hipStream_t stream,
+                          int force_family = -1);
+
+// The measurement behind pst_converter::family_choice.  Runs on the caller's buffers and range (both families write the same bytes, the source is
+// only read): per family one untimed pass and two timed ones between HIP events on the caller's stream, then ONE host wait.  Skipped (and left
+// for a later call) while the stream is being captured into a graph, below 2^22 points, and when the plan-specialised kernel is not compiled
+// yet.  PST_FAMILY_AUTOTUNE=0 switches it off (the default order of preference then stands: plan-specialised first).
+static void family_autotune(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1, double* bounds_out6, hipStream_t stream) {
+  static const bool on = [] { const char* v = std::getenv("PST_FAMILY_AUTOTUNE"); return !(v && *v == '0'); }();
+  const uint64_t n = s1 - s0;
+  std::atomic<int>& choice = c.family_choice[dst.columnar ? 1 : 0][bounds_out6 ? 1 : 0];
+  if (!on || choice != -1 || n < ((uint64_t)1 << 22) || src.columnar || &src == &dst) return;
+  // is this one of the two LAS-shaped plans at all?
+  if (c.las_typed_format == -2) {
+    int f = -1;
+    if (match_identity_records(c))
+      for (uint32_t k = 0; k <= 10; ++k)
+        if (c.to == laslayout::typed_layout(k)) { f = (int)k; break; }
+    c.las_typed_format = f;
+  }
+  if (c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
+  const bool las_shaped = dst.columnar ? c.las_typed_format >= 0 : c.las_decode_format >= 0;
+  if (!las_shaped) { choice = 2; return; }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+  int pos_slot = -1;
+  if (bounds_out6) { const Member* pm = c.to.find_by_name("Position3D"); if (!pm) return; pos_slot = (int)(pm - c.to.members.data()); }
+  if (!las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, 1)) return;  // (not compiled yet: queued; measured on a later call)
+  hipEvent_t ev[4] = {};
+  bool ok = true;
+  for (hipEvent_t& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+  float ms[2] = {0.f, 0.f};
+  if (ok) {
+    for (int fam = 0; fam < 2; ++fam) {
+      convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
+      ok = ok && hipEventRecord(ev[2 * fam], stream) == hipSuccess;
+      convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
+      convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
+      ok = ok && hipEventRecord(ev[2 * fam + 1], stream) == hipSuccess;
+    }
+    ok = ok && hipEventSynchronize(ev[3]) == hipSuccess;
+    for (int fam = 0; fam < 2 && ok; ++fam) ok = hipEventElapsedTime(&ms[fam], ev[2 * fam], ev[2 * fam + 1]) == hipSuccess;
+  }
+  for (hipEvent_t& e : ev) if (e) (void)hipEventDestroy(e);
+  if (!ok) { (void)hipGetLastError(); return; }
+  for (int fam = 0; fam < 2; ++fam) c.family_ms[dst.columnar ? 1 : 0][bounds_out6 ? 1 : 0][fam] = 0.5f * ms[fam];
+  choice = ms[1] <= ms[0] ? 1 : 0;
+}
+
 // ---- convert_into_range, buffer_conversion.rs:292-359 -----------------------------------------------------
 // bounds_out6: when non-null, {min xyz, max xyz} of the TARGET's POSITION_3D over the target range is written there
 // (device-accessible memory), fused into the conversion pass when possible.
 static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1,
-                          double* bounds_out6, hipStream_t stream) {
+                          double* bounds_out6, hipStream_t stream, int force_family) {
   if (src.layout != c.from) throw Error(PST_ERR_LAYOUT_MISMATCH, "assertion `left == right` failed: source_buffer.point_layout() != from_layout");
   if (dst.layout != c.to) throw Error(PST_ERR_LAYOUT_MISMATCH, "assertion `left == right` failed: target_buffer.point_layout() != to_layout");
   if (s1 < s0 || t1 < t0 || (s1 - s0) != (t1 - t0)) throw Error(PST_ERR_RANGE, "assertion failed: source_range.len() == target_range.len()");
@@ -306,6 +362,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   if (t1 > dst.len) throw Error(PST_ERR_RANGE, "assertion failed: target_range.end <= target_buffer.len()");
   const uint64_t n = s1 - s0;
   ensure_device();
+  if (force_family < 0) family_autotune(c, src, s0, s1, dst, t0, t1, bounds_out6, stream);
   pstk::reset_plan_kinds();
 
   // position attribute of the target for the fused / trailing bounds
@@ -339,7 +396,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
         for (uint32_t f = 0; f <= 10; ++f)
           if (c.to == laslayout::typed_layout(f)) { c.las_typed_format = (int)f; break; }
     }
-    if (c.las_typed_format >= 0 && !(!src.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr))) {
+    if (c.las_typed_format >= 0 && !(!src.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, force_family))) {
       // typed LAS points, columns <-> packed records: format-specialised transposition
       const pst_buffer& soa = src.columnar ? src : dst;
       const size_t p0 = src.columnar ? s0 : t0;
@@ -358,7 +415,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   std::vector<PlanEntry> generic;
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
   if (las_fast && n > 0 && !src.columnar && c.las_decode_format >= 0 &&
-      !(!dst.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr))) {
+      !(!dst.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, force_family))) {
     // the production plan of the LAS readers: format-specialised kernel (las_decode.hip)
     const Mapping* pos = nullptr;
     for (const Mapping& m : c.mappings)
@@ -646,6 +703,14 @@ int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_colu
     else if (!err.empty() && err.find("not eligible") == std::string::npos && err != "PST_JIT=0") set_last_error(err);
   }
   if (plan_kind) *plan_kind = kind;
+  PST_API_END
+}
+int pst_converter_family_choice(const pst_converter* c, int dst_columnar, int with_bounds, int* choice, float ms2[2]) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  const int d = dst_columnar ? 1 : 0, b = with_bounds ? 1 : 0;
+  *not_null(choice, "choice") = c->family_choice[d][b];
+  if (ms2) { ms2[0] = c->family_ms[d][b][0]; ms2[1] = c->family_ms[d][b][1]; }
   PST_API_END
 }
 // The translation unit the run-time compiler is given for this converter and storage pairing (empty when the plan takes another family).

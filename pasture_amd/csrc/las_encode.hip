@@ -47,8 +47,9 @@ struct EncodeArgs {
   uint32_t tile;                    // points per tile (multiple of kBlock)
 };
 
-// a / b for a divisor that is the same for every point, WITHOUT the division sequence (v_div_scale, the quarter-rate v_rcp_f64, six fused
-// multiply-adds, v_div_fmas, v_div_fixup: a third of this kernel's vector instructions, round-4 review item 7) and still the CORRECTLY ROUNDED
+// (An alternative, OFF by default -- see las_encode_fast_div_allowed: built on the round-4 review's suggestion, proven and tested, and measured
+// to change nothing.)  a / b for a divisor that is the same for every point, WITHOUT the division sequence (v_div_scale, the quarter-rate
+// v_rcp_f64, six fused multiply-adds, v_div_fmas, v_div_fixup: a third of this kernel's vector instructions) and still the CORRECTLY ROUNDED
 // quotient, which the record needs bit for bit: LAS positions are multiples of the scale, so (p - offset) / scale sits within an ulp of an integer
 // for nearly every point and the truncation of write_helpers.rs:15-17 sees the last bit.
 //   y = RN(1 / b) (host, one IEEE division);  q0 = RN(a y)  -- relative error <= 2^-52 (1 + 2^-53), up to two ulps;
@@ -399,9 +400,13 @@ uint32_t las_raw_record_size(int format) { return raw_size(fmt_of(format)); }
 // attr_base / attr_stride: typed attributes in LasPointFormatN field order.  out_bounds (6 doubles) and out_counts (16 u64)
 // are device-accessible.  workspace must hold las_encode_workspace_bytes().
 constexpr uint32_t kMaxGrid = 16384, kFoldGrid = 64;
-static bool las_encode_fast_div_allowed() {  // PST_LAS_EXACT_DIV=1: the division instruction sequence for every launch (A/B, and the parity test's other side)
-  const char* e = std::getenv("PST_LAS_EXACT_DIV");
-  return !(e && e[0] == '1');
+// PST_LAS_RECIPROCAL_DIV=1 selects quotient_by_reciprocal (read per launch: the parity test runs both forms in one process).  OFF by default:
+// measured on the quad path (10^8 LAS-0 points, 8 interleaved pairs, profiles/r05_abab.txt) the two forms are indistinguishable -- 0.941 ms with
+// the division sequence, 0.967 ms with the reciprocal, IQRs overlapping --: the encoder is bound by LDS / vector-memory issue (r04_sq_cycles.txt),
+// not by its vector arithmetic, so the form that needs no proof stays the default.
+static bool las_encode_fast_div_allowed() {
+  const char* e = std::getenv("PST_LAS_RECIPROCAL_DIV");
+  return e && e[0] == '1';
 }
 size_t las_encode_workspace_bytes() { return (size_t)(kMaxGrid + kFoldGrid) * (6 * sizeof(double) + kReturnSlots * sizeof(unsigned long long)); }
 

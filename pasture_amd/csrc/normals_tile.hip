@@ -43,6 +43,12 @@ using namespace pstn;
 namespace {
 
 // step / candidate statistics of the search (a build with -DPST_KNN_STATS prints them per launch; off: the counters cost registers)
+// -DPST_KNN_MARKS (analysis builds only, tools/knn_phase_budget.py): comment lines in the assembly that delimit the phases of knn_tile2_kernel
+#ifdef PST_KNN_MARKS
+#define PST_KNN_MARK(name) asm volatile("; PSTMARK " name)
+#else
+#define PST_KNN_MARK(name)
+#endif
 #ifdef PST_KNN_STATS
 #define PST_KNN_STAT(...) __VA_ARGS__
 #else
@@ -712,6 +718,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     }
   }
   __syncthreads();  // (4) points staged
+  PST_KNN_MARK("staged");
   PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 8, (unsigned long long)(clock64() - t_start));)
   const float* Rx = R3;
   const float* Ry = R3 + CS;
@@ -728,6 +735,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     if (lane == 0) c0 = atomicAdd(&s_next, 64u);
     c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
     if (c0 >= Q) break;
+    PST_KNN_MARK("chunk_begin");
     const uint32_t q = c0 + lane;
     const bool active = q < Q;
     PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 2, 1ull);)
@@ -790,7 +798,9 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       uint32_t p0 = qbuf[tid];
       uint32_t p1 = qbuf[THREADS + tid];
       float x0 = Rx[p0], y0 = Ry[p0], z0 = Rz[p0];
+      PST_KNN_MARK("flush_loop_begin");
       for (uint32_t i = 0; i < qmax; ++i) {
+        PST_KNN_MARK("flush_iter");
         const bool has = i < qn;
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 1, 1ull);)
         const uint32_t p2 = qbuf[(i + 2 < (uint32_t)kQ ? i + 2 : (uint32_t)kQ - 1u) * THREADS + tid];
@@ -806,7 +816,9 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         key = has ? key : 0xFFFFFFFFu;
         best.insert(key);
         p0 = p1; p1 = p2; x0 = x1; y0 = y1; z0 = z1;
+        PST_KNN_MARK("flush_iter_end");
       }
+      PST_KNN_MARK("flush_loop_end");
       qaddr = qbase;
       // every later candidate that could still enter the list has an f32 distance below the upper edge of the last key's bin
       const uint32_t kl = best.key[K];
@@ -835,7 +847,9 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     PST_KNN_STAT(const long long t_scan = clock64(); if (lane == 0) atomicAdd(a.dbg + 9, (unsigned long long)(t_scan - t_chunk));)
     uint32_t left = kSegs;
     uint32_t p = 0, pe = 0;
+    PST_KNN_MARK("scan_loop_begin");
     for (;;) {
+      PST_KNN_MARK("step_head");
       // ONE shift of the segment table per step, written as selects (a branch made the compiler copy the table at the loop's latch):
       // a lane that drew an empty range idles this step and draws again in the next
       {
@@ -854,6 +868,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
         PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(scan ? BATCH : 0));)
         if (scan) {  // ONE predicate per step; inside, nothing branches and the execution mask stays put
+          PST_KNN_MARK("step_body");
           f2v cxs[BATCH / 2], cys[BATCH / 2], czs[BATCH / 2];
 #pragma unroll
           for (int u = 0; u < BATCH / 2; ++u) {
@@ -879,9 +894,11 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           }
           const uint32_t pn = p + (uint32_t)BATCH;
           p = pn < pe ? pn : pe;
+          PST_KNN_MARK("step_body_end");
         }
       } else {
         PST_KNN_STAT(const long long t_f0 = clock64();)
+        PST_KNN_STAT(if (lane == 0 && __builtin_amdgcn_ballot_w64(qaddr != qbase)) atomicAdd(a.dbg + 7, 1ull);)
         if (__builtin_amdgcn_ballot_w64(qaddr != qbase)) flush();  // ONE inlined copy of the insertion code
         PST_KNN_STAT(t_flush += clock64() - t_f0;)
         if (!__builtin_amdgcn_ballot_w64(p < pe || left != 0u)) break;
@@ -899,6 +916,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     // The k-th exact distance must also lie below tau0 (the 3 x 3 rows cover that radius): its bin's upper edge + eps < tau0 * s2.
     bool ok;
     uint32_t nb[K];
+    PST_KNN_MARK("proof_begin");
     {
       const uint32_t kk = a.k;
       uint32_t amb = 0;  // bit t: the pair (t, t + 1) is closer than `gap`
@@ -945,6 +963,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         }
       }
     }
+    PST_KNN_MARK("proof_end");
     const bool done = a.ablate ? true : !outside && ok;
     PST_KNN_STAT(if (active && !outside && !ok) atomicAdd(a.dbg + 5, 1ull);)
     if (active && !done) a.fb_list[atomicAdd(a.fb_count, 1u)] = j;
@@ -1001,6 +1020,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           write_knn(a.out, orig, a.k, t, v);
         }
       }
+      PST_KNN_MARK("fit_begin");
       Fit f{0, 0, 0, 0, 1};
       bool handed = false;
       if constexpr (FIT == 2) {
@@ -1055,7 +1075,9 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
           exact_xyz(pl, x, y, z);
         });
       }
+      PST_KNN_MARK("fit_end");
       if (!handed) write_record(a.out, orig, f);
+      PST_KNN_MARK("results_end");
     }
     PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
   }
@@ -1489,6 +1511,8 @@ void launch_knn_tile(const TileShape& t, const double* sxyz, const uint32_t* cel
                 t.tag, 100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot, 100.0 * h[13] / tot,
                 100.0 * (tot - (double)(h[8] + h[9] + h[10] + h[11] + h[12] + h[13])) / tot, tot / 1000.0 / (double)(h[2] ? h[2] : 1));
       }
+      fprintf(stderr, "[pst knn tile2 %c] boxes %u (%.1f query waves per box, %u waves per workgroup); insertion rounds %.2f per query wave\n", t.tag, a.n_boxes,
+              (double)h[2] / (double)(a.n_boxes ? a.n_boxes : 1), t.threads / 64u, (double)h[7] / (double)(h[2] ? h[2] : 1));
       fprintf(stderr, "[pst knn tile2 %c] query waves %llu: scan steps %.1f, insertion steps %.1f per wave; slots tested %.1f, queued %.1f per query; %.4f %% failed the proof; %.4f %% handed to the exact search by the fit's conditioning guard; eps %.2f\n",
               t.tag, h[2], (double)h[0] / (double)(h[2] ? h[2] : 1), (double)h[1] / (double)(h[2] ? h[2] : 1), (double)h[3] / (double)nf, (double)h[4] / (double)nf,
               100.0 * (double)h[5] / (double)nf, 100.0 * (double)h[6] / (double)nf, eps);

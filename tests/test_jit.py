@@ -579,3 +579,60 @@ def test_in_place_transform_on_packed_records_takes_the_specialised_kernel(hip, 
             assert "jit" in cv.last_plan_kinds(hip) or "static" in cv.last_plan_kinds(hip), cv.last_plan_kinds(hip)
         out[name] = buf.get_point_range(range(0, n))
     assert np.array_equal(out["hip"], out["oracle"])
+
+
+@pytest.mark.gpu
+def test_family_autotune_measures_once_and_changes_no_byte(hip):
+    """Round-4 review, item 6: two kernel families can serve interleaved LAS-shaped plans and trade places from box to box.  The converter
+    measures them on the first conversion of >= 2^22 points (pst_converter_family_choice) and keeps the winner: the choice is one of the two,
+    both timings are positive, the call after it takes the chosen family, smaller calls and plans with one family do not measure, and the
+    converted bytes are the source's fields whichever family ran."""
+    from pasture_amd import conversion as cv
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    n = (1 << 22) + 5
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True, api=hip)
+    # (a) typed LAS-0 records -> 10 columns
+    src = VectorBuffer.new_from_layout(typed)
+    src.resize(n)
+    src.synth_fill(5, 0)
+    dst = HashMapBuffer.new_from_layout(typed)
+    dst.resize(n)
+    conv = BufferLayoutConverter.for_layouts(typed, typed)
+    conv.prepare(VectorBuffer, HashMapBuffer)
+    assert conv.family_choice(HashMapBuffer)[0] == -1
+    conv.convert_into_range(src, range(0, 1000), dst, range(0, 1000))  # below 2^22 points: no measurement
+    assert conv.family_choice(HashMapBuffer)[0] == -1
+    conv.convert_into(src, dst)
+    choice, ms = conv.family_choice(HashMapBuffer)
+    assert choice in (0, 1) and ms[0] > 0 and ms[1] > 0, (choice, ms)
+    kinds = cv.last_plan_kinds(hip)
+    assert kinds == (["las-specialised"] if choice == 0 else ["static"]), (choice, kinds)
+    m = 50_000
+    for lo in (0, n - m):
+        rec = src.get_point_range(range(lo, lo + m)).reshape(-1).view(typed.numpy_record_dtype())
+        for a in typed.attributes():
+            assert np.array_equal(dst.get_attribute_range(a.attribute_definition(), range(lo, lo + m)), rec[a.name()]), a.name()
+    conv.convert_into(src, dst)
+    assert conv.family_choice(HashMapBuffer)[0] == choice and cv.last_plan_kinds(hip) == kinds
+    assert conv.family_choice(VectorBuffer)[0] == -1  # (per target storage)
+    # (b) raw LAS-0 records -> typed records: the decoder against the plan-specialised kernel
+    rsrc = VectorBuffer.new_from_layout(raw)
+    rsrc.resize(n)
+    rsrc.synth_fill(6, 0)
+    rdst = VectorBuffer.new_from_layout(typed)
+    rdst.resize(n)
+    rconv = las.get_default_las_converter(raw, typed, (0.001, 0.001, 0.001), (5.0, 6.0, 7.0))
+    rconv.prepare(VectorBuffer, VectorBuffer)
+    rconv.convert_into(rsrc, rdst)
+    rchoice, rms = rconv.family_choice(VectorBuffer)
+    assert rchoice in (0, 1) and rms[0] > 0 and rms[1] > 0, (rchoice, rms)
+    want = VectorBuffer.new_from_layout(typed)
+    want.resize(m)
+    rconv.convert_into_range(rsrc, range(n - m, n), want, range(0, m))  # small call: not measured, default order of preference
+    assert np.array_equal(rdst.get_point_range(range(n - m, n)), want.get_point_range(range(0, m)))
+    # (c) a plan with one family only: raw records -> columns always takes the LAS decoder
+    cdst = HashMapBuffer.new_from_layout(typed)
+    cdst.resize(n)
+    rconv.convert_into(rsrc, cdst)
+    assert rconv.family_choice(HashMapBuffer)[0] == 2

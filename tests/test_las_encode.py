@@ -258,8 +258,8 @@ def test_reciprocal_division_is_the_ieee_quotient(api, case, src_kind, monkeypat
     """write_helpers.rs:15-17: `((p - offset) / scale) as i64` truncates the IEEE quotient.  The HIP encoder forms it from a host-side
     reciprocal and two fused correction steps (las_encode.hip quotient_by_reciprocal); positions ON the LAS grid sit within an ulp of an
     integer quotient, where the last bit decides the record.  Adversarial inputs: grid points k * scale + offset over the whole i32 range and
-    their neighbours a few ulps away, against numpy's IEEE division; the HIP path runs both forms (PST_LAS_EXACT_DIV=1 = the division
-    instruction sequence) and both must give these bytes."""
+    their neighbours a few ulps away, against numpy's IEEE division; the HIP path runs both forms (the division instruction sequence = the
+    default, and PST_LAS_RECIPROCAL_DIV=1 = host reciprocal + two fused correction steps) and both must give these bytes."""
     typed, raw = layouts(0, api)
     n = 200_000 + 37
     rng = np.random.default_rng(1000 + case)
@@ -286,7 +286,7 @@ def test_reciprocal_division_is_the_ieee_quotient(api, case, src_kind, monkeypat
     want = numpy_encode(rec, 0, scale, offset)
     src = BUFFER_KINDS[src_kind].from_numpy(rec, typed)
     for exact in ("0", "1"):
-        monkeypatch.setenv("PST_LAS_EXACT_DIV", exact)
+        monkeypatch.setenv("PST_LAS_RECIPROCAL_DIV", exact)
         dst = VectorBuffer.new_from_layout(raw)
         dst.resize(n)
         las.encode_points(src, 0, scale, offset, dst)

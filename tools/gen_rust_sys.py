@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 hdr = open(os.path.join(ROOT, "include", "pasture_amd.h")).read()
 hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
 
-TYPES = {"int": "c_int", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "int64_t": "i64", "void": "c_void",
+TYPES = {"int": "c_int", "uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64", "float": "f32", "int64_t": "i64", "void": "c_void",
          "char": "c_char", "pst_layout": "pst_layout", "pst_buffer": "pst_buffer", "pst_converter": "pst_converter",
          "pst_datatype": "pst_datatype", "pst_member": "pst_member", "pst_transform": "pst_transform", "pst_mapping_info": "pst_mapping_info",
          "pst_point_converter": "pst_point_converter", "pst_comm": "pst_comm", "pst_comm_id": "pst_comm_id", "pst_jit_stats": "pst_jit_stats", "pst_voxel_plan": "pst_voxel_plan", "pst_normals_plan": "pst_normals_plan"}
