@@ -208,6 +208,9 @@ int pst_buffer_filter(const pst_buffer* src, const uint8_t* mask, uint32_t mask_
  *                     attribute may give three, `x-expr ; y-expr ; z-expr`.  The result is converted to T's component type with Rust `as`.
  *   predicates:       every attribute of the buffer's layout whose name is a C identifier -- scalars by value, Vec3 as .x .y .z --, i, p0 .. p3:
  *                     "Classification == 2 && Position3D.z < 120.0".
+ * Results are those of the same arithmetic on the host, bit for bit, EXCEPT which NaN an operation returns: sign and payload of a NaN result
+ * are unspecified in Rust and differ between gfx950 and x86 (`y - z` with a NaN z: the GPU evaluates y + (-z) and returns the NaN with its sign
+ * flipped); a NaN is a NaN on both.
  * Scalar and Vec3 attributes only.  A text that does not compile is PST_ERR_UNSUPPORTED_TRANSFORM with the compiler's log in pst_last_error;
  * PST_JIT=0 (no run-time compiler) makes every expression PST_ERR_UNSUPPORTED_TRANSFORM.  The closed descriptors (pst_transform) remain the
  * fast path for the in-tree callers' closures; an expression mapping is its own strided launch. */

@@ -49,6 +49,9 @@ namespace {
 #else
 #define PST_KNN_MARK(name)
 #endif
+// (knn_tile2_kernel's counters are added by lane ONE: a trailing `if (lane == 0) <global store>` at the chunk loop's latch, next to the hand-out's
+//  `if (lane == 0) atomicAdd(&s_next, ...)` at its head, makes this toolchain emit a loop that hands the same chunks out again and again -- the
+//  fallback list overflows and the kernel faults; found in round 5 with three probe builds, tools/README.md)
 #ifdef PST_KNN_STATS
 #define PST_KNN_STAT(...) __VA_ARGS__
 #else
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
   }
   __syncthreads();  // (4) points staged
   PST_KNN_MARK("staged");
-  PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 8, (unsigned long long)(clock64() - t_start));)
+  PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg + 8, (unsigned long long)(clock64() - t_start));)
   const float* Rx = R3;
   const float* Ry = R3 + CS;
   const float* Rz = R3 + 2 * CS;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     PST_KNN_MARK("chunk_begin");
     const uint32_t q = c0 + lane;
     const bool active = q < Q;
-    PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 2, 1ull);)
+    PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg + 2, 1ull);)
     PST_KNN_STAT(const long long t_chunk = clock64(); t_flush = 0;)
     int qr = 0;
     {
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       for (uint32_t i = 0; i < qmax; ++i) {
         PST_KNN_MARK("flush_iter");
         const bool has = i < qn;
-        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 1, 1ull);)
+        PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg + 1, 1ull);)
         const uint32_t p2 = qbuf[(i + 2 < (uint32_t)kQ ? i + 2 : (uint32_t)kQ - 1u) * THREADS + tid];
         const float x1 = Rx[p1], y1 = Ry[p1], z1 = Rz[p1];
         // the same three operations, in the same order, as the scan's packed ones: the same value
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       }
     }
     const f2v qx2 = {rqx, rqx}, qy2 = {rqy, rqy}, qz2 = {rqz, rqz};
-    PST_KNN_STAT(const long long t_scan = clock64(); if (lane == 0) atomicAdd(a.dbg + 9, (unsigned long long)(t_scan - t_chunk));)
+    PST_KNN_STAT(const long long t_scan = clock64(); if (lane == 1) atomicAdd(a.dbg + 9, (unsigned long long)(t_scan - t_chunk));)
     uint32_t left = kSegs;
     uint32_t p = 0, pe = 0;
     PST_KNN_MARK("scan_loop_begin");
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       const bool scan = p < pe && room;
       const uint64_t can = __builtin_amdgcn_ballot_w64(scan || (p >= pe && left != 0u)), waiting = __builtin_amdgcn_ballot_w64(p < pe && !room);
       if (can != 0 && !(waiting != 0 && (uint32_t)__builtin_popcountll(can) <= a.flush_at)) {
-        PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(scan ? BATCH : 0));)
+        PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg, 1ull); atomicAdd(a.dbg + 3, (unsigned long long)(scan ? BATCH : 0));)
         if (scan) {  // ONE predicate per step; inside, nothing branches and the execution mask stays put
           PST_KNN_MARK("step_body");
           f2v cxs[BATCH / 2], cys[BATCH / 2], czs[BATCH / 2];
@@ -898,13 +901,13 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         }
       } else {
         PST_KNN_STAT(const long long t_f0 = clock64();)
-        PST_KNN_STAT(if (lane == 0 && __builtin_amdgcn_ballot_w64(qaddr != qbase)) atomicAdd(a.dbg + 7, 1ull);)
+        PST_KNN_STAT(if (lane == 1 && __builtin_amdgcn_ballot_w64(qaddr != qbase)) atomicAdd(a.dbg + 7, 1ull);)
         if (__builtin_amdgcn_ballot_w64(qaddr != qbase)) flush();  // ONE inlined copy of the insertion code
         PST_KNN_STAT(t_flush += clock64() - t_f0;)
         if (!__builtin_amdgcn_ballot_w64(p < pe || left != 0u)) break;
       }
     }
-    PST_KNN_STAT(const long long t_proof = clock64(); if (lane == 0) { atomicAdd(a.dbg + 10, (unsigned long long)(t_proof - t_scan - t_flush)); atomicAdd(a.dbg + 11, (unsigned long long)t_flush); })
+    PST_KNN_STAT(const long long t_proof = clock64(); if (lane == 1) { atomicAdd(a.dbg + 10, (unsigned long long)(t_proof - t_scan - t_flush)); atomicAdd(a.dbg + 11, (unsigned long long)t_flush); })
     // ---- the proof ------------------------------------------------------------------------------------------------------------
     // Keys ascend.  F = key >> SLOT_BITS is the candidate's f32 squared distance in bins of `unit` key units, and the exact squared
     // distance (times s2) lies within eps of the f32 one.  Two entries whose bins are at least `gap` = floor(1 + 2 eps / unit) + 1
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
     // (the original index is requested here, together with the neighbours' coordinates: a load left in flight across the scan loop is
     //  waited for at the loop's head, and this one comes from HBM)
     const uint32_t orig = active && done ? a.out.sidx[j] : 0u;
-    PST_KNN_STAT(const long long t_fit = clock64(); if (lane == 0) atomicAdd(a.dbg + 12, (unsigned long long)(t_fit - t_proof));)
+    PST_KNN_STAT(const long long t_fit = clock64(); if (lane == 1) atomicAdd(a.dbg + 12, (unsigned long long)(t_fit - t_proof));)
     // FIT 2: sixteen rounds; in round r the sixteen lanes of row g serve the query of lane 16 g + r (same row: the owner keeps its own lane's
     // totals), lane t of the row fetching neighbour t.  The lists cross the lanes through the candidate queue's LDS (free after the search).
     // Per round: 1 LDS read + 1 ds_bpermute (the owner's slot) + 2 gathers of 24 bytes + 3 subtractions + 6 products + 6 selects (lanes t >= m)
@@ -1079,9 +1082,9 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
       if (!handed) write_record(a.out, orig, f);
       PST_KNN_MARK("results_end");
     }
-    PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
+    PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg + 13, (unsigned long long)(clock64() - t_fit));)
   }
-  PST_KNN_STAT(if (lane == 0) atomicAdd(a.dbg + 14, (unsigned long long)(clock64() - t_start));)
+  PST_KNN_STAT(if (lane == 1) atomicAdd(a.dbg + 14, (unsigned long long)(clock64() - t_start));)
 }
 
 // ---- density probe: how many points does a ball of radius h (and h / 2) around a typical point hold? ---------------------------------

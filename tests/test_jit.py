@@ -287,6 +287,9 @@ def test_specialised_conversions_vs_oracle(hip, oracle, jit_sync, seed):
     n = int(rng.choice([256, 257, 1000, 4099, 20_011, 70_001]))
     aligned = bool(rng.random() < 0.75)
     kinds = [("V", "H"), ("H", "V"), ("V", "V")][seed % 3]
+    if test_specialised_conversions_vs_oracle.failures_before is None:
+        # (texts that are MEANT not to compile -- tests/test_expressions.py -- count as failures of the run-time compiler too, and run before this module)
+        test_specialised_conversions_vs_oracle.failures_before = cv.jit_stats(hip)["failures"]
     h, plan = _run_case(hip, 99000 + seed, n, aligned, kinds, True)
     o, _ = _run_case(oracle, 99000 + seed, n, aligned, kinds, False)
     assert_same_columns(h, o)
@@ -294,6 +297,7 @@ def test_specialised_conversions_vs_oracle(hip, oracle, jit_sync, seed):
 
 
 test_specialised_conversions_vs_oracle.plans = []
+test_specialised_conversions_vs_oracle.failures_before = None
 
 
 @pytest.mark.gpu
@@ -305,7 +309,7 @@ def test_specialised_kernels_were_taken(hip):
     taken = sum(1 for p in plans if "jit" in p)
     assert taken >= len(plans) // 3, (taken, len(plans))
     st = cv.jit_stats(hip)
-    assert st["failures"] == 0 and st["compiled"] + st["disk_hits"] >= taken // 2
+    assert st["failures"] == test_specialised_conversions_vs_oracle.failures_before and st["compiled"] + st["disk_hits"] >= taken // 2
 
 
 @pytest.mark.gpu
