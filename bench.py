@@ -857,7 +857,7 @@ def main():
     plan_kinds = cv.last_plan_kinds() if (conv is not None or args.workload.startswith("filter_")) else None
     family_rep = None
     _src, _dst = locals().get("src"), locals().get("dst")
-    if conv is not None and _dst is not None and getattr(_src, "_storage", None) == pa.VectorBuffer._storage and hasattr(conv, "family_choice"):
+    if conv is not None and _dst is not None and _src is not None and hasattr(conv, "family_choice"):
         family_rep = _family_report(conv, type(_dst), has_reduction)
     if after is not None:
         after()  # (a workload's own check of what its stream-ordered steps left behind; outside the timed region)

@@ -284,7 +284,7 @@ int pst_last_plan_kinds(uint32_t* mask);
 /* Compiles (or fetches from the cache) the specialised kernel for conversions between buffers of these storage kinds NOW, so that the first
  * call already takes it.  *plan_kind: the family such a call will use (PST_PLAN_JIT when a specialised kernel is ready). */
 int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, uint32_t* plan_kind);
-/* Two families can serve interleaved LAS-shaped plans (typed LasPointFormatN records -> columns; raw LAS records -> typed records): the
+/* Two families can serve LAS-shaped plans (typed LasPointFormatN records -> columns and columns -> records; raw LAS records -> typed records): the
  * format-specialised LAS kernels and the plan-specialised kernel.  Which one is faster differs from box to box by a few per cent, so the
  * converter MEASURES it once per target storage on the first conversion of at least 2^22 points (both families run on the caller's range --
  * they write the same bytes --, one host wait; not while the stream is being captured; PST_FAMILY_AUTOTUNE=0: never, plan-specialised first)

@@ -241,8 +241,25 @@ static std::vector<PlanEntry> interleaved_source_entries(const pst_converter& c,
 static bool las_plan_prefers_generic(const pst_converter& c, const pst_buffer& src, size_t s0, const pst_buffer& dst, size_t t0, uint64_t n, int pos_slot,
                                      bool with_bounds, int force_family) {
   static const bool on = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();  // the A/B switch
-  if (!on || src.columnar || force_family == 0) return false;
-  if (force_family < 0 && c.family_choice[dst.columnar ? 1 : 0][with_bounds ? 1 : 0] == 0) return false;
+  if (!on || force_family == 0) return false;
+  const int choice = c.family_choice[dst.columnar ? 1 : 0][with_bounds ? 1 : 0];
+  if (force_family < 0 && choice == 0) return false;
+  if (src.columnar) {
+    // columns -> typed LAS records: the LAS transposer stays the default; the plan-specialised kernel runs when the measurement chose it (or forces it)
+    if (dst.columnar || (force_family < 0 && choice != 1)) return false;
+    std::vector<PlanEntry> entries;
+    bool bounds_done = false;
+    for (const Mapping& m : c.mappings) {
+      if (!m.expr.empty()) return false;
+      PlanEntry e = entry_from_mapping(m);
+      const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
+      e.src_col = col_addr(src, (size_t)sslot, s0);
+      if (with_bounds && tslot == pos_slot && m.target.def.datatype.kind == PST_VEC3F64 && !bounds_done) { e.bounds = 1; bounds_done = true; }
+      entries.push_back(e);
+    }
+    if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES) return false;
+    return specialised_kernel_ready(false, 0, (uint32_t)c.from.size, true, aos_addr(dst, t0), (uint32_t)c.to.size, n, entries, with_bounds);
+  }
   const std::vector<PlanEntry> entries = interleaved_source_entries(c, &dst, t0, dst.columnar, pos_slot, with_bounds);
   if (entries.empty() || entries.size() > PST_PLAN_MAX_ENTRIES) return false;
   return specialised_kernel_ready(true, aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar, dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, entries,
@@ -312,7 +329,7 @@ static void family_autotune(const pst_converter& c, pst_buffer& src, size_t s0, 
   static const bool on = [] { const char* v = std::getenv("PST_FAMILY_AUTOTUNE"); return !(v && *v == '0'); }();
   const uint64_t n = s1 - s0;
   std::atomic<int>& choice = c.family_choice[dst.columnar ? 1 : 0][bounds_out6 ? 1 : 0];
-  if (!on || choice != -1 || n < ((uint64_t)1 << 22) || src.columnar || &src == &dst) return;
+  if (!on || choice != -1 || n < ((uint64_t)1 << 22) || (src.columnar && dst.columnar) || &src == &dst) return;
   // is this one of the two LAS-shaped plans at all?
   if (c.las_typed_format == -2) {
     int f = -1;
@@ -322,7 +339,7 @@ static void family_autotune(const pst_converter& c, pst_buffer& src, size_t s0, 
     c.las_typed_format = f;
   }
   if (c.las_decode_format == -2) c.las_decode_format = match_las_decode_plan(c);
-  const bool las_shaped = dst.columnar ? c.las_typed_format >= 0 : c.las_decode_format >= 0;
+  const bool las_shaped = (dst.columnar || src.columnar) ? c.las_typed_format >= 0 : c.las_decode_format >= 0;  // (columns <-> typed records; raw -> typed records)
   if (!las_shaped) { choice = 2; return; }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
@@ -396,7 +413,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
         for (uint32_t f = 0; f <= 10; ++f)
           if (c.to == laslayout::typed_layout(f)) { c.las_typed_format = (int)f; break; }
     }
-    if (c.las_typed_format >= 0 && !(!src.columnar && las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, force_family))) {
+    if (c.las_typed_format >= 0 && !las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, force_family)) {
       // typed LAS points, columns <-> packed records: format-specialised transposition
       const pst_buffer& soa = src.columnar ? src : dst;
       const size_t p0 = src.columnar ? s0 : t0;
@@ -515,7 +532,7 @@ static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool
   //  las_plan_prefers_generic above; pst_converter_prepare then compiles the generic plan, and the LAS kernel stays the stand-in)
   static const bool prefer_generic = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();
   const bool jit_on = prefer_generic && pstjit::mode() != pstjit::Mode::Off;
-  if (las_fast && src_columnar != dst_columnar && match_identity_records(c) && !(jit_on && !src_columnar))
+  if (las_fast && src_columnar != dst_columnar && match_identity_records(c) && !jit_on)  // (with the compiler on: the generic plan is compiled for BOTH directions, family_autotune picks)
     for (uint32_t f = 0; f <= 10; ++f)
       if (c.to == laslayout::typed_layout(f)) return PST_PLAN_LAS;
   if (las_fast && !src_columnar && match_las_decode_plan(c) >= 0 && !(jit_on && !dst_columnar)) return PST_PLAN_LAS;

@@ -4,6 +4,8 @@
 // direction for format 0.  Same building blocks as las_encode.hip / las_decode.hip with the point format as a template
 // parameter: four consecutive points per lane for every narrow attribute, the Vec3f64 position column in its lane-contiguous
 // 16-byte chunk layout, records staged in an LDS tile (LDS-DMA in, 16-byte stores out).  Pure byte moves: bit-exact.
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "kernels.hpp"
 #include "las_device.hpp"
@@ -77,6 +79,15 @@ __device__ __forceinline__ void write_partial_bounds(double* partials, double (&
 }
 
 // ---- columns -> records -------------------------------------------------------------------------------------------------
+// -DPST_LAS_ALIGNED_LDS (A/B builds): the record pieces leave for LDS as naturally aligned b8 / b16 / b32 stores (RecordImage::store_aligned)
+// instead of one store per piece at whatever alignment the odd record size gives it.  Measured and left OFF: SQ_LDS_UNALIGNED_STALL is 90 % of this
+// kernel's LDS-active cycles (profiles/r05_record_side_pmc.txt), yet five aligned stores per double cost more than one stalled one -- typed LAS-0
+// columns -> records, 8 interleaved pairs: 1.186 ms as is, 1.263 ms aligned (-6.1 %, 8 of 8, profiles/r05_abab.txt).
+#ifdef PST_LAS_ALIGNED_LDS
+constexpr bool kAlignedLdsStores = true;
+#else
+constexpr bool kAlignedLdsStores = false;
+#endif
 template <int FORMAT>
 __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const TransposeArgs a) {
   constexpr Fmt F = fmt_of(FORMAT);
@@ -126,14 +137,20 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
           const bool wrap = c0 + r >= 3u;
           const uint32_t c = wrap ? c0 + r - 3u : c0 + r, q = q0 + A + (wrap ? 1u : 0u);
           const uint64_t bits = (uint64_t)(e ? pc[j].z : pc[j].x) | ((uint64_t)(e ? pc[j].w : pc[j].y) << 32);
-          store_un<uint64_t>(lds + (mis + q * TS + 8u * c), bits);
+          if constexpr (kAlignedLdsStores) {
+            RecordImage<8> img;
+            img.w[0] = (uint32_t)bits; img.w[1] = (uint32_t)(bits >> 32);
+            img.store_aligned(lds + (mis + q * TS + 8u * c));
+          } else {
+            store_un<uint64_t>(lds + (mis + q * TS + 8u * c), bits);
+          }
           if (a.partial_bounds) rb.fold(r, bits);
         }
       }
       if (a.partial_bounds) rb.unrotate(c0, mn, mx);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        RecTail<TS - 24> rec;
+        typename std::conditional<kAlignedLdsStores, RecordImage<TS - 24>, RecTail<TS - 24>>::type rec;
         int i1 = 0, i2 = 0, i4 = 0, i8 = 0;
         for_each_tail_slot<FORMAT>([&](int, uint32_t off, uint32_t size) __attribute__((always_inline)) {
           const int o = (int)off - 24;
@@ -144,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void las_columns_to_records_kernel(const Tr
           else if (size == 6) rec.put(o, 6, c6.value(t));
           else { rec.put(o, 8, c12.bytes_at(12 * t)); rec.put(o + 8, 4, c12.bytes_at(12 * t + 8) & 0xFFFFFFFFull); }
         });
-        rec.store(lds + (mis + (4u * tid + t) * TS + 24u));
+        if constexpr (kAlignedLdsStores) rec.store_aligned(lds + (mis + (4u * tid + t) * TS + 24u));
+        else rec.store(lds + (mis + (4u * tid + t) * TS + 24u));
       }
     } else {
       for (uint32_t lp = tid; lp < cnt; lp += kBlock) {  // ragged last tile: one lane per point

@@ -620,6 +620,16 @@ def test_family_autotune_measures_once_and_changes_no_byte(hip):
     conv.convert_into(src, dst)
     assert conv.family_choice(HashMapBuffer)[0] == choice and cv.last_plan_kinds(hip) == kinds
     assert conv.family_choice(VectorBuffer)[0] == -1  # (per target storage)
+    # (a') the same converter the other way round: 10 columns -> typed records (the LAS transposer against the plan-specialised kernel)
+    conv.prepare(HashMapBuffer, VectorBuffer)
+    back = VectorBuffer.new_from_layout(typed)
+    back.resize(n)
+    conv.convert_into(dst, back)
+    bchoice, bms = conv.family_choice(VectorBuffer)
+    assert bchoice in (0, 1) and bms[0] > 0 and bms[1] > 0, (bchoice, bms)
+    assert cv.last_plan_kinds(hip) == (["las-specialised"] if bchoice == 0 else ["static"]) or (bchoice == 1 and cv.last_plan_kinds(hip) == ["jit"])
+    for lo in (0, n - m):
+        assert np.array_equal(back.get_point_range(range(lo, lo + m)), src.get_point_range(range(lo, lo + m)))
     # (b) raw LAS-0 records -> typed records: the decoder against the plan-specialised kernel
     rsrc = VectorBuffer.new_from_layout(raw)
     rsrc.resize(n)
