@@ -326,6 +326,7 @@ __device__ __forceinline__ Fit plane_fit(uint32_t m, GetPoint&& get) {
 // The sums are NOT the reference's sequence of operations (12 instead of 18 f64 operations per neighbour, fused multiply-adds): results agree
 // to ~1e-14 relative, inside the north star's 1e-9; PST_KNN_FIT=seq selects the reference-order instance for bit comparison.
 // Finite coordinates only (the grid searches never see another kind).
+__device__ __forceinline__ Fit pivot_fit_finish(uint32_t m, double sx, double sy, double sz, double mxx, double mxy, double mxz, double myy, double myz, double mzz, bool* ill);
 template <int KMAX, typename GetPoint>
 __device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py, double pz, GetPoint&& get, bool* ill = nullptr) {
   double sx = 0, sy = 0, sz = 0, mxx = 0, mxy = 0, mxz = 0, myy = 0, myz = 0, mzz = 0;
@@ -339,6 +340,10 @@ __device__ __forceinline__ Fit plane_fit_pivot(uint32_t m, double px, double py,
       myy = __builtin_fma(uy, uy, myy); myz = __builtin_fma(uy, uz, myz); mzz = __builtin_fma(uz, uz, mzz);
     }
   }
+  return pivot_fit_finish(m, sx, sy, sz, mxx, mxy, mxz, myy, myz, mzz, ill);
+}
+// the fit behind the twelve pivot sums (shared by plane_fit_pivot and the box search's batched gather, knn_tile2_kernel)
+__device__ __forceinline__ Fit pivot_fit_finish(uint32_t m, double sx, double sy, double sz, double mxx, double mxy, double mxz, double myy, double myz, double mzz, bool* ill) {
   if (m < 3) { Fit f{0, 0, 0, 0, 0}; if (ill) *ill = false; return f; }  // Err(...) :293-295 -> unwrap panic :471
   const double inv = 1.0 / (double)m;
   const double tx = sx * inv, ty = sy * inv, tz = sz * inv;  // centroid - pivot

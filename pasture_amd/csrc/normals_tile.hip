@@ -1041,6 +1041,10 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
         bool ill = false;
+        // (Measured and dropped, round 5: the sixteen gathers in batches of eight / four instead of sixteen dependent round trips -- the loop's `t < m`
+        //  test makes every neighbour a basic block of its own: slot -> sorted index (LDS) -> 24 bytes (L2) -> wait -> twelve operations --: the other
+        //  three waves of the SIMD already hide that latency, and the 48 extra live registers spill: 29.53 -> 29.77 ms with eight in flight, 30.59 with
+        //  four, profiles/r05_abab.txt.)
         if (!(a.ablate & 2u)) f = plane_fit_pivot<K>(m, qx, qy, qz, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
           uint32_t pl = 0;
 #pragma unroll
