@@ -97,6 +97,37 @@ struct Fit { double nx, ny, nz, curvature; int ok; };
 // at Chebyshev nodes against 50-digit references: 2.2e-16 relative), and the Taylor polynomials of cos and sin on [0, pi / 3] (nine terms:
 // 1.1e-16 absolute / 2.1e-16 relative) -- each within an ulp or two of the correctly rounded value, like the functions they replace; the
 // results enter the eigenvalue exactly as before.  PST_FIT_LIBM_TRIG (compile time) restores the libm calls for an A/B.
+// The polynomials' coefficients live in constant memory and reach the arithmetic as SCALAR operands (s_load into an SGPR pair, one per fused
+// multiply-add): written as literals, the compiler hoisted all thirty of them out of the box kernel's chunk loop into 60 vector registers and
+// spilled those -- 5.6 GB of scratch write-back per 10^8-point launch for constants (rocprofv3 WRITE_SIZE of the box kernel 9.4 -> 15.4 GB when the
+// polynomials replaced libm), and scratch reloads inside the fit.
+#ifndef PST_FIT_LITERAL_CONSTANTS
+static __device__ __constant__ double kThirdAngleTable[30] = {
+    // atan(u) / u - 1 in u^2, degree 11 (highest first)
+    0.011133722158619984, -0.029802426579855917, 0.043605084067176156, -0.05187003409810214, 0.058727581474367595, -0.06665857298205219,
+    0.07692262470384811, -0.09090907471736968, 0.11111111076292801, -0.14285714285314552, 0.1999999999999803, -0.3333333333333335,
+    // cos: 1 + w (-1/2! + w (1/4! - ... + w / 18!)), highest first
+    1.0 / 6402373705728000.0, -1.0 / 20922789888000.0, 1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
+    // sin: theta + theta w (-1/3! + w (1/5! - ... - w / 19!)), highest first
+    -1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0,
+    -1.0 / 6.0};
+// (read through an index the optimiser cannot see through -- an `s_mov_b32 sN, 0` it takes for a run-time value --: a table it can read at compile
+//  time is folded back into literals and hoisted again)
+__device__ __forceinline__ double third_angle_coefficient(int i) {
+  uint32_t z;
+  asm("s_mov_b32 %0, 0" : "=s"(z));
+  return kThirdAngleTable[(uint32_t)i + z];
+}
+#define PST_TA(i) third_angle_coefficient(i)
+#else
+#define PST_TA(i) kThirdAngleLiterals[i]
+constexpr double kThirdAngleLiterals[30] = {
+    0.011133722158619984, -0.029802426579855917, 0.043605084067176156, -0.05187003409810214, 0.058727581474367595, -0.06665857298205219,
+    0.07692262470384811, -0.09090907471736968, 0.11111111076292801, -0.14285714285314552, 0.1999999999999803, -0.3333333333333335,
+    1.0 / 6402373705728000.0, -1.0 / 20922789888000.0, 1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
+    -1.0 / 121645100408832000.0, 1.0 / 355687428096000.0, -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0,
+    -1.0 / 6.0};
+#endif
 __device__ __forceinline__ void cos_sin_third_angle(double s, double b, double& ct, double& st) {
 #ifdef PST_FIT_LIBM_TRIG
   const double theta = ::atan2(s, b) * (1.0 / 3.0);
@@ -109,43 +140,22 @@ __device__ __forceinline__ void cos_sin_third_angle(double s, double b, double& 
   const double un = hi ? num - den : num, ud = hi ? num + den : den;
   const double u = ud > 0.0 ? un / ud : 0.0;                // (s = b = 0: phi = 0 or pi by the sign of b, below)
   const double z = u * u;
-  double p = 0.011133722158619984;
-  p = __builtin_fma(p, z, -0.029802426579855917);
-  p = __builtin_fma(p, z, 0.043605084067176156);
-  p = __builtin_fma(p, z, -0.05187003409810214);
-  p = __builtin_fma(p, z, 0.058727581474367595);
-  p = __builtin_fma(p, z, -0.06665857298205219);
-  p = __builtin_fma(p, z, 0.07692262470384811);
-  p = __builtin_fma(p, z, -0.09090907471736968);
-  p = __builtin_fma(p, z, 0.11111111076292801);
-  p = __builtin_fma(p, z, -0.14285714285314552);
-  p = __builtin_fma(p, z, 0.1999999999999803);
-  p = __builtin_fma(p, z, -0.3333333333333335);
+  double p = PST_TA(0);
+#pragma unroll
+  for (int i = 1; i < 12; ++i) p = __builtin_fma(p, z, PST_TA(i));
   double a = __builtin_fma(u * z, p, u);                    // atan(u)
   if (hi) a += 0.7853981633974483;                          // + pi / 4
   double phi = swap ? 1.5707963267948966 - a : a;           // atan2(s, |b|)
   if (__builtin_signbit(b)) phi = 3.141592653589793 - phi;  // atan2(s, b), b < 0 (and atan2(0, -0) = pi)
   const double theta = phi * (1.0 / 3.0);
   const double w = theta * theta;
-  double c = 1.0 / 6402373705728000.0;                      // cos: 1 + w (-1/2! + w (1/4! - ... + w / 18!))
-  c = __builtin_fma(c, w, -1.0 / 20922789888000.0);
-  c = __builtin_fma(c, w, 1.0 / 87178291200.0);
-  c = __builtin_fma(c, w, -1.0 / 479001600.0);
-  c = __builtin_fma(c, w, 1.0 / 3628800.0);
-  c = __builtin_fma(c, w, -1.0 / 40320.0);
-  c = __builtin_fma(c, w, 1.0 / 720.0);
-  c = __builtin_fma(c, w, -1.0 / 24.0);
-  c = __builtin_fma(c, w, 0.5);
+  double c = PST_TA(12);
+#pragma unroll
+  for (int i = 13; i < 21; ++i) c = __builtin_fma(c, w, PST_TA(i));
   ct = __builtin_fma(-w, c, 1.0);
-  double q = -1.0 / 121645100408832000.0;                   // sin: theta + theta w (-1/3! + w (1/5! - ... - w / 19!))
-  q = __builtin_fma(q, w, 1.0 / 355687428096000.0);
-  q = __builtin_fma(q, w, -1.0 / 1307674368000.0);
-  q = __builtin_fma(q, w, 1.0 / 6227020800.0);
-  q = __builtin_fma(q, w, -1.0 / 39916800.0);
-  q = __builtin_fma(q, w, 1.0 / 362880.0);
-  q = __builtin_fma(q, w, -1.0 / 5040.0);
-  q = __builtin_fma(q, w, 1.0 / 120.0);
-  q = __builtin_fma(q, w, -1.0 / 6.0);
+  double q = PST_TA(21);
+#pragma unroll
+  for (int i = 22; i < 30; ++i) q = __builtin_fma(q, w, PST_TA(i));
   st = __builtin_fma(theta * w, q, theta);
 #endif
 }
