@@ -1041,10 +1041,46 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         double qx, qy, qz;
         exact_xyz(slot, qx, qy, qz);
         bool ill = false;
-        // (Measured and dropped, round 5: the sixteen gathers in batches of eight / four instead of sixteen dependent round trips -- the loop's `t < m`
-        //  test makes every neighbour a basic block of its own: slot -> sorted index (LDS) -> 24 bytes (L2) -> wait -> twelve operations --: the other
-        //  three waves of the SIMD already hide that latency, and the 48 extra live registers spill: 29.53 -> 29.77 ms with eight in flight, 30.59 with
-        //  four, profiles/r05_abab.txt.)
+        // The sixteen gathers in TWO batches of eight instead of sixteen dependent round trips.  plane_fit_pivot's loop tests `t < m` per neighbour,
+        // every iteration is a basic block of its own and no load is lifted over a branch: slot -> sorted index (LDS) -> 24 bytes (L2) -> wait ->
+        // twelve operations, sixteen times in a row (37 % of a wave's cycles for 13 % of its instructions, profiles/r05_knn_phases.txt).  Here all
+        // sorted indices are read at once and eight neighbours' coordinates are in flight together; entries t >= m name the query itself, whose
+        // u = 0 adds nothing to any sum: no branch, no select.  The sums are plane_fit_pivot's operations in plane_fit_pivot's order: bit-identical
+        // results.  Only worth it since the kernel holds no scratch (normals_device.hpp kThirdAngleTable): with the solver's literals spilled the
+        // 48 extra live registers spilled too and the same change LOST 0.8 %; without, +3.5 % (27.74 -> 26.80 ms, 6 of 6 pairs; four in flight and
+        // sixteen in flight spill again).  -DPST_KNN_FIT_BATCH=0 restores the loop for the A/B.
+#ifndef PST_KNN_FIT_BATCH
+#define PST_KNN_FIT_BATCH 8
+#endif
+#if PST_KNN_FIT_BATCH > 0
+        if constexpr (!P3LDS) {
+          if (!(a.ablate & 2u)) {
+            uint32_t jm[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) jm[u] = Jmap[(uint32_t)u < m ? nb[u] : slot];
+            double sx = 0, sy = 0, sz = 0, mxx = 0, mxy = 0, mxz = 0, myy = 0, myz = 0, mzz = 0;
+            constexpr int H = K < PST_KNN_FIT_BATCH ? K : PST_KNN_FIT_BATCH;
+#pragma unroll
+            for (int h = 0; h < K; h += H) {
+              if (h > 0) {
+#pragma unroll
+                for (int u = 0; u < H; ++u) asm volatile("" : "+v"(jm[h + u]), "+v"(sx), "+v"(mzz));
+              }
+              double x[H], y[H], z[H];
+#pragma unroll
+              for (int u = 0; u < H; ++u) { const double* pp = a.sxyz + 3ull * jm[h + u]; x[u] = pp[0]; y[u] = pp[1]; z[u] = pp[2]; }
+#pragma unroll
+              for (int u = 0; u < H; ++u) {
+                const double ux = x[u] - qx, uy = y[u] - qy, uz = z[u] - qz;
+                sx += ux; sy += uy; sz += uz;
+                mxx = __builtin_fma(ux, ux, mxx); mxy = __builtin_fma(ux, uy, mxy); mxz = __builtin_fma(ux, uz, mxz);
+                myy = __builtin_fma(uy, uy, myy); myz = __builtin_fma(uy, uz, myz); mzz = __builtin_fma(uz, uz, mzz);
+              }
+            }
+            f = pivot_fit_finish(m, sx, sy, sz, mxx, mxy, mxz, myy, myz, mzz, &ill);
+          }
+        } else
+#endif
         if (!(a.ablate & 2u)) f = plane_fit_pivot<K>(m, qx, qy, qz, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
           uint32_t pl = 0;
 #pragma unroll

@@ -138,6 +138,26 @@ def test_in_tree_plan_kernels_use_no_scratch_memory():
     assert not bad, bad
 
 
+def test_knn_box_kernel_with_the_one_pass_fit_uses_no_scratch_memory():
+    """knn_tile2_kernel<K, ..., FIT = 1> (the instances a volume-filling cloud runs on): .private_segment_fixed_size == 0.  Round 5 found the
+    cubic solver's polynomial literals hoisted out of the chunk loop into vector registers and spilled -- 104 bytes of scratch per lane, 5.8 GB of
+    write-back per 10^8-point launch, scratch reloads inside the fit; with the coefficients in constant memory (normals_device.hpp
+    kThirdAngleTable) the kernels hold everything in registers, which was worth 6 % of the call (10 % on a LiDAR-like sheet).  A change that brings
+    a spill back shows up here, without a GPU."""
+    from pasture_amd import _capi
+    data = open(_capi.LIB_PATH, "rb").read()
+    key = b".private_segment_fixed_size"
+    seen = {}
+    for m in re.finditer(rb"\.name[\xa0-\xbf\xd9\xda].?.?(_Z[0-9A-Za-z_]*knn_tile2_kernelILi(?:8|16)E[0-9A-Za-z_]*)", data):
+        j = data.find(key, m.end())
+        assert 0 <= j - m.end() <= 4, "metadata layout changed"
+        seen[m.group(1).decode()] = _scratch_bytes(data[j:j + len(key) + 8])
+    # template arguments: K, THREADS, CAP, P3LDS, BATCH, WPE, WITH_KNN, ROT, FIT -- the plain one-pass instances: no lists, unrotated, FIT = 1
+    plain = {k: v for k, v in seen.items() if k.endswith("ELb0ELb0ELi1EEEvNS_9Tile2ArgsE")}
+    assert len(plain) >= 6, sorted(seen)
+    assert all(v == 0 for v in plain.values()), plain
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_generated_plans_compile_under_hiprtc(hip, seed):
     """Host logic only: random converters -> the translation unit jit.cpp would hand to hipRTC -> compiled for gfx950 against the embedded
