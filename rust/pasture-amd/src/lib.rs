@@ -194,6 +194,20 @@ impl DeviceBufferLayoutConverter {
         check(unsafe { pst_converter_set_custom_mapping_with_expression(self.handle, fname.as_ptr(), &datatype_to_c(from.datatype()), tname.as_ptr(),
                                                                        &datatype_to_c(to.datatype()), text.as_ptr(), apply_to_source_attribute as c_int) })
     }
+    /// Compiles (or fetches) the plan-specialised kernel for conversions between these storage kinds now instead of in the background
+    /// (`pst_converter_prepare`); returns the PST_PLAN_* family such a conversion takes.
+    pub fn prepare(&self, source_columnar: bool, target_columnar: bool, with_bounds: bool) -> u32 {
+        let mut kind = 0u32;
+        check(unsafe { pst_converter_prepare(self.handle, source_columnar as c_int, target_columnar as c_int, with_bounds as c_int, &mut kind) });
+        kind
+    }
+    /// Which of the two kernel families that can serve a LAS-shaped plan this converter measured to be the faster one on this device (its first
+    /// conversion of at least 2^22 points measures): `None` = not measured yet or one family only, `Some((plan_specialised, [ms LAS, ms plan-specialised]))`.
+    pub fn family_choice(&self, target_columnar: bool, with_bounds: bool) -> Option<(bool, [f32; 2])> {
+        let (mut choice, mut ms) = (0 as c_int, [0f32; 2]);
+        check(unsafe { pst_converter_family_choice(self.handle, target_columnar as c_int, with_bounds as c_int, &mut choice, ms.as_mut_ptr()) });
+        if choice == 0 || choice == 1 { Some((choice == 1, ms)) } else { None }
+    }
     pub fn convert_into(&self, source: &impl DeviceBuffer, target: &mut impl DeviceBuffer, n: usize) { self.convert_into_range(source, 0..n, target, 0..n) }
     pub fn convert_into_range(&self, source: &impl DeviceBuffer, source_range: Range<usize>, target: &mut impl DeviceBuffer, target_range: Range<usize>) {
         check(unsafe { pst_converter_convert_into_range(self.handle, source.handle(), source_range.start, source_range.end, target.handle(),
