@@ -155,11 +155,12 @@ def _torch_bytes(ptr, nbytes):
     return torch.as_tensor(_Mem(), device="cuda")
 
 
-def _family_report(conv, dst_type, with_bounds):
+def _family_report(conv, dst_type, with_bounds, src_type=None):
     """What the converter measured on this device for plans two kernel families can serve (pst_converter_family_choice): the first call of
-    >= 2^22 points times the LAS-format kernels against the plan-specialised one and keeps the faster -- the choice config.plan then shows."""
+    >= 2^22 points through a synchronous entry point (or measure_families) times the LAS-format kernels against the plan-specialised one, median of three
+    passes each, and keeps the faster -- the choice config.plan then shows."""
     try:
-        choice, ms = conv.family_choice(dst_type, with_bounds)
+        choice, ms = conv.family_choice(dst_type, with_bounds, src_type)
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:200]}
     names = {-1: "not measured", 0: "las", 1: "plan-specialised", 2: "one family only"}
@@ -180,6 +181,7 @@ def leg_configs2(pa, las, cv, torch, stream, n, seed):
     dst.resize(n)
     conv = pa.BufferLayoutConverter.for_layouts(src_layout, src_layout)
     plan = cv.PLAN_NAMES[conv.prepare(type(src), type(dst), False)]
+    conv.measure_families(src, dst, False)  # (the stream-ordered calls below never measure: once, before the loop)
     steps = 10
     for _ in range(2):
         conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
@@ -191,7 +193,7 @@ def leg_configs2(pa, las, cv, torch, stream, n, seed):
         e1.record(stream)
     torch.cuda.synchronize()
     kinds = cv.last_plan_kinds()
-    family = _family_report(conv, type(dst), False)
+    family = _family_report(conv, type(dst), False, type(src))
     ms_all = [a.elapsed_time(b) for a, b in ev]
     ms = sum(ms_all) / steps
     gbs = 70 * n / (ms * 1e-3) / 1e9
@@ -813,6 +815,9 @@ def main():
     if conv is not None and args.plan != "interpreted":
         # the run-time compiler normally works on a background thread while the first calls are interpreted; a benchmark wants the steady state
         prepared_plan = cv.PLAN_NAMES[conv.prepare(type(src), type(dst), has_reduction)]
+        _s, _d = locals().get("src"), locals().get("dst")
+        if _s is not None and _d is not None and _s is not _d and hasattr(conv, "measure_families") and _s.len() == _d.len():
+            conv.measure_families(_s, _d, has_reduction)  # (the `_async` conversions of the timed steps never measure: once, before the loop)
 
     def full_step():
         step()
@@ -858,7 +863,7 @@ def main():
     family_rep = None
     _src, _dst = locals().get("src"), locals().get("dst")
     if conv is not None and _dst is not None and _src is not None and hasattr(conv, "family_choice"):
-        family_rep = _family_report(conv, type(_dst), has_reduction)
+        family_rep = _family_report(conv, type(_dst), has_reduction, type(_src))
     if after is not None:
         after()  # (a workload's own check of what its stream-ordered steps left behind; outside the timed region)
     per_rank = None

@@ -286,11 +286,16 @@ int pst_last_plan_kinds(uint32_t* mask);
 int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_columnar, int with_bounds, uint32_t* plan_kind);
 /* Two families can serve LAS-shaped plans (typed LasPointFormatN records -> columns and columns -> records; raw LAS records -> typed records): the
  * format-specialised LAS kernels and the plan-specialised kernel.  Which one is faster differs from box to box by a few per cent, so the
- * converter MEASURES it once per target storage on the first conversion of at least 2^22 points (both families run on the caller's range --
- * they write the same bytes --, one host wait; not while the stream is being captured; PST_FAMILY_AUTOTUNE=0: never, plan-specialised first)
- * and keeps the winner.  *choice: -1 not measured yet, 0 = PST_PLAN_LAS, 1 = plan-specialised (PST_PLAN_STATIC / PST_PLAN_JIT), 2 = the plan
- * has no second family; ms2 (optional): milliseconds per pass the measurement saw for {LAS, plan-specialised}. */
+ * converter MEASURES it once per storage pairing on the first SYNCHRONOUS conversion of at least 2^22 points (convert / convert_into_range /
+ * ..._with_bounds; both families run on the caller's range -- they write the same bytes --, median of three timed passes each, one host wait; not
+ * while the stream is being captured, not when source and target memory overlap; PST_FAMILY_AUTOTUNE=0: never, plan-specialised first) and
+ * keeps the winner.  The stream-ordered `_async` entry points never measure (they neither block the host nor repeat the caller's conversion):
+ * callers of those run pst_converter_measure_families once, before their loop.
+ * dst_columnar: 0 = records from records, 1 = columns (from records), 2 = records from columns.  *choice: -1 not measured yet, 0 = PST_PLAN_LAS,
+ * 1 = plan-specialised (PST_PLAN_STATIC / PST_PLAN_JIT), 2 = the plan has no second family; ms2 (optional): milliseconds per pass the
+ * measurement saw for {LAS, plan-specialised}.  (No reference counterpart: the reference has one loop, buffer_conversion.rs:292-359.) */
 int pst_converter_family_choice(const pst_converter* c, int dst_columnar, int with_bounds, int* choice, float ms2[2]);
+int pst_converter_measure_families(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1, int with_bounds);
 /* Introspection of the run-time compiler (tests, tools): the translation unit generated for a converter (empty when the plan takes another
  * family; *needed = bytes incl. the terminator); compilation of a translation unit against the embedded device headers for gfx950 WITHOUT a
  * device (the code object is copied to code_buf when given; *code_bytes = its size); counters. */

@@ -168,6 +168,7 @@ _PRODUCT_SIGNATURES = {
     "last_plan_kinds": [C.POINTER(C.c_uint32)],
     "converter_prepare": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)],
     "converter_family_choice": [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
+    "converter_measure_families": [_P, _P, C.c_size_t, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_int],
     "converter_jit_source": [_P, C.c_int, C.c_int, C.c_int, C.c_char_p, _SZ, C.POINTER(_SZ)],
     "jit_compile_source": [C.c_char_p, _P, _SZ, C.POINTER(_SZ), C.c_char_p, _SZ],
     "jit_get_stats": [C.POINTER(JitStatsStruct)],

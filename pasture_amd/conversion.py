@@ -232,13 +232,25 @@ class BufferLayoutConverter:
                                    1 if target_type._storage == HashMapBuffer._storage else 0, 1 if with_bounds else 0, C.byref(kind))
         return kind.value
 
-    def family_choice(self, target_type: Type[_Buffer], with_bounds: bool = False):
+    def family_choice(self, target_type: Type[_Buffer], with_bounds: bool = False, source_type: Optional[Type[_Buffer]] = None):
         """Which of the two kernel families that can serve an interleaved LAS-shaped plan this converter measured to be the faster one on this
-        device (first conversion of at least 2^22 points): (choice, (ms LAS family, ms plan-specialised)); choice -1 = not measured yet,
-        0 = LAS family, 1 = plan-specialised, 2 = the plan has one family only."""
+        device (first SYNCHRONOUS conversion of at least 2^22 points, or measure_families): (choice, (ms LAS family, ms plan-specialised));
+        choice -1 = not measured yet, 0 = LAS family, 1 = plan-specialised, 2 = the plan has one family only.  source_type (default: records)
+        selects the pairing: records from COLUMNS has its own slot."""
         choice, ms = C.c_int(), (C.c_float * 2)()
-        self.api.converter_family_choice(self._h, 1 if target_type._storage == HashMapBuffer._storage else 0, 1 if with_bounds else 0, C.byref(choice), ms)
+        dst_col = target_type._storage == HashMapBuffer._storage
+        src_col = source_type is not None and source_type._storage == HashMapBuffer._storage
+        self.api.converter_family_choice(self._h, 1 if dst_col else (2 if src_col else 0), 1 if with_bounds else 0, C.byref(choice), ms)
         return choice.value, (ms[0], ms[1])
+
+    def measure_families(self, source_buffer: _Buffer, target_buffer: _Buffer, with_bounds: bool = False, source_range: Optional[range] = None,
+                         target_range: Optional[range] = None) -> None:
+        """The measurement behind family_choice, run NOW on these buffers (converts the range several times -- same bytes -- and waits): what a
+        caller of the stream-ordered `_async` conversions does once before its loop, since those never measure."""
+        n = source_buffer.len()
+        sr = range(0, n) if source_range is None else source_range
+        tr = range(0, n) if target_range is None else target_range
+        self.api.converter_measure_families(self._h, source_buffer._h, sr.start, sr.stop, target_buffer._h, tr.start, tr.stop, 1 if with_bounds else 0)
 
     def jit_source(self, source_type: Type[_Buffer], target_type: Type[_Buffer], with_bounds: bool = False) -> str:
         """The translation unit the run-time compiler is handed for this converter and storage pairing ('' if another family serves it)."""

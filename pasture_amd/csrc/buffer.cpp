@@ -316,6 +316,7 @@ int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbyte
     throw Error(PST_ERR_INVALID_ARGUMENT, "external memory size is not a multiple of the point size");
   if (nbytes && !device_ptr) throw Error(PST_ERR_INVALID_ARGUMENT, "device_ptr must not be NULL");
   b->owns = false;
+  b->epoch.reset();  // (the caller's memory: nothing of ours can move under a slice of it)
   b->data = (uint8_t*)device_ptr;
   b->len = b->capacity = stride ? nbytes / stride : 0;
   *not_null(out, "out") = b.release();
@@ -327,6 +328,7 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
   b->layout = not_null(l, "layout")->l;
   b->columnar = true;
   b->owns = false;
+  b->epoch.reset();
   for (size_t a = 0; a < b->layout.members.size(); ++a) {
     void* p = not_null(column_ptrs, "column_ptrs")[a];
     if (len && !p) throw Error(PST_ERR_INVALID_ARGUMENT, "column pointer must not be NULL");
@@ -348,7 +350,6 @@ int pst_buffer_slice(const pst_buffer* parent, size_t first, size_t count, pst_b
   b->memkind = parent->memkind;
   b->len = b->capacity = count;
   b->is_slice = true;
-  if (parent->owns && !parent->epoch) parent->epoch = std::make_shared<std::atomic<uint64_t>>(0);
   b->epoch = parent->epoch;  // a slice of a slice watches the same owning ancestor; a slice of external memory watches nothing
   b->epoch_cut = parent->is_slice ? parent->epoch_cut : (parent->epoch ? parent->epoch->load(std::memory_order_acquire) : 0);
   if (parent->columnar) {

@@ -212,6 +212,31 @@ static bool launch_specialised(const ConvertPlan& plan, bool src_aos, bool dst_a
   return true;
 }
 
+// A plan with fused expression entries (PST_XF_EXPR; plan.expr_texts): the plan-specialised kernel or nothing -- the interpreter cannot evaluate an
+// expression.  Compiled in the calling thread (an expression has always been compiled at its first use: its syntax errors are that call's
+// error).  *done = the points covered (full tiles; 0 = this plan has no specialised form, or, with *error set, its kernel does not compile); the
+// caller runs the rest -- the ragged tail, or everything -- through expr.cpp's strided kernel and the interpreter.
+bool launch_convert_fused_expressions(const ConvertPlan& plan, bool src_aos, bool dst_aos, hipStream_t stream, uint64_t* done, std::string* error) {
+  *done = 0;
+  if (pstjit::mode() == pstjit::Mode::Off) return true;
+  pstjit::QuadSpec spec;
+  if (!pstjit::spec_from_plan(plan, src_aos, dst_aos, &spec)) return true;
+  pstjit::Kernel k;
+  if (!pstjit::acquire(spec, pstjit::spec_source(spec), pstjit::Acquire::Wait, &k, error)) return true;
+  const uint64_t n_tiles = plan.h.n / k.tile;
+  if (n_tiles == 0 || n_tiles > (1ull << 30)) return true;
+  const PlanEntry* entries = upload_entries(plan, stream);
+  if (!entries) return false;
+  ConvertHeader h = plan.h;
+  h.n = n_tiles * k.tile;
+  const unsigned grid = (unsigned)((n_tiles + 7) / 8 * 8);
+  void* args[] = {(void*)&h, (void*)&entries};
+  if (hipModuleLaunchKernel(k.fn, grid, 1, 1, k.blk, 1, 1, lds_with_resident_cap(k.lds_bytes, kResidentQuad), stream, args, nullptr) != hipSuccess) return false;
+  note_plan_kind(PST_PLAN_JIT);
+  *done = h.n;
+  return true;
+}
+
 // Is a plan-specialised kernel (in-tree instantiation or run-time compiled) at hand for this plan?  A missing one is queued for the compiler
 // thread (or compiled here in PST_JIT=sync), exactly as a launch would.  converter.cpp asks before it prefers the generic path over a
 // format-specialised LAS kernel that the plan-specialised kernels have overtaken (round 4).

@@ -89,8 +89,8 @@ struct pst_converter {
   // (las_transpose.hip / las_decode.hip) or the plan-specialised quad kernel (convert_static.hip / hipRTC) -- is MEASURED, once per converter and
   // target storage, on the first call of at least 2^22 points (convert_range: family_autotune): the two trade places from box to box by +-5 %
   // (round-4 review, item 6).  [dst columnar][with bounds]: -1 not measured, 0 = LAS family, 1 = plan-specialised, 2 = nothing to choose.
-  mutable std::atomic<int> family_choice[2][2] = {{{-1}, {-1}}, {{-1}, {-1}}};
-  mutable std::atomic<float> family_ms[2][2][2] = {};  // [dst columnar][with bounds][family]: what the measurement saw (pst_converter_family_choice)
+  mutable std::atomic<int> family_choice[3][2] = {{{-1}, {-1}}, {{-1}, {-1}}, {{-1}, {-1}}};
+  mutable std::atomic<float> family_ms[3][2][2] = {};  // [storage pairing, family_slot()][with bounds][family]: what the measurement saw (pst_converter_family_choice)
   mutable std::atomic<int> las_typed_format{-2};  // -2 not examined, -1 no, 0..10: identity plan over LasPointFormatN::layout() (las_transpose.hip)  // -2 not examined, 1 = every byte of every record is copied to the same offset (same packed layout)
 };
 
@@ -225,6 +225,10 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
 // LAS records -> columns (same box: 0.81 against 0.78 of peak) and raw LAS records -> typed records (0.74 against 0.65).  Those two plans take
 // the generic path WHEN a specialised kernel for them is at hand (in-tree, compiled, or PST_JIT=sync), and the LAS kernel otherwise
 // (PST_JIT=0, hipRTC missing, the first calls while the compiler thread works).  The mappings of such a plan, as the generic path lists them:
+// Slot of a storage pairing in pst_converter::family_choice: 0 = records -> records, 1 = records -> columns, 2 = columns -> records (columns -> columns
+// has one family).  Keyed by the SOURCE storage too since round 6: an identity LAS converter used records -> records (one family: choice 2) no longer
+// shares -- and blocks -- the slot of its columns -> records direction.
+static inline int family_slot(bool src_columnar, bool dst_columnar) { return dst_columnar ? 1 : (src_columnar ? 2 : 0); }
 static std::vector<PlanEntry> interleaved_source_entries(const pst_converter& c, const pst_buffer* dst, size_t t0, bool dst_columnar, int pos_slot, bool with_bounds) {
   std::vector<PlanEntry> out;
   bool bounds_done = false;
@@ -242,7 +246,7 @@ static bool las_plan_prefers_generic(const pst_converter& c, const pst_buffer& s
                                      bool with_bounds, int force_family) {
   static const bool on = [] { const char* v = std::getenv("PST_LAS_PREFER_SPECIALISED"); return !(v && *v == '0'); }();  // the A/B switch
   if (!on || force_family == 0) return false;
-  const int choice = c.family_choice[dst.columnar ? 1 : 0][with_bounds ? 1 : 0];
+  const int choice = c.family_choice[family_slot(src.columnar, dst.columnar)][with_bounds ? 1 : 0];
   if (force_family < 0 && choice == 0) return false;
   if (src.columnar) {
     // columns -> typed LAS records: the LAS transposer stays the default; the plan-specialised kernel runs when the measurement chose it (or forces it)
@@ -318,18 +322,41 @@ static int match_las_decode_plan(const pst_converter& c) {
   return format;
 }
 
+// force_family: -1 = the converter's choice, 0 / 1 = that family (the measurement's own passes); kMeasureFamilies = -1 plus: measure the two families first if
+// this converter has not yet (synchronous entry points only)
+constexpr int kMeasureFamilies = -2;
 static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1, double* bounds_out6, hipStream_t stream,
                           int force_family = -1);
 
+// Do the byte ranges the conversion reads and writes overlap?  (Two slice handles of one parent are different pst_buffer objects over the same
+// memory: the measurement below repeats the conversion, which is only idempotent when the source is not written.)
+static bool storage_overlaps(const pst_buffer& src, size_t s0, size_t s1, const pst_buffer& dst, size_t t0, size_t t1) {
+  struct Span { uint64_t lo, hi; };
+  auto spans = [](const pst_buffer& b, size_t p0, size_t p1) {
+    std::vector<Span> v;
+    if (!b.columnar) v.push_back({aos_addr(b, p0), aos_addr(b, p1)});
+    else
+      for (size_t a = 0; a < b.layout.members.size(); ++a) v.push_back({col_addr(b, a, p0), col_addr(b, a, p1)});
+    return v;
+  };
+  for (const Span& a : spans(src, s0, s1))
+    for (const Span& b : spans(dst, t0, t1))
+      if (a.lo < b.hi && b.lo < a.hi) return true;
+  return false;
+}
+
 // The measurement behind pst_converter::family_choice.  Runs on the caller's buffers and range (both families write the same bytes, the source is
-// only read): per family one untimed pass and two timed ones between HIP events on the caller's stream, then ONE host wait.  Skipped (and left
-// for a later call) while the stream is being captured into a graph, below 2^22 points, and when the plan-specialised kernel is not compiled
-// yet.  PST_FAMILY_AUTOTUNE=0 switches it off (the default order of preference then stands: plan-specialised first).
+// only read): per family one untimed pass and THREE timed ones, each between its own pair of HIP events on the caller's stream (the median decides),
+// then ONE host wait.  Since round 6 it runs from the SYNCHRONOUS conversion entry points and from pst_converter_measure_families only: a
+// stream-ordered (`_async`) call never blocks the host for it, nor repeats the caller's conversion.  Skipped (and left for a later call) while the
+// stream is being captured into a graph, below 2^22 points, when source and target memory overlap, and when the plan-specialised kernel is not
+// compiled yet.  PST_FAMILY_AUTOTUNE=0 switches it off (the default order of preference then stands: plan-specialised first).
 static void family_autotune(const pst_converter& c, pst_buffer& src, size_t s0, size_t s1, pst_buffer& dst, size_t t0, size_t t1, double* bounds_out6, hipStream_t stream) {
   static const bool on = [] { const char* v = std::getenv("PST_FAMILY_AUTOTUNE"); return !(v && *v == '0'); }();
   const uint64_t n = s1 - s0;
-  std::atomic<int>& choice = c.family_choice[dst.columnar ? 1 : 0][bounds_out6 ? 1 : 0];
-  if (!on || choice != -1 || n < ((uint64_t)1 << 22) || (src.columnar && dst.columnar) || &src == &dst) return;
+  const int slot = family_slot(src.columnar, dst.columnar), bslot = bounds_out6 ? 1 : 0;
+  std::atomic<int>& choice = c.family_choice[slot][bslot];
+  if (!on || choice != -1 || n < ((uint64_t)1 << 22) || (src.columnar && dst.columnar) || storage_overlaps(src, s0, s1, dst, t0, t1)) return;
   // is this one of the two LAS-shaped plans at all?
   if (c.las_typed_format == -2) {
     int f = -1;
@@ -346,25 +373,32 @@ static void family_autotune(const pst_converter& c, pst_buffer& src, size_t s0, 
   int pos_slot = -1;
   if (bounds_out6) { const Member* pm = c.to.find_by_name("Position3D"); if (!pm) return; pos_slot = (int)(pm - c.to.members.data()); }
   if (!las_plan_prefers_generic(c, src, s0, dst, t0, n, pos_slot, bounds_out6 != nullptr, 1)) return;  // (not compiled yet: queued; measured on a later call)
-  hipEvent_t ev[4] = {};
+  constexpr int kTimed = 3;
+  hipEvent_t ev[2][kTimed + 1] = {};
   bool ok = true;
-  for (hipEvent_t& e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-  float ms[2] = {0.f, 0.f};
+  for (auto& row : ev) for (hipEvent_t& e : row) ok = ok && hipEventCreate(&e) == hipSuccess;
+  float med[2] = {0.f, 0.f};
   if (ok) {
     for (int fam = 0; fam < 2; ++fam) {
       convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
-      ok = ok && hipEventRecord(ev[2 * fam], stream) == hipSuccess;
-      convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
-      convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
-      ok = ok && hipEventRecord(ev[2 * fam + 1], stream) == hipSuccess;
+      ok = ok && hipEventRecord(ev[fam][0], stream) == hipSuccess;
+      for (int r = 0; r < kTimed; ++r) {
+        convert_range(c, src, s0, s1, dst, t0, t1, bounds_out6, stream, fam);
+        ok = ok && hipEventRecord(ev[fam][r + 1], stream) == hipSuccess;
+      }
     }
-    ok = ok && hipEventSynchronize(ev[3]) == hipSuccess;
-    for (int fam = 0; fam < 2 && ok; ++fam) ok = hipEventElapsedTime(&ms[fam], ev[2 * fam], ev[2 * fam + 1]) == hipSuccess;
+    ok = ok && hipEventSynchronize(ev[1][kTimed]) == hipSuccess;
+    for (int fam = 0; fam < 2 && ok; ++fam) {
+      float t[kTimed];
+      for (int r = 0; r < kTimed && ok; ++r) ok = hipEventElapsedTime(&t[r], ev[fam][r], ev[fam][r + 1]) == hipSuccess;
+      std::sort(t, t + kTimed);
+      med[fam] = t[kTimed / 2];
+    }
   }
-  for (hipEvent_t& e : ev) if (e) (void)hipEventDestroy(e);
+  for (auto& row : ev) for (hipEvent_t& e : row) if (e) (void)hipEventDestroy(e);
   if (!ok) { (void)hipGetLastError(); return; }
-  for (int fam = 0; fam < 2; ++fam) c.family_ms[dst.columnar ? 1 : 0][bounds_out6 ? 1 : 0][fam] = 0.5f * ms[fam];
-  choice = ms[1] <= ms[0] ? 1 : 0;
+  for (int fam = 0; fam < 2; ++fam) c.family_ms[slot][bslot][fam] = med[fam];
+  choice = med[1] <= med[0] ? 1 : 0;
 }
 
 // ---- convert_into_range, buffer_conversion.rs:292-359 -----------------------------------------------------
@@ -379,7 +413,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
   if (t1 > dst.len) throw Error(PST_ERR_RANGE, "assertion failed: target_range.end <= target_buffer.len()");
   const uint64_t n = s1 - s0;
   ensure_device();
-  if (force_family < 0) family_autotune(c, src, s0, s1, dst, t0, t1, bounds_out6, stream);
+  if (force_family == kMeasureFamilies) { family_autotune(c, src, s0, s1, dst, t0, t1, bounds_out6, stream); force_family = -1; }
   pstk::reset_plan_kinds();
 
   // position attribute of the target for the fused / trailing bounds
@@ -458,19 +492,46 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
     return;
   }
   if (!c.mappings.empty() && n > 0) {  // no mappings => silent no-op (:308-313)
+    // User-written transformations (expr.cpp).  The reference applies the closure INSIDE the conversion loop (buffer_conversion.rs:569-590, 471-484).
+    // Round 6: where a side is interleaved -- where a pass of its own re-reads and re-writes whole records for one attribute -- the expressions become
+    // part of the plan's specialised kernel (PST_XF_EXPR entries; jit.cpp writes their text into the translation unit): ONE kernel, the plan's
+    // algorithmic bytes.  Columns -> columns is one launch per mapping anyway (the expression's kernel IS that mapping's pass: source read once,
+    // target written once).  The fused AABB is not combined with expressions (bounds_of_range follows).  Fall-back -- no specialised form for this
+    // plan (unaligned record bases, records beyond the register images, PST_JIT=0 refused earlier) and the ragged tail: one strided launch per
+    // expression mapping, the index the expression sees is the point's index in the SOURCE buffer either way.
+    bool any_expr = false;
+    for (const Mapping& m : c.mappings) any_expr = any_expr || !m.expr.empty();
+    static const bool fuse_env = [] { const char* v = std::getenv("PST_EXPR_FUSE"); return !(v && *v == '0'); }();  // the A/B switch
+    const bool fuse_expr = any_expr && fuse_env && !(src.columnar && dst.columnar) && c.mappings.size() <= PST_PLAN_MAX_ENTRIES && pstjit::mode() != pstjit::Mode::Off;
+    struct ExprPass { const Mapping* m; uint64_t src, sstride, dst, dstride; };
+    std::vector<ExprPass> expr_passes;
+    std::vector<std::string> expr_texts;
+    std::vector<PlanEntry> fused;  // fuse_expr: every mapping, in order
+    auto run_expr_pass = [&](const ExprPass& x, uint64_t first, uint64_t count) {
+      launch_expression_mapping(x.m->source.def.datatype, x.m->target.def.datatype, x.m->apply_to_source, x.m->expr, x.src + first * x.sstride, x.sstride,
+                                x.dst + first * x.dstride, x.dstride, count, s0 + first, stream);
+    };
     for (const Mapping& m : c.mappings) {
       PlanEntry e = entry_from_mapping(m);
       const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
       if (src.columnar) e.src_col = col_addr(src, (size_t)sslot, s0);
       if (dst.columnar) e.dst_col = col_addr(dst, (size_t)tslot, t0);
       if (!m.expr.empty()) {
-        // a user-written transformation (expr.cpp): this mapping is its own strided launch, whatever the storage pairing; the index the
-        // expression sees is the point's index in the SOURCE buffer
-        launch_expression_mapping(m.source.def.datatype, m.target.def.datatype, m.apply_to_source, m.expr,
-                                  src.columnar ? e.src_col : aos_addr(src, s0) + m.source.offset, src.columnar ? m.source.size : c.from.size,
-                                  dst.columnar ? e.dst_col : aos_addr(dst, t0) + m.target.offset, dst.columnar ? m.target.size : c.to.size, n, s0, stream);
+        const ExprPass x{&m, src.columnar ? e.src_col : aos_addr(src, s0) + m.source.offset, src.columnar ? m.source.size : c.from.size,
+                         dst.columnar ? e.dst_col : aos_addr(dst, t0) + m.target.offset, dst.columnar ? m.target.size : c.to.size};
+        if (fuse_expr) {
+          e.xf_kind = (uint8_t)PST_XF_EXPR;
+          e.xf_on_source = m.apply_to_source ? 1 : 0;
+          e.mask = expr_texts.size();
+          expr_texts.push_back(m.expr);
+          expr_passes.push_back(x);
+          fused.push_back(e);
+        } else {
+          run_expr_pass(x, 0, n);
+        }
         continue;
       }
+      if (fuse_expr) { fused.push_back(e); generic.push_back(e); continue; }  // (generic: the same plan without its expressions, for the fall-back and the tail)
       if (src.columnar && dst.columnar) {
         const bool same_type = !m.has_converter;
         const bool vec3f64 = m.source.def.datatype.kind == PST_VEC3F64;
@@ -511,9 +572,34 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       }
       generic.push_back(e);
     }
-    if (!generic.empty())
-      execute_entries(!src.columnar, src.columnar ? 0 : aos_addr(src, s0), (uint32_t)c.from.size, !dst.columnar,
-                      dst.columnar ? 0 : aos_addr(dst, t0), (uint32_t)c.to.size, n, generic, true, stream, bounds_out6);
+    uint64_t fused_done = 0;
+    if (fuse_expr) {
+      const bool sa = !src.columnar, da = !dst.columnar;
+      const uint32_t tile = pick_tile(sa, (uint32_t)c.from.size, da, (uint32_t)c.to.size);
+      if (tile >= 1) {
+        bool wants_bounds = false;
+        ConvertPlan plan = build_plan(sa, sa ? aos_addr(src, s0) : 0, (uint32_t)c.from.size, da, da ? aos_addr(dst, t0) : 0, (uint32_t)c.to.size, n, fused.data(), fused.size(), tile,
+                                      false, false, &wants_bounds);
+        plan.expr_texts = &expr_texts;
+        plan.h.first_index = s0;
+        std::string err;
+        if (!pstk::launch_convert_fused_expressions(plan, sa, da, stream, &fused_done, &err))
+          throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+        if (!err.empty()) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "transformation expression: the conversion kernel with the expression(s) in it does not compile:\n" + err);
+      }
+      // what the fused kernel did not cover -- the ragged tail (less than one tile), or everything: the expressions' own strided launches ...
+      if (fused_done < n)
+        for (const ExprPass& x : expr_passes) run_expr_pass(x, fused_done, n - fused_done);
+      // ... and the other mappings of those points through the generic path
+      if (fused_done > 0)
+        for (PlanEntry& e : generic) {
+          if (src.columnar) e.src_col += fused_done * e.src_size;
+          if (dst.columnar) e.dst_col += fused_done * e.dst_size;
+        }
+    }
+    if (!generic.empty() && fused_done < n)
+      execute_entries(!src.columnar, src.columnar ? 0 : aos_addr(src, s0 + fused_done), (uint32_t)c.from.size, !dst.columnar,
+                      dst.columnar ? 0 : aos_addr(dst, t0 + fused_done), (uint32_t)c.to.size, n - fused_done, generic, true, stream, fuse_expr ? nullptr : bounds_out6);
   }
   PST_HIP_CHECK(hipGetLastError());
   if (bounds_out6 && !bounds_done) {
@@ -524,7 +610,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
 // The plan a conversion between buffers of the given storage kinds would hand to the generic tile kernels, with placeholder addresses
 // (only their equality pattern matters to the specialised kernels): what pst_converter_prepare compiles ahead of the first call.
 // Returns the PST_PLAN_* family the call would take WITHOUT a specialised kernel, and fills `plan` when that family is the generic one.
-static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool dst_columnar, bool with_bounds, ConvertPlan* plan) {
+static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool dst_columnar, bool with_bounds, ConvertPlan* plan, std::vector<std::string>* expr_texts) {
   static const bool las_fast = [] { const char* v = std::getenv("PST_LAS_DECODE"); return !(v && *v == '0'); }();
   if (c.mappings.empty()) return PST_PLAN_NONE;
   if (!src_columnar && !dst_columnar && !with_bounds && match_identity_records(c)) return PST_PLAN_COPY;
@@ -537,12 +623,19 @@ static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool
       if (c.to == laslayout::typed_layout(f)) return PST_PLAN_LAS;
   if (las_fast && !src_columnar && match_las_decode_plan(c) >= 0 && !(jit_on && !dst_columnar)) return PST_PLAN_LAS;
   if (src_columnar && dst_columnar) return PST_PLAN_COLUMN;
-  const Member* pm = with_bounds ? c.to.find_by_name("Position3D") : nullptr;
+  bool any_expr = false;
+  for (const Mapping& m : c.mappings) any_expr = any_expr || !m.expr.empty();
+  const Member* pm = (with_bounds && !any_expr) ? c.to.find_by_name("Position3D") : nullptr;  // (a plan with expressions does not fuse the AABB: convert_range)
   std::vector<PlanEntry> generic;
   bool bounds_done = false;
   for (const Mapping& m : c.mappings) {
-    if (!m.expr.empty()) continue;  // (its own launch, compiled at the first conversion)
     PlanEntry e = entry_from_mapping(m);
+    if (!m.expr.empty()) {  // fused into the plan's kernel, as convert_range does
+      e.xf_kind = (uint8_t)PST_XF_EXPR;
+      e.xf_on_source = m.apply_to_source ? 1 : 0;
+      e.mask = expr_texts->size();
+      expr_texts->push_back(m.expr);
+    }
     const int sslot = c.from.index_of(m.source.def), tslot = c.to.index_of(m.target.def);
     if (src_columnar) e.src_col = 0x100000ull * (uint64_t)(sslot + 1);
     if (dst_columnar) e.dst_col = 0x100000ull * (uint64_t)(tslot + 1);
@@ -557,6 +650,7 @@ static uint32_t plan_for_storage(const pst_converter& c, bool src_columnar, bool
   *plan = build_plan(!src_columnar, src_columnar ? 0 : 0x10000000ull, ss, !dst_columnar, dst_columnar ? 0 : 0x20000000ull, ds, (uint64_t)1 << 30,
                      generic.data(), generic.size(), tile, false, with_bounds, &wants_bounds);
   if (wants_bounds) plan->h.bounds_partials = 0x30000000ull;
+  plan->expr_texts = expr_texts->empty() ? nullptr : expr_texts;
   return PST_PLAN_INTERPRETED;
 }
 
@@ -712,7 +806,8 @@ int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_colu
   PST_API_BEGIN
   not_null(c, "converter");
   ConvertPlan plan{};
-  uint32_t kind = plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan);
+  std::vector<std::string> texts;
+  uint32_t kind = plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan, &texts);
   if (kind == PST_PLAN_INTERPRETED && plan.h.n_entries) {
     std::string err;
     bool in_tree = false;
@@ -725,9 +820,22 @@ int pst_converter_prepare(const pst_converter* c, int src_columnar, int dst_colu
 int pst_converter_family_choice(const pst_converter* c, int dst_columnar, int with_bounds, int* choice, float ms2[2]) {
   PST_API_BEGIN
   not_null(c, "converter");
-  const int d = dst_columnar ? 1 : 0, b = with_bounds ? 1 : 0;
+  // dst_columnar: 0 = records from records, 1 = columns (from records), 2 = records from COLUMNS (its own slot since round 6)
+  const int d = dst_columnar == 2 ? 2 : (dst_columnar ? 1 : 0), b = with_bounds ? 1 : 0;
   *not_null(choice, "choice") = c->family_choice[d][b];
   if (ms2) { ms2[0] = c->family_ms[d][b][0]; ms2[1] = c->family_ms[d][b][1]; }
+  PST_API_END
+}
+// The explicit form of the measurement (stream-ordered callers: once, before their loop).  Converts the range like pst_converter_convert_into_range
+// (same bytes, several times) and waits for the stream; a no-op when the pairing was measured already or has one family.
+int pst_converter_measure_families(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1, int with_bounds) {
+  PST_API_BEGIN
+  not_null(c, "converter");
+  Workspace& ws = workspace();
+  double* dev_rec = (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
+  const bool has_pos = c->to.find_by_name("Position3D") != nullptr;
+  convert_range(*c, *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, (with_bounds && has_pos && t1 > t0) ? dev_rec : nullptr, current_stream(), kMeasureFamilies);
+  stream_sync(current_stream());
   PST_API_END
 }
 // The translation unit the run-time compiler is given for this converter and storage pairing (empty when the plan takes another family).
@@ -736,7 +844,8 @@ int pst_converter_jit_source(const pst_converter* c, int src_columnar, int dst_c
   not_null(c, "converter");
   ConvertPlan plan{};
   std::string src;
-  if (plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan) == PST_PLAN_INTERPRETED && plan.h.n_entries) {
+  std::vector<std::string> texts;
+  if (plan_for_storage(*c, src_columnar != 0, dst_columnar != 0, with_bounds != 0, &plan, &texts) == PST_PLAN_INTERPRETED && plan.h.n_entries) {
     pstjit::QuadSpec spec;
     if (pstjit::spec_from_plan(plan, !src_columnar, !dst_columnar, &spec)) src = pstjit::spec_source(spec);
   }
@@ -809,7 +918,7 @@ int pst_converter_convert_into_range_async(const pst_converter* c, pst_buffer* s
 }
 int pst_converter_convert_into_range(const pst_converter* c, pst_buffer* src, size_t s0, size_t s1, pst_buffer* dst, size_t t0, size_t t1) {
   PST_API_BEGIN
-  convert_range(*not_null(c, "converter"), *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, nullptr, current_stream());
+  convert_range(*not_null(c, "converter"), *not_null(src, "src"), s0, s1, *not_null(dst, "dst"), t0, t1, nullptr, current_stream(), kMeasureFamilies);
   stream_sync(current_stream());
   PST_API_END
 }
@@ -844,7 +953,7 @@ int pst_converter_convert(const pst_converter* c, pst_buffer* src, uint32_t out_
       const bool full = std::all_of(covered.begin(), covered.end(), [](uint8_t v) { return v != 0; });
       if (!full && c->to.size) PST_HIP_CHECK(hipMemsetAsync(target->data, 0, n * c->to.size, s));
     }
-    convert_range(*c, *src, 0, n, *target, 0, n, nullptr, s);
+    convert_range(*c, *src, 0, n, *target, 0, n, nullptr, s, kMeasureFamilies);
     stream_sync(s);
   }
   *not_null(out, "out") = guard.release();
@@ -868,7 +977,7 @@ int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buf
   double* dev_rec = (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
   double* host_rec = (double*)ws.pinned;
   const bool has_pos = not_null(c, "converter")->to.find_by_name("Position3D") != nullptr;
-  convert_range(*c, *not_null(src, "src"), s0, s1, *dst, t0, t1, (has_pos && t1 > t0) ? dev_rec : nullptr, s);
+  convert_range(*c, *not_null(src, "src"), s0, s1, *dst, t0, t1, (has_pos && t1 > t0) ? dev_rec : nullptr, s, kMeasureFamilies);
   // calculate_bounds(target): None for an empty range or a layout without Position3D (bounds.rs:12-21)
   if (!has_pos || t1 <= t0) {
     stream_sync(s);

@@ -47,9 +47,11 @@ static std::vector<std::string> split_components(const std::string& expr) {
   for (char ch : expr) {
     if (ch == '(' || ch == '[') ++depth;
     if (ch == ')' || ch == ']') --depth;
+    if (depth < 0) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression: a closing parenthesis or bracket without its opening one");
     if (ch == ';' && depth == 0) { out.push_back(cur); cur.clear(); }
     else cur += ch;
   }
+  if (depth != 0) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression: unbalanced parentheses or brackets");
   out.push_back(cur);
   auto blank = [](const std::string& s) { for (char c : s) if (!std::isspace((unsigned char)c)) return false; return true; };
   if (out.size() > 1 && blank(out.back())) out.pop_back();  // a trailing ';'
@@ -57,6 +59,7 @@ static std::vector<std::string> split_components(const std::string& expr) {
     if (blank(s)) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression: an empty component expression");
   return out;
 }
+std::vector<std::string> split_expression_components(const std::string& expr) { return split_components(expr); }  // (jit.cpp: fused into a plan's kernel)
 
 static void check_text(const char* expr) {
   if (!expr || !*expr) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "expression must not be empty");
@@ -65,6 +68,18 @@ static void check_text(const char* expr) {
   for (const char* p = expr; *p; ++p)
     if (*p == '{' || *p == '}' || *p == '#' || *p == '"' || *p == '\'' || *p == '\\' || *p == '\n' || *p == '\r')
       throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string("expression: character '") + *p + "' is not allowed (an expression, not statements)");
+  // The text is pasted between `rust_as<T>(` / `(bool)(` and `)`: parentheses and brackets must nest and close, or `x) , (y` would escape the cast
+  // that wraps it (round-5 advisor finding).
+  std::string open;
+  for (const char* p = expr; *p; ++p) {
+    if (*p == '(' || *p == '[') open += *p;
+    else if (*p == ')' || *p == ']') {
+      if (open.empty() || open.back() != (*p == ')' ? '(' : '['))
+        throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string("expression: '") + *p + "' closes nothing that is open at that point");
+      open.pop_back();
+    }
+  }
+  if (!open.empty()) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, std::string("expression: '") + open.back() + "' is never closed");
 }
 
 struct MapSpec {
@@ -211,6 +226,29 @@ void launch_pred(const std::vector<PredAttr>& attrs, const std::string& expr, ui
     throw Error(PST_ERR_HIP, std::string("predicate kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
 }
 
+static bool is_reserved_name(const std::string& n) {
+  static const char* const names[] = {
+      "i", "p0", "p1", "p2", "p3",  // the predicate function's own parameters
+      "alignas", "alignof", "and", "and_eq", "asm", "auto", "bitand", "bitor", "bool", "break", "case", "catch", "char", "char16_t", "char32_t", "class", "compl", "const",
+      "constexpr", "const_cast", "continue", "decltype", "default", "delete", "do", "double", "dynamic_cast", "else", "enum", "explicit", "export", "extern", "false", "float",
+      "for", "friend", "goto", "if", "inline", "int", "long", "mutable", "namespace", "new", "noexcept", "not", "not_eq", "nullptr", "operator", "or", "or_eq", "private",
+      "protected", "public", "register", "reinterpret_cast", "return", "short", "signed", "sizeof", "static", "static_assert", "static_cast", "struct", "switch", "template",
+      "this", "thread_local", "throw", "true", "try", "typedef", "typeid", "typename", "union", "unsigned", "using", "virtual", "void", "volatile", "wchar_t", "while", "xor",
+      "xor_eq", "uint8_t", "int8_t", "uint16_t", "int16_t", "uint32_t", "int32_t", "uint64_t", "int64_t", "size_t", "threadIdx", "blockIdx", "blockDim", "gridDim"};
+  for (const char* r : names) if (n == r) return true;
+  return n.compare(0, 2, "__") == 0 || n.compare(0, 4, "pst_") == 0 || n.compare(0, 3, "Pst") == 0;
+}
+// `name` followed by '(' somewhere in the text (and not a member access `.name`)
+static bool names_a_call(const std::string& expr, const std::string& name) {
+  for (size_t p = expr.find(name); p != std::string::npos; p = expr.find(name, p + 1)) {
+    const bool starts = p == 0 || !(std::isalnum((unsigned char)expr[p - 1]) || expr[p - 1] == '_' || expr[p - 1] == '.');
+    size_t q = p + name.size();
+    if (!starts || (q < expr.size() && (std::isalnum((unsigned char)expr[q]) || expr[q] == '_'))) continue;
+    while (q < expr.size() && std::isspace((unsigned char)expr[q])) ++q;
+    if (q < expr.size() && expr[q] == '(') return true;
+  }
+  return false;
+}
 // the attributes of `layout` an expression names (C identifiers only; scalars and Vec3)
 std::vector<PredAttr> referenced_attributes(const Layout& layout, const std::string& expr) {
   std::vector<PredAttr> out;
@@ -220,6 +258,13 @@ std::vector<PredAttr> referenced_attributes(const Layout& layout, const std::str
     bool used = false;
     for (const std::string& id : ids) used = used || id == m.def.name;
     if (!used) continue;
+    // An attribute becomes a PARAMETER of the predicate function under its own name: names the wrapper or the language already use would end as
+    // a duplicate-parameter or keyword error somewhere inside generated code (round-5 advisor finding) -- said here instead.
+    if (is_reserved_name(m.def.name))
+      throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression: the attribute name `" + m.def.name + "` collides with a name the expression language reserves (i, p0 .. p3, "
+                                                 "C++ keywords and type names): such an attribute cannot be named in a predicate");
+    if (names_a_call(expr, m.def.name))
+      throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression: `" + m.def.name + "(` -- the name is an attribute of the layout (a value) and is used as a function");
     if (!(m.def.datatype.is_scalar() || m.def.datatype.is_vec3()))
       throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression: attribute " + m.def.name + " of datatype " + m.def.datatype.display() + " cannot be named (scalars and Vec3 only)");
     PredAttr a;

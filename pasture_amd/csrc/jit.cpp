@@ -172,11 +172,24 @@ void write_file_atomic(const std::string& path, const std::vector<char>& data) {
   else (void)unlink(tmp.c_str());
 }
 
-std::string device_arch() {
+// The architecture name of the calling thread's current device.  Asked on the launch path of every plan-specialised conversion and filter, so the
+// answer is kept per device id (hipGetDeviceProperties fills a multi-kilobyte struct each time).
+const std::string& device_arch() {
+  static const std::string fallback = "gfx950";
+  constexpr int kMaxDevices = 64;
+  static std::string names[kMaxDevices];
+  static std::atomic<bool> known[kMaxDevices];
+  static std::mutex mu;
   int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) return prop.gcnArchName;
-  return "gfx950";
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return fallback; }
+  if (known[dev].load(std::memory_order_acquire)) return names[dev];
+  std::lock_guard<std::mutex> lock(mu);
+  if (!known[dev].load(std::memory_order_relaxed)) {
+    hipDeviceProp_t prop;
+    names[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) ? prop.gcnArchName : fallback;
+    known[dev].store(true, std::memory_order_release);
+  }
+  return names[dev];
 }
 
 // ---- the cache --------------------------------------------------------------------------------------------------------------------
@@ -195,7 +208,7 @@ struct Entry {
 struct Cache {
   std::mutex mu;
   std::condition_variable cv;
-  std::map<std::string, std::shared_ptr<Entry>> by_source;
+  std::map<std::string, std::map<std::string, std::shared_ptr<Entry>>> by_source;  // [architecture][source text]: looked up without building a joined key per launch
   std::deque<std::shared_ptr<Entry>> queue;
   bool worker_started = false;
   int compiling = 0;       // compilations in flight (the exit handler waits for them: hipRTC's libraries must not be torn down under a compile)
@@ -333,6 +346,12 @@ bool spec_from_plan(const ConvertPlan& plan, bool src_aos, bool dst_aos, QuadSpe
     q.src_size = e.src_size; q.dst_size = e.dst_size; q.ncomp = e.ncomp;
     q.src_ct = e.src_ct; q.dst_ct = e.dst_ct; q.convert = e.convert ? 1u : 0u;
     q.xf_kind = e.xf_kind; q.xf_pre = e.xf_kind ? (e.xf_on_source ? 1u : 0u) : 0u;
+    if (e.xf_kind == PST_XF_EXPR) {  // a device expression: its text becomes part of the translation unit (PlanEntry::mask = its index in the plan's table)
+      const std::vector<std::string>* texts = (const std::vector<std::string>*)plan.expr_texts;
+      if (!texts || e.mask >= texts->size() || (*texts)[(size_t)e.mask].empty() || !(e.ncomp == 1 || e.ncomp == 3) || e.bounds) return false;
+      if (s.exprs.empty()) s.exprs.resize(h.n_entries);
+      s.exprs[m] = (*texts)[(size_t)e.mask];
+    }
     q.bounds = (e.bounds && h.bounds_partials && e.dst_ct == 9 /*F64*/ && e.ncomp == 3) ? 1u : 0u;
     if (e.bounds && h.bounds_partials && !q.bounds) return false;
     if (!src_aos) {  // one image per distinct source column (one source -> many targets: the bit fields of raw_readers.rs:61-164)
@@ -377,6 +396,11 @@ bool spec_from_plan(const ConvertPlan& plan, bool src_aos, bool dst_aos, QuadSpe
   return true;
 }
 
+// expr.cpp: the component expressions of a transformation text (one, or one per component separated by top-level ';')
+}  // namespace pstjit
+namespace pstexpr { std::vector<std::string> split_expression_components(const std::string& expr); }
+namespace pstjit {
+using pstexpr::split_expression_components;
 static std::string spec_source_uncached(const QuadSpec& s);
 // The text is a pure function of the spec, and a converter hands the same plan to every call: a small per-thread memo keyed by the spec's
 // bytes saves the ~15 us of formatting per conversion call (two of them since converter.cpp asks whether a kernel is at hand before it
@@ -393,6 +417,7 @@ std::string spec_source(const QuadSpec& s) {
                           e.src_stage, e.dst_wide, e.dst_stage};
     put(f, sizeof(f));
   }
+  for (const std::string& t : s.exprs) { const uint32_t len = (uint32_t)t.size(); put(&len, sizeof(len)); put(t.data(), t.size()); }
   thread_local std::unordered_map<std::string, std::string> memo;
   auto it = memo.find(key);
   if (it != memo.end()) return it->second;
@@ -415,7 +440,22 @@ static std::string spec_source_uncached(const QuadSpec& s) {
     o << "      {" << e.src_off << ", " << e.dst_off << ", " << e.src_size << ", " << e.dst_size << ", " << e.ncomp << ", " << e.src_ct << ", " << e.dst_ct << ", "
       << e.convert << ", " << e.xf_kind << ", " << e.xf_pre << ", " << e.bounds << ", " << e.src_img << ", " << e.src_load << ", " << e.src_wide << ", " << e.dst_wide
       << ", " << e.src_stage << ", " << e.dst_stage << "},\n";
-  o << "    };\n    return t[m];\n  }\n};\n";
+  o << "    };\n    return t[m];\n  }\n";
+  if (!s.exprs.empty()) {
+    // the fused expressions (expr.cpp's names: v, x, y, z, c, i, p0 .. p3 -- a conversion captures no arrays: p0 .. p3 are null): one `if constexpr`
+    // arm per (mapping, component); a Vec3 mapping may give one text for all components or three separated by ';' (split by expr.cpp)
+    o << "  template <int M, int C, typename TI>\n  __device__ static __forceinline__ TI expr(const TI v, const TI x, const TI y, const TI z, const uint64_t i) {\n";
+    o << "    using namespace pstd;\n    constexpr int c = C;\n    const double* const p0 = nullptr; const double* const p1 = nullptr; const double* const p2 = nullptr; const double* const p3 = nullptr;\n";
+    o << "    (void)v; (void)x; (void)y; (void)z; (void)c; (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n";
+    for (size_t m = 0; m < s.exprs.size(); ++m) {
+      if (s.exprs[m].empty()) continue;
+      const std::vector<std::string> comps = split_expression_components(s.exprs[m]);
+      for (uint32_t cc = 0; cc < s.entries[m].ncomp; ++cc)
+        o << "    if constexpr (M == " << m << " && C == " << cc << ") return rust_as<TI>(\n" << comps[comps.size() == 1 ? 0 : cc] << "\n    );\n";
+    }
+    o << "    return v;\n  }\n";
+  }
+  o << "};\n";
   o << "extern \"C\" __global__ __launch_bounds__(" << s.blk << ") void pst_jit_convert(const ConvertHeader h, const PlanEntry* __restrict__ entries) {\n";
   o << "  pstq::quad_convert_body<PstJitPlan>(h, entries);\n}\n";
   return o.str();
@@ -472,14 +512,17 @@ bool acquire_source(const std::string& src, const char* entry, unsigned blk, uin
   std::shared_ptr<Entry> e;
   bool compile_here = false;
   // entries are per (architecture, source): the requesting thread's device decides the architecture, not the compiler thread's
-  const std::string arch = device_arch();
-  const std::string key = arch + '\n' + src;
+  const std::string& arch = device_arch();
   {
     std::unique_lock<std::mutex> lock(c.mu);
     static bool at_exit = false;
-    if (!at_exit) { at_exit = true; std::atexit(drain_at_exit); }
-    auto it = c.by_source.find(key);
-    if (it == c.by_source.end()) {
+    // exit handlers run last-registered-first: hipRTC (and the comgr / LLVM it links) must be LOADED before drain_at_exit is registered, or their
+    // static destructors would run before the drain -- under a compilation still in flight on the compiler thread (seen in round 6: a process that
+    // ended 50 ms after it queued a plan dumped core at exit)
+    if (!at_exit) { (void)rtc(); at_exit = true; std::atexit(drain_at_exit); }
+    auto& of_arch = c.by_source[arch];
+    auto it = of_arch.find(src);
+    if (it == of_arch.end()) {
       if (how == Acquire::IfReady) return false;
       e = std::make_shared<Entry>();
       e->arch = arch;
@@ -488,7 +531,7 @@ bool acquire_source(const std::string& src, const char* entry, unsigned blk, uin
       e->blk = blk;
       e->lds_bytes = lds_bytes;
       e->tile = tile;
-      c.by_source.emplace(key, e);
+      of_arch.emplace(src, e);
       if (wait) {
         compile_here = true;
       } else {

@@ -18,6 +18,7 @@ struct QuadSpec {
   int blk = 256;
   uint32_t xcd = 0, nt = 1, src_words = 0, lds_per_point = 0, dst_tile_off = 0, alias = 0;
   std::vector<pstq::QEntry> entries;
+  std::vector<std::string> exprs;  // empty, or one text per entry: the device expression of a PST_XF_EXPR entry ("" for the others), already validated (expr.cpp)
   uint32_t tile() const { return 4u * (uint32_t)blk; }
   uint32_t lds_bytes() const;
 };

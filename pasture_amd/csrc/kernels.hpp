@@ -27,6 +27,7 @@ uint32_t plan_kinds();
 void note_slow_family(const char* what, uint64_t n_points, const char* why);
 // compile (or fetch) the plan-specialised kernel this plan would take (jit.cpp); false + message when it cannot have one
 bool prepare_convert(const ConvertPlan& plan, bool src_aos, bool dst_aos, std::string* error, bool* in_tree = nullptr);
+bool launch_convert_fused_expressions(const ConvertPlan& plan, bool src_aos, bool dst_aos, hipStream_t stream, uint64_t* done, std::string* error);
 bool convert_specialised_ready(const ConvertPlan& plan, bool src_aos, bool dst_aos);
 size_t bounds_partials_bytes(unsigned n_records);
 // fold n_records per-block {min xyz, max xyz} records into out6

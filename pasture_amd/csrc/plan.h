@@ -7,6 +7,10 @@
 #endif
 
 #define PST_PLAN_MAX_ENTRIES 30
+// PlanEntry::xf_kind of a mapping whose transformation is a device expression (expr.cpp): internal -- pst_transform descriptors stop at
+// PST_XF_BITFIELD -- and understood by the plan-specialised kernels only, whose translation unit carries the expression's text
+// (PlanEntry::mask = index into the plan's expression table, host side).
+#define PST_XF_EXPR 3u
 
 struct PlanEntry {
   uint64_t src_col;  // columnar source: device address of element 0 of the source RANGE; interleaved: unused
@@ -43,12 +47,16 @@ struct ConvertHeader {
   uint64_t bounds_partials;   // 0, or device address of gridDim.x records {min xyz, max xyz} (f64) for entries with .bounds
   uint32_t quad;              // tile kernels, columnar -> interleaved: four consecutive points per lane (wave-uniform LDS alignment classes)
   uint32_t reserved;
+  uint64_t first_index;       // index of the range's first point in the SOURCE buffer: the `i` of a fused expression (plan-specialised kernels)
 };
 struct ConvertPlan {
   ConvertHeader h;
   PlanEntry e[PST_PLAN_MAX_ENTRIES];
   // tile kernels: masks[0] = entries every wave of a block works on; masks[1 + w] = entries owned by wave w (mod 16)
   uint32_t masks[20];
+  // HOST side only (never uploaded: the kernels get h by value and e + masks by copy): the texts of the plan's PST_XF_EXPR entries, as a
+  // `const std::vector<std::string>*`
+  const void* expr_texts;
 };
 
 // SoA Vec3f64 streaming kernel (copy / affine / bounds in one pass)

@@ -26,7 +26,9 @@ struct pst_buffer {
   // borrow checker, so an owning buffer carries a storage epoch -- bumped whenever its storage moves, shrinks, grows or dies -- and a slice
   // remembers the epoch it was cut at: any use of a slice whose parent has been resized or destroyed since is PST_ERR_INVALID_ARGUMENT
   // instead of a read of freed device memory.
-  mutable std::shared_ptr<std::atomic<uint64_t>> epoch;  // owning buffers: their own, made when the first slice is cut; slices: the owning ancestor's; external memory: none
+  // owning buffers: their own, made WITH the buffer (cutting a slice only reads the parent: two threads may slice one buffer at once); slices: the owning
+  // ancestor's; external memory: none
+  std::shared_ptr<std::atomic<uint64_t>> epoch = std::make_shared<std::atomic<uint64_t>>(0);
   uint64_t epoch_cut = 0;                        // slices: the ancestor's epoch when the slice was cut
   bool is_slice = false;
   ~pst_buffer();

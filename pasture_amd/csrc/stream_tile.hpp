@@ -63,8 +63,8 @@ __device__ __forceinline__ P* uniform_ptr(P* p) {
 }
 
 // Block-wide fold of three minima and three maxima (BLK threads); the result is valid in lanes 0, 8, 16 (minima x y z) and
-// 24, 32, 40 (maxima) of wave 0, as `out`; `lds` holds 6 * (BLK + 8) doubles.  No NaN can sit in an accumulator (seeds are finite and a
-// NaN never wins a fold), so max(a, b) = -min(-a, -b) exactly.
+// 24, 32, 40 (maxima) of wave 0, as `out`; `lds` holds 6 * (BLK + 8) doubles.  No NaN can sit in an accumulator (seeds are finite, a quiet
+// NaN never wins a fold and signalling ones are quieted before they are folded), so max(a, b) = -min(-a, -b) exactly.
 template <int BLK>
 __device__ __forceinline__ bool block_reduce_minmax3_lds(const double (&mn)[3], const double (&mx)[3], double* lds, double& out, uint32_t& which) {
   constexpr int kStride = BLK + 8;  // rows shifted by 16 banks against each other
@@ -132,10 +132,16 @@ __global__ __launch_bounds__(BLK) void vec3f64_stream2_kernel(const Stream2Param
       b = b + orr[k1];
     }
     if constexpr (BOUNDS) {
-      mn[k0] = vmin_f64(mn[k0], a);
-      mx[k0] = vmax_f64(mx[k0], a);
-      mn[k1] = vmin_f64(mn[k1], b);
-      mx[k1] = vmax_f64(mx[k1], b);
+      // Raw v_min_f64 / v_max_f64 return the non-NaN operand only for QUIET NaNs: in IEEE mode a signalling NaN comes back quieted and would
+      // poison the accumulator (the next fold then replaces it: the lane's earlier minimum is lost).  Products and sums are always quiet, so the
+      // affine modes need nothing; the plain copy folds the LOADED bits, which are canonicalised first (one v_max_f64 v, v per value on a kernel
+      // with vector slots to spare) -- the reference's strict `<` / `>` ignore every NaN (bounds.rs:34-51).  The stored value keeps its bits.
+      double fa = a, fb = b;
+      if constexpr (!AFFINE) { fa = __builtin_canonicalize(a); fb = __builtin_canonicalize(b); }
+      mn[k0] = vmin_f64(mn[k0], fa);
+      mx[k0] = vmax_f64(mx[k0], fa);
+      mn[k1] = vmin_f64(mn[k1], fb);
+      mx[k1] = vmax_f64(mx[k1], fb);
     }
     f64x2_t r;
     r.x = a;
@@ -197,10 +203,11 @@ __global__ __launch_bounds__(BLK) void vec3f64_stream2_kernel(const Stream2Param
       }
       if constexpr (WRITE) p.dst[idx] = a;
       if constexpr (BOUNDS) {
+        const double fa = AFFINE ? a : __builtin_canonicalize(a);  // (see body: a signalling NaN must not reach the raw fold)
 #pragma unroll
         for (uint32_t cc = 0; cc < 3; ++cc) {
-          bmn[cc] = vmin_f64(bmn[cc], cc == c ? a : kF64Max);
-          bmx[cc] = vmax_f64(bmx[cc], cc == c ? a : -kF64Max);
+          bmn[cc] = vmin_f64(bmn[cc], cc == c ? fa : kF64Max);
+          bmx[cc] = vmax_f64(bmx[cc], cc == c ? fa : -kF64Max);
         }
       }
     }

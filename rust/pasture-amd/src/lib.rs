@@ -202,11 +202,17 @@ impl DeviceBufferLayoutConverter {
         kind
     }
     /// Which of the two kernel families that can serve a LAS-shaped plan this converter measured to be the faster one on this device (its first
-    /// conversion of at least 2^22 points measures): `None` = not measured yet or one family only, `Some((plan_specialised, [ms LAS, ms plan-specialised]))`.
-    pub fn family_choice(&self, target_columnar: bool, with_bounds: bool) -> Option<(bool, [f32; 2])> {
+    /// SYNCHRONOUS conversion of at least 2^22 points measures, or `measure_families`): `None` = not measured yet or one family only,
+    /// `Some((plan_specialised, [ms LAS, ms plan-specialised]))`.  Records produced from columns have their own slot.
+    pub fn family_choice(&self, source_columnar: bool, target_columnar: bool, with_bounds: bool) -> Option<(bool, [f32; 2])> {
         let (mut choice, mut ms) = (0 as c_int, [0f32; 2]);
-        check(unsafe { pst_converter_family_choice(self.handle, target_columnar as c_int, with_bounds as c_int, &mut choice, ms.as_mut_ptr()) });
+        let pairing: c_int = if target_columnar { 1 } else if source_columnar { 2 } else { 0 };
+        check(unsafe { pst_converter_family_choice(self.handle, pairing, with_bounds as c_int, &mut choice, ms.as_mut_ptr()) });
         if choice == 0 || choice == 1 { Some((choice == 1, ms)) } else { None }
+    }
+    /// The measurement behind `family_choice`, run now (callers of stream-ordered conversions: once before their loop).
+    pub fn measure_families(&self, source: &impl DeviceBuffer, target: &mut impl DeviceBuffer, n: usize, with_bounds: bool) {
+        check(unsafe { pst_converter_measure_families(self.handle, source.handle(), 0, n, target.handle(), 0, n, with_bounds as c_int) })
     }
     pub fn convert_into(&self, source: &impl DeviceBuffer, target: &mut impl DeviceBuffer, n: usize) { self.convert_into_range(source, 0..n, target, 0..n) }
     pub fn convert_into_range(&self, source: &impl DeviceBuffer, source_range: Range<usize>, target: &mut impl DeviceBuffer, target_range: Range<usize>) {

@@ -62,6 +62,36 @@ def test_bounds_nan_semantics(api, kind):  # strict < / > from +-f64::MAX seeds:
     assert b.min() == (1.7976931348623157e308, -inf, 0.0) and b.max() == (inf, -1.7976931348623157e308, 1.0)
 
 
+@pytest.mark.parametrize("n", [7, 3000, 50_001])
+def test_bounds_ignore_signalling_nans_in_the_fused_copy(api, n):
+    """A SIGNALLING NaN (0x7FF0000000000001) in a Vec3f64 column: the reference's strict `<` / `>` ignore it like any NaN (bounds.rs:34-51).  The
+    plain copy + AABB mode folds loaded bits with raw v_min_f64 / v_max_f64, which quiet an sNaN operand and return it (round-5 advisor finding): every
+    lane's accumulator must survive.  The copied column keeps the sNaN's bits."""
+    from pasture_amd.conversion import BufferLayoutConverter
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3)) * 100.0 - 50.0
+    snan = np.frombuffer(np.uint64(0x7FF0000000000001).tobytes(), dtype=np.float64)[0]
+    bits = pts.view(np.uint64)
+    for i in range(0, n, 5):  # a fifth of the points carry one in some component; extremes before AND after them in every lane's stride
+        bits[i, i % 3] = np.uint64(0x7FF0000000000001)
+    assert np.isnan(snan) and np.isnan(pts[0, 0])
+    src = positions_buffer(api, "H", pts)
+    layout = src.point_layout()
+    dst = HashMapBuffer.new_from_layout(layout)
+    dst.resize(n)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    if api.is_product:
+        fused = conv.convert_into_with_bounds(src, dst)  # (the fused entry point is the product's own: one pass over HBM)
+    else:
+        conv.convert_into(src, dst)
+        fused = calculate_bounds(dst)
+    quiet = np.where(np.isnan(pts), np.nan, pts)  # (numpy's own nanmin / nanmax go wrong on signalling NaNs: the expectation is taken from quieted copies)
+    assert fused.min() == tuple(np.nanmin(quiet, axis=0)) and fused.max() == tuple(np.nanmax(quiet, axis=0))
+    assert fused == calculate_bounds(dst) == calculate_bounds(src)
+    out = dst.get_attribute_range(A.POSITION_3D, range(0, n))
+    assert np.asarray(out).tobytes() == pts.tobytes()
+
+
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("dtype", [T.Vec3f32, T.Vec3i32, T.Vec3u16, T.Vec3u8])
 def test_bounds_custom_position_datatype(api, kind, dtype):  # calculate_bounds_from_custom_positions bounds.rs:56-85

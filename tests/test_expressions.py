@@ -86,6 +86,52 @@ def test_expression_shape_errors(hip):
     assert "error" in str(e.value)
 
 
+@pytest.mark.parametrize("src_kind,dst_kind", [("V", "V"), ("V", "H"), ("H", "V")])
+@pytest.mark.parametrize("apply_to_source", [False, True])
+def test_expression_mappings_are_part_of_the_plan_specialised_kernel(hip, src_kind, dst_kind, apply_to_source):
+    """Round 6 (review: closures are applied INSIDE the reference's conversion loop, buffer_conversion.rs:569-590): wherever a side is interleaved
+    the expression is a device function of the plan's own translation unit -- one kernel, no strided pass of its own.  CPU: the generated unit of the
+    reference's `+ 42.0` scenario (CustomPointTypeBig -> [POSITION_3D]) and of a converting Vec3 mapping with three component texts carries the
+    text(s) and compiles for gfx950."""
+    big = custom_point_type_big(hip)
+    custom = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    conv = BufferLayoutConverter.for_layouts_with_default(big, custom)
+    conv.set_custom_mapping_with_expression(A.POSITION_3D, A.POSITION_3D, "v + 42.0", apply_to_source)
+    unit = conv.jit_source(BUFFER_KINDS[src_kind], BUFFER_KINDS[dst_kind])
+    assert "v + 42.0" in unit and "static __forceinline__ TI expr(" in unit and "pst_jit_convert" in unit
+    assert cv.jit_compile_source(unit, api=hip)[:4] == b"\x7fELF"
+    sa, da = PointAttributeDefinition("Value", T.Vec3i32), PointAttributeDefinition("Value", T.Vec3f32)
+    sl = PointLayout.from_attributes_packed([A.CLASSIFICATION, sa, A.GPS_TIME], 1, api=hip)
+    dl = PointLayout.from_attributes_packed([A.GPS_TIME, da, A.CLASSIFICATION], 1, api=hip)
+    conv = BufferLayoutConverter.for_layouts(sl, dl)
+    conv.set_custom_mapping_with_expression(sa, da, "x * 2.0 ; y - z ; (double)c + floor((double)z) + (double)(i % 7)", apply_to_source)
+    unit = conv.jit_source(BUFFER_KINDS[src_kind], BUFFER_KINDS[dst_kind])
+    assert "if constexpr (M == 1 && C == 2) return rust_as<TI>(" in unit and "y - z" in unit
+    assert cv.jit_compile_source(unit, api=hip)[:4] == b"\x7fELF"
+    # without an expression the unit is what it was (the in-tree instantiations are matched by their text)
+    plain = BufferLayoutConverter.for_layouts(sl, dl).jit_source(BUFFER_KINDS[src_kind], BUFFER_KINDS[dst_kind])
+    assert "expr(" not in plain
+
+
+def test_expression_text_must_nest_and_predicates_cannot_name_reserved_attributes(hip):
+    """Round-5 advisor findings: `x) , (y` would escape the cast the text is pasted into; an attribute called `i` / `p0` / `int` would end as a
+    duplicate-parameter or keyword error inside generated code.  Both are PST_ERR_UNSUPPORTED_TRANSFORM with a message that says so."""
+    for bad in ("x) , (y", "(v + 1", "v + 1)", "p0[i) + (1]", "((v)"):
+        with pytest.raises(PastureError) as e:
+            cv.expr_source("transform", bad, src_datatype=T.Vec3f64, dst_datatype=T.Vec3f64, api=hip)
+        assert e.value.code == 7 and ("close" in str(e.value) or "open" in str(e.value)), (bad, str(e.value))
+    for name in ("i", "p0", "int", "double", "return"):
+        layout = PointLayout.from_attributes([A.POSITION_3D, PointAttributeDefinition(name, T.U16)], api=hip)
+        with pytest.raises(PastureError) as e:
+            cv.expr_source("predicate", f"{name} > 3", layout=layout, api=hip)
+        assert e.value.code == 7 and "reserve" in str(e.value), (name, str(e.value))
+    layout = PointLayout.from_attributes([A.POSITION_3D, PointAttributeDefinition("sqrt", T.F64)], api=hip)
+    with pytest.raises(PastureError) as e:
+        cv.expr_source("predicate", "sqrt (Position3D.x) > 2.0", layout=layout, api=hip)
+    assert e.value.code == 7 and "used as a function" in str(e.value)
+    assert "const double sqrt" in cv.expr_source("predicate", "sqrt > 2.0", layout=layout, api=hip)  # (as a value it is an attribute like any other)
+
+
 def test_twin_semantics_are_rust_as():
     """The g++ twin itself against numpy on the documented rules: the result is converted to T with Rust `as`."""
     f = expr_twin.map_twin("u16", "u8", 1, True, "v * 2.0 + 0.5")  # T = u16: 400.5 -> 400; then u16 -> u8 truncates: 144
@@ -118,6 +164,35 @@ def test_reference_plus_42_scenarios_through_the_expression_path(hip, src_kind, 
     out = conv.convert(src, BUFFER_KINDS[dst_kind])
     assert out.point_layout() == custom
     assert np.array_equal(out.view_attribute(A.POSITION_3D), rec["Position3D"] + 42.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_kind,dst_kind", [("V", "V"), ("V", "H"), ("H", "V")])
+@pytest.mark.parametrize("apply_to_source", [False, True])
+def test_plus_42_at_scale_runs_as_one_fused_kernel(hip, src_kind, dst_kind, apply_to_source):
+    """The same scenario on 2^18 points (whole tiles, aligned records): pst_last_plan_kinds names ONE family -- the plan-specialised kernel with the
+    closure inside --, the positions are the source's + 42.0, every other attribute of a wider target arrives unchanged; with a ragged point count the
+    tail (less than one tile) goes through the expression's strided kernel and the interpreter, same values; PST_EXPR_FUSE is the A/B switch."""
+    big = custom_point_type_big(hip)
+    target = PointLayout.from_attributes_packed([A.POSITION_3D, A.GPS_TIME, A.CLASSIFICATION], 1, api=hip)
+    for n in (1 << 18, (1 << 18) + 77):
+        rec = random_records(big, n, 5)
+        src = make_buffer(src_kind, big, rec)
+        conv = BufferLayoutConverter.for_layouts_with_default(big, target)
+        conv.set_custom_mapping_with_expression(A.POSITION_3D, A.POSITION_3D, "v + 42.0 + (double)(i & 1)", apply_to_source)
+        dst = BUFFER_KINDS[dst_kind].new_from_layout(target)
+        dst.resize(n)
+        conv.convert_into(src, dst)
+        kinds = cv.last_plan_kinds(hip)
+        assert kinds == (["jit"] if n % 256 == 0 else ["interpreted", "jit"]), kinds
+        want = rec["Position3D"] + 42.0 + (np.arange(n) & 1)[:, None]
+        assert np.array_equal(dst.view_attribute(A.POSITION_3D), want)
+        assert np.array_equal(dst.view_attribute(A.GPS_TIME), rec["GpsTime"]) and np.array_equal(dst.view_attribute(A.CLASSIFICATION), rec["Classification"])
+        # a sub-range that starts mid-buffer: the expression's index is the point's index in the SOURCE buffer
+        part = BUFFER_KINDS[dst_kind].new_from_layout(target)
+        part.resize(4096)
+        conv.convert_into_range(src, range(5001, 5001 + 4096), part, range(0, 4096))
+        assert np.array_equal(part.view_attribute(A.POSITION_3D), want[5001:5001 + 4096])
 
 
 @pytest.mark.gpu
