@@ -104,12 +104,15 @@ def jit_compile_source(source: str, api=None) -> bytes:
 
 
 def expr_source(kind: str, expression: str, layout: PointLayout = None, src_datatype=None, dst_datatype=None, apply_to_source: bool = False, api=None) -> str:
-    """The translation unit a device expression becomes (kind "transform" between the two datatypes, or "predicate" over `layout`)."""
+    """The translation unit a device expression becomes: kind "transform" between the two datatypes; over `layout`: "predicate" (-> byte mask),
+    "predicate-count" (-> matches per 2048-point tile), "predicate-filter-columns" / "predicate-filter-records" (the streaming compaction kernel
+    with the predicate inside; '' when the layout does not take that kernel)."""
     api = api or (layout.api if layout is not None else _capi.product_api())
     n = C.c_size_t()
     sd = src_datatype.to_c() if src_datatype is not None else None
     dd = dst_datatype.to_c() if dst_datatype is not None else None
-    args = (0 if kind == "transform" else 1, layout._h if layout is not None else None, C.byref(sd) if sd is not None else None,
+    kinds = {"transform": 0, "predicate": 1, "predicate-count": 2, "predicate-filter-columns": 3, "predicate-filter-records": 4}
+    args = (kinds[kind], layout._h if layout is not None else None, C.byref(sd) if sd is not None else None,
             C.byref(dd) if dd is not None else None, 1 if apply_to_source else 0, expression.encode())
     api.expr_source(*args, None, 0, C.byref(n))
     buf = C.create_string_buffer(n.value)

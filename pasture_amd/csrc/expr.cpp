@@ -27,14 +27,17 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "jit.hpp"
+#include "kernels.hpp"
 #include "runtime.hpp"
 
 using namespace pst;
 
 namespace pstexpr {
 
-static const char* ct_name(uint32_t ct) {
+const char* ct_name(uint32_t ct) {
   static const char* names[10] = {"uint8_t", "int8_t", "uint16_t", "int16_t", "uint32_t", "int32_t", "uint64_t", "int64_t", "float", "double"};
   return ct < 10 ? names[ct] : "uint8_t";
 }
@@ -161,28 +164,60 @@ static std::vector<std::string> identifiers(const std::string& expr) {
   return out;
 }
 
-std::string pred_source(const std::vector<PredAttr>& attrs, const std::string& expr) {
-  std::string t = "// pasture_amd device expression (expr.cpp): filter predicate -> byte mask\n#include \"device_common.hpp\"\nusing namespace pstd;\n";
-  t += "template <typename T> struct PstV3 { T x, y, z; };\nstruct PstPredArgs { uint64_t base[" + std::to_string(kMaxPredAttrs) + "], stride[" + std::to_string(kMaxPredAttrs) + "]; };\n";
-  std::string params, args;
+// `PstV3` and the predicate as a device function of the named attributes (by value), the index and the parameter arrays: shared by the three
+// translation units a predicate can be part of (byte-mask kernel, per-tile count kernel, the streaming compaction kernel of filter_stream.hpp)
+std::string pred_function_text(const std::vector<PredAttr>& attrs, const std::string& expr) {
+  std::string t = "template <typename T> struct PstV3 { T x, y, z; };\n";
+  std::string params;
   for (size_t a = 0; a < attrs.size(); ++a) {
     const std::string ty = attrs[a].ncomp == 3 ? std::string("PstV3<") + ct_name(attrs[a].ct) + ">" : std::string(ct_name(attrs[a].ct));
     params += "const " + ty + " " + attrs[a].name + ", ";
   }
   t += "__device__ __forceinline__ bool pst_pred(" + params +
        "const uint64_t i, const double* __restrict__ p0, const double* __restrict__ p1, const double* __restrict__ p2, const double* __restrict__ p3) {\n"
-       "  (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n  return (bool)(\n" + expr + "\n  );\n}\n";
-  t += "extern \"C\" __global__ __launch_bounds__(256) void pst_jit_expr_pred(const PstPredArgs a, uint64_t n, uint64_t first, uint8_t* __restrict__ mask,\n"
-       "                                                                      const double* p0, const double* p1, const double* p2, const double* p3) {\n"
-       "  for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256u) {\n";
+       "  using namespace pstd;\n  (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n  return (bool)(\n" + expr + "\n  );\n}\n";
+  return t;
+}
+// the loads of point `e`'s named attributes (v0, v1, ...) and the argument list that hands them to pst_pred
+static std::string pred_loads(const std::vector<PredAttr>& attrs, std::string* args) {
+  std::string t;
   for (size_t a = 0; a < attrs.size(); ++a) {
     const std::string T = ct_name(attrs[a].ct), A = std::to_string(a), q = "(cgptr_t)as_global(a.base[" + A + "]) + e * a.stride[" + A + "]";
     if (attrs[a].ncomp == 3)
       t += "    const PstV3<" + T + "> v" + A + " = {load_un<" + T + ">(" + q + "), load_un<" + T + ">(" + q + " + sizeof(" + T + ")), load_un<" + T + ">(" + q + " + 2 * sizeof(" + T + "))};\n";
     else
       t += "    const " + T + " v" + A + " = load_un<" + T + ">(" + q + ");\n";
-    args += "v" + A + ", ";
+    *args += "v" + A + ", ";
   }
+  return t;
+}
+// The count pass of a compaction whose predicate is fused (round 6): one wave per 2048-point tile evaluates the predicate on the columns it names
+// and leaves the tile's number of matches where filter.hip's scan expects it -- the mask_count_kernel of a mask that is never written.
+std::string pred_count_source(const std::vector<PredAttr>& attrs, const std::string& expr) {
+  std::string t = "// pasture_amd device expression (expr.cpp): filter predicate -> matches per 2048-point tile\n#include \"device_common.hpp\"\nusing namespace pstd;\n";
+  t += "struct PstPredArgs { uint64_t base[" + std::to_string(kMaxPredAttrs) + "], stride[" + std::to_string(kMaxPredAttrs) + "]; };\n";
+  t += pred_function_text(attrs, expr);
+  std::string args;
+  const std::string loads = pred_loads(attrs, &args);
+  t += "extern \"C\" __global__ __launch_bounds__(256) void pst_jit_pred_count(const PstPredArgs a, uint64_t n, uint64_t first, uint32_t* __restrict__ counts,\n"
+       "                                                                       const double* p0, const double* p1, const double* p2, const double* p3) {\n"
+       "  const uint32_t lane = threadIdx.x & 63u;\n  const uint64_t tile = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);\n  const uint64_t b = tile * 2048u;\n"
+       "  if (b >= n) return;\n  const uint64_t end = b + 2048u < n ? b + 2048u : n;\n  uint32_t c = 0;\n"
+       "  for (uint64_t e = b + lane; e < end; e += 64u) {\n" + loads +
+       "    c += pst_pred(" + args + "first + e, p0, p1, p2, p3) ? 1u : 0u;\n  }\n"
+       "#pragma unroll\n  for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);\n  if (lane == 0) counts[tile] = c;\n}\n";
+  return t;
+}
+
+std::string pred_source(const std::vector<PredAttr>& attrs, const std::string& expr) {
+  std::string t = "// pasture_amd device expression (expr.cpp): filter predicate -> byte mask\n#include \"device_common.hpp\"\nusing namespace pstd;\n";
+  t += "struct PstPredArgs { uint64_t base[" + std::to_string(kMaxPredAttrs) + "], stride[" + std::to_string(kMaxPredAttrs) + "]; };\n";
+  t += pred_function_text(attrs, expr);
+  std::string args;
+  t += "extern \"C\" __global__ __launch_bounds__(256) void pst_jit_expr_pred(const PstPredArgs a, uint64_t n, uint64_t first, uint8_t* __restrict__ mask,\n"
+       "                                                                      const double* p0, const double* p1, const double* p2, const double* p3) {\n"
+       "  for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256u) {\n";
+  t += pred_loads(attrs, &args);
   t += "    mask[e] = pst_pred(" + args + "first + e, p0, p1, p2, p3) ? (uint8_t)1 : (uint8_t)0;\n  }\n}\n";
   return t;
 }
@@ -249,6 +284,18 @@ static bool names_a_call(const std::string& expr, const std::string& name) {
   }
   return false;
 }
+void launch_pred_count(const std::vector<PredAttr>& attrs, const std::string& expr, uint64_t n, uint64_t first_index, uint32_t* counts_dev, const double* const p[4], hipStream_t stream) {
+  const pstjit::Kernel k = compile(pred_count_source(attrs, expr), "pst_jit_pred_count", "predicate expression");
+  if (n == 0) return;
+  PredArgs a{};
+  for (size_t i = 0; i < attrs.size(); ++i) { a.base[i] = attrs[i].base; a.stride[i] = attrs[i].stride; }
+  const double *p0 = p ? p[0] : nullptr, *p1 = p ? p[1] : nullptr, *p2 = p ? p[2] : nullptr, *p3 = p ? p[3] : nullptr;
+  void* args[] = {&a, &n, &first_index, &counts_dev, &p0, &p1, &p2, &p3};
+  const uint64_t n_tiles = (n + 2047) / 2048;
+  if (hipModuleLaunchKernel(k.fn, (unsigned)((n_tiles + 3) / 4), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
+    throw Error(PST_ERR_HIP, std::string("predicate count kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+}
+
 // the attributes of `layout` an expression names (C identifiers only; scalars and Vec3)
 std::vector<PredAttr> referenced_attributes(const Layout& layout, const std::string& expr) {
   std::vector<PredAttr> out;
@@ -364,6 +411,82 @@ int pst_buffer_filter_expr(const pst_buffer* src, const char* expr, const double
   pstexpr::fill_params(device_params, n_params, p);
   ensure_device();
   hipStream_t st = current_stream();
+  if (out_storage > PST_STORAGE_COLUMNAR) throw Error(PST_ERR_INVALID_ARGUMENT, "invalid storage kind");
+  // Round 6: the predicate INSIDE the compaction (the reference evaluates the closure in filter's own loop, point_buffer.rs:1064-1136).  Where the
+  // layout takes the streaming compaction kernel (filter_stream.hpp: points of at most 64 / 96 bytes), the count pass evaluates the predicate on the
+  // columns it names and the scatter pass evaluates it again on the values it holds in registers: no byte mask is written or read, one launch
+  // less.  Everything else -- wider points, PST_JIT constraints, PST_EXPR_FUSE=0 (the A/B switch) -- keeps the mask.
+  static const bool fuse_env = [] { const char* v = std::getenv("PST_EXPR_FUSE"); return !(v && *v == '0'); }();
+  const size_t na = src->layout.members.size();
+  std::vector<uint32_t> sizes(na);
+  size_t covered_bytes = 0;
+  for (size_t a = 0; a < na; ++a) { sizes[a] = (uint32_t)src->layout.members[a].size; covered_bytes += sizes[a]; }
+  const bool dst_aos = out_storage != PST_STORAGE_COLUMNAR;
+  const uint32_t dst_stride = (uint32_t)src->layout.size;
+  if (fuse_env && src->len > 0 && pstk::filter_predicate_streams(sizes.data(), (int)na, dst_aos, dst_stride, covered_bytes == src->layout.size)) {
+    const uint64_t n = src->len;
+    const uint32_t tile = pstk::filter_tile(dst_aos, dst_stride);
+    pstk::FilterPredicate fp;
+    fp.function_text = pstexpr::pred_function_text(attrs, expr);
+    for (const pstexpr::PredAttr& a : attrs) {
+      const Member* m = src->layout.find_by_name(a.name);
+      fp.attrs.push_back({(int)(m - src->layout.members.data()), pstexpr::ct_name(a.ct), a.ncomp});
+    }
+    for (int q = 0; q < 4; ++q) fp.p[q] = p[q];
+    // 1. matches per tile, straight from the columns; scan
+    uint8_t* scratch = workspace().partials(pstk::filter_workspace_bytes(n));
+    pstexpr::launch_pred_count(attrs, expr, n, 0, pstk::filter_counts(scratch, n, tile), p, st);
+    const unsigned long long* total_dev = nullptr;
+    pstk::launch_filter_scan(n, tile, scratch, &total_dev, st);
+    Workspace& ws = workspace();
+    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    stream_sync(st);
+    const size_t matches = (size_t)*(const unsigned long long*)(ws.pinned + 768);
+    // 2. the target, exactly as large as the count says (filter(): count, allocate, filter_into -- :1071-1075)
+    auto b = std::make_unique<pst_buffer>();
+    b->layout = src->layout;
+    b->columnar = !dst_aos;
+    if (b->columnar) b->columns.assign(na, nullptr);
+    resize_buffer(*b, matches, false);
+    if (dst_aos && matches && covered_bytes != src->layout.size) PST_HIP_CHECK(hipMemsetAsync(b->data, 0, matches * src->layout.size, st));  // record padding: VectorBuffer::resize zero-fills (:831-835)
+    if (matches) {
+      std::vector<uint64_t> src_addr(na), dst_addr(na);
+      std::vector<uint32_t> src_stride(na), dst_off(na);
+      for (size_t a = 0; a < na; ++a) {
+        const Member& m = src->layout.members[a];
+        src_addr[a] = col_addr(*src, a, 0);
+        src_stride[a] = (uint32_t)m.size;
+        dst_addr[a] = b->columnar ? col_addr(*b, a, 0) : 0;
+        dst_off[a] = (uint32_t)m.offset;
+      }
+      // the ragged last tile (less than 2048 points) goes through the gather kernel, which reads a mask: its bytes only
+      const uint64_t n_full = n / tile * tile;
+      TempDev tail(n - n_full);
+      if (n_full < n) {
+        std::vector<pstexpr::PredAttr> shifted = attrs;
+        for (pstexpr::PredAttr& a : shifted) a.base += n_full * a.stride;
+        pstexpr::launch_pred(shifted, expr, n - n_full, n_full, tail.p, p, st);
+      }
+      std::string err;
+      const uint8_t* tail_mask = n_full < n ? tail.p - n_full : nullptr;  // (rebased: mask[i] is point i's byte)
+      bool ok = pstk::launch_filter_scatter(tail_mask, n, tile, scratch, matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(), sizes.data(), (int)na, dst_aos,
+                                            dst_aos ? aos_addr(*b, 0) : 0, dst_stride, covered_bytes == src->layout.size, st, &fp, &err);
+      if (!ok) {
+        if (err.find("hipRTC compilation failed") != std::string::npos)
+          throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "predicate expression: the compaction kernel with the predicate in it does not compile:\n" + err);
+        // no streaming kernel after all (target alignment): the counts stand, the mask is written now and the gather kernels take it
+        TempDev mask(n);
+        pstexpr::launch_pred(attrs, expr, n, 0, mask.p, p, st);
+        ok = pstk::launch_filter_scatter(mask.p, n, tile, scratch, matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(), sizes.data(), (int)na, dst_aos,
+                                         dst_aos ? aos_addr(*b, 0) : 0, dst_stride, covered_bytes == src->layout.size, st);
+        stream_sync(st);
+        if (!ok) throw Error(PST_ERR_HIP, std::string("filter launch failed: ") + hipGetErrorString(hipGetLastError()));
+      }
+      stream_sync(st);  // (the tail mask is freed on return)
+    }
+    *out = b.release();
+    return PST_OK;
+  }
   TempDev mask(src->len);
   pstexpr::launch_pred(attrs, expr, src->len, 0, mask.p, p, st);
   static uint8_t empty_mask = 0;
@@ -385,8 +508,20 @@ int pst_expr_source(int kind, const pst_layout* layout, const pst_datatype* src_
     text = pstexpr::map_source(pstexpr::map_spec(DataType::from_c(not_null(src_dt, "src_dt")), DataType::from_c(not_null(dst_dt, "dst_dt")), apply_to_source != 0, expr));
   } else if (kind == 1) {
     text = pstexpr::pred_source(pstexpr::referenced_attributes(not_null(layout, "layout")->l, expr), expr);
+  } else if (kind == 2) {  // the per-tile count pass of a compaction with the predicate fused (round 6)
+    text = pstexpr::pred_count_source(pstexpr::referenced_attributes(not_null(layout, "layout")->l, expr), expr);
+  } else if (kind == 3 || kind == 4) {  // the streaming compaction kernel with the predicate inside, into columns (3) / records (4); empty: no such kernel for this layout
+    const Layout& l = not_null(layout, "layout")->l;
+    const std::vector<pstexpr::PredAttr> attrs = pstexpr::referenced_attributes(l, expr);
+    pstk::FilterPredicate fp;
+    fp.function_text = pstexpr::pred_function_text(attrs, expr);
+    for (const pstexpr::PredAttr& a : attrs) fp.attrs.push_back({(int)(l.find_by_name(a.name) - l.members.data()), pstexpr::ct_name(a.ct), a.ncomp});
+    std::vector<uint32_t> sizes;
+    size_t cov = 0;
+    for (const Member& m : l.members) { sizes.push_back((uint32_t)m.size); cov += m.size; }
+    text = pstk::filter_stream_source(sizes.data(), (int)sizes.size(), kind == 4, (uint32_t)l.size, cov == l.size, &fp);
   } else {
-    throw Error(PST_ERR_INVALID_ARGUMENT, "pst_expr_source: kind must be 0 (transformation) or 1 (predicate)");
+    throw Error(PST_ERR_INVALID_ARGUMENT, "pst_expr_source: kind must be 0 (transformation), 1 (predicate -> byte mask), 2 (predicate -> matches per tile), 3 / 4 (compaction with the predicate inside)");
   }
   copy_out(text, buf, cap, needed);
   PST_API_END

@@ -576,12 +576,33 @@ static bool stream_sig_from_args(const FilterArgs& a, bool dst_aos, StreamSig* s
   return true;
 }
 // the translation unit hipRTC compiles for `sig` (also the cache key)
-static std::string stream_source(const StreamSig& s) {
+static std::string stream_source(const StreamSig& s, const pstk::FilterPredicate* pred = nullptr) {
   std::ostringstream o;
   o << "#include \"filter_stream.hpp\"\n";
+  if (pred) o << pred->function_text;  // PstV3 and pst_pred(<attributes by name>, i, p0 .. p3), written by expr.cpp
   o << "struct PstFilterPlan {\n";
   o << "  static constexpr int n = " << s.n << ";\n";
-  o << "  static constexpr bool dst_columns = " << (s.dst_columns ? "true" : "false") << ", covered = " << (s.covered ? "true" : "false") << ";\n";
+  o << "  static constexpr bool dst_columns = " << (s.dst_columns ? "true" : "false") << ", covered = " << (s.covered ? "true" : "false") << ", has_pred = " << (pred ? "true" : "false") << ";\n";
+  if (pred) {
+    // the lane's four points are in `w`, attribute after attribute (4 x size(k) bytes each): the predicate's arguments are cut out of it at
+    // compile-time offsets and the four answers packed like four mask bytes
+    o << "  template <int W> __device__ static __forceinline__ uint32_t pred_mask(const uint32_t (&w)[W], const uint64_t i0, const double* const (&p)[4]) {\n";
+    o << "    using namespace pstd;\n    uint32_t m = 0;\n";
+    o << "    pstq::static_for<0, 4>([&](auto I) __attribute__((always_inline)) {\n      constexpr uint32_t t = (uint32_t) decltype(I)::value;\n";
+    std::string call;
+    for (size_t q = 0; q < pred->attrs.size(); ++q) {
+      const pstk::FilterPredicate::Attr& pa = pred->attrs[q];
+      uint32_t before = 0;
+      for (int j = 0; j < pa.slot; ++j) before += s.size[j];
+      const uint32_t S = s.size[pa.slot], cs = S / pa.ncomp;
+      const std::string T = pa.type_name, base = std::to_string(4u * before) + "u + t * " + std::to_string(S) + "u";
+      auto comp = [&](uint32_t c) { return "pstq::from_bits<" + T + ">(pstq::img_get<" + base + " + " + std::to_string(c * cs) + "u, " + std::to_string(cs) + "u>(w))"; };
+      if (pa.ncomp == 3) o << "      const PstV3<" << T << "> a" << q << " = {" << comp(0) << ", " << comp(1) << ", " << comp(2) << "};\n";
+      else o << "      const " << T << " a" << q << " = " << comp(0) << ";\n";
+      call += "a" + std::to_string(q) + ", ";
+    }
+    o << "      m |= (pst_pred(" << call << "i0 + t, p[0], p[1], p[2], p[3]) ? 1u : 0u) << (8u * t);\n    });\n    return m;\n  }\n";
+  }
   o << "  static constexpr uint32_t dst_stride = " << s.dst_stride << ", cap = " << s.cap << ";\n";
   o << "  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {";
   for (int i = 0; i < s.n; ++i) o << (i ? ", " : "") << s.size[i];
@@ -608,7 +629,7 @@ struct LasStreamPlan {
     return k;
   }
   static constexpr int n = slots();
-  static constexpr bool dst_columns = COLUMNS, covered = true;
+  static constexpr bool dst_columns = COLUMNS, covered = true, has_pred = false;
   static constexpr uint32_t dst_stride = COLUMNS ? 0u : pstlas::typed_size(F), cap = stream_cap_for(pstlas::typed_size(F));
   __host__ __device__ static constexpr uint32_t size(int k) { return pstlas::typed_slot_offset(F, k + 1) - pstlas::typed_slot_offset(F, k); }
   __host__ __device__ static constexpr uint32_t dst_off(int k) { return COLUMNS ? 0u : pstlas::typed_slot_offset(F, k); }
@@ -619,7 +640,7 @@ static_assert(LasStreamPlan<0, false>::n == 10 && LasStreamPlan<0, false>::dst_s
 template <bool COLUMNS>
 struct BigStreamPlan {
   static constexpr int n = 5;
-  static constexpr bool dst_columns = COLUMNS, covered = true;
+  static constexpr bool dst_columns = COLUMNS, covered = true, has_pred = false;
   static constexpr uint32_t dst_stride = COLUMNS ? 0u : 41u, cap = stream_cap_for(41u);
   __host__ __device__ static constexpr uint32_t size(int k) {
     constexpr uint32_t t[n] = {8, 6, 24, 1, 2};
@@ -650,13 +671,29 @@ static void launch_stream_static(unsigned grid, hipStream_t stream, const Filter
 }
 // The full tiles of the launch through a streaming kernel, if one is at hand (in-tree, compiled, or PST_JIT=sync); returns the number of tiles it
 // covered (0: none -- the caller takes the gather kernel for everything) and the plan family.
-static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream_t stream, uint32_t* kind) {
+static uint32_t launch_stream_tiles(const FilterArgs& a, bool dst_aos, hipStream_t stream, uint32_t* kind, const pstk::FilterPredicate* pred = nullptr,
+                                    std::string* error = nullptr) {
   static const bool enabled = [] { const char* v = std::getenv("PST_FILTER_STREAM"); return !(v && *v == '0'); }();
   static const bool in_tree = [] { const char* v = std::getenv("PST_STATIC_PLANS"); return !(v && *v == '0'); }();
   const uint64_t n_full = a.n / pstf::kStreamTile;
   StreamSig sig;
   const pstjit::Mode mode = pstjit::mode();
   if (!enabled || mode == pstjit::Mode::Off || n_full == 0 || n_full > (1ull << 30) || !stream_sig_from_args(a, dst_aos, &sig)) return 0;
+  if (pred) {  // the predicate is part of the translation unit: always run-time compiled, in the calling thread (its syntax errors are this call's error)
+    const std::string source = stream_source(sig, pred);
+    const uint32_t lds = sig.dst_columns ? sig.total * sig.cap + 32u * (uint32_t)sig.n : sig.cap * sig.dst_stride + 64u;
+    pstjit::Kernel k;
+    if (!pstjit::acquire_source(source, "pst_jit_filter", pstf::kStreamThreads, lds, pstf::kStreamTile, pstjit::Acquire::Wait, &k, error)) return 0;
+    FilterArgs b = a;
+    for (int q = 0; q < 4; ++q) b.p[q] = pred->p[q];
+    void* args[] = {(void*)&b};
+    if (hipModuleLaunchKernel(k.fn, (unsigned)n_full, 1, 1, k.blk, 1, 1, pstk::lds_with_resident_cap(k.lds_bytes, pstk::kResidentFilterStream), stream, args, nullptr) != hipSuccess) {
+      if (error) *error = std::string("launch failed: ") + hipGetErrorString(hipGetLastError());
+      return 0;
+    }
+    *kind = PST_PLAN_JIT;
+    return (uint32_t)n_full;
+  }
   if (in_tree && stream_sig_is<BigStreamPlan<true>>(sig)) { launch_stream_static<BigStreamPlan<true>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
   if (in_tree && stream_sig_is<BigStreamPlan<false>>(sig)) { launch_stream_static<BigStreamPlan<false>>((unsigned)n_full, stream, a); *kind = PST_PLAN_STATIC; return (uint32_t)n_full; }
 #define PST_TRY_LAS(FMT)                                                                                                                   \
@@ -705,10 +742,46 @@ static uint32_t filter_chunk(uint32_t dst_stride, long default_budget = 15L * 10
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
                          hipStream_t stream, unsigned long long* total_also) {
   const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
-  unsigned long long* offsets = (unsigned long long*)workspace;
-  uint32_t* counts = (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
+  uint32_t* counts = filter_counts(workspace, n, tile);
   const uint32_t tiles_per_block = (kBlock / 64) * kCountTilesPerWave;
   hipLaunchKernelGGL(mask_count_kernel, dim3((n_tiles + tiles_per_block - 1) / tiles_per_block), dim3(kBlock), 0, stream, mask_dev, n, tile, n_tiles, counts);
+  launch_filter_scan(n, tile, workspace, out_total_dev, stream, total_also);
+}
+uint32_t* filter_counts(uint8_t* workspace, uint64_t n, uint32_t tile) {
+  const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+  return (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
+}
+static bool synthetic_stream_sig(const uint32_t* size, int n_attrs, bool dst_aos, uint32_t dst_stride, bool dst_covered, StreamSig* sig) {
+  if (n_attrs <= 0 || n_attrs > kMaxFilterAttrs) return false;
+  FilterArgs a{};
+  a.tile = pstf::kStreamTile;
+  a.n_attrs = (uint32_t)n_attrs;
+  a.dst_stride = dst_stride;
+  a.dst_covered = dst_covered ? 1u : 0u;
+  uint32_t off = 0;
+  for (int i = 0; i < n_attrs; ++i) {
+    const uint32_t sz = size[i];
+    a.attrs[i].unit = sz % 16 == 0 ? 16u : sz % 8 == 0 ? 8u : sz % 4 == 0 ? 4u : sz % 2 == 0 ? 2u : 1u;
+    a.attrs[i].cnt = sz / a.attrs[i].unit;
+    a.attrs[i].src_stride = sz;
+    a.attrs[i].dst_off = off;
+    off += sz;
+  }
+  return stream_sig_from_args(a, dst_aos, sig);
+}
+bool filter_predicate_streams(const uint32_t* size, int n_attrs, bool dst_aos, uint32_t dst_stride, bool dst_covered) {
+  static const bool enabled = [] { const char* v = std::getenv("PST_FILTER_STREAM"); return !(v && *v == '0'); }();
+  StreamSig sig;
+  return enabled && pstjit::mode() != pstjit::Mode::Off && synthetic_stream_sig(size, n_attrs, dst_aos, dst_stride, dst_covered, &sig);
+}
+std::string filter_stream_source(const uint32_t* size, int n_attrs, bool dst_aos, uint32_t dst_stride, bool dst_covered, const FilterPredicate* pred) {
+  StreamSig sig;
+  return synthetic_stream_sig(size, n_attrs, dst_aos, dst_stride, dst_covered, &sig) ? stream_source(sig, pred) : std::string();
+}
+void launch_filter_scan(uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev, hipStream_t stream, unsigned long long* total_also) {
+  const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+  unsigned long long* offsets = (unsigned long long*)workspace;
+  uint32_t* counts = (uint32_t*)(workspace + ((size_t)n_tiles + 1) * sizeof(unsigned long long));
   static const bool scan_blocks = [] { const char* v = std::getenv("PST_FILTER_SCAN_BLOCKS"); return !(v && *v == '0'); }();  // (0: the one-block scan, the A/B)
   if (scan_blocks && n_tiles > kScanBlockTiles && n_tiles <= (1u << 19))
     hipLaunchKernelGGL(tile_scan_blocks_kernel, dim3((n_tiles + kScanBlockTiles - 1) / kScanBlockTiles), dim3(kScanBlockTiles), 0, stream, (const uint32_t*)counts, n_tiles,
@@ -721,8 +794,10 @@ void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uin
 // Phase 2: attribute copies.  attrs: all attributes of the layout (launched in groups of kMaxFilterAttrs).
 bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, uint64_t limit, const uint64_t* src_addr,
                            const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_off, const uint32_t* size, int n_attrs,
-                           bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream) {
+                           bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream, const FilterPredicate* pred,
+                           std::string* error) {
   const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+  if (pred && n_attrs > kMaxFilterAttrs) { if (error) *error = "more attributes than one streaming launch takes"; return false; }
   FilterArgs a{};
   a.mask = mask_dev;
   a.offsets = (const unsigned long long*)workspace;
@@ -762,9 +837,10 @@ bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, u
     //    PST_JIT=0 / pst_jit_set_mode(0) switches every plan-specialised kernel off, the in-tree ones included (bench.py --plan interpreted).
     if (n_attrs <= kMaxFilterAttrs) {
       uint32_t kind = 0;
-      const uint32_t covered = launch_stream_tiles(a, dst_aos, stream, &kind);
-      if (covered) {
-        note_plan_kind(kind);
+      const uint32_t covered = launch_stream_tiles(a, dst_aos, stream, &kind, pred, error);
+      if (pred && !covered && n / pstf::kStreamTile > 0) return false;  // (the caller falls back to a byte mask)
+      if (covered || pred) {
+        if (covered) note_plan_kind(kind);
         if ((uint64_t)covered * tile < n) {
           FilterArgs b = a;
           b.tile0 = covered;

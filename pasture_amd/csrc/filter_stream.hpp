@@ -17,6 +17,10 @@
 //     static constexpr uint32_t size(int k), dst_off(int k);
 //     static constexpr uint32_t piece(int k);          // LDS store width of attribute k's values (8 / 4 / 2 / 1): divides the size and the
 //                                                     // alignment the host found for the target (column address; record base, stride, offset)
+//     static constexpr bool has_pred;                 // the predicate is a device function of the plan's translation unit (round 6: filter's
+//                                                     // closure, point_buffer.rs:1064-1136, evaluated on the values the kernel holds anyway): no byte mask
+//     template <int W> static uint32_t pred_mask(const uint32_t (&w)[W], uint64_t i0, const double* const (&p)[4]);
+//                                                     // has_pred: byte t of the result != 0 <=> the predicate holds for the lane's point t (index i0 + t)
 #pragma once
 #include "jit_quad.hpp"
 
@@ -49,6 +53,7 @@ struct FilterArgs {
   uint32_t chunk;        // interleaved target: records per LDS chunk (multiple of 16)
   uint32_t tile0;        // the launch's block 0 is tile `tile0` (the ragged last tile after the streaming kernel took the full ones)
   FilterAttr attrs[kMaxFilterAttrs];
+  const double* p[4];    // plans with a fused predicate (P::has_pred): the arrays the expression names p0 .. p3 (null otherwise)
 };
 
 constexpr uint32_t kStreamThreads = 512, kStreamTile = 2048;
@@ -97,13 +102,15 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
   if (m == 0 || out0 >= a.limit) return;
   if (out0 + m > a.limit) m = (uint32_t)(a.limit - out0);
   const uint32_t p0 = threadIdx.x * 4u;
-  const uint32_t mw = load_un<uint32_t>((cgptr_t)((uint64_t)(uintptr_t)a.mask + first) + p0);
+  uint32_t mw = 0;
+  if constexpr (!P::has_pred) mw = load_un<uint32_t>((cgptr_t)((uint64_t)(uintptr_t)a.mask + first) + p0);
   uint32_t w[W];  // the lane's four points, attribute after attribute: 4 x size(k) bytes = size(k) dwords each
   static_for<0, P::n>([&](auto K) __attribute__((always_inline)) {
     constexpr int k = decltype(K)::value;
     constexpr uint32_t S = P::size(k), WB = words_before<P>(k);  // (constexpr locals: a plan's functions may be loops the optimiser would not fold)
     pstq::load_words<S, false>((cgptr_t)as_global(a.attrs[k].src) + (first + p0) * S, w, WB);
   });
+  if constexpr (P::has_pred) mw = P::template pred_mask<W>(w, first + p0, a.p);  // the same predicate the count pass evaluated, on the values in registers
   // ranks: matches before this lane's points, within the tile
   uint32_t c = 0;
 #pragma unroll

@@ -128,9 +128,26 @@ size_t filter_workspace_bytes(uint64_t n);
 uint32_t filter_tile(bool dst_aos, uint32_t dst_stride);
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
                          hipStream_t stream, unsigned long long* total_also = nullptr);
+// A predicate fused into the streaming compaction kernel (round 6; expr.cpp writes the text): filter's closure (point_buffer.rs:1064-1136) evaluated by
+// the count pass on the columns it names and AGAIN by the scatter pass on the values it holds in registers anyway -- no byte mask in between.
+struct FilterPredicate {
+  struct Attr { int slot; const char* type_name; uint32_t ncomp; };  // an argument of pst_pred: layout slot, component type (C name), components (1 / 3)
+  std::string function_text;  // `PstV3`, and `pst_pred(<the named attributes>, i, p0, p1, p2, p3)`
+  std::vector<Attr> attrs;    // in pst_pred's parameter order
+  const double* p[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+// does a compaction of attributes of these sizes take the streaming kernel at all (bytes per point, record size)?  The fused predicate lives there only.
+bool filter_predicate_streams(const uint32_t* size, int n_attrs, bool dst_aos, uint32_t dst_stride, bool dst_covered);
+std::string filter_stream_source(const uint32_t* size, int n_attrs, bool dst_aos, uint32_t dst_stride, bool dst_covered, const FilterPredicate* pred);  // '' = no streaming kernel
+uint32_t* filter_counts(uint8_t* workspace, uint64_t n, uint32_t tile);  // where the scan expects the per-tile counts
+void launch_filter_scan(uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev, hipStream_t stream,
+                        unsigned long long* total_also = nullptr);
+// pred != nullptr: the full tiles through the streaming kernel with the predicate inside (compiled in the calling thread; false + *error when it has
+// none), `mask_dev` then covers the ragged last tile only -- rebased so that mask_dev[i] is point i's byte -- and may be null when there is none
 bool launch_filter_scatter(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, uint64_t limit, const uint64_t* src_addr,
                            const uint32_t* src_stride, const uint64_t* dst_addr, const uint32_t* dst_off, const uint32_t* size, int n_attrs,
-                           bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream);
+                           bool dst_aos, uint64_t dst_aos_base, uint32_t dst_stride, bool dst_covered, hipStream_t stream,
+                           const FilterPredicate* pred = nullptr, std::string* error = nullptr);
 
 
 // voxel-grid down-sampling (voxel.hip)

@@ -113,6 +113,26 @@ def test_expression_mappings_are_part_of_the_plan_specialised_kernel(hip, src_ki
     assert "expr(" not in plain
 
 
+def test_predicates_are_part_of_the_compaction_kernels(hip):
+    """Round 6 (review: filter takes ANY predicate and evaluates it in its own loop, point_buffer.rs:1064-1136): for layouts that take the streaming
+    compaction kernel the predicate is a device function of the count pass (matches per tile, straight from the columns it names) and of the scatter
+    pass (evaluated again on the values the kernel holds in registers) -- no byte mask.  CPU: both translation units carry the text and compile."""
+    layout = las.point_layout_from_las_point_format(las.Format(3), False, api=hip)
+    text = "Classification == 2 && Position3D.z < 120.0 && (i & 1) == 0 && p0[i % 7] > 0.5 && ColorRGB.y >= ColorRGB.x"
+    count = cv.expr_source("predicate-count", text, layout=layout, api=hip)
+    assert "pst_jit_pred_count" in count and "counts[tile] = c" in count and text in count
+    assert cv.jit_compile_source(count, api=hip)[:4] == b"\x7fELF"
+    for kind in ("predicate-filter-columns", "predicate-filter-records"):
+        unit = cv.expr_source(kind, text, layout=layout, api=hip)
+        assert "has_pred = true" in unit and "pred_mask(" in unit and text in unit and "pst_jit_filter" in unit
+        assert "const PstV3<double> a0 = {" in unit  # Position3D cut out of the lane's words
+        assert cv.jit_compile_source(unit, api=hip)[:4] == b"\x7fELF"
+    # a layout whose points do not fit four to a lane has no such kernel: the predicate keeps its byte mask there
+    wide = PointLayout.from_attributes([A.POSITION_3D, A.GPS_TIME, A.COLOR_RGB, A.WAVEFORM_PARAMETERS, A.NORMAL, A.POINT_ID, A.INTENSITY,
+                                        PointAttributeDefinition("Extra", T.Vec3f64), PointAttributeDefinition("Extra2", T.Vec3f64)], api=hip)
+    assert cv.expr_source("predicate-filter-columns", "Intensity > 3", layout=wide, api=hip) == ""
+
+
 def test_expression_text_must_nest_and_predicates_cannot_name_reserved_attributes(hip):
     """Round-5 advisor findings: `x) , (y` would escape the cast the text is pasted into; an attribute called `i` / `p0` / `int` would end as a
     duplicate-parameter or keyword error inside generated code.  Both are PST_ERR_UNSUPPORTED_TRANSFORM with a message that says so."""
@@ -336,6 +356,7 @@ def test_filter_expressions_against_the_gxx_twin_and_the_mask_path(hip, case, ou
     p0 = np.random.default_rng(9).random(256)
     keep, ptr = _device_array(p0)
     out = src.filter_expr(BUFFER_KINDS[out_kind], text, [ptr])
+    assert cv.last_plan_kinds(hip) == ["jit"], cv.last_plan_kinds(hip)  # the streaming compaction kernel with the predicate inside (the ragged last tile: the gather kernel)
     attrs = [(a.name(), {v: k for k, v in SCALARS.items()}.get(a.datatype()) or {v: k for k, v in VEC3.items()}.get(a.datatype()), a.datatype().num_components())
              for a in layout.attributes() if a.name() in text]
     mask = expr_twin.pred_twin(attrs, text)({name: rec[name] for name, _, _ in attrs}, n, 0, [p0])
