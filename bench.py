@@ -904,6 +904,9 @@ def main():
         rec = final
     elif has_reduction and ring.i:
         rec = ring.recs[(ring.i - 1) % len(ring.recs)]
+    if final is None and getattr(ring, "encoded", False):  # (the ring's records are kept as {min, -max}: pst_bounds_record_set_form)
+        rec = rec.cpu()
+        rec[3:] = -rec[3:]
     result = bounds_from_record(rec.cpu())
     # BASELINE.json configs[3] made driver-visible: a driver that passes only `--gpus N` gets the weak-scaling line above AND this leg --
     # ONE 10^9-point cloud sharded by index range over the N ranks (strong scaling), the same fused step, the same exchange per step,

@@ -409,6 +409,12 @@ int pst_comm_destroy(pst_comm* comm);
 int pst_bounds_allreduce(pst_comm* comm, double* device_rec6);
 /* the same for a pst_comm_init handle: device_recs[d] lives on GPU d, streams[d] (array nullable = default streams) is its stream */
 int pst_bounds_allreduce_multi(pst_comm* comm, double* const* device_recs, void* const* streams);
+/* The sharded path's per-step exchange as ONE launch (round 6): form = 1 registers a device record address -- from then on every AABB record the
+ * library is asked to leave THERE (pst_calculate_bounds_async, pst_converter_convert_into_range_with_bounds_async) is written as
+ * {min xyz, -max xyz} by the producing kernel's own last fold, pst_bounds_allreduce[_multi] on it is the ncclAllReduce alone (no negation kernels
+ * before and after) and the record STAYS in that form: its reader negates components 3..5.  An empty shard's record is +f64::MAX six times
+ * (the identities of bounds.rs:31-32).  form = 0 forgets the address.  Unregistered records keep {min, max} and the three-launch exchange. */
+int pst_bounds_record_set_form(double* device_rec6, int form);
 
 #ifdef __cplusplus
 }

@@ -165,6 +165,7 @@ _PRODUCT_SIGNATURES = {
     "comm_destroy": [_P],
     "bounds_allreduce": [_P, _P],
     "bounds_allreduce_multi": [_P, _PP, _PP],
+    "bounds_record_set_form": [_P, C.c_int],
     "last_plan_kinds": [C.POINTER(C.c_uint32)],
     "converter_prepare": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)],
     "converter_family_choice": [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],

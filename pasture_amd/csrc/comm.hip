@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "device_common.hpp"
+#include "kernels.hpp"
 #include "runtime.hpp"
 
 using namespace pst;
@@ -165,10 +166,22 @@ int pst_bounds_allreduce(pst_comm* comm, double* device_rec6) {
     throw Error(PST_ERR_INVALID_ARGUMENT, "pst_bounds_allreduce: the communicator was created on device " + std::to_string(comm->devices[0]) +
                                               ", the calling thread's current device is " + std::to_string(dev));
   hipStream_t s = current_stream();
-  hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, s, device_rec6);
+  // a record the library itself leaves as {min, -max} (pst_bounds_record_set_form: written in that form by the producing kernel's last fold) needs
+  // nothing around the collective and stays in that form: the exposed exchange is ONE launch
+  const bool encoded = pstk::bounds_record_negates_max(device_rec6);
+  if (!encoded) hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, s, device_rec6);
   check(rccl().AllReduce(device_rec6, device_rec6, 6, ncclFloat64, ncclMin, comm->comms[0], s), "ncclAllReduce");
-  hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, s, device_rec6);
+  if (!encoded) hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, s, device_rec6);
   PST_HIP_CHECK(hipGetLastError());
+  PST_API_END
+}
+
+// From now on (form = 1) every AABB record the library is asked to leave at this device address -- pst_calculate_bounds_async,
+// pst_converter_convert_into_range_with_bounds_async -- is written as {min xyz, -max xyz} by the producing kernel's own last fold, and
+// pst_bounds_allreduce on it is the collective alone; form = 0 forgets the address.  An empty shard's record is then {+f64::MAX x 6} (bounds.rs:31-32).
+int pst_bounds_record_set_form(double* device_rec6, int form) {
+  PST_API_BEGIN
+  pstk::set_bounds_record_form(not_null(device_rec6, "device_rec6"), form);
   PST_API_END
 }
 
@@ -190,7 +203,7 @@ int pst_bounds_allreduce_multi(pst_comm* comm, double* const* device_recs, void*
   MultiGuard guard;
   for (size_t d = 0; d < n; ++d) {
     PST_HIP_CHECK(hipSetDevice(comm->devices[d]));
-    hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
+    if (!pstk::bounds_record_negates_max(device_recs[d])) hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
   }
   check(r.GroupStart(), "ncclGroupStart");
   guard.group_open = true;
@@ -200,7 +213,7 @@ int pst_bounds_allreduce_multi(pst_comm* comm, double* const* device_recs, void*
   check(r.GroupEnd(), "ncclGroupEnd");
   for (size_t d = 0; d < n; ++d) {
     PST_HIP_CHECK(hipSetDevice(comm->devices[d]));
-    hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
+    if (!pstk::bounds_record_negates_max(device_recs[d])) hipLaunchKernelGGL(negate_max_kernel, dim3(1), dim3(64), 0, streams ? (hipStream_t)streams[d] : nullptr, device_recs[d]);
   }
   PST_HIP_CHECK(hipGetLastError());
   PST_API_END

@@ -32,6 +32,9 @@ bool convert_specialised_ready(const ConvertPlan& plan, bool src_aos, bool dst_a
 size_t bounds_partials_bytes(unsigned n_records);
 // fold n_records per-block {min xyz, max xyz} records into out6
 void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream);
+// pst_bounds_record_set_form: records at these addresses leave the last fold kernel as {min, -max}
+void set_bounds_record_form(const void* device_rec6, int form);
+bool bounds_record_negates_max(const void* device_rec6);
 int device_cus();
 // Dynamic LDS bytes of a launch that needs `lds_bytes` and wants at most `resident` workgroups per CU (0 = whatever fits): the memory side of
 // MI355X saturates with FEW bytes in flight per CU and loses throughput beyond that (profiles/r05_stream_sweeps.txt), so the streaming kernels

@@ -25,9 +25,30 @@
 #include "stream_tile.hpp"
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include <cstdlib>
 
 using namespace pstd;
+
+namespace pstk {
+// Device AABB records the library has been told to leave as {min, -max} (pst_bounds_record_set_form): what ONE ncclAllReduce(ncclMin) reduces.  The last
+// fold kernel of whichever path writes such a record negates its three maxima as it stores them, so the exposed exchange of the sharded path is the
+// collective alone (round-5 review: two one-block negation launches around a 48-byte all-reduce).  A handful of addresses per process (an exchange ring).
+static std::mutex g_form_mu;
+static std::vector<const void*> g_negated_records;
+void set_bounds_record_form(const void* device_rec6, int form) {
+  std::lock_guard<std::mutex> lock(g_form_mu);
+  auto it = std::find(g_negated_records.begin(), g_negated_records.end(), device_rec6);
+  if (form && it == g_negated_records.end()) g_negated_records.push_back(device_rec6);
+  if (!form && it != g_negated_records.end()) g_negated_records.erase(it);
+}
+bool bounds_record_negates_max(const void* device_rec6) {
+  std::lock_guard<std::mutex> lock(g_form_mu);
+  return !g_negated_records.empty() && std::find(g_negated_records.begin(), g_negated_records.end(), device_rec6) != g_negated_records.end();
+}
+}  // namespace pstk
+using pstk::bounds_record_negates_max;
 
 namespace {
 
@@ -182,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void vec3f64_stream_kernel(const StreamPara
 // Launched with one block (chunk >= n_records) for the final fold, or as a first level when there are many records.
 template <typename T, int NV>
 __global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __restrict__ partials, uint32_t n_records, uint32_t chunk,
-                                                                 T* __restrict__ out, T seed_min, T seed_max) {
+                                                                 T* __restrict__ out, T seed_min, T seed_max, uint32_t negate_max = 0) {
   T mn[NV], mx[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) { mn[i] = seed_min; mx[i] = seed_max; }
@@ -200,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __rest
   if (threadIdx.x == 0) {
     T* o = out + (uint64_t)blockIdx.x * 2 * NV;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { o[i] = mn[i]; o[NV + i] = mx[i]; }
+    for (int i = 0; i < NV; ++i) { o[i] = mn[i]; o[NV + i] = negate_max ? (T)(-mx[i]) : mx[i]; }  // (negate_max: the record leaves as {min, -max}, see pst_set_bounds_record_form)
   }
 }
 
@@ -208,17 +229,18 @@ __global__ __launch_bounds__(kBlock) void finalize_minmax_kernel(const T* __rest
 // n_records + kFoldBlocks records
 constexpr uint32_t kFoldBlocks = 128;
 template <typename T, int NV>
-void launch_finalize(T* partials, uint32_t n_records, T* out, T seed_min, T seed_max, hipStream_t stream) {
+void launch_finalize(T* partials, uint32_t n_records, T* out, T seed_min, T seed_max, hipStream_t stream, bool negate_max = false) {
+  const uint32_t neg = negate_max ? 1u : 0u;  // (the LAST level only)
   if (n_records > 4096) {
     const uint32_t chunk = (n_records + kFoldBlocks - 1) / kFoldBlocks;
     T* level1 = partials + (uint64_t)n_records * 2 * NV;
     hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(kFoldBlocks), dim3(kBlock), 0, stream, (const T*)partials, n_records, chunk, level1,
-                       seed_min, seed_max);
+                       seed_min, seed_max, 0u);
     hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(1), dim3(kBlock), 0, stream, (const T*)level1, kFoldBlocks, kFoldBlocks, out,
-                       seed_min, seed_max);
+                       seed_min, seed_max, neg);
   } else {
     hipLaunchKernelGGL((finalize_minmax_kernel<T, NV>), dim3(1), dim3(kBlock), 0, stream, (const T*)partials, n_records, n_records, out, seed_min,
-                       seed_max);
+                       seed_max, neg);
   }
 }
 
@@ -265,7 +287,7 @@ template <typename T, int NCOMP>
 void launch_minmax_typed(const ReduceParams& p, bool acc_f64, void* out, unsigned grid, hipStream_t stream) {
   if (acc_f64) {
     hipLaunchKernelGGL((strided_minmax_kernel<T, double, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, kF64Max, -kF64Max);
-    launch_finalize<double, NCOMP>((double*)p.partials, grid, (double*)out, kF64Max, -kF64Max, stream);
+    launch_finalize<double, NCOMP>((double*)p.partials, grid, (double*)out, kF64Max, -kF64Max, stream, NCOMP == 3 && bounds_record_negates_max(out));
   } else {
     hipLaunchKernelGGL((strided_minmax_kernel<T, T, NCOMP>), dim3(grid), dim3(kBlock), 0, stream, p, Identity<T>::min_seed(),
                        Identity<T>::max_seed());
@@ -419,7 +441,7 @@ void launch_vec3f64_stream(const double* src, double* dst, uint64_t n_points, co
     if (mode & 1u) hipLaunchKernelGGL((vec3f64_stream_kernel<true, false, true, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
     else hipLaunchKernelGGL((vec3f64_stream_kernel<false, false, true, kStreamLoads, true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
   }
-  if (bounds) launch_finalize<double, 3>(partials, grid, out6, kF64Max, -kF64Max, stream);
+  if (bounds) launch_finalize<double, 3>(partials, grid, out6, kF64Max, -kF64Max, stream, bounds_record_negates_max(out6));
 }
 
 size_t centroid_partials_bytes() { return (size_t)reduce_grid() * 8 * sizeof(double); }
@@ -432,7 +454,7 @@ unsigned launch_centroid(const uint8_t* base, uint64_t stride, uint64_t n, doubl
 
 size_t bounds_partials_bytes(unsigned n_records) { return (size_t)(n_records + kFoldBlocks) * 6 * sizeof(double); }
 void launch_finalize_bounds(double* partials, unsigned n_records, double* out6, hipStream_t stream) {
-  launch_finalize<double, 3>(partials, n_records, out6, kF64Max, -kF64Max, stream);
+  launch_finalize<double, 3>(partials, n_records, out6, kF64Max, -kF64Max, stream, bounds_record_negates_max(out6));
 }
 
 void launch_minmax(const uint8_t* base, uint64_t stride, uint64_t n, uint32_t ct, uint32_t ncomp, bool acc_f64, void* partials, void* out,

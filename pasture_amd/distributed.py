@@ -81,11 +81,18 @@ class CapiTransport:
     rendezvous (rank 0's 128-byte id broadcast over the torch group), then `pst_bounds_allreduce` per record -- ONE
     ncclAllReduce(6 x f64, ncclMin) over {min, -max}, in place, ordered on the stream it is given."""
     name = "pst_bounds_allreduce (C ABI: one ncclAllReduce of 6 x f64 with ncclMin over {min, -max}, RCCL)"
+    # BoundsExchange registers its ring records with pst_bounds_record_set_form: the kernels that produce them write {min, -max} themselves and the
+    # exchange is the collective ALONE (round 6; before: a one-block negation kernel on either side of it -- three launches of latency per step)
+    encoded_records = True
 
     def __init__(self, group=None, api=None):
         from ._capi import product_api
         self.api = api or product_api()
         self.comm = Communicator.from_torch_group(group, self.api)
+
+    def set_record_form(self, rec, encoded: bool) -> None:
+        import ctypes as C
+        self.api.bounds_record_set_form(C.c_void_p(rec.data_ptr()), 1 if encoded else 0)
 
     def size(self) -> int:
         return self.comm.size()
@@ -136,6 +143,11 @@ class BoundsExchange:
         self.i = 0
         self._cuda = bool(self.recs[0].is_cuda)
         self._done = [None] * depth
+        # records the producing kernels leave as {min, -max} (CapiTransport on a GPU): registered for the ring's lifetime, decoded by finish()
+        self.encoded = bool(self._cuda and getattr(transport, "encoded_records", False))
+        if self.encoded:
+            for rec in self.recs:
+                transport.set_record_form(rec, True)
         if self._cuda:
             import torch
             self._main = torch.cuda.current_stream()
@@ -144,7 +156,7 @@ class BoundsExchange:
             # reduction of a buffer RCCL has not seen costs tens of milliseconds (measured at one rank: 20 timed steps 2.7 ms each with a cold
             # fourth record, 0.80 with all four warm), and that must not land in a timed region
             for rec in self.recs:
-                rec.copy_(torch.tensor([F64_MAX] * 3 + [-F64_MAX] * 3, dtype=rec.dtype, device=rec.device))
+                rec.copy_(torch.tensor([F64_MAX] * 3 + [F64_MAX if self.encoded else -F64_MAX] * 3, dtype=rec.dtype, device=rec.device))
                 self._side.wait_stream(self._main)
                 self.transport.allreduce(rec, self._side.cuda_stream, self._main.cuda_stream)
             self._side.synchronize()
@@ -177,10 +189,33 @@ class BoundsExchange:
         self.i += 1
 
     def finish(self):
+        """Waits for every pending reduction; returns the last global record as {min xyz, max xyz} (a decoded copy when the ring's records are kept
+        as {min, -max}), or None."""
         if self._cuda:
             self._side.synchronize()
             self._done = [None] * len(self.recs)
-        return self.recs[(self.i - 1) % len(self.recs)] if self.i else None
+        if not self.i:
+            return None
+        rec = self.recs[(self.i - 1) % len(self.recs)]
+        if self.encoded:
+            # decoded on the HOST (a copy of 48 bytes): the first launch of a torch elementwise kernel loads its code object -- ten milliseconds
+            # that would land inside the caller's timed region
+            rec = rec.cpu()
+            rec[3:] = -rec[3:]
+        return rec
+
+    def close(self) -> None:
+        """Forgets the ring's record addresses (a later allocation at the same address must not inherit the {min, -max} form)."""
+        if self.encoded:
+            for rec in self.recs:
+                self.transport.set_record_form(rec, False)
+            self.encoded = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def exposed_us(self):
         """Microseconds between "the timed step's kernels are done" and "its global record is there" (None without a timed submit)."""

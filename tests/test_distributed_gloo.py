@@ -427,6 +427,71 @@ def test_capi_bounds_allreduce_world_size_1_rccl(hip):
     multi.destroy()
 
 
+@pytest.mark.gpu
+def test_registered_records_leave_the_producer_as_min_negmax_and_the_exchange_is_the_collective_alone(hip):
+    """Round 6 (review: three launches of latency on the one exposed exchange): a record address registered with pst_bounds_record_set_form is written
+    as {min, -max} by the producing kernel's own last fold -- every producer: the Vec3f64 stream (fused conversion + AABB, plain AABB), the strided
+    fold (interleaved positions), a plan-specialised conversion -- , pst_bounds_allreduce on it is then ONE ncclAllReduce and the record stays in that
+    form; an unregistered address keeps {min, max}; an empty shard's registered record is +f64::MAX six times; forgetting the address restores {min, max}."""
+    import ctypes as C
+    import torch
+    from pasture_amd import las
+    from pasture_amd.algorithms import calculate_bounds, calculate_bounds_async
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    from pasture_amd.conversion import BufferLayoutConverter, Transform
+    from pasture_amd.distributed import Communicator
+    from pasture_amd.layout import PointAttributeDataType as T, PointLayout, attributes as A
+    xyz = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    n = 3_000_017
+    col = HashMapBuffer.new_from_layout(xyz)
+    col.resize(n)
+    col.synth_fill(42, 9)
+    aos = VectorBuffer.new_from_layout(PointLayout.from_attributes_packed([A.INTENSITY, A.POSITION_3D], 1, api=hip))
+    aos.resize(n)
+    aos.synth_fill(43, 0)
+    dst = HashMapBuffer.new_from_layout(xyz)
+    dst.resize(n)
+    conv = BufferLayoutConverter.for_layouts(xyz, xyz)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, (2.0, 0.5, 1.0), (1.0, -3.0, 0.25)), False)
+    typed = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    recs = VectorBuffer.new_from_layout(typed)
+    recs.resize(n)
+    recs.synth_fill(5, 0)
+    cols = HashMapBuffer.new_from_layout(typed)
+    cols.resize(n)
+    lconv = BufferLayoutConverter.for_layouts(typed, typed)
+    lconv.prepare(VectorBuffer, HashMapBuffer, True)
+    comm = Communicator.from_unique_id(1, 0, Communicator.unique_id())
+    reg = torch.full((6,), float("nan"), dtype=torch.float64, device="cuda")
+    plain = torch.full((6,), float("nan"), dtype=torch.float64, device="cuda")
+    hip.bounds_record_set_form(C.c_void_p(reg.data_ptr()), 1)
+    producers = [("stream AABB", lambda p: calculate_bounds_async(col, p), lambda: calculate_bounds(col)),
+                 ("strided AABB", lambda p: calculate_bounds_async(aos, p), lambda: calculate_bounds(aos)),
+                 ("fused affine conversion", lambda p: conv.convert_into_with_bounds_async(col, dst, p), lambda: calculate_bounds(dst)),
+                 ("plan-specialised conversion", lambda p: lconv.convert_into_with_bounds_async(recs, cols, p), lambda: calculate_bounds(cols))]
+    for name, produce, truth in producers:
+        produce(reg.data_ptr())
+        produce(plain.data_ptr())
+        torch.cuda.synchronize()
+        want = truth()
+        assert plain.cpu().tolist() == list(want.min()) + list(want.max()), name
+        assert reg.cpu().tolist() == list(want.min()) + [-v for v in want.max()], name
+        comm.allreduce_bounds(reg.data_ptr())    # the collective alone: the record keeps its form
+        comm.allreduce_bounds(plain.data_ptr())  # negate, collective, negate
+        torch.cuda.synchronize()
+        assert reg.cpu().tolist() == list(want.min()) + [-v for v in want.max()] and plain.cpu().tolist() == list(want.min()) + list(want.max()), name
+    empty = HashMapBuffer.new_from_layout(xyz)
+    calculate_bounds_async(empty, reg.data_ptr())
+    torch.cuda.synchronize()
+    assert reg.cpu().tolist() == [F64] * 6
+    hip.bounds_record_set_form(C.c_void_p(reg.data_ptr()), 0)
+    calculate_bounds_async(col, reg.data_ptr())
+    torch.cuda.synchronize()
+    want = calculate_bounds(col)
+    assert reg.cpu().tolist() == list(want.min()) + list(want.max())
+    comm.destroy()
+
+
 F64 = 1.7976931348623157e308
 
 
@@ -448,7 +513,10 @@ def _capi_rccl_worker(rank, world, port, q):
     out = []
     for i in range(5):
         rec = ring.current()
-        rec.copy_(torch.tensor(_exchange_records(rank, i), dtype=torch.float64))
+        v = _exchange_records(rank, i)
+        if ring.encoded:  # (round 6: the ring's records are registered as {min, -max}; a producer kernel writes that form itself, this test plays producer)
+            v = v[:3] + [-x for x in v[3:]]
+        rec.copy_(torch.tensor(v, dtype=torch.float64))
         ring.submit()
     last = ring.finish()
     torch.cuda.synchronize()
