@@ -206,8 +206,21 @@ def leg_configs2(pa, las, cv, torch, stream, n, seed):
     return report, {"points": m, "seed": seed, "columns": sample}
 
 
-def leg_configs4(pa, torch, stream, n, seed, n_queries=48):
-    """BASELINE.json configs[4]: kNN(k = 16) normal estimation over n uniform points, NORMAL (Vec3f32) + Curvature (F64) written to columns.
+def _sheet_cloud(torch, n, seed):
+    """The LiDAR-shaped input of the kNN legs: a noisy 2-D manifold z = f(x, y) in a 3-D box (23 % of the box occupied) with 0.001 % stray points far
+    above and below it -- compute_normals is run on scans, not on uniform boxes (normal_estimation.rs:79-130)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    xy = torch.rand(n, 2, device="cuda", dtype=torch.float64, generator=g) * 1000.0
+    z = 10.0 * torch.sin(xy[:, 0] / 50.0) * torch.cos(xy[:, 1] / 80.0) + 50.0 + 0.02 * torch.randn(n, device="cuda", dtype=torch.float64, generator=g)
+    sheet = torch.cat([xy, z[:, None]], dim=1).contiguous()
+    n_stray = max(1, n // 100000)
+    sheet[torch.randint(0, n, (n_stray,), device="cuda", generator=g), 2] = (torch.rand(n_stray, device="cuda", dtype=torch.float64, generator=g) - 0.5) * 6000.0
+    return sheet
+
+
+def leg_configs4(pa, torch, stream, n, seed, n_queries=48, sheet=False):
+    """BASELINE.json configs[4]: kNN(k = 16) normal estimation over n uniform points (sheet: over the LiDAR-shaped sheet), NORMAL (Vec3f32) + Curvature (F64) written to columns.
     Timed: the synchronous call (wall clock around call + synchronize) and the planned stream-ordered form (HIP events).  Then, outside the timing:
     the raw f64 results + neighbour lists once more (pst_compute_normals_device), `n_queries` sampled neighbour lists against a brute force over all
     n points on the device, and the columns against the f64 results narrowed with `as`.  Returns (report, sample for the oracle's plane fit)."""
@@ -215,9 +228,14 @@ def leg_configs4(pa, torch, stream, n, seed, n_queries=48):
     from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, attributes as A
     k = 16
     layout = pa.PointLayout.from_attributes([A.POSITION_3D])
-    src = pa.HashMapBuffer.new_from_layout(layout)
-    src.resize(n)
-    src.synth_fill(seed, 0)
+    cloud = None
+    if sheet:
+        cloud = _sheet_cloud(torch, n, seed)
+        src = pa.ExternalColumnsBuffer([cloud], layout, n)
+    else:
+        src = pa.HashMapBuffer.new_from_layout(layout)
+        src.resize(n)
+        src.synth_fill(seed, 0)
     curv_def = PointAttributeDefinition("Curvature", T.F64)
     dst = pa.HashMapBuffer.new_from_layout(pa.PointLayout.from_attributes([A.NORMAL, curv_def]))
     dst.resize(n)
@@ -251,7 +269,7 @@ def leg_configs4(pa, torch, stream, n, seed, n_queries=48):
     curv = torch.empty(n, dtype=torch.float64, device="cuda")
     knn = torch.empty((n, k), dtype=torch.int32, device="cuda")  # uint32 bit patterns; n < 2^31
     compute_normals_device(src, k, normals.data_ptr(), curv.data_ptr(), knn.data_ptr())
-    pts = _torch_bytes(src.column_ptr(A.POSITION_3D), n * 24).view(torch.float64).view(n, 3)
+    pts = cloud if sheet else _torch_bytes(src.column_ptr(A.POSITION_3D), n * 24).view(torch.float64).view(n, 3)
     n32 = _torch_bytes(dst.column_ptr(A.NORMAL), n * 12).view(torch.float32).view(n, 3)
     c64 = _torch_bytes(dst.column_ptr(curv_def), n * 8).view(torch.float64)
     columns_equal = bool(torch.equal(n32, normals.to(torch.float32))) and bool(torch.equal(c64, curv))
@@ -272,20 +290,122 @@ def leg_configs4(pa, torch, stream, n, seed, n_queries=48):
               "ms_per_call_planned": round(sum(plan_ms) / len(plan_ms), 3) if plan_ms else None, "planned_status": plan_status,
               "algorithmic_bytes_per_point": 44, "frac_of_hbm_lower_bound": round(44 * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
               "checks": {"columns_equal_f64_results_narrowed": columns_equal, "neighbour_lists_checked": n_queries, "neighbour_lists_exact": lists_exact},
-              "note": "BASELINE.json configs[4]: uniform cloud, k = 16, NORMAL (Vec3f32) + Curvature (F64) columns; ms_per_call = median wall time of 3 synchronous "
+              "note": ("the reference's caller shape of configs[4]: a LiDAR-like sheet (noisy 2-D manifold in a 3-D box, 0.001 % far strays)" if sheet else "BASELINE.json configs[4]: uniform cloud") +
+                      ", k = 16, NORMAL (Vec3f32) + Curvature (F64) columns; ms_per_call = median wall time of 3 synchronous "
                       "pst_compute_normals_into calls (index build, sort, searches, fits; host round trips included), ms_per_call_planned = HIP events around the "
                       "stream-ordered replay; the call is bound by its vector instructions, not by HBM (bound_valu)"}
     try:
-        v = json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get("normals_knn16")
+        v = json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get("normals_knn16_sheet" if sheet else "normals_knn16")
         if v and v.get("points") == n:
             issue_rate = 256 * 4 * 2.4e9 / 4.0
             bound_ms = v["valu_wave_instructions_per_launch"] / issue_rate * 1e3
             report["bound_valu"] = {"kernel": v["kernel"], "valu_wave_instructions_per_launch": v["valu_wave_instructions_per_launch"], "bound_ms": round(bound_ms, 3),
-                                    "frac_of_call": round(bound_ms / med, 4),
-                                    "source": f"profiles/knn_valu.json (round {v.get('round')}: rocprofv3 --pmc SQ_INSTS_VALU pass); NOT measured in this run"}
+                                    "frac_of_call": round(bound_ms / med, 4), "kernel_ms_in_that_profile": v.get("kernel_ms"),
+                                    "source": f"profiles/knn_valu.json (round {v.get('round')}, tree {v.get('commit', '?')}: rocprofv3 --pmc SQ_INSTS_VALU + --kernel-trace passes); NOT measured in this run"}
     except Exception:
         pass
     return report, {"k": k, "fits": fits}
+
+
+def leg_dropin(pa, cv, torch, stream, n, seed, fused_bounds):
+    """What an UNMODIFIED pasture caller issues for the headline workload: BufferLayoutConverter::convert_into (the affine mapping on POSITION_3D), then
+    calculate_bounds on the result (bounds.rs:11) -- two calls, 24 R + 24 W + 24 R = 72 B per point, against the fused entry point's 48.  HIP events around
+    each pair of 10 steps; the AABB must be the fused run's, digit for digit."""
+    from pasture_amd.conversion import Transform
+    from pasture_amd.distributed import bounds_from_record
+    from pasture_amd.layout import PointAttributeDataType as T, attributes as A
+    layout = pa.PointLayout.from_attributes([A.POSITION_3D])
+    src = pa.HashMapBuffer.new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(seed, 0)
+    dst = pa.HashMapBuffer.new_from_layout(layout)
+    dst.resize(n)
+    conv = pa.BufferLayoutConverter.for_layouts(layout, layout)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, SCALE, OFFSET), False)
+    rec = torch.empty(6, dtype=torch.float64, device="cuda")
+    steps = 10
+
+    def pair():
+        conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+        pa.calculate_bounds_async(dst, rec.data_ptr())
+    for _ in range(2):
+        pair()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1, e2 in ev:
+        e0.record(stream)
+        conv.convert_into_range_async(src, range(0, n), dst, range(0, n))
+        e1.record(stream)
+        pa.calculate_bounds_async(dst, rec.data_ptr())
+        e2.record(stream)
+    torch.cuda.synchronize()
+    conv_ms = [a.elapsed_time(b) for a, b, _ in ev]
+    bnd_ms = [b.elapsed_time(c) for _, b, c in ev]
+    ms = (sum(conv_ms) + sum(bnd_ms)) / steps
+    got = bounds_from_record(rec.cpu())
+    # the synchronous drop-in calls themselves (host round trip and the record's read-back included): wall clock
+    t0 = time.perf_counter()
+    for _ in range(5):
+        conv.convert_into(src, dst)
+        sync_b = pa.calculate_bounds(dst)
+    wall = (time.perf_counter() - t0) / 5 * 1e3
+    gbs = 72 * n / (ms * 1e-3) / 1e9
+    return {"points": n, "steps": steps, "ms_per_step": round(ms, 4), "ms_convert_into": round(sum(conv_ms) / steps, 4), "ms_calculate_bounds": round(sum(bnd_ms) / steps, 4),
+            "ms_per_step_synchronous_calls": round(wall, 4), "value": round(n / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s", "algorithmic_bytes_per_point": 72,
+            "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "plan": cv.last_plan_kinds(),
+            "verified": bool(got == fused_bounds and (sync_b.min(), sync_b.max()) == tuple(fused_bounds)) if fused_bounds else None,
+            "note": "the reference's caller shape of the headline: convert_into then calculate_bounds (bounds.rs:11), unfused -- 72 B per point; HIP events around each "
+                    "call of 10 steps (stream-ordered forms), and the wall time of the synchronous pair; verified = both AABBs equal the fused run's (config.bounds)"}
+
+
+def leg_chunked(pa, las, cv, torch, stream, seed):
+    """pasture-io's LAS reader (raw_readers.rs:309-349): raw point records arrive in 1 MiB chunks and every chunk goes through convert_into_range into the
+    caller's buffer.  Raw LAS-0 records (20 B) -> typed LAS-0 columns (35 B), 55 B per point, chunk = 1 MiB / 20 B = 52 428 points, 256 chunks: the synchronous
+    call per chunk (what a drop-in issues: launch + wait) and the stream-ordered loop (one wait at the end); then single calls over chunk sizes from 2^4 to
+    2^22 points -- the oracle times the same sizes on the host (cpu_baseline leg) and the line reports where the GPU call overtakes it."""
+    raw = las.point_layout_from_las_point_format(las.Format(0), True)
+    typed = las.point_layout_from_las_point_format(las.Format(0), False)
+    chunk = (1 << 20) // 20
+    n_chunks = 256
+    total = chunk * n_chunks
+    src = pa.VectorBuffer.new_from_layout(raw)
+    src.resize(total)
+    src.synth_fill(seed, 0)
+    dst = pa.HashMapBuffer.new_from_layout(typed)
+    dst.resize(total)
+    conv = las.get_default_las_converter(raw, typed, SCALE, OFFSET)
+    conv.prepare(type(src), type(dst), False)
+    for c in range(4):
+        conv.convert_into_range(src, range(c * chunk, (c + 1) * chunk), dst, range(c * chunk, (c + 1) * chunk))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(n_chunks):
+        conv.convert_into_range(src, range(c * chunk, (c + 1) * chunk), dst, range(c * chunk, (c + 1) * chunk))
+    sync_us = (time.perf_counter() - t0) / n_chunks * 1e6
+    kinds = cv.last_plan_kinds()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(n_chunks):
+        conv.convert_into_range_async(src, range(c * chunk, (c + 1) * chunk), dst, range(c * chunk, (c + 1) * chunk))
+    torch.cuda.synchronize()
+    async_us = (time.perf_counter() - t0) / n_chunks * 1e6
+    sizes = [1 << b for b in range(4, 23, 2)] + [chunk]
+    per_size = {}
+    for m in sorted(sizes):
+        ts = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            conv.convert_into_range(src, range(0, m), dst, range(0, m))
+            ts.append((time.perf_counter() - t0) * 1e6)
+        per_size[m] = round(statistics.median(ts), 2)
+    m = min(chunk, 100_000)
+    sample = {a.name(): dst.get_attribute_range(a.attribute_definition(), range(0, m)).tobytes() for a in typed.attributes()}
+    rep = {"chunk_points": chunk, "chunk_bytes": chunk * 20, "chunks": n_chunks, "us_per_chunk_synchronous": round(sync_us, 2), "us_per_chunk_stream_ordered": round(async_us, 2),
+           "value": round(chunk / sync_us, 2), "value_stream_ordered": round(chunk / async_us, 2), "unit": "Mpoints/s", "algorithmic_bytes_per_point": 55,
+           "achieved_GBps_stream_ordered": round(55 * chunk / async_us / 1e3, 1), "plan": kinds, "us_per_call_by_points": {str(k): v for k, v in sorted(per_size.items())},
+           "note": "the reference's production caller (raw_readers.rs:309-349): raw LAS-0 records -> typed LAS-0 columns in 1 MiB chunks through convert_into_range; wall clock "
+                   "per chunk of 256 chunks, synchronous (launch + wait per chunk) and stream-ordered (one wait at the end); us_per_call_by_points = median of 9 synchronous calls"}
+    return rep, {"points": m, "seed": seed, "columns": sample, "sizes": sorted(sizes)}
 
 
 def oracle_spot_checks(lib_path, checks):
@@ -310,7 +430,36 @@ def oracle_spot_checks(lib_path, checks):
                if cols.get_attribute_range(a.attribute_definition(), range(0, c2["points"])).tobytes() != c2["columns"][a.name()]]
         out["configs2"] = {"verified": not bad, "points_compared": c2["points"], "columns_compared": len(c2["columns"]), "columns_differing": bad,
                            "how": "the first points of the GPU's 10 columns, byte for byte against the oracle's conversion of the same synthetic records"}
-    c4 = checks.get("configs4")
+    ck = checks.get("chunked")
+    if ck:
+        raw = las.point_layout_from_las_point_format(las.Format(0), True, api=orc)
+        typed = las.point_layout_from_las_point_format(las.Format(0), False, api=orc)
+        biggest = max(ck["sizes"])
+        src = pa.VectorBuffer.new_from_layout(raw)
+        src.resize(biggest)
+        src.synth_fill(ck["seed"], 0)
+        dst = pa.HashMapBuffer.new_from_layout(typed)
+        dst.resize(biggest)
+        conv = las.get_default_las_converter(raw, typed, SCALE, OFFSET)
+        per_size = {}
+        for m in ck["sizes"]:
+            ts = []
+            for _ in range(3 if m > (1 << 20) else 7):
+                t0 = time.perf_counter()
+                conv.convert_into_range(src, range(0, m), dst, range(0, m))
+                ts.append((time.perf_counter() - t0) * 1e6)
+            per_size[m] = round(statistics.median(ts), 2)
+        bad = [a.name() for a in typed.attributes()
+               if dst.get_attribute_range(a.attribute_definition(), range(0, ck["points"])).tobytes() != ck["columns"][a.name()]]
+        out["chunked"] = {"verified": not bad, "points_compared": ck["points"], "columns_differing": bad, "oracle_us_per_call_by_points": {str(k): v for k, v in sorted(per_size.items())},
+                          "how": "the first chunk of the GPU's 10 columns byte for byte against the oracle's convert_into_range of the same raw records; the oracle's own "
+                                 "call times (one pinned core, through the same ctypes binding) for the crossover"}
+    for key in ("configs4", "configs4_sheet"):
+        _spot_check_fits(out, key, checks.get(key), pa, orc, np, A, compute_normals)
+    return out
+
+
+def _spot_check_fits(out, key, c4, pa, orc, np, A, compute_normals):
     if c4:
         k, worst_n, worst_c, failed = c4["k"], 0.0, 0.0, 0
         for f in c4["fits"]:
@@ -324,11 +473,10 @@ def oracle_spot_checks(lib_path, checks):
             cdiff = abs(f["curvature"] - float(oc[0]))
             worst_n, worst_c = max(worst_n, nerr), max(worst_c, cdiff)
             failed += int(nerr > 1e-9 or cdiff > 1e-9 * abs(float(oc[0])) + floor)
-        out["configs4"] = {"verified": failed == 0, "fits_compared": len(c4["fits"]), "fits_outside_window": failed, "worst_rel_normal_diff": worst_n,
-                           "worst_abs_curvature_diff": worst_c,
-                           "how": "the oracle's plane fit of the GPU's own neighbour lists (16-point clouds, k = 16) against the GPU's f64 normals (1e-9 relative) "
-                                  "and curvatures (1e-9 relative + the documented floor)"}
-    return out
+        out[key] = {"verified": failed == 0, "fits_compared": len(c4["fits"]), "fits_outside_window": failed, "worst_rel_normal_diff": worst_n,
+                    "worst_abs_curvature_diff": worst_c,
+                    "how": "the oracle's plane fit of the GPU's own neighbour lists (16-point clouds, k = 16) against the GPU's f64 normals (1e-9 relative) "
+                           "and curvatures (1e-9 relative + the documented floor)"}
 
 
 def cpu_baseline(workload, sample_points, checks=None):
@@ -995,6 +1143,22 @@ def main():
             release_scratch()
         except Exception as e:  # noqa: BLE001
             extra_legs["configs4_knn16"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        try:
+            rep, smp = leg_configs4(pa, torch, stream, n, SEED, n_queries=16, sheet=True)
+            extra_legs["configs4_knn16_sheet"], extra_checks["configs4_sheet"] = rep, smp
+            from pasture_amd.algorithms import release_scratch
+            release_scratch()
+        except Exception as e:  # noqa: BLE001
+            extra_legs["configs4_knn16_sheet"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        try:
+            extra_legs["dropin_convert_then_bounds"] = leg_dropin(pa, cv, torch, stream, n, SEED, result)
+        except Exception as e:  # noqa: BLE001
+            extra_legs["dropin_convert_then_bounds"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        try:
+            rep, smp = leg_chunked(pa, las, cv, torch, stream, SEED)
+            extra_legs["chunked_rawlas_1MiB"], extra_checks["chunked"] = rep, smp
+        except Exception as e:  # noqa: BLE001
+            extra_legs["chunked_rawlas_1MiB"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         src = dst = None
 
     # north_star size made driver-visible: the same fused convert + AABB over 10^9 points (24 GB in, 24 GB out) on ONE GPU, measured in this
@@ -1121,6 +1285,18 @@ def main():
                 sc = cb.get("spot_checks") if isinstance(cb.get("spot_checks"), dict) else {}
                 if "configs2" in sc and "configs2_las0_to_columns" in line:
                     line["configs2_las0_to_columns"]["verified"] = bool(sc["configs2"].get("verified"))
+                if "configs4_sheet" in sc and "configs4_knn16_sheet" in line:
+                    ck = line["configs4_knn16_sheet"].get("checks", {})
+                    line["configs4_knn16_sheet"]["verified"] = bool(sc["configs4_sheet"].get("verified")) and bool(ck.get("columns_equal_f64_results_narrowed")) \
+                        and ck.get("neighbour_lists_exact") == ck.get("neighbour_lists_checked")
+                if "chunked" in sc and "chunked_rawlas_1MiB" in line:
+                    leg = line["chunked_rawlas_1MiB"]
+                    leg["verified"] = bool(sc["chunked"].get("verified"))
+                    orc_us = sc["chunked"].get("oracle_us_per_call_by_points", {})
+                    leg["oracle_us_per_call_by_points"] = orc_us
+                    gpu_us = leg.get("us_per_call_by_points", {})
+                    faster = [int(k) for k in gpu_us if k in orc_us and gpu_us[k] < orc_us[k]]
+                    leg["gpu_call_overtakes_the_oracle_from_points"] = min(faster) if faster else None
                 if "configs4" in sc and "configs4_knn16" in line:
                     ck = line["configs4_knn16"].get("checks", {})
                     line["configs4_knn16"]["verified"] = bool(sc["configs4"].get("verified")) and bool(ck.get("columns_equal_f64_results_narrowed")) \
