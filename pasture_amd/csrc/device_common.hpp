@@ -142,21 +142,26 @@ __device__ __forceinline__ To rust_as(From v) {
     constexpr int digits = std::is_signed<To>::value ? (int)sizeof(To) * 8 - 1 : (int)sizeof(To) * 8;
     // 2^digits is exactly representable in f32 and f64 for digits <= 64
     const From hi = (From)__builtin_ldexp(1.0, digits);
-    if (v != v) return (To)0;
-    if (v >= hi) return std::numeric_limits<To>::max();
-    if constexpr (std::is_signed<To>::value) {
-      if (v <= -hi) return std::numeric_limits<To>::min();  // -2^digits == To::MIN exactly
-    } else {
-      if (v < (From)0) return (To)0;  // (-1, 0) truncates to 0 as well
-    }
-    // in range: truncation toward zero, defined behaviour
+    // SELECTS, not early returns (round 6): written with `if (...) return`, every conversion became two or three execution-mask branches in the
+    // kernels that convert in bulk (the LAS encoder: twelve per lane and tile).  The value handed to the conversion instruction is always in range
+    // (0 stands in for NaN and for the saturating cases), so the C++ conversion is defined; the results of those cases are selected afterwards.
+    const bool over = v >= hi;
+    bool under;
+    if constexpr (std::is_signed<To>::value) under = v <= -hi;  // -2^digits == To::MIN exactly
+    else under = v < (From)0;                                   // (-1, 0) truncates to 0 as well
+    const bool in_range = v == v && !over && !under;
+    const From safe = in_range ? v : (From)0;
+    To r;
     if constexpr (sizeof(To) <= 4) {
-      if constexpr (std::is_signed<To>::value) return (To)(int32_t)v;
-      else return (To)(uint32_t)v;
+      if constexpr (std::is_signed<To>::value) r = (To)(int32_t)safe;
+      else r = (To)(uint32_t)safe;
     } else {
-      if constexpr (std::is_signed<To>::value) return (To)(int64_t)v;
-      else return (To)(uint64_t)v;
+      if constexpr (std::is_signed<To>::value) r = (To)(int64_t)safe;
+      else r = (To)(uint64_t)safe;
     }
+    r = over ? std::numeric_limits<To>::max() : r;
+    r = under ? (std::is_signed<To>::value ? std::numeric_limits<To>::min() : (To)0) : r;
+    return r;
   } else {
     return static_cast<To>(v);
   }
