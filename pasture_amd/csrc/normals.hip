@@ -8,7 +8,7 @@
 // has no effect; normal = largest of three row cross products, NOT normalised :395-426).
 //
 // Spatial index: points are binned into a uniform grid whose cell edge is chosen so that a sphere of one cell edge holds about k
-// points, radix-sorted by cell key (rocPRIM, device_sort.hip — library plumbing) and reordered once, so that every search reads
+// points, radix-sorted by cell key (radix_sort.hip) and reordered once, so that every search reads
 // contiguous runs of sorted points.
 //   volume-like clouds (cells <= 4 n): keys are row-major cell numbers (x fastest, 32-bit) with a DENSE directory cell_start[];
 //       the search runs in normals_tile.hip (a box of cells staged in LDS per workgroup); queries it cannot finish come back as a list

@@ -5,8 +5,7 @@
 //
 //   voxel_keys_kernel    per point: find_leaf (:21-52) = lower_bound over the axis markers + "better fitting marker" step;
 //                        key = x | y | z packed x-major in as few bits as the marker counts need (fewer radix passes)
-//   rocPRIM radix sort   (key, point index) pairs; stable, so points keep ascending index order inside a voxel  (library plumbing,
-//                        device_sort.hip)
+//   radix sort           (key, point index) pairs (radix_sort.hip: 32- and 64-bit keys); stable, so points keep ascending index order inside a voxel
 //   voxel_heads_*        run heads of the sorted keys: per-tile counts, exclusive scan, voxel starts (two light passes over the keys)
 //   voxel_reduce_kernel  a wave per 64 voxels: averages / max-pools of small voxels one voxel per LANE (sequential loop = the
 //                        reference's loop); most-common attributes and large voxels one voxel per WAVE (set_all_attributes :459-689):
