@@ -240,7 +240,7 @@ def _filter_plan_source(sizes, columns, offsets=None, stride=None):
     pieces = [piece_of(z) if covered else min(piece_of(z), piece_of(o_) if o_ else 8) for z, o_ in zip(sizes, offs)]
     cap = min(2048, (52 * 1024 // (stride or total)) // 16 * 16)
     return ('#include "filter_stream.hpp"\nstruct PstFilterPlan {\n'
-            f'  static constexpr int n = {len(sizes)};\n  static constexpr bool dst_columns = {"true" if columns else "false"}, covered = {"true" if covered else "false"};\n'
+            f'  static constexpr int n = {len(sizes)};\n  static constexpr bool dst_columns = {"true" if columns else "false"}, covered = {"true" if covered else "false"}, has_pred = false;\n'
             f'  static constexpr uint32_t dst_stride = {stride}, cap = {cap};\n'
             '  __host__ __device__ static constexpr uint32_t size(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, sizes)) + '};\n    return t[k];\n  }\n'
             '  __host__ __device__ static constexpr uint32_t dst_off(int k) {\n    constexpr uint32_t t[n] = {' + ", ".join(map(str, offs)) + '};\n    return t[k];\n  }\n'
