@@ -218,6 +218,41 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
   }
 }
 
+// transform_attribute with the closure as a device expression, IN PLACE on the records of an interleaved buffer without padding (round 6): the
+// transformation as a records -> records plan whose other attributes are identity copies and whose transformed attribute is a PST_XF_EXPR entry
+// -- the plan-specialised kernel reads every tile into registers before it writes it, tiles are disjoint --, the expression's index `i` is the
+// point's index, p[0 .. 3] the arrays it names.  Returns the points covered (full tiles; 0: no such kernel for this layout / PST_JIT=0 -- the caller's
+// strided kernel takes everything); throws when the kernel with the expression in it does not compile.
+uint64_t transform_records_with_expression(const pst_buffer& b, int slot, const std::string& expr, const double* const p[4], hipStream_t stream) {
+  static const bool fuse_env = [] { const char* v = std::getenv("PST_EXPR_FUSE"); return !(v && *v == '0'); }();
+  uint64_t attr_bytes = 0;
+  for (const Member& mm : b.layout.members) attr_bytes += mm.size;
+  if (!fuse_env || b.columnar || b.len == 0 || attr_bytes != b.layout.size || b.layout.members.size() > PST_PLAN_MAX_ENTRIES || pstjit::mode() == pstjit::Mode::Off) return 0;
+  std::vector<PlanEntry> all;
+  for (size_t a = 0; a < b.layout.members.size(); ++a) {
+    PlanEntry e = identity_entry(b.layout.members[a], b.layout.members[a]);
+    if ((int)a == slot) { e.xf_kind = (uint8_t)PST_XF_EXPR; e.xf_on_source = 0; e.mask = 0; }
+    all.push_back(e);
+  }
+  const uint32_t stride = (uint32_t)b.layout.size;
+  const uint32_t tile = pick_tile(true, stride, true, stride);
+  if (tile < 1) return 0;
+  const std::vector<std::string> texts{expr};
+  bool wants_bounds = false;
+  const uint64_t base = aos_addr(b, 0);
+  ConvertPlan plan = build_plan(true, base, stride, true, base, stride, b.len, all.data(), all.size(), tile, false, false, &wants_bounds);
+  plan.expr_texts = &texts;
+  plan.h.first_index = 0;
+  for (int q = 0; q < 4; ++q) plan.h.expr_params[q] = p ? (uint64_t)(uintptr_t)p[q] : 0;
+  uint64_t done = 0;
+  std::string err;
+  pstk::reset_plan_kinds();
+  if (!pstk::launch_convert_fused_expressions(plan, true, true, stream, &done, &err))
+    throw Error(PST_ERR_HIP, std::string("transformation kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+  if (!err.empty()) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "transformation expression: the kernel with the expression in it does not compile:\n" + err);
+  return done;
+}
+
 // Identity between two buffers of the same layout in which the mappings cover every byte of the record (no padding, no
 // unmapped attribute): interleaved -> interleaved is then a plain byte copy of the records (what the reference's per-attribute
 // loops add up to, buffer_conversion.rs:606-662).

@@ -340,6 +340,7 @@ MapSpec map_spec(const DataType& src, const DataType& dst, bool pre, const char*
 }  // namespace pstexpr
 
 namespace pst {
+uint64_t transform_records_with_expression(const pst_buffer& b, int slot, const std::string& expr, const double* const p[4], hipStream_t stream);  // converter.cpp
 // converter.cpp: a mapping whose transformation is an expression (one strided launch per such mapping)
 void launch_expression_mapping(const DataType& src_dt, const DataType& dst_dt, bool apply_to_source, const std::string& expr, uint64_t src, uint64_t sstride, uint64_t dst,
                                uint64_t dstride, uint64_t n, uint64_t first_index, hipStream_t stream) {
@@ -385,7 +386,10 @@ int pst_transform_attribute_expr(pst_buffer* b, const char* name, const pst_data
   const Member& m = b->layout.members[(size_t)slot];
   const uint64_t base = b->columnar ? col_addr(*b, (size_t)slot, 0) : aos_addr(*b, 0) + m.offset;
   const uint64_t stride = b->columnar ? m.size : b->layout.size;
-  pstexpr::launch_map(s, base, stride, base, stride, b->len, 0, p, st);
+  // interleaved records without padding: the whole tiles through the plan-specialised kernel with the expression inside (one pass over the
+  // records instead of a strided read-modify-write of one attribute); the ragged rest -- or everything -- through the expression's own kernel
+  const uint64_t done = transform_records_with_expression(*b, slot, s.expr, p, st);
+  if (done < b->len) pstexpr::launch_map(s, base + done * stride, stride, base + done * stride, stride, b->len - done, done, p, st);
   stream_sync(st);
   PST_API_END
 }

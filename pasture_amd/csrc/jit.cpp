@@ -442,10 +442,10 @@ static std::string spec_source_uncached(const QuadSpec& s) {
       << ", " << e.src_stage << ", " << e.dst_stage << "},\n";
   o << "    };\n    return t[m];\n  }\n";
   if (!s.exprs.empty()) {
-    // the fused expressions (expr.cpp's names: v, x, y, z, c, i, p0 .. p3 -- a conversion captures no arrays: p0 .. p3 are null): one `if constexpr`
+    // the fused expressions (expr.cpp's names: v, x, y, z, c, i, p0 .. p3 -- the arrays travel in ConvertHeader::expr_params; a conversion captures none): one `if constexpr`
     // arm per (mapping, component); a Vec3 mapping may give one text for all components or three separated by ';' (split by expr.cpp)
-    o << "  template <int M, int C, typename TI>\n  __device__ static __forceinline__ TI expr(const TI v, const TI x, const TI y, const TI z, const uint64_t i) {\n";
-    o << "    using namespace pstd;\n    constexpr int c = C;\n    const double* const p0 = nullptr; const double* const p1 = nullptr; const double* const p2 = nullptr; const double* const p3 = nullptr;\n";
+    o << "  template <int M, int C, typename TI>\n  __device__ static __forceinline__ TI expr(const TI v, const TI x, const TI y, const TI z, const uint64_t i, const uint64_t (&pp)[4]) {\n";
+    o << "    using namespace pstd;\n    constexpr int c = C;\n    const double* const p0 = (const double*)pp[0]; const double* const p1 = (const double*)pp[1]; const double* const p2 = (const double*)pp[2]; const double* const p3 = (const double*)pp[3];\n";
     o << "    (void)v; (void)x; (void)y; (void)z; (void)c; (void)i; (void)p0; (void)p1; (void)p2; (void)p3;\n";
     for (size_t m = 0; m < s.exprs.size(); ++m) {
       if (s.exprs[m].empty()) continue;

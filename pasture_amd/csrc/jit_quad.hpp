@@ -268,7 +268,8 @@ __device__ __forceinline__ QXf load_qxf(const PlanEntry* entries, int m) {
 // attribute's own quad image of a columnar one).
 // (pidx: the point's index in the source buffer -- the `i` of a fused expression; unused, and folded away, in every other plan)
 template <typename P, int M, uint32_t T, int SW, int TW>
-__device__ __forceinline__ void move_point(const uint32_t (&sw)[SW], uint32_t (&tw)[TW], const QXf& x, double (&lo)[3], double (&hi)[3], const uint64_t pidx) {
+__device__ __forceinline__ void move_point(const uint32_t (&sw)[SW], uint32_t (&tw)[TW], const QXf& x, double (&lo)[3], double (&hi)[3], const uint64_t pidx,
+                                           const uint64_t (&params)[4]) {
   constexpr QEntry e = P::entry(M);
   typedef typename CtType<e.src_ct>::type S;
   typedef typename CtType<e.dst_ct>::type D;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void move_point(const uint32_t (&sw)[SW], uint32_t (&
     if constexpr (e.ncomp < 3) { in[1] = in[0]; in[2] = in[0]; }
     static_for<0, (int)e.ncomp>([&](auto C) __attribute__((always_inline)) {
       constexpr uint32_t c = (uint32_t) decltype(C)::value;
-      const TI r = P::template expr<M, (int)c, TI>(in[c], in[0], in[1], in[2], pidx);
+      const TI r = P::template expr<M, (int)c, TI>(in[c], in[0], in[1], in[2], pidx, params);
       const D d = rust_as<D, TI>(r);
       img_put<clear, dofs + c * (uint32_t)sizeof(D), (uint32_t)sizeof(D)>(tw, to_bits<D>(d));
     });
@@ -356,7 +357,7 @@ __device__ __forceinline__ void lds_read_words(clptr_t p, uint32_t (&w)[NW], uin
 //   static constexpr uint32_t lds_per_point;                 // LDS bytes per point of the tile: record tiles + staged wide columns
 //   static constexpr uint32_t dst_tile_off, alias;           // target record tile at LDS byte T * dst_tile_off; alias: the outgoing regions overlay the incoming ones
 //   static constexpr QEntry entry(int m);
-//   template <int M, int C, typename TI> static TI expr(TI v, TI x, TI y, TI z, uint64_t i);   // plans with PST_XF_EXPR entries only (jit.cpp writes it)
+//   template <int M, int C, typename TI> static TI expr(TI v, TI x, TI y, TI z, uint64_t i, const uint64_t (&params)[4]);   // plans with PST_XF_EXPR entries only (jit.cpp writes it)
 // LDS regions (all flat, 16-byte aligned, at T * {0, src_stride, entry.src_stage / dst_stage}): the source record tile, the target record tile,
 // and one region per WIDE columnar attribute (>= 8 bytes per value).  A wide column's tile crosses HBM lane-contiguously -- a lane's own four
 // values are 32 ... 96 bytes apart from its neighbour's, which wastes most of every memory transaction --, LDS-DMA in / 16-byte stores out like
@@ -435,8 +436,8 @@ __device__ __forceinline__ void quad_convert_body(const ConvertHeader& h, const 
       QXf x;
       if constexpr (e.xf_kind != 0 && e.xf_kind != PST_XF_EXPR) x = load_qxf(entries, M);
       static_for<0, 4>([&](auto TT) __attribute__((always_inline)) {
-        if constexpr (P::dst_aos) move_point<P, M, (uint32_t) decltype(TT)::value>(sw, dw, x, lo, hi, h.first_index + p0 + (uint32_t) decltype(TT)::value);
-        else move_point<P, M, (uint32_t) decltype(TT)::value>(sw, cw, x, lo, hi, h.first_index + p0 + (uint32_t) decltype(TT)::value);
+        if constexpr (P::dst_aos) move_point<P, M, (uint32_t) decltype(TT)::value>(sw, dw, x, lo, hi, h.first_index + p0 + (uint32_t) decltype(TT)::value, h.expr_params);
+        else move_point<P, M, (uint32_t) decltype(TT)::value>(sw, cw, x, lo, hi, h.first_index + p0 + (uint32_t) decltype(TT)::value, h.expr_params);
       });
       if constexpr (!P::dst_aos) {
         if constexpr (e.dst_wide != 0) {

@@ -48,6 +48,7 @@ struct ConvertHeader {
   uint32_t quad;              // tile kernels, columnar -> interleaved: four consecutive points per lane (wave-uniform LDS alignment classes)
   uint32_t reserved;
   uint64_t first_index;       // index of the range's first point in the SOURCE buffer: the `i` of a fused expression (plan-specialised kernels)
+  uint64_t expr_params[4];    // device addresses of the f64 arrays a fused expression names p0 .. p3 (0: none; conversions capture nothing)
 };
 struct ConvertPlan {
   ConvertHeader h;
