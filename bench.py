@@ -115,6 +115,7 @@ def parse():
     p.add_argument("--no-extra-legs", action="store_true",
                    help="skip the configs[2] (LAS-0 records -> 10 columns) and configs[4] (kNN(16) normals) legs appended at N=1 to the default workload's line")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-traffic-run", action="store_true", help="do not re-run the workload under rocprofv3 for roofline.traffic (the committed profiles/hbm_traffic.json figure is quoted instead)")
     p.add_argument("--cpu-sample-points", type=int, default=100_000_000, help="CPU baseline sample (default: the whole 10^8-point workload, ~10 s of CPU work)")
     return p.parse_args()
 
@@ -168,6 +169,43 @@ def _family_report(conv, dst_type, with_bounds, src_type=None):
     if choice in (0, 1):
         rep["ms_per_pass"] = {"las": round(ms[0], 4), "plan-specialised": round(ms[1], 4)}
     return rep
+
+
+def measure_traffic_in_run(workload, n, kernel_substr, timeout_s=150):
+    """roofline.traffic measured IN this run (round-5 review, weak #9): the same workload re-executed under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one; no other trace domain with --pmc), 3 steps each, in child processes; per launch of the
+    dominant kernel FETCH_SIZE x 2 (lane-contiguous streaming reads: the counter reports half the bytes, profiles/pmc_calibration.json) + WRITE_SIZE, KiB x 1024
+    -- the correction of /opt/skills/guides/MI355X_MICROARCH.md's HBM section as tools/rocprof_summary.py applies it.  Returns (bytes, source) or None."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pst_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__), "--workload", workload, "--points", str(n),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-north-star", "--no-extra-legs", "--no-traffic-run"]
+            subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = list(cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? and kernel_name like ? group by kernel_name",
+                                    (counter, f"%{kernel_substr}%")))
+            if not rows:
+                return None
+            vals[counter] = max(rows, key=lambda r: r[2])[1]
+        except Exception:  # noqa: BLE001  (no profiler, no counters, a time-out: the committed figure stands in, and the line says which it is)
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = 2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
+    return round(total), ("measured IN THIS RUN: child processes of this bench.py under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 3 steps each); "
+                          f"per launch of {kernel_substr}: FETCH_SIZE x 2 (streaming reads: counter reports half, profiles/pmc_calibration.json) + WRITE_SIZE, KiB x 1024")
 
 
 def leg_configs2(pa, las, cv, torch, stream, n, seed):
@@ -1220,6 +1258,10 @@ def main():
                                    f"{t.get('fetch_factor', 2)}: {t.get('calibrated_on', 'wide coalesced reads')}); NOT measured in this run")
             except Exception:
                 pass
+        if world == 1 and not distributed and args.workload == "convert_affine_bounds" and not args.no_traffic_run and not args.no_extra_legs and not args.global_points:  # (the default driver run only: the tools pass --no-extra-legs, some of them run under rocprofv3 themselves)
+            m = measure_traffic_in_run(args.workload, n, "vec3f64_stream2_kernel")
+            if m is not None:
+                traffic, traffic_src = m
         line = {
             "metric": "Mpoints/sec + achieved HBM GB/s (% of peak), 10^8-pt POSITION_3D convert+AABB",
             "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
