@@ -208,6 +208,35 @@ def measure_traffic_in_run(workload, n, kernel_substr, timeout_s=150):
                           f"per launch of {kernel_substr}: FETCH_SIZE x 2 (streaming reads: counter reports half, profiles/pmc_calibration.json) + WRITE_SIZE, KiB x 1024")
 
 
+def measure_valu_in_run(workload, n, kernel_substr="knn_tile2_kernel", timeout_s=240):
+    """bound_valu measured IN this run: the kNN workload once more in a child process under `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU` (its own pass, no
+    other trace domain); vector wave-instructions per launch of the box kernel and that kernel's name.  None when the profiler or the counter is not to be had."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    d = tempfile.mkdtemp(prefix="pst_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", "SQ_INSTS_VALU", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__), "--workload", workload, "--points", str(n),
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-north-star", "--no-extra-legs", "--no-traffic-run"]
+        subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        cur = sqlite3.connect(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0]).cursor()
+        rows = list(cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name='SQ_INSTS_VALU' and kernel_name like ? group by kernel_name",
+                                (f"%{kernel_substr}%",)))
+        if not rows:
+            return None
+        name, val, _cnt = max(rows, key=lambda r: r[1])
+        return {"kernel": name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], "valu_wave_instructions_per_launch": round(val)}
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def leg_configs2(pa, las, cv, torch, stream, n, seed):
     """BASELINE.json configs[2]: n typed LAS-0 points (35 B, 10 attributes, packed) VectorBuffer -> HashMapBuffer of 10 columns, 70 B/point,
     HIP events around each of 10 steps.  Returns (report, sample): sample = the first 10^5 points of every column as bytes, for the oracle check."""
@@ -257,7 +286,7 @@ def _sheet_cloud(torch, n, seed):
     return sheet
 
 
-def leg_configs4(pa, torch, stream, n, seed, n_queries=48, sheet=False):
+def leg_configs4(pa, torch, stream, n, seed, n_queries=48, sheet=False, pmc=True):
     """BASELINE.json configs[4]: kNN(k = 16) normal estimation over n uniform points (sheet: over the LiDAR-shaped sheet), NORMAL (Vec3f32) + Curvature (F64) written to columns.
     Timed: the synchronous call (wall clock around call + synchronize) and the planned stream-ordered form (HIP events).  Then, outside the timing:
     the raw f64 results + neighbour lists once more (pst_compute_normals_device), `n_queries` sampled neighbour lists against a brute force over all
@@ -333,7 +362,14 @@ def leg_configs4(pa, torch, stream, n, seed, n_queries=48, sheet=False):
                       "pst_compute_normals_into calls (index build, sort, searches, fits; host round trips included), ms_per_call_planned = HIP events around the "
                       "stream-ordered replay; the call is bound by its vector instructions, not by HBM (bound_valu)"}
     try:
-        v = json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get("normals_knn16_sheet" if sheet else "normals_knn16")
+        wl = "normals_knn16_sheet" if sheet else "normals_knn16"
+        live = None if (sheet or not pmc) else measure_valu_in_run(wl, n)  # (the uniform leg: ~10 s of a child process; the sheet quotes its committed pass)
+        if live is not None:
+            issue_rate = 256 * 4 * 2.4e9 / 4.0
+            bound_ms = live["valu_wave_instructions_per_launch"] / issue_rate * 1e3
+            report["bound_valu"] = {**live, "bound_ms": round(bound_ms, 3), "frac_of_call": round(bound_ms / med, 4),
+                                    "source": "measured IN THIS RUN: a child process of this bench.py under rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU (2 calls); issue rate = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles"}
+        v = None if live is not None else json.load(open(os.path.join(ROOT, "profiles", "knn_valu.json"))).get(wl)
         if v and v.get("points") == n:
             issue_rate = 256 * 4 * 2.4e9 / 4.0
             bound_ms = v["valu_wave_instructions_per_launch"] / issue_rate * 1e3
@@ -1175,7 +1211,7 @@ def main():
         except Exception as e:  # noqa: BLE001  (a failed leg is reported, it does not take the headline with it)
             extra_legs["configs2_las0_to_columns"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         try:
-            rep, smp = leg_configs4(pa, torch, stream, n, SEED)
+            rep, smp = leg_configs4(pa, torch, stream, n, SEED, pmc=not args.no_traffic_run)
             extra_legs["configs4_knn16"], extra_checks["configs4"] = rep, smp
             from pasture_amd.algorithms import release_scratch
             release_scratch()
