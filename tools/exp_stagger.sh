@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 6, review item 6: does the phase of the columns' base addresses explain the box-to-box spread of the ten-column kernels?  Every column of a
 # HashMapBuffer is its own allocation (same phase of the channel interleave); PST_COLUMN_STAGGER places column a `a x step` bytes into its allocation.
+# NOTE: PST_COLUMN_STAGGER was read by an allocator patch (buffer.cpp: column a placed (a mod 16) x step bytes into its padded allocation) that was REMOVED after this
+# sweep showed no effect (profiles/r06_column_stagger_sweep.txt); the script is the record of how the sweep was run.
 # Sweeps the step for the workloads that walk many columns, kernel ms (HIP events, 20 steps) per step; run on several boxes (each gpurun call is a fresh one).
 cd "$(dirname "$0")/.."
 B="--steps 20 --warmup 3 --no-cpu-baseline --no-north-star --no-extra-legs"
