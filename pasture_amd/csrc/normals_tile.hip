@@ -1098,18 +1098,59 @@ __global__ __launch_bounds__(THREADS, WPE) void knn_tile2_kernel(const Tile2Args
         PST_KNN_STAT(if (ill) atomicAdd(a.dbg + 6, 1ull);)
         if (ill) { a.fb_list[atomicAdd(a.fb_count, 1u)] = j; handed = true; }
       } else if constexpr (!P3LDS && K <= 16) {
-        // f64 coordinates from global memory: every neighbour is fetched ONCE (the plane fit walks the neighbours twice, and a gather of
-        // 64 scattered 24-byte points keeps the texture path busy for ~64 cycles whether it hits the cache or not)
-        double nx[K], ny[K], nz[K];
+        // The reference's order of operations (centroid, then the moments about it: plane_fit<K, true>, bit for bit) WITHOUT holding the neighbours
+        // across the two passes.  Rounds 3-5 fetched every neighbour once and kept 6 k registers per lane -- 96 of the 128 this kernel may use at
+        // k = 16: 60-108 bytes of scratch per lane in every instance of this fit (the surfaces' and strips' instance: WRITE_SIZE 9.7 GB against
+        // the one-pass instance's 7.0, profiles/r06_normals_knn16_sheet_rocprof.txt).  Round 6: both passes gather, eight neighbours in flight
+        // (the batches of the one-pass fit above); the second gather of a neighbour hits the cache the first one filled.  Entries t >= m name
+        // the query itself (a valid address) and are not added: m is a kernel argument, the tests below are wave-uniform.
+        if (!(a.ablate & 2u)) {
+          uint32_t jm[K];
 #pragma unroll
-        for (int u = 0; u < K; ++u) {
-          nx[u] = 0; ny[u] = 0; nz[u] = 0;
-          if ((uint32_t)u < m) exact_xyz(nb[u], nx[u], ny[u], nz[u]);
+          for (int u = 0; u < K; ++u) jm[u] = Jmap[(uint32_t)u < m ? nb[u] : slot];
+          // the first KEEP neighbours stay in registers across the two passes, the others are gathered twice, four in flight
+          constexpr int KEEP = K < 8 ? K : 8, H = 4;
+          double kx[KEEP], ky[KEEP], kz[KEEP];
+#pragma unroll
+          for (int u = 0; u < KEEP; ++u) { const double* pp = a.sxyz + 3ull * jm[u]; kx[u] = pp[0]; ky[u] = pp[1]; kz[u] = pp[2]; }
+          double ax = 0, ay = 0, az = 0;
+#pragma unroll
+          for (int u = 0; u < KEEP; ++u) if ((uint32_t)u < m) { ax += kx[u]; ay += ky[u]; az += kz[u]; }
+#pragma unroll
+          for (int h = KEEP; h < K; h += H) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) asm volatile("" : "+v"(jm[h + u]), "+v"(ax));
+            double x[H], y[H], z[H];
+#pragma unroll
+            for (int u = 0; u < H; ++u) { const double* pp = a.sxyz + 3ull * jm[h + u]; x[u] = pp[0]; y[u] = pp[1]; z[u] = pp[2]; }
+#pragma unroll
+            for (int u = 0; u < H; ++u) if ((uint32_t)(h + u) < m) { ax += x[u]; ay += y[u]; az += z[u]; }
+          }
+          const double div = (double)m;
+          const double cx = ax / div, cy = ay / div, cz = az / div;
+          double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+          auto moment = [&](double x, double y, double z) __attribute__((always_inline)) {  // compute_covariance_matrix :240-305, plane_fit's operations in plane_fit's order
+            double d0 = x - cx, d1 = y - cy, d2 = z - cz;
+            c11 += d1 * d1; c12 += d1 * d2; c22 += d2 * d2;
+            const double dx = d0;
+            d0 *= dx; d1 *= dx; d2 *= dx;
+            c00 += d0; c01 += d1; c02 += d2;
+          };
+#pragma unroll
+          for (int u = 0; u < KEEP; ++u) if ((uint32_t)u < m) moment(kx[u], ky[u], kz[u]);
+#pragma unroll
+          for (int h = KEEP; h < K; h += H) {
+#pragma unroll
+            for (int u = 0; u < H; ++u) asm volatile("" : "+v"(jm[h + u]), "+v"(c00), "+v"(c22));
+            double x[H], y[H], z[H];
+#pragma unroll
+            for (int u = 0; u < H; ++u) { const double* pp = a.sxyz + 3ull * jm[h + u]; x[u] = pp[0]; y[u] = pp[1]; z[u] = pp[2]; }
+#pragma unroll
+            for (int u = 0; u < H; ++u) if ((uint32_t)(h + u) < m) moment(x[u], y[u], z[u]);
+          }
+          if (m < 3) f.ok = 0;  // Err(...) :293-295 -> unwrap panic :471
+          else f = fit_from_covariance(c00, c01, c02, c11, c12, c22);
         }
-        if (!(a.ablate & 2u)) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
-#pragma unroll
-          for (int u = 0; u < K; ++u) if ((uint32_t)u == t) { x = nx[u]; y = ny[u]; z = nz[u]; }
-        });
       } else {
         if (!(a.ablate & 2u)) f = plane_fit<K, true>(m, [&](uint32_t t, double& x, double& y, double& z) __attribute__((always_inline)) {
           uint32_t pl = 0;

@@ -156,6 +156,11 @@ def test_knn_box_kernel_with_the_one_pass_fit_uses_no_scratch_memory():
     plain = {k: v for k, v in seen.items() if k.endswith("ELb0ELb0ELi1EEEvNS_9Tile2ArgsE")}
     assert len(plain) >= 6, sorted(seen)
     assert all(v == 0 for v in plain.values()), plain
+    # round 6: the reference-order fit (FIT = 0, the instances a LiDAR-like sheet runs on) keeps eight neighbours in registers and gathers the other
+    # eight twice instead of holding sixteen positions across both passes -- it had 48 bytes of scratch per lane (2.7 GB of write-back per launch)
+    in_order = {k: v for k, v in seen.items() if k.endswith("ELb0ELb0ELi0EEEvNS_9Tile2ArgsE")}
+    assert len(in_order) >= 6, sorted(seen)
+    assert all(v == 0 for v in in_order.values()), in_order
 
 
 @pytest.mark.parametrize("seed", range(10))
