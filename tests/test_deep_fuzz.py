@@ -8,6 +8,7 @@ import os
 
 import pytest
 
+import test_expressions as te
 import test_gpu_parity as gp
 import test_jit as tj
 
@@ -24,6 +25,9 @@ SUITES = [
     ("voxelgrid", lambda hip, oracle, seed: gp.test_random_voxelgrid_vs_oracle(hip, oracle, seed), 40),
     ("knn_normals", lambda hip, oracle, seed: gp.test_random_knn_normals_vs_oracle(hip, oracle, seed), 24),
     ("knn_sparse_clouds", lambda hip, oracle, seed: gp.test_random_sparse_clouds_knn_vs_oracle(hip, oracle, seed), 8),
+    # round 6: expression mappings inside the plan-specialised kernels, random layouts (seeds far from test_expressions' own)
+    ("expression_mappings", lambda hip, oracle, seed: te.random_expression_conversion(hip, 1000 + seed), 8),
+    ("expression_predicates", lambda hip, oracle, seed: te.random_predicate_filter(hip, 1000 + seed), 8),
 ]
 
 

@@ -7,6 +7,7 @@ GPU suite: the reference's own scenarios (`+ 42.0` before and after the conversi
 index, point_buffer.rs:2007-2043) with numpy expectations, and a differential suite against the SAME text compiled by g++ (tests/expr_twin.py),
 bit for bit, over datatypes, storage pairings, apply_to_source, parameters and slices."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -328,6 +329,111 @@ def test_mapping_expressions_with_conversion_against_the_gxx_twin(hip, src_kind,
             assert _bits(part.view_attribute(da)) == _bits(twin(vals[1234:1734], 1234))
 
 
+def _ct_of(dt):
+    for table, nc in ((SCALARS, 1), (VEC3, 3)):
+        for name, v in table.items():
+            if v == dt:
+                return name, nc
+    return None, 0
+
+
+def _same_values(a, b):
+    """Two results of the SAME library on the same input (the plan with and without the expression mappings): equal bit for bit outside NaNs."""
+    if a.dtype.kind == "f":
+        return np.array_equal(np.isnan(a), np.isnan(b)) and _bits(a) == _bits(b)
+    return a.tobytes() == b.tobytes()
+
+
+FUZZ = int(os.environ.get("PST_FUZZ_SCALE", "1"))
+
+
+def random_expression_conversion(hip, seed):
+    """One case of the fuzz below; False when the random layouts offer no attribute an expression could map."""
+    import test_jit as tj
+    sl, tl, plain, rng = tj.random_converter(hip, 52000 + seed)
+    _, _, fused, _ = tj.random_converter(hip, 52000 + seed)  # the same converter again: it gets the expression mappings on top
+    srcs = [a.attribute_definition() for a in sl.attributes()]
+    tgts = [a.attribute_definition() for a in tl.attributes()]
+    picks = {}
+    for ti in rng.permutation(len(tgts))[: int(rng.integers(1, 4))]:
+        t = tgts[ti]
+        d_ct, nc = _ct_of(t.datatype())
+        cands = [a for a in srcs if d_ct is not None and _ct_of(a.datatype())[1] == nc]
+        if not cands:
+            continue
+        a = cands[rng.integers(0, len(cands))]
+        s_ct = _ct_of(a.datatype())[0]
+        on_source = bool(rng.random() < 0.5)
+        is_float = (s_ct if on_source else d_ct) in ("f32", "f64")
+        texts = [e[0] for e in EXPRS[:6] + EXPRS[7:] if (e[2] if is_float else e[1]) and (";" not in e[0] or nc == 3)]
+        text = texts[rng.integers(0, len(texts))]
+        fused.set_custom_mapping_with_expression(a, t, text, on_source)
+        picks[t.name()] = (a, s_ct, d_ct, nc, on_source, text)
+    if not picks:
+        return False
+    n = int(rng.choice([int(rng.integers(1, 3000)), int(rng.integers(3000, 70_000)), 1 << 16, (1 << 16) + int(rng.integers(1, 300))]))
+    rec = tj.random_source_records(sl, n, rng)
+    sk, dk = PAIRINGS[rng.integers(0, 4)]
+    src = BUFFER_KINDS[sk].from_numpy(rec, sl)
+
+    def check(got, want, first, lo, hi, d0):
+        for t in tgts:
+            g, w = got.view_attribute(t), want.view_attribute(t)
+            if t.name() in picks:
+                a, s_ct, d_ct, nc, on_source, text = picks[t.name()]
+                twin = expr_twin.map_twin(s_ct, d_ct, nc, on_source, text)(rec[a.name()][lo:hi], first)
+                assert _bits(g[d0:d0 + (hi - lo)]) == _bits(twin), (seed, t.name(), text, s_ct, d_ct, on_source, sk, dk, n, lo, hi)
+                assert _same_values(g[:d0], w[:d0]) and _same_values(g[d0 + hi - lo:], w[d0 + hi - lo:]), (seed, t.name(), "outside the target range")
+            else:
+                assert _same_values(g, w), (seed, t.name(), "not an expression's target", sk, dk, n, lo, hi)
+
+    out_fused = fused.convert(src, BUFFER_KINDS[dk])
+    random_expression_conversion.plans.append((sk + dk, n, tuple(cv.last_plan_kinds(hip))))
+    check(out_fused, plain.convert(src, BUFFER_KINDS[dk]), 0, 0, n, 0)
+    # a sub-range: starts on a 16-point multiple (the specialised kernels' precondition for interleaved sides) or anywhere; the expression's index
+    # is the point's index in the SOURCE buffer
+    m = int(rng.integers(1, n + 1))
+    lo = int(rng.integers(0, n - m + 1))
+    d0 = int(rng.integers(0, 40))
+    if rng.random() < 0.6:
+        lo, d0 = lo - lo % 16, d0 - d0 % 16
+    outs = []
+    for conv in (fused, plain):
+        dst = BUFFER_KINDS[dk].new_from_layout(tl)
+        dst.resize(d0 + m + int(rng.integers(0, 20)) if conv is fused else outs[0].len())
+        conv.convert_into_range(src, range(lo, lo + m), dst, range(d0, d0 + m))
+        outs.append(dst)
+    check(outs[0], outs[1], lo, lo, lo + m, d0)
+    return True
+
+
+random_expression_conversion.plans = []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24 * FUZZ))
+def test_random_layouts_with_expression_mappings_against_the_twin_and_the_plain_plan(hip, seed):
+    """Differential fuzz of round 6's fused path: test_jit's random converters (every datatype, packed / repr(C) layouts, unmapped target attributes,
+    affine and bit-field mappings) with one to three EXPRESSION mappings on top, random storage pairing, point count and sub-range.  The expressions'
+    targets equal the g++ twin bit for bit; every other target attribute -- same kernel when the plan is fused, the expression's entry beside it --
+    equals what the converter WITHOUT the expression mappings writes (that one is pinned against the oracle by test_jit / test_gpu_parity)."""
+    random_expression_conversion(hip, seed)
+
+
+@pytest.mark.gpu
+def test_expression_fuzz_ran_on_fused_kernels(hip):
+    """Of the cases above with an interleaved side and at least one whole tile of points, a good share must have run as the plan-specialised kernel
+    with the expressions in it (`jit` among pst_last_plan_kinds); columns -> columns never does (one launch per mapping is that pairing's form)."""
+    plans = random_expression_conversion.plans
+    if not plans:
+        pytest.skip("runs after the fuzz cases")
+    eligible = [p for p in plans if p[0] != "HH" and p[1] >= 4096]
+    taken = [p for p in eligible if "jit" in p[2]]
+    print(f"expression fuzz: {len(plans)} cases, {len(eligible)} with an interleaved side and >= 4096 points, {len(taken)} of them fused")
+    assert not any("jit" in p[2] for p in plans if p[0] == "HH")
+    assert len(taken) >= len(eligible) // 3, (len(taken), len(eligible), eligible[:6])
+
+
 PREDICATES = [
     "Classification == 2 && Position3D.z < 50.0",
     "(Intensity & 1) == 0 || GpsTime > 0.75",
@@ -367,6 +473,77 @@ def test_filter_expressions_against_the_gxx_twin_and_the_mask_path(hip, case, ou
         assert np.array_equal(out.view_attribute(d), rec[a.name()][mask.astype(bool)])
         assert out.view_attribute(d).tobytes() == ref.view_attribute(d).tobytes()
     del keep
+
+
+def _random_term(rng, name, ct, nc):
+    comp = name + "." + "xyz"[rng.integers(0, 3)] if nc == 3 else name
+    if ct in ("f32", "f64"):
+        c = float(np.round(rng.uniform(-8000, 8000), 3))
+        return [f"{comp} > {c}", f"{comp} * 0.5 < {c}", f"{comp} == {comp}", f"fabs((double){comp}) >= {abs(c)}"][rng.integers(0, 4)]
+    info = np.iinfo(expr_twin._NP[ct])
+    c = int(rng.integers(max(info.min, -(1 << 62)), min(info.max, 1 << 62), endpoint=True))
+    lit = f"{c}ull" if ct == "u64" else f"{c}ll" if ct == "i64" else str(c)
+    terms = [f"{comp} > {lit}", f"({comp} & {int(rng.integers(1, 8))}) == {int(rng.integers(0, 2))}", f"{comp} % 3 != 1", f"{comp} <= {lit}"]
+    if nc == 3:
+        terms.append(f"{name}.x < {name}.y")
+    return terms[rng.integers(0, len(terms))]
+
+
+def random_predicate_filter(hip, seed):
+    """One case of the fuzz below."""
+    import re
+    import test_jit as tj
+    rng = np.random.default_rng(61000 + seed)
+    ALL = list(SCALARS.values()) + list(VEC3.values()) + [T.Vec4u8, T.ByteArray(5), T.ByteArray(16)]
+    limit = 64 if rng.random() < 0.8 else 120  # beyond 64 bytes per point: no streaming form, the mask route
+    attrs, total = [], 0
+    for k in range(int(rng.integers(1, 13))):
+        t = ALL[rng.integers(0, len(ALL))]
+        if total + t.size() > limit:
+            continue
+        attrs.append(PointAttributeDefinition(f"a{k}", t))
+        total += t.size()
+    if not attrs:
+        attrs = [PointAttributeDefinition("a0", T.U16)]
+    layout = PointLayout.from_attributes(attrs, api=hip) if rng.integers(0, 3) == 0 else PointLayout.from_attributes_packed(attrs, 1, api=hip)
+    n = int(rng.choice([1, 2047, 2048, 2049, 10_000, 33_333, 70_001]))
+    rec = tj.random_source_records(layout, n, rng)
+    src = HashMapBuffer.from_numpy(rec, layout)
+    typed = [(a.name(),) + _ct_of(a.datatype()) for a in attrs if _ct_of(a.datatype())[0]]
+    terms = []
+    for _ in range(int(rng.integers(1, 4))):
+        r = rng.random()
+        if typed and r < 0.75:
+            terms.append(_random_term(rng, *typed[rng.integers(0, len(typed))]))
+        elif r < 0.9:
+            terms.append(f"i % {int(rng.integers(2, 6))} == 0")
+        else:
+            terms.append("p0[i % 256] > 0.4")
+    text = terms[0]
+    for t in terms[1:]:
+        text = f"({text}) {['&&', '||'][rng.integers(0, 2)]} {'!' if rng.random() < 0.2 else ''}({t})"
+    p0 = rng.random(256)
+    keep, ptr = _device_array(p0)
+    kind = "VH"[rng.integers(0, 2)]
+    out = src.filter_expr(BUFFER_KINDS[kind], text, [ptr])
+    used = [(name, ct, nc) for name, ct, nc in typed if re.search(rf"\b{name}\b", text)]
+    mask = expr_twin.pred_twin(used, text)({name: rec[name] for name, _, _ in used}, n, 0, [p0]).astype(bool)
+    assert out.len() == int(mask.sum()), (seed, text, out.len(), int(mask.sum()))
+    for a in attrs:
+        got = out.view_attribute(a)
+        assert np.ascontiguousarray(got).tobytes() == np.ascontiguousarray(rec[a.name()][mask]).tobytes(), (seed, text, a.name(), kind, n)
+    del keep
+    return True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24 * FUZZ))
+def test_random_layouts_with_random_predicates_against_the_twin(hip, seed):
+    """Differential fuzz of the predicate inside the compaction kernels (count pass + scatter pass of the layout's run-time compiled plan): random
+    columnar layouts (every datatype, packed / repr(C), some beyond the 64 bytes the streaming form takes), random predicates over their attributes,
+    the point index and a parameter array, point counts around the 2048-point tile; the selected points are numpy's selection with the g++ twin's
+    mask, byte for byte, in both target kinds."""
+    random_predicate_filter(hip, seed)
 
 
 @pytest.mark.gpu
