@@ -278,7 +278,9 @@ enum {
   PST_PLAN_STREAM = 5,      /* columnar Vec3f64 stream kernel (copy / affine / AABB) */
   PST_PLAN_COLUMN = 6,      /* one wide-vector launch per columnar -> columnar mapping */
   PST_PLAN_COPY = 7,        /* identity between equal packed layouts: one byte copy of the records */
-  PST_PLAN_DIRECT = 8       /* strided fall-back without LDS staging (records too large for a tile) */
+  PST_PLAN_DIRECT = 8,      /* strided fall-back without LDS staging (records too large for a tile) */
+  PST_PLAN_EXPRESSION = 9   /* an expression mapping's OWN strided pass (one launch per mapping: columns -> columns, ragged tails, plans without a
+                               specialised form); an expression that runs INSIDE the plan-specialised kernel reports PST_PLAN_JIT only */
 };
 int pst_last_plan_kinds(uint32_t* mask);
 /* Compiles (or fetches from the cache) the specialised kernel for conversions between buffers of these storage kinds NOW, so that the first

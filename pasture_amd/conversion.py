@@ -72,7 +72,7 @@ class MappingInfo:
 
 # kernel families a conversion call can take (include/pasture_amd.h PST_PLAN_*)
 PLAN_NONE, PLAN_INTERPRETED, PLAN_JIT, PLAN_STATIC, PLAN_LAS, PLAN_STREAM, PLAN_COLUMN, PLAN_COPY, PLAN_DIRECT = range(9)
-PLAN_NAMES = ("none", "interpreted", "jit", "static", "las-specialised", "stream", "column", "copy", "direct")
+PLAN_NAMES = ("none", "interpreted", "jit", "static", "las-specialised", "stream", "column", "copy", "direct", "expression")
 
 
 def last_plan_kinds(api=None) -> List[str]:

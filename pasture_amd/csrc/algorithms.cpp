@@ -59,9 +59,9 @@ int pst_calculate_bounds(const pst_buffer* b, double out_min[3], double out_max[
   }
   Workspace& ws = workspace();
   hipStream_t s = current_stream();
-  double* dev_rec = (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
+  double* dev_rec = results_to_host() ? (double*)ws.pinned : (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
   bounds_of_range(*b, 0, b->len, dev_rec, s);
-  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned, dev_rec, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (!results_to_host()) PST_HIP_CHECK(hipMemcpyAsync(ws.pinned, dev_rec, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
   stream_sync(s);
   check_bounds_record((const double*)ws.pinned, not_null(out_min, "out_min"), not_null(out_max, "out_max"));
   *has_value = 1;

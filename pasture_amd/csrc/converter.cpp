@@ -1009,8 +1009,8 @@ int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buf
   not_null(has_value, "has_value");
   Workspace& ws = workspace();
   hipStream_t s = current_stream();
-  double* dev_rec = (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
   double* host_rec = (double*)ws.pinned;
+  double* dev_rec = results_to_host() ? host_rec : (double*)(ws.dev + Workspace::kWorkspaceBytes - 64);
   const bool has_pos = not_null(c, "converter")->to.find_by_name("Position3D") != nullptr;
   convert_range(*c, *not_null(src, "src"), s0, s1, *dst, t0, t1, (has_pos && t1 > t0) ? dev_rec : nullptr, s, kMeasureFamilies);
   // calculate_bounds(target): None for an empty range or a layout without Position3D (bounds.rs:12-21)
@@ -1019,7 +1019,7 @@ int pst_converter_convert_into_range_with_bounds(const pst_converter* c, pst_buf
     *has_value = 0;
     return PST_OK;
   }
-  PST_HIP_CHECK(hipMemcpyAsync(host_rec, dev_rec, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (dev_rec != host_rec) PST_HIP_CHECK(hipMemcpyAsync(host_rec, dev_rec, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
   stream_sync(s);
   check_bounds_record(host_rec, out_min, out_max);
   *has_value = 1;

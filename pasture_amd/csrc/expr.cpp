@@ -247,7 +247,7 @@ void launch_map(const MapSpec& s, uint64_t src, uint64_t sstride, uint64_t dst, 
   void* args[] = {&src, &sstride, &dst, &dstride, &n, &first_index, &p0, &p1, &p2, &p3};
   if (hipModuleLaunchKernel(k.fn, grid_for(n), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
     throw Error(PST_ERR_HIP, std::string("expression kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
-  pstk::note_plan_kind(PST_PLAN_JIT);
+  pstk::note_plan_kind(PST_PLAN_EXPRESSION);
 }
 
 void launch_pred(const std::vector<PredAttr>& attrs, const std::string& expr, uint64_t n, uint64_t first_index, uint8_t* mask_dev, const double* const p[4], hipStream_t stream) {
@@ -441,9 +441,10 @@ int pst_buffer_filter_expr(const pst_buffer* src, const char* expr, const double
     uint8_t* scratch = workspace().partials(pstk::filter_workspace_bytes(n));
     pstexpr::launch_pred_count(attrs, expr, n, 0, pstk::filter_counts(scratch, n, tile), p, st);
     const unsigned long long* total_dev = nullptr;
-    pstk::launch_filter_scan(n, tile, scratch, &total_dev, st);
     Workspace& ws = workspace();
-    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    unsigned long long* const host_word = (unsigned long long*)(ws.pinned + 768);
+    pstk::launch_filter_scan(n, tile, scratch, &total_dev, st, results_to_host() ? host_word : nullptr);
+    if (!results_to_host()) PST_HIP_CHECK(hipMemcpyAsync(host_word, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     stream_sync(st);
     const size_t matches = (size_t)*(const unsigned long long*)(ws.pinned + 768);
     // 2. the target, exactly as large as the count says (filter(): count, allocate, filter_into -- :1071-1075)

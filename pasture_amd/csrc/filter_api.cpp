@@ -44,8 +44,10 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   Workspace& ws = workspace();
   if (!counted) {
     // (stream-ordered form: the scan kernel writes the total to the caller's word itself -- no copy operation between the kernels)
-    pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s, stream_ordered ? count_out : nullptr);
-    if (!stream_ordered) PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 768, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    // (synchronous form: the same, into the pinned mirror the host reads after the wait -- results_to_host, runtime.hpp)
+    unsigned long long* const host_word = (unsigned long long*)(ws.pinned + 768);
+    pstk::launch_filter_count(mask_dev, n, tile, scratch, &total_dev, s, stream_ordered ? count_out : results_to_host() ? host_word : nullptr);
+    if (!stream_ordered && !results_to_host()) PST_HIP_CHECK(hipMemcpyAsync(host_word, total_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   }
   // With Some(num_matches) (the reference's bench passes it) nothing on the host depends on the count before the copies are
   // launched: count, scan and scatter run back to back and the count is read once, at the end.  Without it the target check

@@ -70,11 +70,14 @@ extern "C" int pst_las_encode_points(const pst_buffer* src, uint32_t point_forma
   }
   hipStream_t s = current_stream();
   Workspace& ws = workspace();
-  double* dev_bounds = (double*)(ws.dev + 1024);
-  unsigned long long* dev_counts = (unsigned long long*)(ws.dev + 1024 + 64);
+  const bool direct = results_to_host();  // the fold kernel's last block writes the 48 + 128 bytes into the pinned mirror itself
+  double* dev_bounds = direct ? (double*)(ws.pinned + 256) : (double*)(ws.dev + 1024);
+  unsigned long long* dev_counts = direct ? (unsigned long long*)(ws.pinned + 512) : (unsigned long long*)(ws.dev + 1024 + 64);
   encode_range(src, 0, n, point_format, scale, offset, dst, dst_first, bounds_inout, max_return, dev_bounds, dev_counts, s);
-  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 256, dev_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
-  PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 512, dev_counts, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (!direct) {
+    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 256, dev_bounds, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    PST_HIP_CHECK(hipMemcpyAsync(ws.pinned + 512, dev_counts, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  }
   stream_sync(s);
   const unsigned long long* counts = (const unsigned long long*)(ws.pinned + 512);
   if (counts[0] != 0)  // write_helpers.rs:15-17 .expect(...)

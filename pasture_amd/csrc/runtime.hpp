@@ -1,5 +1,6 @@
 // Internal host runtime declarations: device buffers, per-thread workspace, plan execution.
 #pragma once
+#include <cstdlib>
 #include <atomic>
 #include <memory>
 #include <vector>
@@ -48,6 +49,13 @@ struct Workspace {
   uint8_t* partials(size_t bytes);
 };
 Workspace& workspace();
+// Small result records a SYNCHRONOUS entry point waits for (an AABB, the encoder's header contribution) are written by the call's last kernel straight
+// into the pinned mirror -- host memory the device addresses -- instead of into device memory and copied out by one more launch (a blit kernel per
+// hipMemcpyAsync).  PST_RESULTS_TO_HOST=0: the copy (the A/B switch).
+inline bool results_to_host() {
+  static const bool on = [] { const char* v = std::getenv("PST_RESULTS_TO_HOST"); return !(v && *v == '0'); }();
+  return on;
+}
 
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind);
 void dev_free(uint8_t* p, uint32_t memkind);
