@@ -654,6 +654,17 @@ struct BigStreamPlan {
 };
 template <typename P>
 __global__ __launch_bounds__(pstf::kStreamThreads) void filter_stream_static_kernel(const FilterArgs a) { pstf::filter_stream_body<P>(a); }
+// Three workgroups per CU instead of two (round 6): the kernel waits for data 0.45 of its wave cycles (profiles/r05_record_side_pmc.txt) and is held at
+// two 512-lane workgroups per CU by its registers (97 for typed LAS-0 into columns; the LDS spans were sized for three all along).  Six waves per SIMD
+// mean 80 registers: with two chunks in flight per lane instead of four, typed LAS-0 -> columns and the bench layout -> columns fit WITHOUT scratch --
+// same box, 5 alternating pairs: LAS-0 0.970 -> 0.940 ms (+3.3 %, IQRs disjoint), the bench layout 1.065 -> 1.077 (-1.1 %), and every plan that
+// spills loses (LAS-0 into records, 8 bytes of scratch: -7 %).  So: the one plan that gains (profiles/r06_experiments.txt E13).
+template <typename P> struct StreamOccupancy { static constexpr bool three_blocks = false; };
+template <> struct StreamOccupancy<LasStreamPlan<0, true>> { static constexpr bool three_blocks = true; };
+template <typename P>
+__global__ __launch_bounds__(pstf::kStreamThreads) __attribute__((amdgpu_waves_per_eu(6, 6))) void filter_stream_static3_kernel(const FilterArgs a) {
+  pstf::filter_stream_body<P, 2>(a);
+}
 
 template <typename P>
 static bool stream_sig_is(const StreamSig& s) {
@@ -665,7 +676,11 @@ static bool stream_sig_is(const StreamSig& s) {
 template <typename P>
 static void launch_stream_static(unsigned grid, hipStream_t stream, const FilterArgs& a) {
   const uint32_t lds = pstk::lds_with_resident_cap(pstf::stream_lds_bytes<P>(), pstk::kResidentFilterStream);
+  static const bool three = [] { const char* v = std::getenv("PST_FILTER_THREE_BLOCKS"); return !(v && *v == '0'); }();  // (0: the A/B switch)
   auto kfn = filter_stream_static_kernel<P>;
+  if constexpr (StreamOccupancy<P>::three_blocks) {
+    if (three) kfn = filter_stream_static3_kernel<P>;
+  }
   if (lds > 64u * 1024u) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(pstf::kStreamThreads), lds, stream, a);
 }

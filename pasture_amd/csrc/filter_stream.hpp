@@ -83,7 +83,9 @@ template <> struct PieceType<2> { typedef uint16_t type; };
 template <> struct PieceType<4> { typedef uint32_t type; };
 template <> struct PieceType<8> { typedef uint64_t type; };
 
-template <typename P>
+// BATCH: 16-byte chunks a lane has in flight when the spans leave (4; 2 frees the registers an instantiation needs to stay within 80 -- see
+// StreamOccupancy in filter.hip)
+template <typename P, uint32_t BATCH = 4>
 __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
   using pstq::static_for;
   extern __shared__ __attribute__((aligned(16))) uint8_t pstf_lds[];
@@ -182,7 +184,7 @@ __device__ __forceinline__ void filter_stream_body(const FilterArgs& a) {
       // keep 448 of 512 lanes idle, twelve times over for a LAS layout; even the bench layout's five long spans gain 2 % from the list).  The
       // ragged ends of every span (the bytes before its first and after its last whole chunk) go out byte by byte, one lane per byte -- 32
       // lanes of the first wave per span --, so that no byte outside the target range is written.
-      constexpr uint32_t kBatch = 4;
+      constexpr uint32_t kBatch = BATCH;
       for (uint32_t c0 = threadIdx.x; c0 < pre[P::n]; c0 += kBatch * kStreamThreads) {
         u32x4 v[kBatch];
         uint64_t g[kBatch];

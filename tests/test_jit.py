@@ -128,7 +128,7 @@ def test_in_tree_plan_kernels_use_no_scratch_memory():
     data = open(_capi.LIB_PATH, "rb").read()
     key = b".private_segment_fixed_size"
     seen = {}
-    for family in (b"filter_stream_static_kernel", b"quad_convert_static_kernel"):
+    for family in (b"filter_stream_static_kernel", b"filter_stream_static3_kernel", b"quad_convert_static_kernel"):
         for m in re.finditer(rb"\.name[\xa0-\xbf\xd9\xda].?.?(_Z[0-9A-Za-z_]*" + family + rb"[0-9A-Za-z_]*)", data):
             j = data.find(key, m.end())
             assert 0 <= j - m.end() <= 4, "metadata layout changed"
