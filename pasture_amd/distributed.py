@@ -63,14 +63,18 @@ class PipelinedBoundsReduce:
                         dist.all_reduce(rec[3:], op=dist.ReduceOp.MAX, group=self.group, async_op=True))
         self.i += 1
 
-    def finish(self):
-        """Waits for every pending all-reduce; returns the global record of the last submitted step (decoded), or None."""
-        last = None
+    def wait(self) -> None:
+        """Waits for every pending all-reduce (what a timed region ends with; `finish()` afterwards only hands out the record)."""
         for k in range(len(self.recs)):
             if self.work[k] is not None:
                 for w in self.work[k]:
                     w.wait()
                 self.work[k] = None
+
+    def finish(self):
+        """Waits for every pending all-reduce; returns the global record of the last submitted step (decoded), or None."""
+        last = None
+        self.wait()
         if self.i:
             last = self.recs[(self.i - 1) % len(self.recs)]
         return last
@@ -188,12 +192,16 @@ class BoundsExchange:
             self.transport.allreduce(rec)
         self.i += 1
 
-    def finish(self):
-        """Waits for every pending reduction; returns the last global record as {min xyz, max xyz} (a decoded copy when the ring's records are kept
-        as {min, -max}), or None."""
+    def wait(self) -> None:
+        """Waits for every pending reduction (the exchange stream runs dry): what a timed region ends with.  `finish()` afterwards only decodes."""
         if self._cuda:
             self._side.synchronize()
             self._done = [None] * len(self.recs)
+
+    def finish(self):
+        """Waits for every pending reduction; returns the last global record as {min xyz, max xyz} (a decoded copy when the ring's records are kept
+        as {min, -max}), or None."""
+        self.wait()
         if not self.i:
             return None
         rec = self.recs[(self.i - 1) % len(self.recs)]
