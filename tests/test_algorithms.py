@@ -92,6 +92,42 @@ def test_bounds_ignore_signalling_nans_in_the_fused_copy(api, n):
     assert np.asarray(out).tobytes() == pts.tobytes()
 
 
+@pytest.mark.gpu
+def test_fused_bounds_find_planted_extremes_through_the_two_level_fold(hip):
+    """6 * 10^6 points through the fused conversion + AABB: one tile per workgroup = 5 860 block records, more than one fold launch takes (stream.hip
+    launch_finalize: 128 blocks, then one).  250 calls, each with a new minimum and a new maximum planted at random points -- the block that holds an
+    extreme differs from call to call --, compared exactly; every fifth call through the stream-ordered form.  (Written for a one-launch fold with a
+    ticket, profiles/r06_experiments.txt E15: measured, not faster, not kept; the test stays for the fold that is.)"""
+    import torch
+    from pasture_amd.buffers import ExternalColumnsBuffer
+    from pasture_amd.conversion import BufferLayoutConverter
+    n = 6_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    src_col = torch.rand(n, 3, dtype=torch.float64, device="cuda", generator=g)
+    dst_col = torch.empty_like(src_col)
+    layout = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    src, dst = ExternalColumnsBuffer([src_col], layout, n), ExternalColumnsBuffer([dst_col], layout, n)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, (2.0, 2.0, 2.0), (1.0, 1.0, 1.0)), False)
+    rng = np.random.default_rng(5)
+    rec = torch.zeros(6, dtype=torch.float64, device="cuda")
+    for it in range(250):
+        lo, hi = rng.integers(0, n, size=3), rng.integers(0, n, size=3)
+        vmin, vmax = -float(it + 1) - rng.random(3), 2.0 + float(it) + rng.random(3)
+        for c in range(3):
+            src_col[int(lo[c]), c] = float(vmin[c])
+            src_col[int(hi[c]), c] = float(vmax[c])
+        want_min, want_max = tuple(2.0 * vmin + 1.0), tuple(2.0 * vmax + 1.0)
+        if it % 5 == 4:
+            conv.convert_into_with_bounds_async(src, dst, rec.data_ptr())
+            got = rec.cpu().numpy()
+            assert tuple(got[:3]) == want_min and tuple(got[3:]) == want_max, it
+        else:
+            bb = conv.convert_into_with_bounds(src, dst)
+            assert bb.min() == want_min and bb.max() == want_max, it
+
+
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("dtype", [T.Vec3f32, T.Vec3i32, T.Vec3u16, T.Vec3u8])
 def test_bounds_custom_position_datatype(api, kind, dtype):  # calculate_bounds_from_custom_positions bounds.rs:56-85
