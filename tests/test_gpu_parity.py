@@ -244,8 +244,24 @@ def test_full_size_shard_1p25e8_first_index(hip):
 
 # ---- interleaved buffers beyond 4 GiB: every byte offset in the record kernels must be 64-bit (buffer_conversion.rs:546-604) ----------
 
+def _trim_device_pool():
+    """Blocks the library's stream-ordered pool keeps after earlier tests (buffer.cpp: release threshold) count as used in mem_get_info:
+    hand them back to the driver before a test decides whether its buffers fit."""
+    import ctypes
+    import torch
+    torch.cuda.synchronize()
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        pool = ctypes.c_void_p()
+        if rt.hipDeviceGetDefaultMemPool(ctypes.byref(pool), ctypes.c_int(torch.cuda.current_device())) == 0:
+            rt.hipMemPoolTrimTo(pool, ctypes.c_size_t(0))
+    except OSError:
+        pass
+
+
 def _needs_free_hbm(gib):
     import torch
+    _trim_device_pool()
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < gib * (1 << 30):
         pytest.skip(f"needs {gib} GiB of free HBM")
@@ -385,6 +401,141 @@ def test_full_size_1e9_single_gpu_convert_bounds(hip):
     b_src, fused = _affine_bounds_properties(n, 0, (0, 499_999_999, n - 4096))
     # 10^9 uniform draws: the extremes are within 1e-5 of the generator's range
     assert b_src.min()[0] < 1e-5 and b_src.max()[0] > 999.99999 and b_src.max()[2] > 99.999999
+
+
+@pytest.mark.parametrize("src_kind", ["H", "V"])
+def test_more_than_2_pow_32_points_convert_bounds_minmax(hip, src_kind):
+    """Maximum sizes: a point COUNT beyond 2^32 (the reference indexes with usize; 288 GB of HBM hold 4.3e9 Vec3f64 points twice).
+    2^32 + 100 003 POSITION_3D points, columnar or interleaved (103 GB) -> affine -> columnar (103 GB) + AABB: extremes PLANTED at indices beyond 2^32
+    must be found by calculate_bounds / the fused AABB / minmax_attribute, a window that straddles index 2^32 and the last window must
+    be bit-exact against numpy, and the generator must address the points beyond 2^32 by their global index."""
+    import torch
+    from pasture_amd.algorithms import minmax_attribute
+    n = (1 << 32) + 100_003
+    _needs_free_hbm(200)  # 2 x 96 GiB
+    layout = PointLayout.from_attributes([A.POSITION_3D])
+    src = BUFFER_KINDS[src_kind].new_from_layout(layout)
+    src.resize(n)
+    src.synth_fill(42, 0)
+    seam = 1 << 32
+    planted = {seam + 7: (-3.0, 2000.0, 50.0), n - 1: (500.0, -7.0, 250.0), seam - 1: (1500.0, 500.0, -1.0)}
+    for i, p in planted.items():
+        src.set_attribute_range(A.POSITION_3D, range(i, i + 1), np.array([p]))
+    want = ((-3.0, -7.0, -1.0), (1500.0, 2000.0, 250.0))
+    b_src = calculate_bounds(src)
+    assert (b_src.min(), b_src.max()) == want
+    lo, hi = minmax_attribute(src, A.POSITION_3D)
+    assert (tuple(lo), tuple(hi)) == want
+    dst = HashMapBuffer.new_from_layout(layout)
+    dst.resize(n)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    conv.set_custom_mapping_with_transformation(A.POSITION_3D, A.POSITION_3D, Transform.affine(T.Vec3f64, SCALE, OFFSET), False)
+    fused = conv.convert_into_with_bounds(src, dst)
+    s, o = np.array(SCALE), np.array(OFFSET)
+    assert fused.min() == tuple((np.array(want[0]) * s) + o) and fused.max() == tuple((np.array(want[1]) * s) + o)
+    assert fused == calculate_bounds(dst)
+    piece = HashMapBuffer.new_from_layout(layout)
+    piece.resize(4096)
+    for first in (0, seam - 2048, seam + 50_000, n - 4096):
+        a = src.get_attribute_range(A.POSITION_3D, range(first, first + 4096))
+        b = dst.get_attribute_range(A.POSITION_3D, range(first, first + 4096))
+        assert ((a * s) + o).tobytes() == b.tobytes(), first
+        piece.synth_fill(42, first)
+        g = piece.get_attribute_range(A.POSITION_3D, range(0, 4096))
+        for i, p in planted.items():
+            if first <= i < first + 4096:
+                assert tuple(a[i - first]) == p
+                g[i - first] = p
+        assert g.tobytes() == a.tobytes(), first
+    # the ranged form with both ranges beyond 2^32: only those points change
+    dst.set_attribute_range(A.POSITION_3D, range(seam + 10, seam + 20), np.zeros((10, 3)))
+    conv.convert_into_range(src, range(seam + 12, seam + 16), dst, range(seam + 12, seam + 16))
+    got = dst.get_attribute_range(A.POSITION_3D, range(seam + 10, seam + 20))
+    exp = np.zeros((10, 3))
+    exp[2:6] = (src.get_attribute_range(A.POSITION_3D, range(seam + 12, seam + 16)) * s) + o
+    assert got.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("target_kind", ["H", "V"])
+def test_more_than_2_pow_32_raw_las_records_to_a_user_layout(hip, target_kind):
+    """The production caller's conversion (raw_readers.rs:31-167: Vec3i32 -> f64 + affine, bit fields of the flags byte, plain copies) over
+    2^32 + 100 003 raw LAS-0 records (86 GB) into a user layout of 28 bytes per point (120 GB), columnar or interleaved, with the fused
+    AABB: windows on both sides of index 2^32 against numpy, and the AABB against the planted extreme records beyond 2^32."""
+    n = (1 << 32) + 100_003
+    seam = 1 << 32
+    _needs_free_hbm(215)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True)
+    tgt = PointLayout.from_attributes_packed([A.POSITION_3D, A.INTENSITY, A.RETURN_NUMBER, A.CLASSIFICATION], 1)
+    assert raw.size_of_point_entry() == 20 and tgt.size_of_point_entry() == 28
+    src = VectorBuffer.new_from_layout(raw)
+    src.resize(n)
+    src.synth_fill(11, 0)
+    lo_i, hi_i = np.array([[-77, -78, -79]], dtype=np.int32), np.array([[2_100_000_000, 2_100_000_001, 2_100_000_002]], dtype=np.int32)
+    src.set_attribute_range(las.ATTRIBUTE_LOCAL_LAS_POSITION, range(seam + 3, seam + 4), lo_i)
+    src.set_attribute_range(las.ATTRIBUTE_LOCAL_LAS_POSITION, range(n - 1, n), hi_i)
+    conv = las.get_default_las_converter(raw, tgt, SCALE, OFFSET)
+    out = BUFFER_KINDS[target_kind].new_from_layout(tgt)
+    out.resize(n)
+    s, o = np.array(SCALE), np.array(OFFSET)
+    fused = conv.convert_into_with_bounds(src, out)
+    assert fused.min() == tuple((lo_i[0].astype(np.float64) * s) + o) and fused.max() == tuple((hi_i[0].astype(np.float64) * s) + o)
+    for first in (0, seam - 2048, seam + 77_777, n - 4096):
+        r = range(first, first + 4096)
+        local = src.get_attribute_range(las.ATTRIBUTE_LOCAL_LAS_POSITION, r)
+        assert out.get_attribute_range(A.POSITION_3D, r).tobytes() == ((local.astype(np.float64) * s) + o).tobytes(), first
+        assert out.get_attribute_range(A.INTENSITY, r).tobytes() == src.get_attribute_range(A.INTENSITY, r).tobytes(), first
+        assert out.get_attribute_range(A.CLASSIFICATION, r).tobytes() == src.get_attribute_range(A.CLASSIFICATION, r).tobytes(), first
+        flags = src.get_attribute_range(las.ATTRIBUTE_BASIC_FLAGS, r)
+        assert out.get_attribute_range(A.RETURN_NUMBER, r).tobytes() == (flags & 7).astype(np.uint8).tobytes(), first
+
+
+def test_more_than_2_pow_32_points_records_columns_casts_compaction(hip):
+    """The other kernel families at a point count beyond 2^32, on 3-byte points (13 GB): packed records -> columns (plan-specialised or
+    interpreted tile kernels), columns -> columns with `as` casts (u8 -> u16, u16 -> f32), columns -> records, minmax of a narrow column,
+    and a compaction whose selected points lie on both sides of index 2^32 (count, scan and the streaming scatter pass)."""
+    import torch
+    from pasture_amd.algorithms import minmax_attribute
+    _needs_free_hbm(80)
+    n = (1 << 32) + 100_003
+    seam = 1 << 32
+    small = PointLayout.from_attributes_packed([A.CLASSIFICATION, A.INTENSITY], 1)
+    assert small.size_of_point_entry() == 3
+    recs = VectorBuffer.new_from_layout(small)
+    recs.resize(n)
+    recs.synth_fill(7, 0)
+    windows = (0, seam - 2048, seam + 31_337, n - 4096)
+    cols = BufferLayoutConverter.for_layouts(small, small).convert(recs, HashMapBuffer)
+    assert cols.len() == n
+    wide = PointLayout.from_attributes([A.CLASSIFICATION.with_custom_datatype(T.U16), A.INTENSITY.with_custom_datatype(T.F32)])
+    cast = BufferLayoutConverter.for_layouts(small, wide).convert(cols, HashMapBuffer)
+    back = BufferLayoutConverter.for_layouts(small, small).convert(cols, VectorBuffer)
+    for first in windows:
+        r = range(first, first + 4096)
+        for a in (A.CLASSIFICATION, A.INTENSITY):
+            want = recs.get_attribute_range(a, r)
+            assert cols.get_attribute_range(a, r).tobytes() == want.tobytes(), (a.name(), first)
+            assert back.get_attribute_range(a, r).tobytes() == want.tobytes(), (a.name(), first)
+        assert cast.get_attribute_range(A.CLASSIFICATION.with_custom_datatype(T.U16), r).tobytes() == recs.get_attribute_range(A.CLASSIFICATION, r).astype(np.uint16).tobytes()
+        assert cast.get_attribute_range(A.INTENSITY.with_custom_datatype(T.F32), r).tobytes() == recs.get_attribute_range(A.INTENSITY, r).astype(np.float32).tobytes()
+    del back
+    # a narrow column whose extremes sit beyond 2^32
+    f32 = A.INTENSITY.with_custom_datatype(T.F32)
+    cast.set_attribute_range(f32, range(seam + 9, seam + 10), np.array([-5.0], dtype=np.float32))
+    cast.set_attribute_range(f32, range(n - 2, n - 1), np.array([70000.0], dtype=np.float32))
+    lo, hi = minmax_attribute(cast, f32)
+    assert (float(lo), float(hi)) == (-5.0, 70000.0)
+    del cast
+    # compaction: seven selected points, four of them beyond 2^32
+    picks = [17, seam - 2049, seam - 1, seam, seam + 5, seam + 2048 * 3 + 1, n - 1]
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[torch.tensor(picks, device="cuda")] = 1
+    for kind in ("H", "V"):
+        out = BUFFER_KINDS[kind].new_from_layout(small)
+        out.resize(len(picks))
+        assert cols.filter_into(out, (mask.data_ptr(), "device"), len(picks)) == len(picks)
+        for a in (A.CLASSIFICATION, A.INTENSITY):
+            want = np.concatenate([recs.get_attribute_range(a, range(i, i + 1)) for i in picks])
+            assert out.get_attribute_range(a, range(0, len(picks))).tobytes() == want.tobytes(), (kind, a.name())
 
 
 # ---- kNN normal estimation (configs[4]) ------------------------------------------------------------------------
