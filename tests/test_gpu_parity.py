@@ -517,7 +517,24 @@ def test_more_than_2_pow_32_points_records_columns_casts_compaction(hip):
             assert back.get_attribute_range(a, r).tobytes() == want.tobytes(), (a.name(), first)
         assert cast.get_attribute_range(A.CLASSIFICATION.with_custom_datatype(T.U16), r).tobytes() == recs.get_attribute_range(A.CLASSIFICATION, r).astype(np.uint16).tobytes()
         assert cast.get_attribute_range(A.INTENSITY.with_custom_datatype(T.F32), r).tobytes() == recs.get_attribute_range(A.INTENSITY, r).astype(np.float32).tobytes()
+    # closures see the point's 64-bit index: transform_attribute(|i, v| ...) in place on the records (the plan-specialised kernel with the
+    # expression inside, or its own strided pass) and filter(|i| ...) across the seam
+    from pasture_amd.algorithms import transform_attribute_expr
+    transform_attribute_expr(back, A.INTENSITY, "i >= 4294967296ull ? (i == 4294967296ull ? 40000 : 7) : v")
+    for first in windows:
+        r = range(first, first + 4096)
+        want = recs.get_attribute_range(A.INTENSITY, r).copy()
+        idx = np.arange(first, first + 4096, dtype=np.uint64)
+        want[idx >= seam] = 7
+        want[idx == seam] = 40000
+        assert back.get_attribute_range(A.INTENSITY, r).tobytes() == want.tobytes(), first
+        assert back.get_attribute_range(A.CLASSIFICATION, r).tobytes() == recs.get_attribute_range(A.CLASSIFICATION, r).tobytes(), first
     del back
+    across = cols.filter_expr(HashMapBuffer, "i >= 4294967290ull && i < 4294967302ull")
+    assert across.len() == 12
+    for a in (A.CLASSIFICATION, A.INTENSITY):
+        assert across.get_attribute_range(a, range(0, 12)).tobytes() == recs.get_attribute_range(a, range(seam - 6, seam + 6)).tobytes(), a.name()
+    del across
     # a narrow column whose extremes sit beyond 2^32
     f32 = A.INTENSITY.with_custom_datatype(T.F32)
     cast.set_attribute_range(f32, range(seam + 9, seam + 10), np.array([-5.0], dtype=np.float32))
