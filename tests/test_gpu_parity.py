@@ -489,6 +489,45 @@ def test_more_than_2_pow_32_raw_las_records_to_a_user_layout(hip, target_kind):
         assert out.get_attribute_range(A.RETURN_NUMBER, r).tobytes() == (flags & 7).astype(np.uint8).tobytes(), first
 
 
+def test_more_than_2_pow_32_typed_las_points_to_raw_records(hip):
+    """The LAS writer's encoder (raw_writers.rs:203-363) over 2^32 + 100 003 typed LAS-0 points in columns (150 GB) -> raw records (86 GB):
+    record windows on both sides of index 2^32 against numpy (truncation toward zero, the flags byte), the header AABB with extremes
+    planted beyond 2^32, and the points-by-return counts against the return-number column counted in pieces."""
+    import torch
+    n = (1 << 32) + 100_003
+    seam = 1 << 32
+    _needs_free_hbm(240)
+    typed = las.point_layout_from_las_point_format(las.Format(0), False)
+    raw = las.point_layout_from_las_point_format(las.Format(0), True)
+    src = HashMapBuffer.new_from_layout(typed)
+    src.resize(n)
+    src.synth_fill(23, 0)
+    src.set_attribute_range(A.POSITION_3D, range(seam + 11, seam + 12), np.array([[-1234.5, 2.0, 3.0]]))
+    src.set_attribute_range(A.POSITION_3D, range(n - 1, n), np.array([[5.0, 6.0, 777.25]]))
+    dst = VectorBuffer.new_from_layout(raw)
+    dst.resize(n)
+    scale, offset = (0.001, 0.002, 0.004), (1.5, -2.5, 100.0)
+    bounds, counts = las.encode_points(src, 0, scale, offset, dst, max_return=7)
+    assert bounds[0][0] == -1234.5 and bounds[1][2] == 777.25 and bounds[0][1] >= 0.0 and bounds[1][0] < 1000.0
+    rn = _torch_view(src.column_ptr(A.RETURN_NUMBER), n)
+    want_counts = torch.zeros(256, dtype=torch.int64, device="cuda")
+    for first in range(0, n, 1 << 28):
+        want_counts += torch.bincount(rn[first:first + (1 << 28)].to(torch.int32), minlength=256)
+    assert counts == [int(c) for c in want_counts[1:8].tolist()] and int(want_counts.sum().item()) == n
+    for first in (0, seam - 2048, seam + 9_000, n - 4096):
+        r = range(first, first + 4096)
+        got = np.ascontiguousarray(dst.get_point_range(r)).view(np.uint8).reshape(4096, 20)
+        pos = src.get_attribute_range(A.POSITION_3D, r)
+        local = np.trunc((pos - np.asarray(offset)) / np.asarray(scale)).astype(np.int64).astype("<i4")
+        assert got[:, :12].tobytes() == local.tobytes(), first
+        assert got[:, 12:14].tobytes() == src.get_attribute_range(A.INTENSITY, r).astype("<u2").tobytes(), first
+        flags = ((src.get_attribute_range(A.RETURN_NUMBER, r) & 7) | ((src.get_attribute_range(A.NUMBER_OF_RETURNS, r) & 7) << 3)
+                 | ((src.get_attribute_range(A.SCAN_DIRECTION_FLAG, r) & 1) << 6) | ((src.get_attribute_range(A.EDGE_OF_FLIGHT_LINE, r) & 1) << 7)).astype(np.uint8)
+        assert got[:, 14].tobytes() == flags.tobytes(), first
+        assert got[:, 15].tobytes() == src.get_attribute_range(A.CLASSIFICATION, r).tobytes(), first
+        assert got[:, 18:20].tobytes() == src.get_attribute_range(A.POINT_SOURCE_ID, r).astype("<u2").tobytes(), first
+
+
 def test_more_than_2_pow_32_points_records_columns_casts_compaction(hip):
     """The other kernel families at a point count beyond 2^32, on 3-byte points (13 GB): packed records -> columns (plan-specialised or
     interpreted tile kernels), columns -> columns with `as` casts (u8 -> u16, u16 -> f32), columns -> records, minmax of a narrow column,
