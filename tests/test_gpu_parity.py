@@ -447,6 +447,12 @@ def test_more_than_2_pow_32_points_convert_bounds_minmax(hip, src_kind):
                 assert tuple(a[i - first]) == p
                 g[i - first] = p
         assert g.tobytes() == a.tobytes(), first
+    # the two calls whose spatial index holds uint32_t point numbers say so instead of wrapping (before anything is allocated)
+    from pasture_amd.algorithms import compute_normals, voxelgrid_filter
+    with pytest.raises(PastureError, match="2\\^32 - 17 points"):
+        compute_normals(src, 16)
+    with pytest.raises(PastureError, match="2\\^32 - 17 points"):
+        voxelgrid_filter(src, 2.5, 2.5, 2.5, HashMapBuffer.new_from_layout(layout))
     # the ranged form with both ranges beyond 2^32: only those points change
     dst.set_attribute_range(A.POSITION_3D, range(seam + 10, seam + 20), np.zeros((10, 3)))
     conv.convert_into_range(src, range(seam + 12, seam + 16), dst, range(seam + 12, seam + 16))
