@@ -111,7 +111,10 @@ int pst_set_stream(void* hip_stream); /* hipStream_t; thread-local; NULL = null 
 int pst_get_stream(void** out_hip_stream); /* the calling thread's current stream (so that a helper can restore it) */
 int pst_stream_synchronize(void);
 /* Frees the device scratch the calling thread's pst_compute_normals* calls keep between calls, per device (about 55 bytes per point of the
- * largest recent cloud, never more than PST_SCRATCH_MAX_BYTES = 16 GiB by default; the reference's temporaries die with every call: normal_estimation.rs:79-130).  Never needed for correctness. */
+ * largest recent cloud, never more than PST_SCRATCH_MAX_BYTES = 16 GiB by default; the reference's temporaries die with every call: normal_estimation.rs:79-130),
+ * and hands the unused blocks of the current device's stream-ordered pool -- the memory of destroyed / shrunk buffers, which the library keeps for its next
+ * allocation -- back to the driver, where other allocators of the process (hipMalloc) can get at them.  Synchronises the device.  Never needed for correctness:
+ * an allocation of the library that fails for lack of memory does the same and tries once more before it reports PST_ERR_OUT_OF_MEMORY. */
 int pst_release_scratch(void);
 /* The PST_KNN_* / PST_SCRATCH_MAX_BYTES tuning switches are read from the environment ONCE (first use) -- never on the call path.  This reads them
  * again: for test and A/B harnesses that change them inside one process.  Not to be called while another thread is inside the library. */

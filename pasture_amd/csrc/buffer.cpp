@@ -62,7 +62,7 @@ Workspace& workspace() {
   }
   Workspace& ws = it->second;
   if (!ws.dev) {
-    PST_HIP_CHECK(hipMalloc((void**)&ws.dev, Workspace::kWorkspaceBytes));
+    PST_HIP_CHECK(dev_malloc_retry((void**)&ws.dev, Workspace::kWorkspaceBytes));
     PST_HIP_CHECK(hipHostMalloc((void**)&ws.pinned, Workspace::kPinnedBytes, hipHostMallocDefault));
   }
   return ws;
@@ -74,7 +74,7 @@ uint8_t* Workspace::partials(size_t bytes) {
     partials_buf = nullptr;
     partials_cap = 0;
     const size_t want = std::max<size_t>(bytes, 16u << 20);  // pre-sized for the largest launch geometry in use: growth mid-pipeline would stall it
-    PST_HIP_CHECK(hipMalloc((void**)&partials_buf, want));
+    PST_HIP_CHECK(dev_malloc_retry((void**)&partials_buf, want));
     partials_cap = want;
   }
   return partials_buf;
@@ -111,10 +111,41 @@ struct AllocOwner { int device; hipStream_t stream; };
 static std::mutex g_alloc_mu;
 static std::unordered_map<void*, AllocOwner> g_alloc_stream;
 
+// Hands the blocks the pool holds but nobody uses back to the driver (the rest of the process allocates with hipMalloc and cannot reach them).
+void trim_device_pool() {
+  int dev = 0;
+  hipMemPool_t pool;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+  (void)hipDeviceSynchronize();  // releases enqueued with hipFreeAsync become "unused" when their stream gets there
+  if (hipMemPoolTrimTo(pool, 0) != hipSuccess) (void)hipGetLastError();
+}
+
+// hipMalloc with the same second chance (workspaces, the kNN scratch cache: blocks that live outside the pool)
+hipError_t dev_malloc_retry(void** p, size_t bytes) {
+  *p = nullptr;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    *p = nullptr;
+    trim_device_pool();
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) *p = nullptr;  // (the caller reads the last error)
+  }
+  return e;
+}
+
 hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s) {
   *p = nullptr;
-  if (!pool_ready()) return hipMalloc(p, bytes);
-  const hipError_t e = hipMallocAsync(p, bytes, s);
+  if (!pool_ready()) return dev_malloc_retry(p, bytes);
+  hipError_t e = hipMallocAsync(p, bytes, s);
+  if (e == hipErrorOutOfMemory) {
+    // the pool may be holding freed blocks of other sizes (release threshold = never): give them back and ask once more
+    (void)hipGetLastError();
+    *p = nullptr;
+    trim_device_pool();
+    e = hipMallocAsync(p, bytes, s);
+    if (e != hipSuccess) *p = nullptr;  // (callers that only see a failed helper read the last error: hip_failure, core.hpp)
+  }
   if (e == hipSuccess) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -171,6 +202,7 @@ void dev_free(uint8_t* p, uint32_t memkind) {
 
 // scratch of the spatial-index builders (device_sort.hpp): same allocator, same PST_NO_POOL / no-pool fallback
 namespace pstk {
+hipError_t device_malloc_retry(void** p, size_t bytes) { return pst::dev_malloc_retry(p, bytes); }
 hipError_t DevBuf::alloc(size_t bytes, hipStream_t stream) {
   release();
   return pst::dev_alloc_stream(&p, bytes ? bytes : 16, stream);

@@ -213,7 +213,7 @@ void execute_entries(bool src_aos, uint64_t src_base, uint32_t src_stride, bool 
       plan.h.bounds_partials = (uint64_t)(uintptr_t)partials;
     }
     if (!pstk::launch_convert(plan, src_aos, dst_aos, use_lds, stream, &records))
-      throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+      throw hip_failure("conversion kernel launch failed: ");
     if (wants_bounds) pstk::launch_finalize_bounds(partials, records, bounds_out6, stream);
   }
 }
@@ -248,7 +248,7 @@ uint64_t transform_records_with_expression(const pst_buffer& b, int slot, const 
   std::string err;
   pstk::reset_plan_kinds();
   if (!pstk::launch_convert_fused_expressions(plan, true, true, stream, &done, &err))
-    throw Error(PST_ERR_HIP, std::string("transformation kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("transformation kernel launch failed: ");
   if (!err.empty()) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "transformation expression: the kernel with the expression in it does not compile:\n" + err);
   return done;
 }
@@ -469,7 +469,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       e.src_size = e.dst_size = (uint32_t)c.to.size;
       e.ncomp = 1;
       if (!pstk::launch_column(e, n, nullptr, stream))
-        throw Error(PST_ERR_HIP, std::string("record copy launch failed: ") + hipGetErrorString(hipGetLastError()));
+        throw hip_failure("record copy launch failed: ");
       pstk::note_plan_kind(PST_PLAN_COPY);
       return;
     }
@@ -492,7 +492,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       const unsigned grid = pstk::las_transpose_grid(n);
       double* partials = bounds_out6 ? (double*)workspace().partials(pstk::bounds_partials_bytes(grid)) : nullptr;
       if (!pstk::launch_las_transpose(c.las_typed_format, src.columnar, aos, cols.data(), (int)cols.size(), n, partials, stream))
-        throw Error(PST_ERR_HIP, std::string("LAS transposition launch failed: ") + hipGetErrorString(hipGetLastError()));
+        throw hip_failure("LAS transposition launch failed: ");
       if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
       pstk::note_plan_kind(PST_PLAN_LAS);
       return;
@@ -510,7 +510,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
       const unsigned grid = pstk::las_decode_aos_grid(c.las_decode_format, n);
       double* partials = bounds_out6 ? (double*)workspace().partials(pstk::bounds_partials_bytes(grid)) : nullptr;
       if (!pstk::launch_las_decode_aos(c.las_decode_format, aos_addr(src, s0), aos_addr(dst, t0), n, pos->xf->scale, pos->xf->offset, partials, stream))
-        throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
+        throw hip_failure("LAS decode launch failed: ");
       if (bounds_out6) pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
       pstk::note_plan_kind(PST_PLAN_LAS);
       return;
@@ -521,7 +521,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
     if (bounds_out6) partials = (double*)workspace().partials(pstk::bounds_partials_bytes(pstk::las_decode_grid(n)));
     if (!pstk::launch_las_decode(c.las_decode_format, aos_addr(src, s0), n, cols.data(), (int)cols.size(), pos->xf->scale, pos->xf->offset, partials,
                                  stream))
-      throw Error(PST_ERR_HIP, std::string("LAS decode launch failed: ") + hipGetErrorString(hipGetLastError()));
+      throw hip_failure("LAS decode launch failed: ");
     if (bounds_out6) pstk::launch_finalize_bounds(partials, pstk::las_decode_grid(n), bounds_out6, stream);
     pstk::note_plan_kind(PST_PLAN_LAS);
     return;
@@ -593,7 +593,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
           partials = (double*)workspace().partials(pstk::bounds_partials_bytes(grid));
         }
         if (!pstk::launch_column(e, n, partials, stream))
-          throw Error(PST_ERR_HIP, std::string("column conversion launch failed: ") + hipGetErrorString(hipGetLastError()));
+          throw hip_failure("column conversion launch failed: ");
         pstk::note_plan_kind(PST_PLAN_COLUMN);
         if (fuse_bounds) {
           pstk::launch_finalize_bounds(partials, grid, bounds_out6, stream);
@@ -619,7 +619,7 @@ static void convert_range(const pst_converter& c, pst_buffer& src, size_t s0, si
         plan.h.first_index = s0;
         std::string err;
         if (!pstk::launch_convert_fused_expressions(plan, sa, da, stream, &fused_done, &err))
-          throw Error(PST_ERR_HIP, std::string("conversion kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+          throw hip_failure("conversion kernel launch failed: ");
         if (!err.empty()) throw Error(PST_ERR_UNSUPPORTED_TRANSFORM, "transformation expression: the conversion kernel with the expression(s) in it does not compile:\n" + err);
       }
       // what the fused kernel did not cover -- the ragged tail (less than one tile), or everything: the expressions' own strided launches ...

@@ -27,6 +27,13 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& m);
 
+// A launch / allocation helper reported failure: the thread's last HIP error names the cause (and is reset by the read).  Running out of device memory is
+// PST_ERR_OUT_OF_MEMORY whichever entry point hits it.
+inline Error hip_failure(const std::string& what) {
+  const hipError_t e = hipGetLastError();
+  return Error(e == hipErrorOutOfMemory ? PST_ERR_OUT_OF_MEMORY : PST_ERR_HIP, what + hipGetErrorString(e));
+}
+
 #define PST_HIP_CHECK(expr)                                                                          \
   do {                                                                                               \
     hipError_t _e = (expr);                                                                          \
@@ -34,6 +41,7 @@ void set_last_error(const std::string& m);
       int _code = (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? PST_ERR_NO_DEVICE        \
                   : (_e == hipErrorOutOfMemory)                           ? PST_ERR_OUT_OF_MEMORY    \
                                                                           : PST_ERR_HIP;             \
+      (void)hipGetLastError(); /* reported through the status: the NEXT call must not find it */     \
       throw ::pst::Error(_code, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
     }                                                                                                \
   } while (0)
@@ -41,7 +49,7 @@ void set_last_error(const std::string& m);
 #define PST_API_BEGIN try {
 #define PST_API_END                                                                 \
   }                                                                                 \
-  catch (const ::pst::Error& e) { ::pst::set_last_error(e.what()); return e.code; } \
+  catch (const ::pst::Error& e) { ::pst::set_last_error(e.what()); (void)hipGetLastError(); return e.code; } \
   catch (const std::bad_alloc&) { ::pst::set_last_error("host allocation failed"); return PST_ERR_OUT_OF_MEMORY; } \
   catch (const std::exception& e) { ::pst::set_last_error(e.what()); return PST_ERR_INVALID_ARGUMENT; }           \
   return PST_OK;

@@ -33,6 +33,9 @@ hipError_t suffix_min_u32(void* tmp, size_t& bytes, uint32_t* data, size_t n, hi
 
 // stream-ordered scratch from the library's allocator (pst::dev_alloc / dev_free: HIP's stream-ordered pool, or plain hipMalloc
 // when the device has no pool support or PST_NO_POOL is set); freed in stream order by the destructor
+// hipMalloc that, out of memory, hands the unused blocks of the stream-ordered pool back to the driver and asks once more (buffer.cpp)
+hipError_t device_malloc_retry(void** p, size_t bytes);
+
 struct DevBuf {
   void* p = nullptr;
   hipError_t alloc(size_t bytes, hipStream_t stream);

@@ -246,7 +246,7 @@ void launch_map(const MapSpec& s, uint64_t src, uint64_t sstride, uint64_t dst, 
   const double *p0 = p ? p[0] : nullptr, *p1 = p ? p[1] : nullptr, *p2 = p ? p[2] : nullptr, *p3 = p ? p[3] : nullptr;
   void* args[] = {&src, &sstride, &dst, &dstride, &n, &first_index, &p0, &p1, &p2, &p3};
   if (hipModuleLaunchKernel(k.fn, grid_for(n), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-    throw Error(PST_ERR_HIP, std::string("expression kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("expression kernel launch failed: ");
   pstk::note_plan_kind(PST_PLAN_EXPRESSION);
 }
 
@@ -258,7 +258,7 @@ void launch_pred(const std::vector<PredAttr>& attrs, const std::string& expr, ui
   const double *p0 = p ? p[0] : nullptr, *p1 = p ? p[1] : nullptr, *p2 = p ? p[2] : nullptr, *p3 = p ? p[3] : nullptr;
   void* args[] = {&a, &n, &first_index, &mask_dev, &p0, &p1, &p2, &p3};
   if (hipModuleLaunchKernel(k.fn, grid_for(n), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-    throw Error(PST_ERR_HIP, std::string("predicate kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("predicate kernel launch failed: ");
 }
 
 static bool is_reserved_name(const std::string& n) {
@@ -293,7 +293,7 @@ void launch_pred_count(const std::vector<PredAttr>& attrs, const std::string& ex
   void* args[] = {&a, &n, &first_index, &counts_dev, &p0, &p1, &p2, &p3};
   const uint64_t n_tiles = (n + 2047) / 2048;
   if (hipModuleLaunchKernel(k.fn, (unsigned)((n_tiles + 3) / 4), 1, 1, 256, 1, 1, 0, stream, args, nullptr) != hipSuccess)
-    throw Error(PST_ERR_HIP, std::string("predicate count kernel launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("predicate count kernel launch failed: ");
 }
 
 // the attributes of `layout` an expression names (C identifiers only; scalars and Vec3)
@@ -485,7 +485,7 @@ int pst_buffer_filter_expr(const pst_buffer* src, const char* expr, const double
         ok = pstk::launch_filter_scatter(mask.p, n, tile, scratch, matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(), sizes.data(), (int)na, dst_aos,
                                          dst_aos ? aos_addr(*b, 0) : 0, dst_stride, covered_bytes == src->layout.size, st);
         stream_sync(st);
-        if (!ok) throw Error(PST_ERR_HIP, std::string("filter launch failed: ") + hipGetErrorString(hipGetLastError()));
+        if (!ok) throw hip_failure("filter launch failed: ");
       }
       stream_sync(st);  // (the tail mask is freed on return)
     }

@@ -77,7 +77,7 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   if (na && (hinted ? num_matches : std::min(matches, num_matches)) > 0 &&
       !pstk::launch_filter_scatter(mask_dev, n, tile, scratch, num_matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(),
                                    size.data(), (int)na, dst_aos, dst_aos ? aos_addr(dst, 0) : 0, dst_stride, covered == dst.layout.size, s))
-    throw Error(PST_ERR_HIP, std::string("filter launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("filter launch failed: ");
   if (stream_ordered) return num_matches;
   stream_sync(s);  // the staged mask is released on return
   if (hinted) matches = (size_t)*(const unsigned long long*)(ws.pinned + 768);

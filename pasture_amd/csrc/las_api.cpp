@@ -35,7 +35,7 @@ void encode_range(const pst_buffer* src, size_t src_first, size_t count, uint32_
   uint8_t* scratch = workspace().partials(pstk::las_encode_workspace_bytes());
   if (!pstk::launch_las_encode((int)point_format, base, stride, esize, (int)na, !src->columnar, aos_addr(*dst, dst_first), count, scale, offset, seeds,
                                max_return, scratch, dev_bounds, dev_counts, s))
-    throw Error(PST_ERR_HIP, std::string("LAS encode launch failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("LAS encode launch failed: ");
 }
 
 }  // namespace

@@ -882,7 +882,16 @@ struct ScratchCache {
       if (!b.busy && b.bytes >= bytes && b.bytes <= bytes + bytes / 8 + 4096 && (!best || b.bytes < best->bytes)) best = &b;
     if (best) { best->busy = true; best->idle_calls = 0; return best->p; }
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      // out of memory: the blocks this cache holds for nobody go back first, then the pool's (device_malloc_retry), then the request is repeated;
+      // a second failure leaves the HIP error for the caller's report
+      (void)hipGetLastError();
+      for (size_t i = 0; i < blocks.size();) {
+        if (!blocks[i].busy) { (void)hipFree(blocks[i].p); blocks[i] = blocks.back(); blocks.pop_back(); }
+        else ++i;
+      }
+      if (device_malloc_retry(&p, bytes) != hipSuccess) return nullptr;
+    }
     blocks.push_back(Block{p, bytes, true, 0});
     return p;
   }

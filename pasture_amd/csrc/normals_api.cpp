@@ -30,7 +30,7 @@ const Member& checked_position(const pst_buffer& b, size_t k) {
 
 void raise_degenerate(long long rc) {
   if (rc == -2) throw Error(PST_ERR_UNSUPPORTED, "pst_compute_normals: more than 2^32 - 17 points per call");
-  if (rc < 0) throw Error(PST_ERR_HIP, std::string("normal estimation failed: ") + hipGetErrorString(hipGetLastError()));
+  if (rc < 0) throw hip_failure("normal estimation failed: ");
   if (rc > 0)  // compute_covariance_matrix Err(..) :293-295, unwrapped at :471
     throw Error(PST_ERR_NOT_ENOUGH_NEIGHBOURS,
                 "called `Result::unwrap()` on an `Err` value: \"The number of valid (finite and non-NaN values) points in a k nearest "
@@ -160,7 +160,7 @@ int pst_compute_normals_plan_create(const pst_buffer* b, size_t k, pst_buffer* d
   plan->k = k;
   const bool packed = t.stride == 24 && (t.base & 7u) == 0;
   plan->plan = pstk::knn_plan_create(rec, packed, s);
-  if (!plan->plan) throw Error(PST_ERR_HIP, std::string("normals plan: allocation failed: ") + hipGetErrorString(hipGetLastError()));
+  if (!plan->plan) throw hip_failure("normals plan: allocation failed: ");
   PST_HIP_CHECK(hipGetDevice(&plan->device));
   stream_sync(s);
   *out = plan.release();
@@ -187,7 +187,7 @@ int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, 
     throw Error(PST_ERR_INVALID_ARGUMENT, "compute_normals_into_async: the plan was made on device " + std::to_string(plan->device) + ", the current device is " + std::to_string(dev));
   if (!pstk::run_normals_replay(plan->plan, (const uint8_t*)(uintptr_t)t.base, t.stride, nullptr, nullptr, nullptr, t.na, t.nst, t.ca, t.cst,
                                 (unsigned long long*)device_status2, current_stream()))
-    throw Error(PST_ERR_HIP, std::string("normal estimation (stream-ordered) failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("normal estimation (stream-ordered) failed: ");
   PST_API_END
 }
 
@@ -196,6 +196,7 @@ int pst_compute_normals_into_async(pst_normals_plan* plan, const pst_buffer* b, 
 int pst_release_scratch(void) {
   PST_API_BEGIN
   pstk::release_normals_scratch();
+  pst::trim_device_pool();  // ... and whatever freed buffers left in the stream-ordered pool (buffer.cpp: release threshold = never)
   PST_API_END
 }
 

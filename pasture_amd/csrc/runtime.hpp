@@ -60,7 +60,9 @@ inline bool results_to_host() {
 uint8_t* dev_alloc(size_t bytes, uint32_t memkind);
 void dev_free(uint8_t* p, uint32_t memkind);
 // no-throw forms on an explicit stream (stream-ordered pool, or hipMalloc / hipFree without pool support or with PST_NO_POOL)
-hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s);
+hipError_t dev_alloc_stream(void** p, size_t bytes, hipStream_t s);  // (out of memory: the pool's unused blocks are given back and the request repeated once)
+hipError_t dev_malloc_retry(void** p, size_t bytes);  // hipMalloc with the same second chance
+void trim_device_pool();  // pst_release_scratch: unused pool blocks of the current device back to the driver
 void dev_free_stream(void* p, hipStream_t s);
 
 // every API entry takes its buffers through not_null(b, "..."): this overload is where a stale slice is caught

@@ -89,7 +89,7 @@ void run_reductions(pstk::VoxelGridState* st, const pst_buffer& buffer, pst_buff
     dst_stride[a] = (uint32_t)(filtered.columnar ? tl.members[a].size : tl.size);
   }
   if (na && !pstk::voxel_grid_reduce(st, src_addr.data(), src_stride.data(), dst_addr.data(), dst_stride.data(), p.reduce.data(), p.kind.data(), (int)na, first, s))
-    throw Error(PST_ERR_HIP, std::string("voxel grid reduction failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("voxel grid reduction failed: ");
 }
 
 struct StateGuard {
@@ -132,7 +132,7 @@ extern "C" int pst_voxelgrid_filter(const pst_buffer* buffer, double leafsize_x,
   const double leafs[3] = {leafsize_x, leafsize_y, leafsize_z};
   const long long nv = pstk::voxel_grid_build(g.st, pos_base, pos_stride, n, mkx.data(), (uint32_t)mkx.size(), mky.data(), (uint32_t)mky.size(), mkz.data(),
                                               (uint32_t)mkz.size(), mn, leafs, s);
-  if (nv < 0) throw Error(PST_ERR_HIP, std::string("voxel grid build failed: ") + hipGetErrorString(hipGetLastError()));
+  if (nv < 0) throw hip_failure("voxel grid build failed: ");
 
   // filtered_buffer.push_points(centroid) per voxel :161-164 == append nv zero-initialised points and fill the attributes
   const size_t old_len = filtered->len;
@@ -193,7 +193,7 @@ extern "C" int pst_voxelgrid_plan_create(const pst_buffer* buffer, double leafsi
   const double leafs[3] = {leafsize_x, leafsize_y, leafsize_z};
   const long long nv = pstk::voxel_grid_build(g.st, pos_base, pos_stride, n, mkx.data(), (uint32_t)mkx.size(), mky.data(), (uint32_t)mky.size(), mkz.data(),
                                               (uint32_t)mkz.size(), mn, leafs, s);
-  if (nv < 0) throw Error(PST_ERR_HIP, std::string("voxel grid build failed: ") + hipGetErrorString(hipGetLastError()));
+  if (nv < 0) throw hip_failure("voxel grid build failed: ");
   stream_sync(s);
   // capacities: an eighth more markers per axis (a later cloud of the same shape may be a little larger), a quarter more voxels
   auto plan = std::make_unique<pst_voxel_plan>();
@@ -216,7 +216,7 @@ extern "C" int pst_voxelgrid_plan_create(const pst_buffer* buffer, double leafsi
     sh.stage_cap = (uint32_t)std::min<uint64_t>(6144, std::max<uint64_t>(1024, ((uint64_t)n * 8 / 5) / std::max<uint64_t>(1, groups) + 63)) & ~63u;
   }
   plan->st = pstk::voxel_plan_create(sh, s);
-  if (!plan->st) throw Error(PST_ERR_HIP, std::string("voxel plan: allocation failed: ") + hipGetErrorString(hipGetLastError()));
+  if (!plan->st) throw hip_failure("voxel plan: allocation failed: ");
   plan->bounds6 = (double*)dev_alloc(64, PST_MEM_DEVICE);
   PST_HIP_CHECK(hipGetDevice(&plan->device));
   plan->partials = dev_alloc(bounds_partials_scratch_bytes(n), PST_MEM_DEVICE);
@@ -256,7 +256,7 @@ extern "C" int pst_voxelgrid_filter_async(pst_voxel_plan* plan, const pst_buffer
   const uint8_t* pos_base = buffer->columnar ? buffer->columns[pslot] : buffer->data + pos->offset;
   const uint64_t pos_stride = buffer->columnar ? pos->size : buffer->layout.size;
   if (!pstk::voxel_grid_build_async(plan->st, pos_base, pos_stride, plan->bounds6, (unsigned long long*)device_count_and_status, s))
-    throw Error(PST_ERR_HIP, std::string("voxel grid build failed: ") + hipGetErrorString(hipGetLastError()));
+    throw hip_failure("voxel grid build failed: ");
   run_reductions(plan->st, *buffer, *filtered, ap, dst_first, s);
   PST_API_END
 }
