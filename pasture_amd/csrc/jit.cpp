@@ -172,6 +172,35 @@ void write_file_atomic(const std::string& path, const std::vector<char>& data) {
   else (void)unlink(tmp.c_str());
 }
 
+// A cache file is the code object inside an envelope: magic, the 32-character key it was stored under (= hash of toolchain, architecture and
+// source text: a file copied or renamed over another one is not taken), the image's length and its 128-bit FNV checksum.  hipModuleLoadData is given
+// a bare pointer -- a truncated or overwritten file must be recognised HERE, before the loader walks an ELF header that promises more bytes than the
+// buffer holds.  (tools/exp_jit_cache_damage.py: a truncated file made the call fail, a valid image of ANOTHER plan under this plan's name faulted the GPU.)
+constexpr char kEnvelopeMagic[8] = {'P', 'S', 'T', 'J', 'I', 'T', '2', '\n'};
+constexpr size_t kEnvelopeHead = 8 + 32 + 8 + 32;
+std::vector<char> seal_envelope(const std::vector<char>& image, const std::string& key) {
+  std::vector<char> out(kEnvelopeHead + image.size());
+  const uint64_t len = image.size();
+  const std::string sum = hash_hex(std::string(image.data(), image.size()));
+  memcpy(out.data(), kEnvelopeMagic, 8);
+  memcpy(out.data() + 8, key.data(), 32);
+  memcpy(out.data() + 40, &len, 8);
+  memcpy(out.data() + 48, sum.data(), 32);
+  memcpy(out.data() + kEnvelopeHead, image.data(), image.size());
+  return out;
+}
+std::vector<char> open_envelope(const std::vector<char>& file, const std::string& key) {
+  std::vector<char> image;
+  uint64_t len = 0;
+  if (file.size() <= kEnvelopeHead || key.size() != 32 || memcmp(file.data(), kEnvelopeMagic, 8) != 0 || memcmp(file.data() + 8, key.data(), 32) != 0) return image;
+  memcpy(&len, file.data() + 40, 8);
+  if (len != file.size() - kEnvelopeHead) return image;
+  const std::string sum = hash_hex(std::string(file.data() + kEnvelopeHead, (size_t)len));
+  if (memcmp(file.data() + 48, sum.data(), 32) != 0) return image;
+  image.assign(file.begin() + (long)kEnvelopeHead, file.end());
+  return image;
+}
+
 // The architecture name of the calling thread's current device.  Asked on the launch path of every plan-specialised conversion and filter, so the
 // answer is kept per device id (hipGetDeviceProperties fills a multi-kilobyte struct each time).
 const std::string& device_arch() {
@@ -233,14 +262,19 @@ void compile_entry(const std::shared_ptr<Entry>& e) {
   const std::string dir = cache_dir();
   std::string path;
   if (!dir.empty()) {
-    path = dir + "/" + hash_hex(toolchain_salt() + arch + e->source) + ".hsaco";
-    if (!e->retried) code = read_file(path);
+    const std::string key = hash_hex(toolchain_salt() + arch + e->source);
+    path = dir + "/" + key + ".pstco";
+    if (!e->retried) {
+      code = open_envelope(read_file(path), key);
+      if (code.empty()) (void)unlink(path.c_str());  // absent, or not what this library wrote under this name: compiled again below
+    }
     from_disk = !code.empty();
+    if (!code.empty()) code.push_back(0);  // (hipModuleLoadData takes no length: a terminator behind the image costs nothing)
   }
   const auto t0 = std::chrono::steady_clock::now();
   if (code.empty()) {
     code = compile_source(e->source, arch, &err);
-    if (!code.empty() && !path.empty()) write_file_atomic(path, code);
+    if (!code.empty() && !path.empty()) write_file_atomic(path, seal_envelope(code, hash_hex(toolchain_salt() + arch + e->source)));
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::lock_guard<std::mutex> lock(c.mu);

@@ -551,7 +551,25 @@ def test_disk_cache_serves_a_second_process(tmp_path):
     assert out1.returncode == 0 and out2.returncode == 0, out1.stderr + out2.stderr
     assert out1.stdout.startswith("2 ") and "'compiled': 1" in out1.stdout and "'disk_hits': 0" in out1.stdout, out1.stdout
     assert out2.stdout.startswith("2 ") and "'compiled': 0" in out2.stdout and "'disk_hits': 1" in out2.stdout, out2.stdout
-    assert len(list((tmp_path / "jit").glob("*.hsaco"))) == 1
+    files = list((tmp_path / "jit").glob("*.pstco"))
+    assert len(files) == 1
+    # A cache file that is not what the library wrote under that name -- truncated, overwritten, or the intact file of ANOTHER plan copied over it -- is
+    # recognised before the loader sees it (hipModuleLoadData takes a bare pointer) and compiled again.  (tools/exp_jit_cache_damage.py, end of round 6:
+    # the truncated file failed the call, the other plan's image under this name faulted the GPU.)
+    intact = files[0].read_bytes()
+    other = prog.replace("[A.CLASSIFICATION, A.POSITION_3D.with_custom_datatype(T.Vec3f32), A.INTENSITY]", "[A.INTENSITY, A.CLASSIFICATION, A.POSITION_3D]")
+    env2 = dict(env, PST_JIT_CACHE_DIR=str(tmp_path / "jit2"))
+    assert subprocess.run([sys.executable, "-c", other], env=env2, capture_output=True, text=True, timeout=300).returncode == 0
+    foreign = list((tmp_path / "jit2").glob("*.pstco"))[0].read_bytes()
+    assert foreign != intact
+    for what, data in (("truncated", intact[: len(intact) // 2]), ("header only", intact[:80]), ("flipped byte", intact[:200] + bytes([intact[200] ^ 0x40]) + intact[201:]),
+                       ("another plan's file", foreign), ("empty", b""), ("bare code object", intact[80:])):
+        files[0].write_bytes(data)
+        out3 = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert out3.returncode == 0, (what, out3.stderr[-2000:])
+        assert out3.stdout.startswith("2 ") and "'compiled': 1" in out3.stdout and "'disk_hits': 0" in out3.stdout and "'failures': 0" in out3.stdout, (what, out3.stdout)
+        out4 = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)  # ... and written again: the next process loads it
+        assert out4.returncode == 0 and "'compiled': 0" in out4.stdout and "'disk_hits': 1" in out4.stdout, (what, out4.stdout, out4.stderr[-1000:])
 
 
 @pytest.mark.gpu
