@@ -140,7 +140,10 @@ enum { PST_MEM_DEVICE = 0, PST_MEM_PINNED_HOST = 1 };
  * Interleaved: one allocation, stride = size_of_point_entry.  Columnar: one 256-B aligned column per attribute. */
 int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, pst_buffer** out);
 /* ExternalMemoryBuffer<T: AsRef<[u8]>> (:1479-1708): interleaved view over caller-owned device-accessible memory;
- * len = nbytes / size_of_point_entry; nbytes must be a multiple of the point size (:1488-1497). */
+ * len = nbytes / size_of_point_entry; nbytes must be a multiple of the point size (:1488-1497).  Any base address (records behind a file header).
+ * "Device-accessible" is checked (both ends of the range, hipPointerGetAttributes): device memory, managed memory, or host memory the device maps
+ * (hipHostMalloc / hipHostRegister); ordinary host memory -- what the reference's type wraps -- is PST_ERR_INVALID_ARGUMENT here instead of a GPU fault
+ * at the first kernel.  PST_EXTERNAL_UNCHECKED=1 skips the check.  The same holds for every column of pst_buffer_wrap_external_columns. */
 int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbytes, pst_buffer** out);
 /* Columnar view over caller-owned columns (one device pointer per layout attribute, layout order), `len` points. */
 int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_ptrs, size_t len, pst_buffer** out);

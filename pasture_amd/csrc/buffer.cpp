@@ -338,6 +338,29 @@ int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, p
   *not_null(out, "out") = b.release();
   PST_API_END
 }
+// ExternalMemoryBuffer wraps any `T: AsRef<[u8]>` in the reference (point_buffer.rs:1479-1497) -- there, ordinary host memory.  Here the kernels must be
+// able to reach the bytes: device memory, or host memory the device maps (hipHostMalloc / hipHostRegister / managed).  A pointer the HIP runtime
+// does not know -- malloc'ed or mmap'ed host memory passed as if it were the reference's buffer -- would fault the GPU at the first kernel and
+// take the process down; it is refused here, with the way out named.  Both ends of the range are asked (an allocation that ends inside it).
+// PST_EXTERNAL_UNCHECKED=1 skips the question (memory of another runtime that HIP cannot describe but the device can reach).
+// Returns PST_MEM_PINNED_HOST for host memory the device maps, PST_MEM_DEVICE otherwise.
+static uint32_t check_device_reaches(const void* p, size_t nbytes, const char* what) {
+  static const bool unchecked = [] { const char* v = std::getenv("PST_EXTERNAL_UNCHECKED"); return v && *v == '1'; }();
+  if (!nbytes || unchecked) return PST_MEM_DEVICE;
+  ensure_device();
+  uint32_t kind = PST_MEM_DEVICE;
+  for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + (nbytes - 1)}) {
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type == hipMemoryTypeUnregistered) {
+      (void)hipGetLastError();
+      throw Error(PST_ERR_INVALID_ARGUMENT, std::string(what) + ": the memory is not known to the HIP runtime (ordinary host memory?) -- the kernels could not reach it.  "
+                                            "Use device memory, hipHostMalloc / hipHostRegister'ed host memory, or a buffer created with PST_MEM_PINNED_HOST and copy into it");
+    }
+    if (at.type == hipMemoryTypeHost) kind = PST_MEM_PINNED_HOST;
+  }
+  return kind;
+}
+
 int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbytes, pst_buffer** out) {
   PST_API_BEGIN
   auto b = std::make_unique<pst_buffer>();
@@ -347,6 +370,7 @@ int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbyte
   else if (nbytes % stride != 0)  // ExternalMemoryBuffer::new, point_buffer.rs:1488-1497
     throw Error(PST_ERR_INVALID_ARGUMENT, "external memory size is not a multiple of the point size");
   if (nbytes && !device_ptr) throw Error(PST_ERR_INVALID_ARGUMENT, "device_ptr must not be NULL");
+  b->memkind = check_device_reaches(device_ptr, nbytes, "pst_buffer_wrap_external");
   b->owns = false;
   b->epoch.reset();  // (the caller's memory: nothing of ours can move under a slice of it)
   b->data = (uint8_t*)device_ptr;
@@ -364,6 +388,7 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
   for (size_t a = 0; a < b->layout.members.size(); ++a) {
     void* p = not_null(column_ptrs, "column_ptrs")[a];
     if (len && !p) throw Error(PST_ERR_INVALID_ARGUMENT, "column pointer must not be NULL");
+    if (check_device_reaches(p, len * b->layout.members[a].size, "pst_buffer_wrap_external_columns") == PST_MEM_PINNED_HOST) b->memkind = PST_MEM_PINNED_HOST;
     b->columns.push_back((uint8_t*)p);
   }
   b->len = b->capacity = len;

@@ -136,3 +136,38 @@ def test_las_file_image_in_device_memory_records_behind_the_header(hip, fmt, mod
         assert bool((t_back[:375] == 0xEE).all()) and bool((t_back[375 + n * R:] == 0xEE).all())
     finally:
         cv.jit_set_mode("env", hip)
+
+
+def test_external_memory_the_device_cannot_reach_is_refused_and_mapped_host_memory_works(hip):
+    """The reference's ExternalMemoryBuffer wraps ordinary host memory (point_buffer.rs:1479-1497).  Passed to this library as it is, such a pointer would
+    fault the GPU at the first kernel (and end the process); pst_buffer_wrap_external[_columns] asks the HIP runtime about both ends of the range
+    and refuses what it does not know.  Host memory the device maps (pinned) is taken, and gives the same results as device memory."""
+    import torch
+    from pasture_amd._capi import PastureError
+    from pasture_amd.buffers import ExternalColumnsBuffer
+    layout = las.point_layout_from_las_point_format(las.Format(0), False, api=hip)
+    n = 20_011
+    rec = _records(layout, n, 5)
+    raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1).copy()
+    with pytest.raises(PastureError, match="not known to the HIP runtime"):
+        ExternalMemoryBuffer(raw.ctypes.data, layout, nbytes=raw.size)  # numpy's (malloc'ed) memory
+    xyz = PointLayout.from_attributes([A.POSITION_3D], api=hip)
+    col = np.zeros((n, 3))
+    with pytest.raises(PastureError, match="not known to the HIP runtime"):
+        ExternalColumnsBuffer([col.ctypes.data], xyz, n)
+    # pinned host memory: the device maps it
+    pinned = torch.from_numpy(raw).pin_memory()
+    src = ExternalMemoryBuffer(pinned.data_ptr(), layout, nbytes=raw.size)
+    aligned = VectorBuffer.from_numpy(rec, layout)
+    conv = BufferLayoutConverter.for_layouts(layout, layout)
+    assert _columns(conv.convert(src, HashMapBuffer)) == _columns(conv.convert(aligned, HashMapBuffer))
+    assert calculate_bounds(src) == calculate_bounds(aligned)
+    out_host = torch.zeros(raw.size, dtype=torch.uint8).pin_memory()
+    dst = ExternalMemoryBuffer(out_host.data_ptr(), layout, nbytes=raw.size)
+    conv.convert_into(conv.convert(aligned, HashMapBuffer), dst)
+    torch.cuda.synchronize()
+    assert out_host.numpy().tobytes() == raw.tobytes()  # the records arrived in host memory, written by the kernels
+    dst.swap(0, n - 1)  # (copies inside mapped host memory take the right copy kind)
+    torch.cuda.synchronize()
+    got = out_host.numpy().reshape(n, 35)
+    assert got[0].tobytes() == raw.reshape(n, 35)[n - 1].tobytes() and got[n - 1].tobytes() == raw.reshape(n, 35)[0].tobytes()
