@@ -257,6 +257,10 @@ void resize_buffer(pst_buffer& b, size_t count, bool zero_fill) {
   if (count != b.len) bump_epoch(b);  // Vec::resize needs &mut: no slice of this buffer can be alive in the reference
   hipStream_t s = current_stream();
   if (count > b.capacity) {
+    // Vec::resize panics with "capacity overflow" when len * size exceeds isize::MAX; here the product must not wrap into a small allocation
+    // that the next kernel overruns
+    const size_t widest = b.columnar ? [&] { size_t w = 0; for (const auto& m : b.layout.members) w = std::max<size_t>(w, m.size); return w; }() : (size_t)b.layout.size;
+    if (widest && count > (size_t)INT64_MAX / widest) throw Error(PST_ERR_OUT_OF_MEMORY, "capacity overflow: " + std::to_string(count) + " points of " + std::to_string(widest) + " bytes");
     // pool allocations are stream-ordered (hipMallocAsync / hipFreeAsync on the current stream): copy and free need no host round trip
     // -- one per column made every growing call (append, filter, voxel grid output) pay several on a loaded host
     const bool ordered = pool_ready() && b.memkind != PST_MEM_PINNED_HOST;

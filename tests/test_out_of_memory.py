@@ -44,6 +44,11 @@ def test_a_failed_allocation_is_a_status_and_does_not_poison_the_next_call(hip):
     with pytest.raises(PastureError, match=r"status 22.*out of memory"):
         b.resize(200_000_000_000)  # 4.8 TB
     assert b.len() == 1000 and b.get_attribute_range(A.POSITION_3D, range(0, 1000)).tobytes() == before  # the buffer is what it was
+    for count in (1 << 61, (1 << 64) // 24 + 1, (1 << 64) - 1):  # count * 24 wraps around 2^64: a SMALL allocation if nobody looks (Vec::resize: "capacity overflow")
+        for buf in (b, VectorBuffer.new_from_layout(layout)):
+            with pytest.raises(PastureError, match=r"status 22.*capacity overflow"):
+                buf.resize(count)
+    assert b.len() == 1000
     _small_round_trip()  # (this call failed with "hipGetLastError(): out of memory" before the fix)
 
 
