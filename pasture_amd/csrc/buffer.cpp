@@ -336,6 +336,7 @@ int pst_buffer_create(const pst_layout* l, uint32_t storage, uint32_t memkind, p
   if (memkind > PST_MEM_PINNED_HOST) throw Error(PST_ERR_INVALID_ARGUMENT, "invalid memory kind");
   auto b = std::make_unique<pst_buffer>();
   b->layout = not_null(l, "layout")->l;
+  check_layout_fits_kernels(b->layout, "pst_buffer_create");
   b->columnar = storage == PST_STORAGE_COLUMNAR;
   b->memkind = memkind;
   if (b->columnar) b->columns.assign(b->layout.members.size(), nullptr);
@@ -369,6 +370,7 @@ int pst_buffer_wrap_external(const pst_layout* l, void* device_ptr, size_t nbyte
   PST_API_BEGIN
   auto b = std::make_unique<pst_buffer>();
   b->layout = not_null(l, "layout")->l;
+  check_layout_fits_kernels(b->layout, "pst_buffer_wrap_external");
   const size_t stride = b->layout.size;
   if (stride == 0) { if (nbytes != 0) throw Error(PST_ERR_INVALID_ARGUMENT, "zero-sized PointLayout with non-empty memory"); }
   else if (nbytes % stride != 0)  // ExternalMemoryBuffer::new, point_buffer.rs:1488-1497
@@ -386,6 +388,7 @@ int pst_buffer_wrap_external_columns(const pst_layout* l, void* const* column_pt
   PST_API_BEGIN
   auto b = std::make_unique<pst_buffer>();
   b->layout = not_null(l, "layout")->l;
+  check_layout_fits_kernels(b->layout, "pst_buffer_wrap_external_columns");
   b->columnar = true;
   b->owns = false;
   b->epoch.reset();

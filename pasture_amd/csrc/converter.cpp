@@ -711,6 +711,8 @@ int pst_point_converter_create(const pst_layout* from, const pst_layout* to, pst
   auto c = std::make_unique<pst_point_converter>();
   c->from = not_null(from, "from")->l;
   c->to = not_null(to, "to")->l;
+  check_layout_fits_kernels(c->from, "pst_point_converter_create");
+  check_layout_fits_kernels(c->to, "pst_point_converter_create");
   for (const Member& from_attr : c->from.members) {  // :70-91
     const Member* to_attr = c->to.find_by_name(from_attr.def.name);
     if (!to_attr) continue;                                       // .filter(has_attribute_with_name)
@@ -758,6 +760,8 @@ int pst_converter_create(const pst_layout* from, const pst_layout* to, int with_
   auto c = std::make_unique<pst_converter>();
   c->from = not_null(from, "from")->l;
   c->to = not_null(to, "to")->l;
+  check_layout_fits_kernels(c->from, "pst_converter_create");
+  check_layout_fits_kernels(c->to, "pst_converter_create");
   for (const Member& to_attr : c->to.members) {  // one default mapping per TARGET attribute, matched BY NAME (:112-143)
     const Member* from_attr = c->from.find_by_name(to_attr.def.name);
     if (!from_attr) {

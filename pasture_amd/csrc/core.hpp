@@ -116,6 +116,15 @@ struct Layout {
   bool operator!=(const Layout& o) const { return !(*this == o); }
 };
 
+// The kernels address a point's bytes with 32-bit strides and sizes (plan.h): a layout whose points (or one attribute: ByteArray(n) takes a u64 in the
+// reference) reach 4 GiB is refused where it meets device memory -- buffers and converters -- instead of being truncated there.  The layout itself can be
+// built and queried like any other (host-only logic).
+inline void check_layout_fits_kernels(const Layout& l, const char* what) {
+  bool ok = l.size < (1ull << 32);
+  for (const Member& m : l.members) ok = ok && m.size < (1ull << 32) && m.offset < (1ull << 32);
+  if (!ok) throw Error(PST_ERR_UNSUPPORTED, std::string(what) + ": points (or attributes) of 4 GiB and more are not supported on the device");
+}
+
 }  // namespace pst
 
 // opaque C handles

@@ -753,6 +753,13 @@ static uint32_t filter_chunk(uint32_t dst_stride, long default_budget = 15L * 10
   return (uint32_t)c;
 }
 
+// Interleaved targets go through an LDS record tile of at least 16 records: does it fit?  (Records beyond ~10 KB -- ByteArray attributes -- do not; the
+// caller then compacts into columns and transposes, filter_api.cpp.)
+bool filter_record_tile_fits(uint32_t tile, uint32_t dst_stride) {
+  const size_t lds_bytes = (((size_t)tile * 2 + 15) & ~(size_t)15) + (size_t)filter_chunk(dst_stride) * dst_stride + 48;
+  return lds_bytes <= 160 * 1024 - 256;
+}
+
 // Phase 1: counts + offsets (offsets[n_tiles] = number of matches), device memory inside `workspace`.
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
                          hipStream_t stream, unsigned long long* total_also) {

@@ -62,6 +62,31 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
   if (dst.len < num_matches)  // :1093-1095
     throw Error(PST_ERR_RANGE, "buffer.len() must be at least as large as the number of predicate matches");
   const size_t na = src.layout.members.size();
+  // An interleaved target whose records do not fit the kernels' LDS record tile (points beyond ~10 KB: ByteArray attributes; the reference copies any
+  // size, point_buffer.rs:1096-1133): the target's first num_matches points are transposed into temporary columns, compacted INTO those (points the
+  // mask does not reach keep what the target held), and transposed back -- three passes instead of one, on a path no bulk workload takes.
+  std::unique_ptr<pst_buffer> staged_cols;
+  pst_buffer* out = &dst;
+  std::vector<PlanEntry> to_cols, to_recs;
+  if (dst_aos && na && num_matches > 0 && !pstk::filter_record_tile_fits(tile, dst_stride)) {
+    staged_cols = std::make_unique<pst_buffer>();
+    staged_cols->layout = dst.layout;
+    staged_cols->columnar = true;
+    staged_cols->columns.assign(na, nullptr);
+    resize_buffer(*staged_cols, num_matches, false);
+    for (size_t a = 0; a < na; ++a) {
+      const Member& m = dst.layout.members[a];
+      PlanEntry e = identity_entry(m, m);
+      e.dst_col = col_addr(*staged_cols, a, 0);
+      to_cols.push_back(e);
+      e.dst_col = 0;
+      e.src_col = col_addr(*staged_cols, a, 0);
+      to_recs.push_back(e);
+    }
+    execute_entries(true, aos_addr(dst, 0), dst_stride, false, 0, 0, num_matches, to_cols, true, s);
+    out = staged_cols.get();
+  }
+  const bool out_aos = !out->columnar;
   std::vector<uint64_t> src_addr(na), dst_addr(na);
   std::vector<uint32_t> src_stride(na), dst_off(na), size(na);
   size_t covered = 0;
@@ -69,15 +94,16 @@ size_t filter_into(const pst_buffer& src, pst_buffer& dst, const uint8_t* mask, 
     const Member& m = src.layout.members[a];
     src_addr[a] = src.columnar ? col_addr(src, a, 0) : aos_addr(src, 0) + m.offset;
     src_stride[a] = (uint32_t)(src.columnar ? m.size : src.layout.size);
-    dst_addr[a] = dst.columnar ? col_addr(dst, a, 0) : 0;
+    dst_addr[a] = out->columnar ? col_addr(*out, a, 0) : 0;
     dst_off[a] = (uint32_t)m.offset;
     size[a] = (uint32_t)m.size;
     covered += m.size;
   }
   if (na && (hinted ? num_matches : std::min(matches, num_matches)) > 0 &&
       !pstk::launch_filter_scatter(mask_dev, n, tile, scratch, num_matches, src_addr.data(), src_stride.data(), dst_addr.data(), dst_off.data(),
-                                   size.data(), (int)na, dst_aos, dst_aos ? aos_addr(dst, 0) : 0, dst_stride, covered == dst.layout.size, s))
+                                   size.data(), (int)na, out_aos, out_aos ? aos_addr(*out, 0) : 0, dst_stride, covered == dst.layout.size, s))
     throw hip_failure("filter launch failed: ");
+  if (staged_cols) execute_entries(false, 0, 0, true, aos_addr(dst, 0), dst_stride, num_matches, to_recs, true, s);
   if (stream_ordered) return num_matches;
   stream_sync(s);  // the staged mask is released on return
   if (hinted) matches = (size_t)*(const unsigned long long*)(ws.pinned + 768);

@@ -129,6 +129,7 @@ bool launch_las_transpose(int format, bool to_records, uint64_t aos, const uint6
 // predicate compaction (filter.hip)
 size_t filter_workspace_bytes(uint64_t n);
 uint32_t filter_tile(bool dst_aos, uint32_t dst_stride);
+bool filter_record_tile_fits(uint32_t tile, uint32_t dst_stride);  // interleaved targets: do 16 records fit the LDS record tile?
 void launch_filter_count(const uint8_t* mask_dev, uint64_t n, uint32_t tile, uint8_t* workspace, const unsigned long long** out_total_dev,
                          hipStream_t stream, unsigned long long* total_also = nullptr);
 // A predicate fused into the streaming compaction kernel (round 6; expr.cpp writes the text): filter's closure (point_buffer.rs:1064-1136) evaluated by
