@@ -439,12 +439,14 @@ int pst_buffer_swap(pst_buffer* b, size_t from_index, size_t to_index) {
   uint8_t* tmp = workspace().dev;  // Workspace::kWorkspaceBytes (1 MiB) of per-thread device scratch; stream order makes the three copies a swap
   auto swap_bytes = [&](uint8_t* base, size_t size) {
     if (!size) return;
-    if (size > Workspace::kWorkspaceBytes) throw Error(PST_ERR_UNSUPPORTED, "pst_buffer_swap: values wider than 1 MiB are not supported");
     uint8_t *a = base + from_index * size, *c = base + to_index * size;
     const hipMemcpyKind kind = b->memkind == PST_MEM_PINNED_HOST ? hipMemcpyDefault : hipMemcpyDeviceToDevice;
-    PST_HIP_CHECK(hipMemcpyAsync(tmp, a, size, kind, s));
-    PST_HIP_CHECK(hipMemcpyAsync(a, c, size, kind, s));
-    PST_HIP_CHECK(hipMemcpyAsync(c, tmp, size, kind, s));
+    for (size_t done = 0; done < size; done += Workspace::kWorkspaceBytes) {  // values wider than the scratch (ByteArray attributes) piece by piece
+      const size_t piece = std::min(size - done, Workspace::kWorkspaceBytes);
+      PST_HIP_CHECK(hipMemcpyAsync(tmp, a + done, piece, kind, s));
+      PST_HIP_CHECK(hipMemcpyAsync(a + done, c + done, piece, kind, s));
+      PST_HIP_CHECK(hipMemcpyAsync(c + done, tmp, piece, kind, s));
+    }
   };
   if (b->columnar) {
     for (size_t a = 0; a < b->columns.size(); ++a) swap_bytes(b->columns[a], b->layout.members[a].size);

@@ -76,6 +76,19 @@ def test_compaction_and_append_of_points_with_large_byte_arrays(hip, out_kind):
     assert both.get_attribute_range(blob, range(0, both.len())).tobytes() == np.ascontiguousarray(np.concatenate([rec["Blob"][:50], rec["Blob"][mask]])).tobytes()
 
 
+@pytest.mark.parametrize("kind", ["V", "H"])
+def test_swap_of_points_wider_than_the_scratch(hip, kind):
+    """BorrowedMutBuffer::swap (point_buffer.rs:229) on 2.5-MB points: the exchange goes through 1 MiB of device scratch piece by piece."""
+    layout, blob = _layout(hip, 2_500_003, False)
+    rec = random_records(layout, 5, 8)
+    buf = BUFFER_KINDS[kind].from_numpy(rec, layout)
+    buf.swap(1, 4)
+    want = rec.copy()
+    want[[1, 4]] = want[[4, 1]]
+    assert buf.get_attribute_range(blob, range(0, 5)).tobytes() == np.ascontiguousarray(want["Blob"]).tobytes()
+    assert buf.get_attribute_range(A.POSITION_3D, range(0, 5)).tobytes() == np.ascontiguousarray(want["Position3D"]).tobytes()
+
+
 def test_points_of_four_gib_are_refused_where_they_meet_device_memory(hip):
     """ByteArray(2^32): a layout like any other on the host (sizes and offsets are u64, point_layout.rs:57), PST_ERR_UNSUPPORTED for buffers and converters."""
     huge = PointLayout.from_attributes_packed([A.POSITION_3D, PointAttributeDefinition("Blob", T.ByteArray(1 << 32))], 1, api=hip)
