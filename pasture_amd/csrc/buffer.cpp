@@ -118,9 +118,8 @@ void trim_device_pool() {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) { (void)hipGetLastError(); return; }
   (void)hipDeviceSynchronize();  // releases enqueued with hipFreeAsync become "unused" when their stream gets there
   if (hipMemPoolTrimTo(pool, 0) != hipSuccess) (void)hipGetLastError();
-  // The pool notices completed releases when it is next asked for memory, not when the stream gets there: one small request makes it look, and what it
-  // then counts as unused goes back as well.  (Seen at the end of a 13-minute test process: the driver refused 12 MiB to another allocator while the
-  // library still got 2.4 GB out of a pool that had just been trimmed.)
+  // (belt and braces: should the pool count a completed release as unused only when it is next asked for memory, one small request makes it look,
+  //  and what it then holds for nobody goes back as well)
   void* nudge = nullptr;
   if (hipMallocAsync(&nudge, 256, nullptr) == hipSuccess) { (void)hipFreeAsync(nudge, nullptr); (void)hipDeviceSynchronize(); }
   else (void)hipGetLastError();
