@@ -69,11 +69,12 @@ def test_release_scratch_hands_the_pool_back(hip):
 
 
 def test_full_device_every_allocating_call_reports_out_of_memory_and_recovers():
-    """In a process of its own, which fills what the parent leaves.  STRICT (every refusal is status 22, the 2.4-GB request and at least one other call
-    are refused) only when the device is the process's own (>= 250 GiB free at its start): at the end of the whole suite, with a parent that keeps
-    a couple of hundred GiB in its pool, the driver refuses 12 MiB to torch's hipMalloc and still finds 2.4 GB for hipMallocAsync (idle memory of the
-    other process gives way) -- "the device is full" cannot be arranged from outside then, and the body only checks that whatever ran is right and that
-    everything works afterwards.  (The whole suite failed here twice -- 1754 passed, this one not -- before the modes were separated.)"""
+    """In a process of its own, which fills the device and then calls everything that allocates.  Whether those calls are REFUSED cannot be arranged
+    from outside while another process (the suite's own) holds memory on the device: the driver then refuses 12 MiB to torch's hipMalloc and still
+    serves 2.4 GB to the library's hipMallocAsync (three whole-suite runs ended here: 1754 passed, this one "did not raise", although the same body
+    alone on a box is refused every time).  So the body checks what holds either way -- whatever ran is right, a refusal is a PastureError, everything
+    works once the memory is back -- and is STRICT (status 22 on every refusal, the 2.4-GB request and at least one more call refused) only under
+    PST_STRICT_OOM=1, which tools/r06_calls/r06_gpu66.sh sets for the stand-alone run."""
     import os
     import subprocess
     import sys
@@ -104,7 +105,8 @@ def _full_device_body():
     gc.collect()
     hip.release_scratch()
     torch.cuda.empty_cache()
-    strict = _free() >= 250 * GIB
+    import os
+    strict = os.environ.get("PST_STRICT_OOM") == "1"
     print("strict" if strict else "tolerant", f"({_free() / GIB:.0f} GiB free before the fill)")
     hog = [torch.empty(max(1, _free() - 64 * (1 << 20)), dtype=torch.uint8, device="cuda")]
     try:
