@@ -111,3 +111,23 @@ def test_layout_equality(lapi):
     assert a == b and a != c and a.compare_without_offsets(c)
     # runtime Packed(n) quirk: layout alignment = min(n, current) => 1 when built from default()
     assert c.alignment() == 1 and c.size_of_point_entry() == 26
+
+
+def test_points_of_four_gib_are_a_layout_but_not_a_device_buffer():
+    """Host-only part of tests/test_big_records.py (runs without a GPU): ByteArray(2^32) builds a layout with u64 sizes like the reference's
+    (point_layout.rs:57), and the product refuses it where it would meet 32-bit strides -- buffers and converters -- before any device is touched."""
+    from pasture_amd import product_api
+    from pasture_amd._capi import PastureError
+    from pasture_amd.buffers import HashMapBuffer, VectorBuffer
+    from pasture_amd.conversion import BufferLayoutConverter
+    from pasture_amd.layout import PointAttributeDataType as T, PointAttributeDefinition, PointLayout, attributes as A
+    api = product_api()
+    huge = PointLayout.from_attributes_packed([A.POSITION_3D, PointAttributeDefinition("Blob", T.ByteArray(1 << 32))], 1, api=api)
+    assert huge.size_of_point_entry() == (1 << 32) + 24
+    just_under = PointLayout.from_attributes_packed([PointAttributeDefinition("Blob", T.ByteArray((1 << 32) - 1))], 1, api=api)
+    small = PointLayout.from_attributes([A.POSITION_3D], api=api)
+    for make in (lambda: VectorBuffer.new_from_layout(huge), lambda: HashMapBuffer.new_from_layout(huge),
+                 lambda: BufferLayoutConverter.for_layouts_with_default(small, huge), lambda: BufferLayoutConverter.for_layouts(huge, small)):
+        with pytest.raises(PastureError, match="4 GiB"):
+            make()
+    assert VectorBuffer.new_from_layout(just_under).len() == 0  # (an empty buffer: nothing is allocated)
