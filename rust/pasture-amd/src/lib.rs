@@ -40,6 +40,12 @@ fn datatype_to_c(dt: PointAttributeDataType) -> pst_datatype {
     d
 }
 
+/// Memory the library has freed stays in its stream-ordered pool (a `convert()` that allocates its target costs microseconds, not 100 ms) and is
+/// invisible to every other allocator of the process.  Hand it back -- together with the kNN search's scratch cache -- before another library needs
+/// the GPU's memory; an allocation of THIS library that fails does so on its own and tries once more before it reports status 22 (out of memory:
+/// `check` turns it into a panic like every other status; a `try_*` surface would return it).  Synchronises the device.
+pub fn release_device_memory() { check(unsafe { pst_release_scratch() }); }
+
 struct LayoutHandle(*mut pst_layout);
 impl LayoutHandle {
     /// Exact transfer of a `PointLayout` (attribute order, offsets, size) via pst_layout_from_members; the type alignment is the caller's.
